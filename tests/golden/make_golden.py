@@ -1,0 +1,137 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/*.npz from the UNMODIFIED reference (oracle/_ref).
+
+Run in the build container only (needs /root/reference):
+    make -C oracle ref && python tests/golden/make_golden.py
+Each fixture stores the exact uint8 IQ input next to what the reference's
+IqDataProcessor::acceptIqData produced for it (PCM per mode, per-block squelch magnitude and
+signalAllowed), so the fixtures stay valid without numpy RNG stream compatibility.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import bindings as B          # noqa: E402
+from rtlsdrdiags_amd import synth          # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+MODES = ["am", "fm", "wbfm", "lsb", "usb"]
+
+
+def run_all_modes(R, u8, block_bytes=32768, threshold=None, rx_gain=None, gains=None):
+    out = {}
+    for mode in ["none"] + MODES:
+        c = R.chain()
+        c.set_rx_gain_db(24 if rx_gain is None else rx_gain)
+        c.set_mode(mode)
+        if threshold is not None:
+            c.set_squelch(threshold)
+        if gains:
+            for which, g in gains.items():
+                c.set_gain(which, g)
+        pcm, mag, allowed = c.accept_stream(u8, block_bytes)
+        out["pcm_" + mode] = pcm
+        out["magnitude"] = mag
+        out["allowed"] = allowed
+        c.close()
+    R.chain().set_rx_gain_db(24)
+    return out
+
+
+def main():
+    R = B.Reference()
+    blk = 16384
+
+    # (i) modulated tone at -Fs/4 + noise, moderate amplitude
+    u8 = synth.fm_tone(4 * blk, seed=1)
+    np.savez_compressed(os.path.join(OUT, "fm_tone.npz"), iq=u8, block_bytes=32768,
+                        **run_all_modes(R, u8))
+    u8 = synth.am_tone(2 * blk, seed=2)
+    np.savez_compressed(os.path.join(OUT, "am_tone.npz"), iq=u8, block_bytes=32768,
+                        **run_all_modes(R, u8))
+    u8 = synth.ssb_tone(2 * blk, seed=5)
+    np.savez_compressed(os.path.join(OUT, "ssb_tone.npz"), iq=u8, block_bytes=32768,
+                        **run_all_modes(R, u8))
+
+    # (ii) edge inputs: full-scale white bytes, rail-to-rail, the 255x4/0x4 pattern
+    u8 = synth.white_u8(3 * blk, seed=3)
+    np.savez_compressed(os.path.join(OUT, "white.npz"), iq=u8, block_bytes=32768,
+                        **run_all_modes(R, u8))
+    u8 = synth.rails_u8(2 * blk, seed=4)
+    np.savez_compressed(os.path.join(OUT, "rails.npz"), iq=u8, block_bytes=32768,
+                        **run_all_modes(R, u8))
+    # huge demodulator gains: drives the (int16) float casts through wrap-around
+    u8 = synth.fm_tone(2 * blk, seed=6, amplitude=100.0)
+    gains = {1: 30000.0, 2: 2.0e6, 3: 8.0e6, 4: 30000.0}
+    np.savez_compressed(os.path.join(OUT, "cast_overflow.npz"), iq=u8, block_bytes=32768,
+                        gain_am=gains[1], gain_fm=gains[2], gain_wbfm=gains[3], gain_ssb=gains[4],
+                        **run_all_modes(R, u8, gains=gains))
+
+    # squelch open/close: amplitude-stepped 4096-byte blocks, threshold -40 dBFS, gain 24 dB
+    amps = [2, 2, 45, 45, 2, 2, 2, 90, 2, 110, 0, 0, 60, 2, 2, 60]
+    u8 = synth.stepped_amplitude(amps, block_samples=2048, seed=7)
+    np.savez_compressed(os.path.join(OUT, "squelch_steps.npz"), iq=u8, block_bytes=4096,
+                        threshold=-40, rx_gain_db=24,
+                        **run_all_modes(R, u8, block_bytes=4096, threshold=-40, rx_gain=24))
+
+    # mode switching mid-stream without reset (Radio never resets)
+    u8 = synth.fm_tone(6 * blk, seed=8)
+    c = R.chain()
+    seq = ["wbfm", "fm", "wbfm", "usb", "am", "lsb"]
+    pcm = []
+    for k, mode in enumerate(seq):
+        c.set_mode(mode)
+        p, _, _ = c.accept_stream(u8[k * 32768:(k + 1) * 32768])
+        pcm.append(p)
+    c.close()
+    np.savez_compressed(os.path.join(OUT, "mode_switch.npz"), iq=u8, block_bytes=32768,
+                        sequence=np.array(seq), pcm=np.concatenate(pcm))
+
+    # primitives: quantised taps recovered from the reference by a -32768 impulse,
+    # clamp behaviour on full-scale int16 noise, float FIR/IIR impulse/step responses
+    O = B.Oracle()
+    prim = {}
+    rng = np.random.default_rng(11)
+    x16 = rng.integers(-32768, 32768, 4096).astype(np.int16)
+    xsat = np.where(rng.random(4096) < 0.5, -32768, 32767).astype(np.int16)
+    prim["x16"], prim["xsat"] = x16, xsat
+    for name, factor in [("wbfm_pre", 1), ("wbfm_d1", 4), ("wbfm_d2", 4), ("audio40", 2),
+                         ("fm_tuner", 4), ("am_s1", 4), ("am_s2", 4), ("am_s3", 2),
+                         ("ssb_delay", 1), ("ssb_hilbert", 1)]:
+        h = O.taps_f32(name)
+        imp = np.zeros(len(h) + 3, np.int16)
+        imp[0] = -32768
+        prim["negimp_" + name] = R.fir_q15(h, imp)
+        if factor == 1:
+            prim["y16_" + name] = R.fir_q15(h, x16)
+            prim["ysat_" + name] = R.fir_q15(h, xsat)
+        else:
+            prim["y16_" + name] = R.decimate_q15(h, factor, x16)
+            prim["ysat_" + name] = R.decimate_q15(h, factor, xsat)
+    # the reference's own filter demos (Filters/testFirFilter.cc:28-69, testIirFilter.cc:35-110)
+    demo_taps = np.array([1, 2, 3, 4, 1, 1, 1, 8], np.float32)
+    impulse = np.zeros(16, np.float32); impulse[0] = 1
+    step = np.ones(32, np.float32)
+    prim["demo_fir_impulse"] = R.fir_f32(demo_taps, impulse)
+    prim["demo_iir_half_step"] = R.iir_f32([1.0], [0.5], step)
+    prim["demo_dcblock_step"] = R.iir_f32([1.0, -1.0], [-0.95], step)
+    xf = rng.normal(0, 5000, 2048).astype(np.float32)
+    prim["xf"] = xf
+    prim["deemph_xf"] = R.iir_f32([0.0253863, 0.0253863], [-0.9492274], xf)
+    prim["dcblock_xf"] = R.iir_f32([1.0, -1.0], [-0.95], xf)
+    prim["dbfs_0_299"] = np.array([R.dbfs(m) for m in range(300)], np.int32)
+    s8 = rng.integers(-128, 128, 4096).astype(np.int8)
+    prim["rot_in"] = s8
+    prim["rot_up"] = R.rotate(s8, +1)
+    prim["rot_down"] = R.rotate(s8, -1)
+    np.savez_compressed(os.path.join(OUT, "primitives.npz"), **prim)
+
+    total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT) if f.endswith(".npz"))
+    print("golden fixtures written: %.1f KiB" % (total / 1024.0))
+
+
+if __name__ == "__main__":
+    main()
