@@ -1,0 +1,159 @@
+/* include/iqdemod.h — C-ABI of libiqdemod.so, the MI355X-native IQ demodulation engine.
+ *
+ * This is the drop-in boundary for the RtlSdrDiags per-sample DSP hot path.  Each entry
+ * point names the reference interface it replaces (paths relative to the reference's
+ * radioDiags/ directory).  Signatures are plain C: pointers, sizes and scalars only.
+ *
+ * One engine owns N independent channels.  Each channel behaves like one reference
+ * IqDataProcessor with its four demodulators attached (hdr_diags/IqDataProcessor.h:16-93):
+ * it keeps its own mode, gains, squelch threshold/tracker and per-demodulator filter state.
+ * A channel's input is the same offset-binary uint8 interleaved I/Q the reference receives
+ * (256 kS/s) and its output the same 8 kS/s S16 PCM (bytes/64 samples per accepted block).
+ *
+ * Threading (IqDataProcessor.h:35-37, DataConsumer.cc:342): one thread at a time may be
+ * inside iqd_accept_*() for a given engine; setters may be called from another thread
+ * between or during accepts and take effect at the next accept (they are mutex-guarded).
+ *
+ * All functions returning int return IQD_OK (0) or a negative IQD_E* code.
+ */
+#ifndef IQDEMOD_H
+#define IQDEMOD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IQD_ABI_VERSION 1
+
+/* IqDataProcessor::demodulatorType, hdr_diags/IqDataProcessor.h:20 */
+enum iqd_mode {
+    IQD_MODE_NONE = 0, IQD_MODE_AM = 1, IQD_MODE_FM = 2,
+    IQD_MODE_WBFM = 3, IQD_MODE_LSB = 4, IQD_MODE_USB = 5
+};
+
+/* Which demodulator a gain applies to: {Am,Fm,WbFm,Ssb}Demodulator::setDemodulatorGain */
+enum iqd_demod { IQD_DEMOD_AM = 1, IQD_DEMOD_FM = 2, IQD_DEMOD_WBFM = 3, IQD_DEMOD_SSB = 4 };
+
+enum iqd_status {
+    IQD_OK = 0,
+    IQD_EINVAL = -1,      /* bad argument (range, alignment, NULL) */
+    IQD_ENODEV = -2,      /* no usable HIP device / HIP runtime error at create */
+    IQD_ENOMEM = -3,      /* host or device allocation failed */
+    IQD_EHIP = -4,        /* a HIP call failed during accept (see iqd_last_error) */
+    IQD_ESTATE = -5       /* exact-state verification could not be repaired (never expected) */
+};
+
+typedef struct iqd_engine iqd_t;
+
+typedef struct iqd_config {
+    uint32_t abi_version;   /* IQD_ABI_VERSION */
+    uint32_t n_channels;    /* >= 1 */
+    uint32_t block_bytes;   /* squelch / acceptIqData granularity per channel.  0 -> 32768
+                               (Radio.cc:16, 1895).  Multiple of 256, <= 32768 (the cap of
+                               SignalDetector.h:49). */
+    int32_t device;         /* HIP device ordinal, -1 -> current device */
+    uint32_t flags;         /* IQD_F_* */
+    uint32_t reserved[3];
+} iqd_config;
+
+#define IQD_F_NO_MAGNITUDE 0x1u /* do not produce per-block magnitudes when no channel's squelch can close
+                                   (the reference only reports them through an optional callback) */
+
+/* Replaces: new IqDataProcessor(...) + new {Am,Fm,WbFm,Ssb}Demodulator(pcmCallback) +
+ * set*Demodulator() wiring, Radio.cc:150-181.  Every channel starts like the reference:
+ * mode None (IqDataProcessor.cc:38), squelch threshold -200 dBFS (:41), receive gain 24 dB
+ * (Radio.cc:325-328), default demodulator gains, zero filter state. */
+int iqd_create(const iqd_config *cfg, iqd_t **out);
+void iqd_destroy(iqd_t *e);
+
+/* Replaces IqDataProcessor::setDemodulatorMode, IqDataProcessor.cc:236-262
+ * (Lsb/Usb also select the SsbDemodulator sideband, :244-256). */
+int iqd_set_mode(iqd_t *e, uint32_t first_ch, uint32_t n_ch, int mode);
+
+/* Replaces {Am,Fm,WbFm,Ssb}Demodulator::setDemodulatorGain (e.g. WbFmDemodulator.cc:341-348). */
+int iqd_set_gain(iqd_t *e, uint32_t first_ch, uint32_t n_ch, int demod, float gain);
+
+/* Replaces IqDataProcessor::setSignalDetectThreshold, IqDataProcessor.cc:284-295. */
+int iqd_set_squelch(iqd_t *e, uint32_t first_ch, uint32_t n_ch, int32_t threshold_dbfs);
+
+/* Replaces the global radio_adjustableReceiveGainInDb read at IqDataProcessor.cc:765
+ * (per channel here, because each channel stands for its own receiver). */
+int iqd_set_rx_gain_db(iqd_t *e, uint32_t first_ch, uint32_t n_ch, uint32_t gain_db);
+
+/* Front-end rotation selector: +1 = upconvertByFsOver4 (what acceptIqData applies,
+ * IqDataProcessor.cc:749, the default), -1 = downconvertByFsOver4 (:496-540), 0 = none. */
+int iqd_set_rotation(iqd_t *e, uint32_t first_ch, uint32_t n_ch, int rotation);
+
+/* Replaces {Am,Fm,WbFm,Ssb}Demodulator::resetDemodulator() for all four demodulators of the
+ * channels (note WbFmDemodulator.cc:304-320 leaves the de-emphasis filter state alone). */
+int iqd_reset(iqd_t *e, uint32_t first_ch, uint32_t n_ch);
+
+/* Replaces IqDataProcessor::acceptIqData(timeStamp, bufferPtr, byteCount),
+ * IqDataProcessor.cc:722-840, for n_ch channels at once, each receiving
+ * bytes_per_ch / block_bytes consecutive calls' worth of data.
+ *
+ *   iq             [n_ch][bytes_per_ch] uint8, channel-major; NOT modified (the reference
+ *                  mutates its buffer in place; callers that relied on that must not).
+ *   bytes_per_ch   multiple of block_bytes.
+ *   pcm            [n_ch][bytes_per_ch/64] int16; channel c's samples are packed at the front
+ *                  of its row (squelched blocks contribute nothing, like the reference's
+ *                  callback, IqDataProcessor.cc:793).
+ *   pcm_count      [n_ch] number of valid PCM samples per channel (may be NULL).
+ *   magnitude      [n_ch][bytes_per_ch/block_bytes] SignalDetector::signalMagnitude per block
+ *                  = what registerSignalMagnitudeCallback would deliver (may be NULL).
+ *   signal_present [n_ch][bytes_per_ch/block_bytes] Squelch::run() result per block = what
+ *                  registerSignalStateCallback would deliver (may be NULL).
+ *
+ * Host-pointer form: copies in, runs, copies out, returns when done. */
+int iqd_accept_iq(iqd_t *e, uint32_t first_ch, uint32_t n_ch,
+                  const uint8_t *iq, size_t bytes_per_ch,
+                  int16_t *pcm, uint32_t *pcm_count,
+                  uint32_t *magnitude, uint8_t *signal_present);
+
+/* Device-pointer form: every pointer is HIP device memory (same layouts); the work is
+ * enqueued on the engine's stream and the call returns without waiting unless a state
+ * repair is needed.  Use iqd_synchronize() before reading results. */
+int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch,
+                         const void *iq_dev, size_t bytes_per_ch,
+                         void *pcm_dev, void *pcm_count_dev,
+                         void *magnitude_dev, void *signal_present_dev);
+
+int iqd_synchronize(iqd_t *e);
+
+/* Diagnostics (the reference's displayInternalInformation() text dumps, e.g.
+ * IqDataProcessor.cc:860-926, become queryable values). */
+typedef struct iqd_stats {
+    uint64_t accepts;            /* iqd_accept_* calls */
+    uint64_t samples;            /* IQ samples accepted, all channels */
+    uint64_t kernel_launches;    /* chain-kernel launches */
+    uint64_t state_checks;       /* tile hand-offs verified bit-exact (WBFM de-emphasis) */
+    uint64_t state_repairs;      /* tiles re-run with an exact carried state */
+    double chain_kernel_ms;      /* HIP-event time of the chain kernels while profiling is on */
+    uint64_t chain_kernel_count; /* launches covered by chain_kernel_ms */
+} iqd_stats;
+
+int iqd_get_stats(iqd_t *e, iqd_stats *out);
+int iqd_set_profiling(iqd_t *e, int enabled);  /* HIP events around the chain kernels */
+int iqd_get_channel_mode(iqd_t *e, uint32_t ch, int *mode);
+int iqd_get_channel_gain(iqd_t *e, uint32_t ch, int demod, float *gain);
+const char *iqd_last_error(iqd_t *e);
+const char *iqd_strerror(int status);
+uint32_t iqd_abi_version(void);
+
+/* Small device-memory helpers so that non-HIP hosts (ctypes, cgo, JNI) can stage
+ * device-resident buffers for iqd_accept_iq_device without linking the HIP runtime. */
+int iqd_dev_alloc(iqd_t *e, size_t bytes, void **out);
+int iqd_dev_free(iqd_t *e, void *p);
+int iqd_dev_upload(iqd_t *e, void *dst_dev, const void *src_host, size_t bytes);
+int iqd_dev_download(iqd_t *e, void *dst_host, const void *src_dev, size_t bytes);
+/* Fills dst_dev with `total` bytes by repeating the first `period` bytes already there. */
+int iqd_dev_tile(iqd_t *e, void *dst_dev, size_t period, size_t total);
+void *iqd_stream(iqd_t *e); /* the engine's hipStream_t */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IQDEMOD_H */

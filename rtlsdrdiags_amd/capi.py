@@ -1,0 +1,206 @@
+"""ctypes binding of include/iqdemod.h (libiqdemod.so).
+
+Mirrors the C ABI one to one; the names, argument meaning and error behaviour are those of the
+header, which in turn cites the reference's IqDataProcessor interface.  No torch types cross
+this boundary: device buffers are passed as integer addresses.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .build import LIB
+
+MODE = {"none": 0, "am": 1, "fm": 2, "wbfm": 3, "lsb": 4, "usb": 5}
+DEMOD = {"am": 1, "fm": 2, "wbfm": 3, "ssb": 4}
+F_NO_MAGNITUDE = 0x1
+
+
+class Config(C.Structure):
+    _fields_ = [("abi_version", C.c_uint32), ("n_channels", C.c_uint32), ("block_bytes", C.c_uint32),
+                ("device", C.c_int32), ("flags", C.c_uint32), ("reserved", C.c_uint32 * 3)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("accepts", C.c_uint64), ("samples", C.c_uint64), ("kernel_launches", C.c_uint64),
+                ("state_checks", C.c_uint64), ("state_repairs", C.c_uint64),
+                ("chain_kernel_ms", C.c_double), ("chain_kernel_count", C.c_uint64)]
+
+
+class IqdError(RuntimeError):
+    def __init__(self, status, detail):
+        super().__init__("libiqdemod: %s (%d): %s" % (_lib().iqd_strerror(status).decode(), status, detail))
+        self.status = status
+
+
+EXPORTS = [
+    "iqd_abi_version", "iqd_strerror", "iqd_last_error", "iqd_create", "iqd_destroy", "iqd_set_mode",
+    "iqd_set_gain", "iqd_set_squelch", "iqd_set_rx_gain_db", "iqd_set_rotation", "iqd_reset",
+    "iqd_accept_iq", "iqd_accept_iq_device", "iqd_synchronize", "iqd_get_stats", "iqd_set_profiling",
+    "iqd_get_channel_mode", "iqd_get_channel_gain", "iqd_dev_alloc", "iqd_dev_free", "iqd_dev_upload",
+    "iqd_dev_download", "iqd_dev_tile", "iqd_stream",
+]
+
+_LIB = None
+
+
+def _lib():
+    """Loads libiqdemod.so (raises if it has not been built — there is no fallback)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(LIB):
+        raise FileNotFoundError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB)
+    L = C.CDLL(LIB)
+    vp, u32, sz = C.c_void_p, C.c_uint32, C.c_size_t
+    L.iqd_abi_version.restype = u32
+    L.iqd_strerror.restype = C.c_char_p
+    L.iqd_strerror.argtypes = [C.c_int]
+    L.iqd_last_error.restype = C.c_char_p
+    L.iqd_last_error.argtypes = [vp]
+    L.iqd_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.iqd_destroy.argtypes = [vp]
+    L.iqd_destroy.restype = None
+    L.iqd_set_mode.argtypes = [vp, u32, u32, C.c_int]
+    L.iqd_set_gain.argtypes = [vp, u32, u32, C.c_int, C.c_float]
+    L.iqd_set_squelch.argtypes = [vp, u32, u32, C.c_int32]
+    L.iqd_set_rx_gain_db.argtypes = [vp, u32, u32, u32]
+    L.iqd_set_rotation.argtypes = [vp, u32, u32, C.c_int]
+    L.iqd_reset.argtypes = [vp, u32, u32]
+    L.iqd_accept_iq.argtypes = [vp, u32, u32, vp, sz, vp, vp, vp, vp]
+    L.iqd_accept_iq_device.argtypes = [vp, u32, u32, vp, sz, vp, vp, vp, vp]
+    L.iqd_synchronize.argtypes = [vp]
+    L.iqd_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.iqd_set_profiling.argtypes = [vp, C.c_int]
+    L.iqd_get_channel_mode.argtypes = [vp, u32, C.POINTER(C.c_int)]
+    L.iqd_get_channel_gain.argtypes = [vp, u32, C.c_int, C.POINTER(C.c_float)]
+    L.iqd_dev_alloc.argtypes = [vp, sz, C.POINTER(vp)]
+    L.iqd_dev_free.argtypes = [vp, vp]
+    L.iqd_dev_upload.argtypes = [vp, vp, vp, sz]
+    L.iqd_dev_download.argtypes = [vp, vp, vp, sz]
+    L.iqd_dev_tile.argtypes = [vp, vp, sz, sz]
+    L.iqd_stream.argtypes = [vp]
+    L.iqd_stream.restype = vp
+    _LIB = L
+    return L
+
+
+def _np_ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Engine:
+    """N independent channels, each one reference IqDataProcessor + its four demodulators."""
+
+    def __init__(self, n_channels=1, block_bytes=0, device=-1, flags=0):
+        self._L = _lib()
+        self._h = C.c_void_p()
+        cfg = Config(self._L.iqd_abi_version(), n_channels, block_bytes, device, flags)
+        rc = self._L.iqd_create(C.byref(cfg), C.byref(self._h))
+        if rc != 0:
+            self._h = C.c_void_p()
+            raise IqdError(rc, "iqd_create failed (is a HIP device visible?)")
+        self.n_channels = n_channels
+        self.block_bytes = block_bytes or 32768
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.iqd_destroy(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc != 0:
+            raise IqdError(rc, self._L.iqd_last_error(self._h).decode())
+
+    def _range(self, first, n):
+        return first, (self.n_channels - first if n is None else n)
+
+    # ---- the reference's control surface -------------------------------------------------
+    def set_mode(self, mode, first=0, n=None):
+        f, n = self._range(first, n)
+        self._check(self._L.iqd_set_mode(self._h, f, n, int(MODE.get(mode, mode))))
+
+    def set_gain(self, demod, gain, first=0, n=None):
+        f, n = self._range(first, n)
+        self._check(self._L.iqd_set_gain(self._h, f, n, int(DEMOD.get(demod, demod)), C.c_float(gain)))
+
+    def set_squelch(self, threshold, first=0, n=None):
+        f, n = self._range(first, n)
+        self._check(self._L.iqd_set_squelch(self._h, f, n, int(threshold)))
+
+    def set_rx_gain_db(self, gain_db, first=0, n=None):
+        f, n = self._range(first, n)
+        self._check(self._L.iqd_set_rx_gain_db(self._h, f, n, int(gain_db)))
+
+    def set_rotation(self, rotation, first=0, n=None):
+        f, n = self._range(first, n)
+        self._check(self._L.iqd_set_rotation(self._h, f, n, int(rotation)))
+
+    def reset(self, first=0, n=None):
+        f, n = self._range(first, n)
+        self._check(self._L.iqd_reset(self._h, f, n))
+
+    # ---- data path ------------------------------------------------------------------------
+    def accept(self, iq_u8, first=0, n=None):
+        """iq_u8: [n_ch, bytes_per_ch] uint8 host array.  Returns (pcm rows, counts, magnitude, allowed)."""
+        f, n = self._range(first, n)
+        iq_u8 = np.ascontiguousarray(iq_u8, dtype=np.uint8).reshape(n, -1)
+        bpc = iq_u8.shape[1]
+        nblk = bpc // self.block_bytes if bpc % self.block_bytes == 0 else 0
+        pcm = np.zeros((n, bpc // 64), dtype=np.int16)
+        cnt = np.zeros(n, dtype=np.uint32)
+        mag = np.zeros((n, max(nblk, 1)), dtype=np.uint32)
+        allowed = np.zeros((n, max(nblk, 1)), dtype=np.uint8)
+        self._check(self._L.iqd_accept_iq(self._h, f, n, _np_ptr(iq_u8), bpc, _np_ptr(pcm), _np_ptr(cnt),
+                                          _np_ptr(mag), _np_ptr(allowed)))
+        return pcm, cnt, mag, allowed
+
+    def accept_device(self, iq_dev, bytes_per_ch, pcm_dev, count_dev=0, mag_dev=0, allowed_dev=0, first=0, n=None):
+        f, n = self._range(first, n)
+        self._check(self._L.iqd_accept_iq_device(self._h, f, n, C.c_void_p(iq_dev), bytes_per_ch,
+                                                 C.c_void_p(pcm_dev), C.c_void_p(count_dev or None),
+                                                 C.c_void_p(mag_dev or None), C.c_void_p(allowed_dev or None)))
+
+    def synchronize(self):
+        self._check(self._L.iqd_synchronize(self._h))
+
+    # ---- diagnostics / device helpers -------------------------------------------------------
+    def stats(self):
+        s = Stats()
+        self._check(self._L.iqd_get_stats(self._h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in Stats._fields_}
+
+    def set_profiling(self, on):
+        self._check(self._L.iqd_set_profiling(self._h, 1 if on else 0))
+
+    def channel_mode(self, ch):
+        m = C.c_int()
+        self._check(self._L.iqd_get_channel_mode(self._h, ch, C.byref(m)))
+        return m.value
+
+    def channel_gain(self, ch, demod):
+        g = C.c_float()
+        self._check(self._L.iqd_get_channel_gain(self._h, ch, int(DEMOD.get(demod, demod)), C.byref(g)))
+        return g.value
+
+    def dev_alloc(self, nbytes):
+        p = C.c_void_p()
+        self._check(self._L.iqd_dev_alloc(self._h, nbytes, C.byref(p)))
+        return p.value
+
+    def dev_free(self, ptr):
+        self._check(self._L.iqd_dev_free(self._h, C.c_void_p(ptr)))
+
+    def dev_upload(self, dst, host_array):
+        a = np.ascontiguousarray(host_array)
+        self._check(self._L.iqd_dev_upload(self._h, C.c_void_p(dst), _np_ptr(a), a.nbytes))
+
+    def dev_download(self, src, nbytes, dtype=np.uint8):
+        out = np.zeros(nbytes // np.dtype(dtype).itemsize, dtype=dtype)
+        self._check(self._L.iqd_dev_download(self._h, _np_ptr(out), C.c_void_p(src), nbytes))
+        return out
+
+    def dev_tile(self, dst, period, total):
+        self._check(self._L.iqd_dev_tile(self._h, C.c_void_p(dst), period, total))

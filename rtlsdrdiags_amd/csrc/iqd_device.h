@@ -1,0 +1,69 @@
+// Shared host/device definitions of the IQ demodulation engine (gfx950).
+#pragma once
+#include <stdint.h>
+
+namespace iqd {
+
+// ---- geometry -------------------------------------------------------------------------
+// A channel's demodulator sees one continuous stream: the concatenation of its squelch-open
+// blocks.  Positions are counted in complex samples.  The engine keeps the last TAIL samples
+// each demodulator family consumed ("tail") instead of per-filter ring buffers: every FIR /
+// decimator history in the chains is then a pure function of raw bytes, and only the float
+// recurrences carry explicit state.
+constexpr int TAIL = 2048;          // raw samples of history kept per channel and demodulator
+constexpr int TAIL_BYTES = 2 * TAIL;
+constexpr int SEG = 128;            // de-emphasis IIR segment (one lane's run)
+constexpr int FORCED_BACK = 768;    // an exact IIR restart point lies this far before a tile
+constexpr int COLD_HALO = 2048;     // zero-state warm-up distance of interior tiles
+constexpr int WBFM_NSEG = 60;       // segments per chunk -> chunk = 7680 samples
+constexpr int WBFM_CHUNK = WBFM_NSEG * SEG;
+constexpr int TSTRIDE = 132;        // dwords between segments of the IIR input buffer
+constexpr int WSTRIDE = 66;         // dwords between segments of the int16 output buffer
+
+enum Family { FAM_AM = 0, FAM_FM = 1, FAM_WBFM = 2, FAM_SSB = 3, FAM_COUNT = 4 };
+
+// ---- per-channel parameters (host mirror uploaded when dirty) ---------------------------
+struct ChanParams {
+    int32_t mode;           // iqd_mode
+    int32_t threshold;      // squelch threshold, dBFS
+    uint32_t rx_gain_db;
+    int32_t rotation;       // +1 / 0 / -1
+    int32_t ssb_lsb;        // SsbDemodulator::lsbDemodulationMode
+    float gain[4];          // demodulatorGain per family
+    float wbfm_k;           // (gain / 75000) * 32767, evaluated in binary32 on the host
+    float fm_k;             // (gain / 15000) * 32767
+    uint32_t pad[3];
+};
+
+// ---- per-channel carried state ------------------------------------------------------------
+struct WbfmCarry {          // exact de-emphasis state `back` samples before the stream end
+    float y;                // IirFilter output y[end - back - 1]
+    float u;                // b1 * x[end - back - 1] (numerator history)
+    int32_t back;           // restart distance (FORCED_BACK once the stream is long enough)
+    float y_end, u_end;     // the same at the stream end (what resetDemodulator() keeps)
+    uint32_t pad[3];
+};
+struct DcCarry { float x_prev, y_prev; };   // AM / SSB DC-removal IIR
+
+struct VerifyRec { float y_in, y_out, u_out; uint32_t flags; };
+
+// ---- constants (taps, packed the way the kernels consume them) ----------------------------
+struct Consts {
+    // WBFM pre-demod 16-tap FIR split into low/high tap bytes for v_dot4_i32_i8;
+    // dword q covers window bytes 4q..4q+3 (oldest sample first).
+    int32_t pre_lo[4], pre_hi[4];
+    // Q15 taps of the decimators, as int16 (index = k, newest sample first)
+    int16_t wbfm_d1[8], post12[12], audio40[40];
+    int16_t fm_tuner[32];
+    int16_t am_s1[8], am_s2[12], am_s3[16];
+    int16_t ssb_delay[16], ssb_hilbert[31], pad0;
+    // dot4 packings (low / high tap bytes, dword q = window bytes 4q..4q+3, oldest first)
+    int32_t fm_tuner_lo[8], fm_tuner_hi[8];
+    int32_t am_s1_lo[2], am_s1_hi[2];
+    int32_t db_table[257];
+    float deemph_b0, deemph_a1;     // 0.0253863, -0.9492274
+    float deemph_c128;              // (-a1)^128, for the state guess only
+    float dc_a1;                    // -0.95
+};
+
+}  // namespace iqd

@@ -1,0 +1,609 @@
+// libiqdemod.so — C-ABI (include/iqdemod.h) over the gfx950 kernels.
+//
+// Host orchestration only: parameter mirrors, per-call bucketing of channels by demodulator
+// family, launch planning, the exact-state verification of the WBFM tile hand-offs and the
+// copies of the host-pointer entry point.  There is no CPU data path in this library: every
+// sample is demodulated by the HIP kernels in iqd_kernels.hip, and creation fails when no HIP
+// device is usable.
+#include "iqdemod.h"
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "iqd_host.h"
+#include "iqd_kernels.h"
+#include "iqd_wbfm.h"
+
+using namespace iqd;
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T> T *as() const { return (T *)p; }
+};
+
+}  // namespace
+
+struct iqd_engine {
+    std::mutex mu;             // parameter mirror + dirty flags (setters vs. accept)
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint32_t n_ch = 0, block_bytes = 0, block_samples = 0, flags = 0;
+    Consts consts;
+
+    std::vector<ChanParams> h_params;
+    bool params_dirty = true;
+    bool lists_dirty = true;
+    uint32_t list_first = 0, list_n = 0;
+    std::vector<uint32_t> h_lists[FAM_COUNT + 1];  // per family; [FAM_COUNT] = mode None
+    bool any_gated = false;
+
+    // persistent device state
+    ChanParams *d_params = nullptr;
+    uint8_t *d_tails = nullptr;
+    WbfmCarry *d_wcarry = nullptr;
+    DcCarry *d_dc = nullptr;
+    uint32_t *d_tracker = nullptr;
+    float *d_atan = nullptr, *d_fmlut = nullptr;
+    uint32_t *d_counters = nullptr, *d_mismatch = nullptr;
+    uint32_t *h_counters = nullptr;  // pinned
+
+    // per-call scratch
+    DevBuf lists[FAM_COUNT + 1], mag_sums, blk_lists, vlen, records, base8k;
+    DevBuf st_iq, st_pcm, st_count, st_mag, st_allowed;  // staging for host-pointer accepts
+
+    bool profiling = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    iqd_stats stats{};
+    std::string last_error;
+
+    int fail(int code, const char *fmt, ...)
+    {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof(buf), fmt, ap);
+        va_end(ap);
+        last_error = buf;
+        return code;
+    }
+};
+
+#define HIP_TRY(e, call)                                                                          \
+    do {                                                                                          \
+        hipError_t err_ = (call);                                                                 \
+        if (err_ != hipSuccess)                                                                   \
+            return (e)->fail(IQD_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(err_),    \
+                             __FILE__, __LINE__);                                                 \
+    } while (0)
+
+static int family_of_mode(int mode)
+{
+    switch (mode) {
+    case IQD_MODE_AM: return FAM_AM;
+    case IQD_MODE_FM: return FAM_FM;
+    case IQD_MODE_WBFM: return FAM_WBFM;
+    case IQD_MODE_LSB: case IQD_MODE_USB: return FAM_SSB;
+    default: return FAM_COUNT;
+    }
+}
+
+static bool range_ok(const iqd_t *e, uint32_t first, uint32_t n)
+{
+    return e && n >= 1 && first < e->n_ch && n <= e->n_ch - first;
+}
+
+extern "C" {
+
+uint32_t iqd_abi_version(void) { return IQD_ABI_VERSION; }
+
+const char *iqd_strerror(int status)
+{
+    switch (status) {
+    case IQD_OK: return "ok";
+    case IQD_EINVAL: return "invalid argument";
+    case IQD_ENODEV: return "no usable HIP device";
+    case IQD_ENOMEM: return "out of memory";
+    case IQD_EHIP: return "HIP runtime error";
+    case IQD_ESTATE: return "exact-state verification failed";
+    default: return "unknown status";
+    }
+}
+
+const char *iqd_last_error(iqd_t *e) { return e ? e->last_error.c_str() : "null engine"; }
+
+int iqd_create(const iqd_config *cfg, iqd_t **out)
+{
+    if (!cfg || !out || cfg->abi_version != IQD_ABI_VERSION || cfg->n_channels == 0) return IQD_EINVAL;
+    uint32_t bb = cfg->block_bytes ? cfg->block_bytes : 32768u;
+    if (bb % 256u != 0 || bb > 32768u) return IQD_EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return IQD_ENODEV;
+    int dev = cfg->device;
+    if (dev < 0) {
+        if (hipGetDevice(&dev) != hipSuccess) return IQD_ENODEV;
+    }
+    if (dev >= ndev || hipSetDevice(dev) != hipSuccess) return IQD_ENODEV;
+
+    iqd_t *e = new (std::nothrow) iqd_engine;
+    if (!e) return IQD_ENOMEM;
+    e->device = dev;
+    e->n_ch = cfg->n_channels;
+    e->block_bytes = bb;
+    e->block_samples = bb / 2;
+    e->flags = cfg->flags;
+    build_consts(e->consts);
+    e->h_params.resize(e->n_ch);
+    for (auto &p : e->h_params) default_params(p);
+
+    std::vector<float> atan_lut, fm_lut;
+    build_atan2_lut(atan_lut);
+    build_fm_lut(fm_lut);
+
+    const size_t n = e->n_ch;
+    bool ok = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipMalloc((void **)&e->d_params, n * sizeof(ChanParams)) == hipSuccess;
+    ok = ok && hipMalloc((void **)&e->d_tails, n * FAM_COUNT * TAIL_BYTES) == hipSuccess;
+    ok = ok && hipMalloc((void **)&e->d_wcarry, n * sizeof(WbfmCarry)) == hipSuccess;
+    ok = ok && hipMalloc((void **)&e->d_dc, n * 2 * sizeof(DcCarry)) == hipSuccess;
+    ok = ok && hipMalloc((void **)&e->d_tracker, n * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMalloc((void **)&e->d_atan, atan_lut.size() * sizeof(float)) == hipSuccess;
+    ok = ok && hipMalloc((void **)&e->d_fmlut, fm_lut.size() * sizeof(float)) == hipSuccess;
+    ok = ok && hipMalloc((void **)&e->d_counters, CNT_COUNT * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMalloc((void **)&e->d_mismatch, MAX_MISMATCH_LIST * 2 * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipHostMalloc((void **)&e->h_counters, CNT_COUNT * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipEventCreate(&e->ev0) == hipSuccess && hipEventCreate(&e->ev1) == hipSuccess;
+    if (ok) {
+        ok = hipMemsetAsync(e->d_tails, 0x80, n * FAM_COUNT * TAIL_BYTES, e->stream) == hipSuccess;
+        ok = ok && hipMemsetAsync(e->d_wcarry, 0, n * sizeof(WbfmCarry), e->stream) == hipSuccess;
+        ok = ok && hipMemsetAsync(e->d_dc, 0, n * 2 * sizeof(DcCarry), e->stream) == hipSuccess;
+        ok = ok && hipMemsetAsync(e->d_tracker, 0, n * sizeof(uint32_t), e->stream) == hipSuccess;
+        ok = ok && hipMemcpyAsync(e->d_atan, atan_lut.data(), atan_lut.size() * sizeof(float),
+                                  hipMemcpyHostToDevice, e->stream) == hipSuccess;
+        ok = ok && hipMemcpyAsync(e->d_fmlut, fm_lut.data(), fm_lut.size() * sizeof(float),
+                                  hipMemcpyHostToDevice, e->stream) == hipSuccess;
+        ok = ok && upload_consts(e->consts, e->stream) == hipSuccess;
+        ok = ok && hipStreamSynchronize(e->stream) == hipSuccess;
+    }
+    if (!ok) {
+        iqd_destroy(e);
+        return IQD_ENOMEM;
+    }
+    *out = e;
+    return IQD_OK;
+}
+
+void iqd_destroy(iqd_t *e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    void *ptrs[] = {e->d_params, e->d_tails, e->d_wcarry, e->d_dc, e->d_tracker,
+                    e->d_atan, e->d_fmlut, e->d_counters, e->d_mismatch};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    if (e->h_counters) (void)hipHostFree(e->h_counters);
+    for (auto &b : e->lists) b.release();
+    DevBuf *bufs[] = {&e->mag_sums, &e->blk_lists, &e->vlen, &e->records, &e->base8k,
+                      &e->st_iq, &e->st_pcm, &e->st_count, &e->st_mag, &e->st_allowed};
+    for (DevBuf *b : bufs) b->release();
+    if (e->ev0) (void)hipEventDestroy(e->ev0);
+    if (e->ev1) (void)hipEventDestroy(e->ev1);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int iqd_set_mode(iqd_t *e, uint32_t first_ch, uint32_t n_ch, int mode)
+{
+    if (!range_ok(e, first_ch, n_ch) || mode < IQD_MODE_NONE || mode > IQD_MODE_USB) return IQD_EINVAL;
+    std::lock_guard<std::mutex> lk(e->mu);
+    for (uint32_t c = first_ch; c < first_ch + n_ch; c++) {
+        e->h_params[c].mode = mode;
+        if (mode == IQD_MODE_LSB) e->h_params[c].ssb_lsb = 1;  // IqDataProcessor.cc:244-256
+        if (mode == IQD_MODE_USB) e->h_params[c].ssb_lsb = 0;
+    }
+    e->params_dirty = e->lists_dirty = true;
+    return IQD_OK;
+}
+
+int iqd_set_gain(iqd_t *e, uint32_t first_ch, uint32_t n_ch, int demod, float gain)
+{
+    if (!range_ok(e, first_ch, n_ch) || demod < IQD_DEMOD_AM || demod > IQD_DEMOD_SSB) return IQD_EINVAL;
+    static const int fam[5] = {0, FAM_AM, FAM_FM, FAM_WBFM, FAM_SSB};
+    std::lock_guard<std::mutex> lk(e->mu);
+    for (uint32_t c = first_ch; c < first_ch + n_ch; c++) {
+        e->h_params[c].gain[fam[demod]] = gain;
+        derive_params(e->h_params[c]);
+    }
+    e->params_dirty = true;
+    return IQD_OK;
+}
+
+int iqd_set_squelch(iqd_t *e, uint32_t first_ch, uint32_t n_ch, int32_t threshold)
+{
+    if (!range_ok(e, first_ch, n_ch)) return IQD_EINVAL;
+    std::lock_guard<std::mutex> lk(e->mu);
+    for (uint32_t c = first_ch; c < first_ch + n_ch; c++) e->h_params[c].threshold = threshold;
+    e->params_dirty = e->lists_dirty = true;
+    return IQD_OK;
+}
+
+int iqd_set_rx_gain_db(iqd_t *e, uint32_t first_ch, uint32_t n_ch, uint32_t gain_db)
+{
+    if (!range_ok(e, first_ch, n_ch)) return IQD_EINVAL;
+    std::lock_guard<std::mutex> lk(e->mu);
+    for (uint32_t c = first_ch; c < first_ch + n_ch; c++) e->h_params[c].rx_gain_db = gain_db;
+    e->params_dirty = e->lists_dirty = true;
+    return IQD_OK;
+}
+
+int iqd_set_rotation(iqd_t *e, uint32_t first_ch, uint32_t n_ch, int rotation)
+{
+    if (!range_ok(e, first_ch, n_ch) || rotation < -1 || rotation > 1) return IQD_EINVAL;
+    std::lock_guard<std::mutex> lk(e->mu);
+    for (uint32_t c = first_ch; c < first_ch + n_ch; c++) e->h_params[c].rotation = rotation;
+    e->params_dirty = true;
+    return IQD_OK;
+}
+
+int iqd_reset(iqd_t *e, uint32_t first_ch, uint32_t n_ch)
+{
+    if (!range_ok(e, first_ch, n_ch)) return IQD_EINVAL;
+    (void)hipSetDevice(e->device);
+    HIP_TRY(e, launch_reset(e->d_tails, e->d_wcarry, e->d_dc, first_ch, n_ch, e->stream));
+    return IQD_OK;
+}
+
+int iqd_get_channel_mode(iqd_t *e, uint32_t ch, int *mode)
+{
+    if (!e || ch >= e->n_ch || !mode) return IQD_EINVAL;
+    std::lock_guard<std::mutex> lk(e->mu);
+    *mode = e->h_params[ch].mode;
+    return IQD_OK;
+}
+
+int iqd_get_channel_gain(iqd_t *e, uint32_t ch, int demod, float *gain)
+{
+    if (!e || ch >= e->n_ch || !gain || demod < IQD_DEMOD_AM || demod > IQD_DEMOD_SSB) return IQD_EINVAL;
+    static const int fam[5] = {0, FAM_AM, FAM_FM, FAM_WBFM, FAM_SSB};
+    std::lock_guard<std::mutex> lk(e->mu);
+    *gain = e->h_params[ch].gain[fam[demod]];
+    return IQD_OK;
+}
+
+int iqd_set_profiling(iqd_t *e, int enabled)
+{
+    if (!e) return IQD_EINVAL;
+    e->profiling = enabled != 0;
+    return IQD_OK;
+}
+
+int iqd_get_stats(iqd_t *e, iqd_stats *out)
+{
+    if (!e || !out) return IQD_EINVAL;
+    *out = e->stats;
+    return IQD_OK;
+}
+
+int iqd_synchronize(iqd_t *e)
+{
+    if (!e) return IQD_EINVAL;
+    (void)hipSetDevice(e->device);
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return IQD_OK;
+}
+
+void *iqd_stream(iqd_t *e) { return e ? (void *)e->stream : nullptr; }
+
+int iqd_dev_alloc(iqd_t *e, size_t bytes, void **out)
+{
+    if (!e || !out) return IQD_EINVAL;
+    (void)hipSetDevice(e->device);
+    if (hipMalloc(out, bytes) != hipSuccess) return e->fail(IQD_ENOMEM, "hipMalloc(%zu) failed", bytes);
+    return IQD_OK;
+}
+
+int iqd_dev_free(iqd_t *e, void *p)
+{
+    if (!e) return IQD_EINVAL;
+    (void)hipSetDevice(e->device);
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    HIP_TRY(e, hipFree(p));
+    return IQD_OK;
+}
+
+int iqd_dev_upload(iqd_t *e, void *dst, const void *src, size_t bytes)
+{
+    if (!e) return IQD_EINVAL;
+    (void)hipSetDevice(e->device);
+    HIP_TRY(e, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return IQD_OK;
+}
+
+int iqd_dev_download(iqd_t *e, void *dst, const void *src, size_t bytes)
+{
+    if (!e) return IQD_EINVAL;
+    (void)hipSetDevice(e->device);
+    HIP_TRY(e, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return IQD_OK;
+}
+
+int iqd_dev_tile(iqd_t *e, void *dst, size_t period, size_t total)
+{
+    if (!e || !dst || period == 0 || period % 16 || total % 16 || total < period) return IQD_EINVAL;
+    (void)hipSetDevice(e->device);
+    HIP_TRY(e, launch_tile_fill((uint8_t *)dst, period, total, e->stream));
+    return IQD_OK;
+}
+
+// ---- accept ------------------------------------------------------------------------------------
+
+static void rebuild_lists(iqd_t *e, uint32_t first_ch, uint32_t n_ch)
+{
+    for (auto &l : e->h_lists) l.clear();
+    e->any_gated = false;
+    for (uint32_t c = 0; c < n_ch; c++) {
+        const ChanParams &p = e->h_params[first_ch + c];
+        e->h_lists[family_of_mode(p.mode)].push_back(c);
+        if (!squelch_always_open(p, e->consts)) e->any_gated = true;
+    }
+    e->list_first = first_ch;
+    e->list_n = n_ch;
+    e->lists_dirty = false;
+}
+
+static int run_wbfm_repairs(iqd_t *e, ChainLaunch a, bool gated, uint32_t n_bad);
+
+int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void *iq_dev, size_t bytes_per_ch,
+                         void *pcm_dev, void *pcm_count_dev, void *magnitude_dev, void *signal_present_dev)
+{
+    if (!range_ok(e, first_ch, n_ch) || !iq_dev || !pcm_dev) return e ? e->fail(IQD_EINVAL, "bad channel range or NULL buffer") : IQD_EINVAL;
+    if (bytes_per_ch == 0 || bytes_per_ch % e->block_bytes != 0)
+        return e->fail(IQD_EINVAL, "bytes_per_ch (%zu) must be a positive multiple of block_bytes (%u)",
+                       bytes_per_ch, e->block_bytes);
+    if (bytes_per_ch / 2 > 0x7fff0000ull) return e->fail(IQD_EINVAL, "bytes_per_ch too large");
+    if (((uintptr_t)iq_dev & 15) != 0) return e->fail(IQD_EINVAL, "iq_dev must be 16-byte aligned");
+    (void)hipSetDevice(e->device);
+    hipStream_t s = e->stream;
+
+    const uint32_t n_blocks = (uint32_t)(bytes_per_ch / e->block_bytes);
+    const uint32_t vlen = (uint32_t)(bytes_per_ch / 2);
+    bool gated;
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        if (e->params_dirty) {
+            HIP_TRY(e, hipMemcpyAsync(e->d_params, e->h_params.data(), e->n_ch * sizeof(ChanParams),
+                                      hipMemcpyHostToDevice, s));
+            HIP_TRY(e, hipStreamSynchronize(s));  // the mirror may change once the lock is dropped
+            e->params_dirty = false;
+        }
+        if (e->lists_dirty || e->list_first != first_ch || e->list_n != n_ch) {
+            rebuild_lists(e, first_ch, n_ch);
+            for (int f = 0; f <= FAM_COUNT; f++) {
+                const auto &l = e->h_lists[f];
+                if (l.empty()) continue;
+                HIP_TRY(e, e->lists[f].ensure(l.size() * sizeof(uint32_t)));
+                HIP_TRY(e, hipMemcpyAsync(e->lists[f].p, l.data(), l.size() * sizeof(uint32_t),
+                                          hipMemcpyHostToDevice, s));
+            }
+            HIP_TRY(e, hipStreamSynchronize(s));
+        }
+        gated = e->any_gated;
+    }
+    const bool want_mag = gated || !(e->flags & IQD_F_NO_MAGNITUDE) || magnitude_dev;
+
+    HIP_TRY(e, e->mag_sums.ensure((size_t)n_ch * n_blocks * sizeof(uint32_t)));
+    HIP_TRY(e, hipMemsetAsync(e->d_counters, 0, CNT_COUNT * sizeof(uint32_t), s));
+    if (want_mag) HIP_TRY(e, hipMemsetAsync(e->mag_sums.p, 0, (size_t)n_ch * n_blocks * sizeof(uint32_t), s));
+
+    SquelchLaunch q{};
+    q.n_ch = n_ch; q.first_ch = first_ch; q.n_blocks = n_blocks; q.block_samples = e->block_samples;
+    q.params = e->d_params;
+    q.mag_sums = e->mag_sums.as<uint32_t>();
+    q.tracker = e->d_tracker;
+    q.magnitude = (uint32_t *)magnitude_dev;
+    q.allowed = (uint8_t *)signal_present_dev;
+    q.pcm_count = (uint32_t *)pcm_count_dev;
+
+    if (gated) {
+        // pass 1: magnitudes of every block, then the squelch decisions and open-block lists
+        HIP_TRY(e, e->blk_lists.ensure((size_t)n_ch * n_blocks * sizeof(uint32_t)));
+        HIP_TRY(e, e->vlen.ensure((size_t)n_ch * sizeof(uint32_t)));
+        HIP_TRY(e, launch_magnitude((const uint8_t *)iq_dev, bytes_per_ch, nullptr, n_ch, e->block_samples,
+                                    n_blocks, e->mag_sums.as<uint32_t>(), s));
+        q.blk_lists = e->blk_lists.as<uint32_t>();
+        q.vlen_out = e->vlen.as<uint32_t>();
+        HIP_TRY(e, launch_squelch(q, s));
+    }
+
+    ChainLaunch base{};
+    base.iq = (const uint8_t *)iq_dev;
+    base.ch_stride_bytes = bytes_per_ch;
+    base.first_ch = first_ch;
+    base.vlen = vlen;
+    base.vlen_gated = gated ? e->vlen.as<uint32_t>() : nullptr;
+    base.blk_lists = gated ? e->blk_lists.as<uint32_t>() : nullptr;
+    base.n_blocks = n_blocks;
+    base.block_samples = e->block_samples;
+    base.block_magic = block_magic(e->block_samples);
+    base.tails = e->d_tails;
+    base.params = e->d_params;
+    base.wbfm_carry = e->d_wcarry;
+    base.dc_carry = e->d_dc;
+    base.atan_lut = e->d_atan;
+    base.fm_lut = e->d_fmlut;
+    base.pcm = (int16_t *)pcm_dev;
+    base.pcm_stride = bytes_per_ch / 64;
+    base.mag_sums = e->mag_sums.as<uint32_t>();
+    base.counters = e->d_counters;
+    base.mismatch_list = e->d_mismatch;
+
+    const bool fused_mag = want_mag && !gated;
+    bool timed = false;
+    ChainLaunch wb{};
+    bool have_wbfm = false;
+    for (int f = 0; f < FAM_COUNT; f++) {
+        const uint32_t n_list = (uint32_t)e->h_lists[f].size();
+        if (!n_list) continue;
+        ChainLaunch a = base;
+        a.ch_list = e->lists[f].as<uint32_t>();
+        a.n_list = n_list;
+        const TilePlan plan = plan_tiles(vlen, n_list);
+        a.tile_len = plan.tile_len;
+        a.tiles_per_ch = plan.tiles_per_ch;
+        if (f == FAM_WBFM) {
+            HIP_TRY(e, e->records.ensure((size_t)n_list * a.tiles_per_ch * sizeof(WbfmRecord)));
+            a.records = e->records.as<WbfmRecord>();
+            if (e->profiling && !timed) HIP_TRY(e, hipEventRecord(e->ev0, s));
+            HIP_TRY(e, launch_wbfm(a, gated, fused_mag, n_list * a.tiles_per_ch, s));
+            if (e->profiling && !timed) { HIP_TRY(e, hipEventRecord(e->ev1, s)); timed = true; }
+            e->stats.kernel_launches++;
+            HIP_TRY(e, launch_wbfm_verify(a, s));
+            wb = a;
+            have_wbfm = true;
+        } else {
+            return e->fail(IQD_EINVAL, "demodulator family %d has no kernel yet", f);
+        }
+    }
+    // channels in mode None still report their magnitudes
+    if (fused_mag && !e->h_lists[FAM_COUNT].empty())
+        HIP_TRY(e, launch_magnitude((const uint8_t *)iq_dev, bytes_per_ch, e->lists[FAM_COUNT].as<uint32_t>(),
+                                    (uint32_t)e->h_lists[FAM_COUNT].size(), e->block_samples, n_blocks,
+                                    e->mag_sums.as<uint32_t>(), s));
+    if (!gated && (want_mag || pcm_count_dev || signal_present_dev)) HIP_TRY(e, launch_squelch(q, s));
+
+    // exact-state verification of the WBFM hand-offs (a mismatch has never been observed;
+    // the repair path re-runs the affected tiles from the neighbour's exact state)
+    HIP_TRY(e, hipMemcpyAsync(e->h_counters, e->d_counters, CNT_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(e, hipStreamSynchronize(s));
+    if (have_wbfm) {
+        e->stats.state_checks += e->h_counters[CNT_TILE_CHECKS];
+        if (e->h_counters[CNT_TILE_MISMATCH]) {
+            int rc = run_wbfm_repairs(e, wb, gated, e->h_counters[CNT_TILE_MISMATCH]);
+            if (rc != IQD_OK) return rc;
+        }
+        HIP_TRY(e, launch_wbfm_commit(wb, s));
+        HIP_TRY(e, launch_tail_update(wb, FAM_WBFM, s));
+    }
+    if (timed) {
+        float ms = 0.f;
+        HIP_TRY(e, hipEventElapsedTime(&ms, e->ev0, e->ev1));
+        e->stats.chain_kernel_ms += ms;
+        e->stats.chain_kernel_count++;
+    }
+    e->stats.accepts++;
+    e->stats.samples += (uint64_t)vlen * n_ch;
+    return IQD_OK;
+}
+
+// Re-runs mismatching tiles, in stream order, from the exact state recorded by the tile before.
+static int run_wbfm_repairs(iqd_t *e, ChainLaunch a, bool gated, uint32_t n_bad)
+{
+    hipStream_t s = e->stream;
+    const size_t nrec = (size_t)a.n_list * a.tiles_per_ch;
+    std::vector<WbfmRecord> recs(nrec);
+    HIP_TRY(e, hipMemcpy(recs.data(), a.records, nrec * sizeof(WbfmRecord), hipMemcpyDeviceToHost));
+    DevBuf forced, sel;
+    HIP_TRY(e, forced.ensure(nrec * sizeof(WbfmStart)));
+    HIP_TRY(e, sel.ensure(2 * sizeof(uint32_t)));
+    std::vector<WbfmStart> starts(nrec);
+    std::vector<uint32_t> h_list(a.n_list), h_vlen;
+    HIP_TRY(e, hipMemcpy(h_list.data(), a.ch_list, a.n_list * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    if (a.vlen_gated) {
+        h_vlen.resize(e->list_n);
+        HIP_TRY(e, hipMemcpy(h_vlen.data(), a.vlen_gated, e->list_n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    }
+    (void)n_bad;
+    for (uint32_t li = 0; li < a.n_list; li++) {
+        const uint32_t vlen = a.vlen_gated ? h_vlen[h_list[li]] : a.vlen;
+        const uint32_t ntiles = (vlen + a.tile_len - 1) / a.tile_len;
+        for (uint32_t tile = 1; tile < ntiles; tile++) {
+            WbfmRecord &cur = recs[(size_t)li * a.tiles_per_ch + tile];
+            const WbfmRecord &prev = recs[(size_t)li * a.tiles_per_ch + tile - 1];
+            if (f2u(cur.y_in) == f2u(prev.y_out)) continue;
+            WbfmStart st;
+            st.y = prev.y_out; st.u = prev.u_out; st.back = prev.back_out; st.cold = 0;
+            starts[(size_t)li * a.tiles_per_ch + tile] = st;
+            const uint32_t pair[2] = {li, tile};
+            HIP_TRY(e, hipMemcpy(forced.p, starts.data(), nrec * sizeof(WbfmStart), hipMemcpyHostToDevice));
+            HIP_TRY(e, hipMemcpy(sel.p, pair, sizeof(pair), hipMemcpyHostToDevice));
+            ChainLaunch r = a;
+            r.forced = forced.as<WbfmStart>();
+            r.tile_sel = sel.as<uint32_t>();
+            r.mag_sums = a.mag_sums;
+            HIP_TRY(e, launch_wbfm(r, gated, false, 1, s));
+            HIP_TRY(e, hipStreamSynchronize(s));
+            HIP_TRY(e, hipMemcpy(&cur, a.records + (size_t)li * a.tiles_per_ch + tile, sizeof(WbfmRecord),
+                                 hipMemcpyDeviceToHost));
+            e->stats.state_repairs++;
+            if (f2u(cur.y_in) != f2u(prev.y_out)) {
+                forced.release();
+                sel.release();
+                return e->fail(IQD_ESTATE, "WBFM tile %u of list entry %u could not be repaired", tile, li);
+            }
+        }
+    }
+    forced.release();
+    sel.release();
+    return IQD_OK;
+}
+
+int iqd_accept_iq(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const uint8_t *iq, size_t bytes_per_ch,
+                  int16_t *pcm, uint32_t *pcm_count, uint32_t *magnitude, uint8_t *signal_present)
+{
+    if (!range_ok(e, first_ch, n_ch) || !iq || !pcm) return e ? e->fail(IQD_EINVAL, "bad channel range or NULL buffer") : IQD_EINVAL;
+    if (bytes_per_ch == 0 || bytes_per_ch % e->block_bytes != 0)
+        return e->fail(IQD_EINVAL, "bytes_per_ch (%zu) must be a positive multiple of block_bytes (%u)",
+                       bytes_per_ch, e->block_bytes);
+    (void)hipSetDevice(e->device);
+    hipStream_t s = e->stream;
+    const size_t in_bytes = (size_t)n_ch * bytes_per_ch;
+    const size_t pcm_bytes = (size_t)n_ch * (bytes_per_ch / 64) * sizeof(int16_t);
+    const size_t nb = (size_t)n_ch * (bytes_per_ch / e->block_bytes);
+    HIP_TRY(e, e->st_iq.ensure(in_bytes));
+    HIP_TRY(e, e->st_pcm.ensure(pcm_bytes));
+    HIP_TRY(e, e->st_count.ensure(n_ch * sizeof(uint32_t)));
+    HIP_TRY(e, e->st_mag.ensure(nb * sizeof(uint32_t)));
+    HIP_TRY(e, e->st_allowed.ensure(nb));
+    HIP_TRY(e, hipMemcpyAsync(e->st_iq.p, iq, in_bytes, hipMemcpyHostToDevice, s));
+    HIP_TRY(e, hipMemsetAsync(e->st_pcm.p, 0, pcm_bytes, s));
+    int rc = iqd_accept_iq_device(e, first_ch, n_ch, e->st_iq.p, bytes_per_ch, e->st_pcm.p, e->st_count.p,
+                                  magnitude ? e->st_mag.p : nullptr, signal_present ? e->st_allowed.p : nullptr);
+    if (rc != IQD_OK) return rc;
+    HIP_TRY(e, hipMemcpyAsync(pcm, e->st_pcm.p, pcm_bytes, hipMemcpyDeviceToHost, s));
+    if (pcm_count) HIP_TRY(e, hipMemcpyAsync(pcm_count, e->st_count.p, n_ch * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    if (magnitude) HIP_TRY(e, hipMemcpyAsync(magnitude, e->st_mag.p, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    if (signal_present) HIP_TRY(e, hipMemcpyAsync(signal_present, e->st_allowed.p, nb, hipMemcpyDeviceToHost, s));
+    HIP_TRY(e, hipStreamSynchronize(s));
+    return IQD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,153 @@
+#include "iqd_host.h"
+
+#include <math.h>
+#include <string.h>
+
+#include "iqd_taps.h"
+
+namespace iqd {
+
+int16_t host_cast_i16(float f)
+{
+    int32_t wide;
+    if (f >= -2147483648.0f && f < 2147483648.0f) wide = (int32_t)f;
+    else wide = INT32_MIN;
+    return (int16_t)(uint16_t)((uint32_t)wide & 0xffffu);
+}
+
+void quantize_q15(const float *h, int n, int16_t *hq)
+{
+    for (int i = 0; i < n; i++) {
+        float scaled = h[i] * 32768;
+        scaled = roundf(scaled);
+        hq[i] = host_cast_i16(scaled);
+    }
+}
+
+// Packs Q15 taps for v_dot4_i32_i8 over a window stored oldest sample first:
+// window byte b multiplies tap h[L-1-b]; each tap is split as h = 256*hi + lo with lo in
+// [-128,127], so that sum(h*x) = sum(lo*x) + 256*sum(hi*x).
+static void pack_dot4(const int16_t *hq, int L, int32_t *lo, int32_t *hi)
+{
+    for (int q = 0; q < L / 4; q++) {
+        uint32_t l = 0, h = 0;
+        for (int b = 0; b < 4; b++) {
+            const int tap = hq[L - 1 - (4 * q + b)];
+            const int8_t tl = (int8_t)(tap & 0xff);
+            const int th = (tap - tl) / 256;
+            l |= (uint32_t)(uint8_t)tl << (8 * b);
+            h |= (uint32_t)(uint8_t)(int8_t)th << (8 * b);
+        }
+        lo[q] = (int32_t)l;
+        hi[q] = (int32_t)h;
+    }
+}
+
+void build_consts(Consts &c)
+{
+    memset(&c, 0, sizeof(c));
+    int16_t pre[16];
+    quantize_q15(taps::WBFM_PRE, 16, pre);
+    pack_dot4(pre, 16, c.pre_lo, c.pre_hi);
+    quantize_q15(taps::WBFM_D1, 8, c.wbfm_d1);
+    quantize_q15(taps::POST12, 12, c.post12);
+    quantize_q15(taps::AUDIO40, 40, c.audio40);
+    quantize_q15(taps::FM_TUNER, 32, c.fm_tuner);
+    pack_dot4(c.fm_tuner, 32, c.fm_tuner_lo, c.fm_tuner_hi);
+    quantize_q15(taps::AM_S1, 8, c.am_s1);
+    pack_dot4(c.am_s1, 8, c.am_s1_lo, c.am_s1_hi);
+    quantize_q15(taps::AM_S2, 12, c.am_s2);
+    quantize_q15(taps::AM_S3, 16, c.am_s3);
+    quantize_q15(taps::SSB_DELAY, 16, c.ssb_delay);
+    quantize_q15(taps::SSB_HILBERT, 31, c.ssb_hilbert);
+    // DbfsCalculator.cc:36-68 (C++: log10((float)i) is the float overload)
+    for (uint32_t i = 1; i <= 256; i++) {
+        float level = 20 * log10f((float)i);
+        c.db_table[i] = (int32_t)level;
+    }
+    c.db_table[0] = c.db_table[1];
+    c.deemph_b0 = taps::DEEMPH_B0;
+    c.deemph_a1 = taps::DEEMPH_A1;
+    c.deemph_c128 = (float)pow(-(double)taps::DEEMPH_A1, 128.0);
+    c.dc_a1 = taps::DCBLOCK_A1;
+}
+
+void build_atan2_lut(std::vector<float> &lut)
+{
+    lut.resize(256 * 256);
+    for (int x = 0; x < 256; x++)
+        for (int y = 0; y < 256; y++)
+            lut[(size_t)y * 256 + x] = (float)atan2((double)y - 128, (double)x - 128);
+}
+
+void build_fm_lut(std::vector<float> &lut)
+{
+    lut.resize((size_t)FM_LUT_W * FM_LUT_W);
+    for (int q = -FM_LUT_R; q <= FM_LUT_R; q++)
+        for (int i = -FM_LUT_R; i <= FM_LUT_R; i++)
+            lut[(size_t)(q + FM_LUT_R) * FM_LUT_W + (i + FM_LUT_R)] = (float)atan2((double)q, (double)i);
+}
+
+void default_params(ChanParams &p)
+{
+    memset(&p, 0, sizeof(p));
+    p.mode = 0;               // IqDataProcessor.cc:38
+    p.threshold = -200;       // IqDataProcessor.cc:41
+    p.rx_gain_db = 24;        // Radio.cc:325-328
+    p.rotation = 1;           // IqDataProcessor.cc:749
+    p.ssb_lsb = 1;            // SsbDemodulator.cc:144
+    p.gain[FAM_AM] = 300;                       // AmDemodulator.cc:104
+    p.gain[FAM_FM] = 64000 / (2 * M_PI);        // FmDemodulator.cc:158
+    p.gain[FAM_WBFM] = 256000 / (2 * M_PI);     // WbFmDemodulator.cc:173
+    p.gain[FAM_SSB] = 300;                      // SsbDemodulator.cc:147
+    derive_params(p);
+}
+
+void derive_params(ChanParams &p)
+{
+    // WbFmDemodulator.cc:447-450 / FmDemodulator.cc:465-471, same operation order, binary32
+    volatile float k = p.gain[FAM_WBFM] / 75000;
+    k = k * 32767;
+    p.wbfm_k = k;
+    volatile float f = p.gain[FAM_FM] / 15000;
+    f = f * 32767;
+    p.fm_k = f;
+}
+
+bool squelch_always_open(const ChanParams &p, const Consts &c)
+{
+    // SignalDetector.cc:259-266: present iff table(avg) - 42 - gain >= threshold, avg clipped to 127
+    for (uint32_t m = 0; m <= 127; m++) {
+        int32_t dbfs = c.db_table[m] - 42;
+        dbfs = (int32_t)((uint32_t)dbfs - p.rx_gain_db);
+        if (dbfs < p.threshold) return false;
+    }
+    return true;
+}
+
+TilePlan plan_tiles(uint32_t vlen, uint32_t n_channels)
+{
+    // One workgroup per tile.  Tiles are as long as possible (the lead-in of COLD_HALO samples
+    // is redone per tile) while the launch still has a few thousand workgroups to fill 256 CUs.
+    const uint32_t max_tile = 8 * WBFM_CHUNK;   // 61440 samples
+    const uint32_t min_tile = WBFM_CHUNK;
+    const uint32_t want_wgs = 3072;
+    TilePlan p;
+    if (vlen == 0 || n_channels == 0) { p.tile_len = min_tile; p.tiles_per_ch = 1; return p; }
+    uint32_t tiles = (vlen + max_tile - 1) / max_tile;
+    const uint32_t want = (want_wgs + n_channels - 1) / n_channels;
+    const uint32_t most = vlen / min_tile ? vlen / min_tile : 1;
+    if (tiles < want) tiles = want < most ? want : most;
+    uint32_t len = (vlen + tiles - 1) / tiles;
+    len = (len + SEG - 1) / SEG * SEG;
+    p.tile_len = len;
+    p.tiles_per_ch = (vlen + len - 1) / len;
+    return p;
+}
+
+uint32_t block_magic(uint32_t block_samples)
+{
+    return (uint32_t)(((1ull << 32) + block_samples - 1) / block_samples);
+}
+
+}  // namespace iqd

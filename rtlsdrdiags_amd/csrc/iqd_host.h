@@ -1,0 +1,37 @@
+// Host-side logic of the engine that needs no GPU: constant tables, derived per-channel
+// parameters, squelch pre-analysis and tile planning.  (Unit-tested on the CPU.)
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include <vector>
+
+#include "iqd_device.h"
+
+namespace iqd {
+
+// (int16_t)float with the x86-64/gcc semantics the reference was built with.
+int16_t host_cast_i16(float f);
+// Decimator_int16.cc:55-63: hq = (int16_t) round(h * 32768)
+void quantize_q15(const float *h, int n, int16_t *hq);
+void build_consts(Consts &c);
+// WbFmDemodulator.cc:159-170: lut[y*256+x] = (float)atan2(y-128., x-128.)
+void build_atan2_lut(std::vector<float> &lut);
+// FmDemodulator.cc:476 for every (q, i) in [-FM_LUT_R, FM_LUT_R]^2
+constexpr int FM_LUT_R = 141;
+constexpr int FM_LUT_W = 2 * FM_LUT_R + 1;
+void build_fm_lut(std::vector<float> &lut);
+
+void default_params(ChanParams &p);
+void derive_params(ChanParams &p);   // wbfm_k / fm_k from the gains, in binary32
+
+// True when SignalDetector can never report "absent" for this channel, whatever the data
+// (then Squelch::run() allows every block and no gating pass is needed).
+bool squelch_always_open(const ChanParams &p, const Consts &c);
+
+struct TilePlan { uint32_t tile_len, tiles_per_ch; };
+TilePlan plan_tiles(uint32_t vlen, uint32_t n_channels);
+
+uint32_t block_magic(uint32_t block_samples);
+
+}  // namespace iqd

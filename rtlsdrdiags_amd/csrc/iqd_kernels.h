@@ -1,0 +1,70 @@
+// Launch descriptors and host-callable launchers of the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "iqd_device.h"
+
+namespace iqd {
+
+struct WbfmStart;
+struct WbfmRecord;
+
+enum Counter { CNT_TILE_MISMATCH = 0, CNT_TILE_CHECKS = 1, CNT_SEG_REPAIRS = 2, CNT_COUNT = 8 };
+constexpr uint32_t MAX_MISMATCH_LIST = 1024;
+
+// One chain launch = the channels of one demodulator family inside one accept call.
+struct ChainLaunch {
+    const uint8_t *iq;            // [n_ch][ch_stride_bytes] this call's input (device)
+    size_t ch_stride_bytes;
+    const uint32_t *ch_list;      // channels (call-relative) handled by this launch
+    uint32_t n_list;
+    uint32_t first_ch;            // engine channel of call-relative channel 0
+    uint32_t vlen;                // samples per channel when no squelch can close
+    const uint32_t *vlen_gated;   // else: open samples per call-relative channel
+    const uint32_t *blk_lists;    //       and [n_ch][n_blocks] open-block indices
+    uint32_t n_blocks;
+    uint32_t block_samples, block_magic;
+    uint32_t tile_len, tiles_per_ch;
+    uint8_t *tails;               // [engine ch][FAM_COUNT][TAIL_BYTES]
+    const ChanParams *params;     // [engine ch]
+    WbfmCarry *wbfm_carry;        // [engine ch]
+    DcCarry *dc_carry;            // [engine ch][2] (AM, SSB)
+    const float *atan_lut;        // 256x256
+    const float *fm_lut;          // 283x283
+    int16_t *pcm;                 // [n_ch][pcm_stride]
+    size_t pcm_stride;
+    uint32_t *mag_sums;           // [n_ch][n_blocks]
+    WbfmRecord *records;          // [n_list][tiles_per_ch]
+    const WbfmStart *forced;      // optional explicit start states, same indexing
+    const uint32_t *tile_sel;     // optional (list index, tile) pairs for a repair launch
+    uint32_t *counters;           // [CNT_COUNT]
+    uint32_t *mismatch_list;      // [MAX_MISMATCH_LIST][2]
+    int32_t *base8k;              // [n_ch][pcm_stride] AM/SSB 8 kS/s intermediates
+};
+
+struct SquelchLaunch {
+    uint32_t n_ch, first_ch, n_blocks, block_samples;
+    const ChanParams *params;
+    const uint32_t *mag_sums;     // [n_ch][n_blocks]
+    uint32_t *tracker;            // [engine ch] SignalTracker state
+    uint32_t *magnitude;          // out, optional
+    uint8_t *allowed;             // out, optional
+    uint32_t *blk_lists;          // out, optional
+    uint32_t *vlen_out;           // out, optional
+    uint32_t *pcm_count;          // out, optional
+};
+
+hipError_t upload_consts(const Consts &c, hipStream_t s);
+hipError_t launch_wbfm(const ChainLaunch &a, bool gated, bool mag, uint32_t n_blocks, hipStream_t s);
+hipError_t launch_reset(uint8_t *tails, WbfmCarry *wc, DcCarry *dc, uint32_t first_ch, uint32_t n_ch, hipStream_t s);
+hipError_t launch_wbfm_verify(const ChainLaunch &a, hipStream_t s);
+hipError_t launch_wbfm_commit(const ChainLaunch &a, hipStream_t s);
+hipError_t launch_tail_update(const ChainLaunch &a, int family, hipStream_t s);
+hipError_t launch_magnitude(const uint8_t *iq, size_t ch_stride_bytes, const uint32_t *ch_list, uint32_t n_list,
+                            uint32_t block_samples, uint32_t n_blocks, uint32_t *mag_sums, hipStream_t s);
+hipError_t launch_squelch(const SquelchLaunch &q, hipStream_t s);
+hipError_t launch_tile_fill(uint8_t *dst, size_t period, size_t total, hipStream_t s);
+
+}  // namespace iqd

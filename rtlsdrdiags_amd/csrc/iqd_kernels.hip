@@ -1,0 +1,305 @@
+// gfx950 kernels of the IQ demodulation engine.  hipcc --offload-arch=gfx950 -ffp-contract=off.
+#include <hip/hip_runtime.h>
+
+#include "iqd_kernels.h"
+#include "iqd_wbfm.h"
+
+namespace iqd {
+
+__constant__ Consts g_consts;
+
+hipError_t upload_consts(const Consts &c, hipStream_t s)
+{
+    return hipMemcpyToSymbolAsync(HIP_SYMBOL(g_consts), &c, sizeof(Consts), 0, hipMemcpyHostToDevice, s);
+}
+
+// SIMT machine for the phase functions (see the host twin in tests/emu).
+struct DeviceExec {
+    int tid;
+    template <class F> __device__ __forceinline__ void all(F f) { f(tid); __syncthreads(); }
+    __device__ __forceinline__ bool in_wave0() const { return tid < 64; }
+    __device__ __forceinline__ void wave_fence() const
+    {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    template <class F> __device__ __forceinline__ void wave0(F f) { f(tid); wave_fence(); }
+    template <class F> __device__ __forceinline__ bool wave0_all(F f)
+    {
+        const bool ok = f(tid);
+        wave_fence();
+        return __all(ok);
+    }
+    __device__ __forceinline__ void sync() const { __syncthreads(); }
+};
+
+__device__ __forceinline__ void rotation_selectors(int rotation, WbfmTile &t)
+{
+    if (rotation == 0) {
+        t.sel_i = 0x06040200u; t.sel_q = 0x07050301u; t.neg_i = 0u; t.neg_q = 0u;
+    } else {
+        t.sel_i = 0x07040300u; t.sel_q = 0x06050201u;
+        t.neg_i = rotation > 0 ? 0x00ffff00u : 0xffff0000u;
+        t.neg_q = rotation > 0 ? 0xffff0000u : 0x00ffff00u;
+    }
+}
+
+template <bool GATED, bool MAG>
+__global__ __launch_bounds__(WB_THREADS) void wbfm_chain_kernel(const ChainLaunch a)
+{
+    __shared__ WbfmLds lds;
+    uint32_t li, tile;
+    if (a.tile_sel) {  // repair launch: explicit (list index, tile) pairs
+        li = a.tile_sel[2 * blockIdx.x];
+        tile = a.tile_sel[2 * blockIdx.x + 1];
+    } else {
+        li = blockIdx.x / a.tiles_per_ch;
+        tile = blockIdx.x - li * a.tiles_per_ch;
+    }
+    const uint32_t ch = a.ch_list[li];            // channel index inside this call
+    const uint32_t ech = a.first_ch + ch;         // engine channel
+    const uint32_t vlen = GATED ? a.vlen_gated[ch] : a.vlen;
+    const int64_t v0 = (int64_t)tile * a.tile_len;
+    if (v0 >= (int64_t)vlen) return;
+
+    const ChanParams &p = a.params[ech];
+    WbfmTile t;
+    t.iq_ch = a.iq + (size_t)ch * a.ch_stride_bytes;
+    t.tail = a.tails + ((size_t)ech * FAM_COUNT + FAM_WBFM) * TAIL_BYTES;
+    t.blk_list = GATED ? a.blk_lists + (size_t)ch * a.n_blocks : nullptr;
+    t.block_samples = a.block_samples;
+    t.block_magic = a.block_magic;
+    t.v0 = v0;
+    t.tlen = (int32_t)(((int64_t)vlen - v0) < (int64_t)a.tile_len ? ((int64_t)vlen - v0) : (int64_t)a.tile_len);
+    rotation_selectors(p.rotation, t);
+    t.k = p.wbfm_k;
+    t.lut = a.atan_lut;
+    t.pcm_row = a.pcm + (size_t)ch * a.pcm_stride;
+    t.mag_row = MAG ? a.mag_sums + (size_t)ch * a.n_blocks : nullptr;
+
+    WbfmStart start;
+    if (a.forced) {
+        start = a.forced[(size_t)li * a.tiles_per_ch + tile];
+    } else if (tile == 0) {
+        const WbfmCarry cy = a.wbfm_carry[ech];
+        start.y = cy.y; start.u = cy.u; start.back = cy.back; start.cold = 0;
+    } else {
+        start.y = 0.f; start.u = 0.f; start.back = 0; start.cold = 1;
+    }
+    DeviceExec ex{(int)threadIdx.x};
+    wbfm_tile<GATED, MAG>(ex, t, g_consts, lds, start, &a.records[(size_t)li * a.tiles_per_ch + tile]);
+    if (threadIdx.x == 0 && lds.repair_count) atomicAdd(&a.counters[CNT_SEG_REPAIRS], lds.repair_count);
+}
+
+// Hand-off check between consecutive tiles of a channel: a cold tile's own state at its
+// restart point must equal, bit for bit, what the tile before it recorded there.
+__global__ void wbfm_verify_kernel(const ChainLaunch a)
+{
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t li = idx / a.tiles_per_ch, tile = idx % a.tiles_per_ch;
+    if (li >= a.n_list) return;
+    const uint32_t ch = a.ch_list[li];
+    const uint32_t vlen = a.vlen_gated ? a.vlen_gated[ch] : a.vlen;
+    const uint32_t ntiles = (vlen + a.tile_len - 1) / a.tile_len;
+    if (tile >= ntiles) return;
+    const WbfmRecord *r = a.records + (size_t)li * a.tiles_per_ch;
+    if (tile > 0) {
+        if (f2u(r[tile].y_in) != f2u(r[tile - 1].y_out)) {
+            const uint32_t slot = atomicAdd(&a.counters[CNT_TILE_MISMATCH], 1u);
+            if (slot < MAX_MISMATCH_LIST) {
+                a.mismatch_list[2 * slot] = li;
+                a.mismatch_list[2 * slot + 1] = tile;
+            }
+        } else {
+            atomicAdd(&a.counters[CNT_TILE_CHECKS], 1u);
+        }
+    }
+}
+
+// Commits the restart state of each channel's last tile (after verification / repair).
+__global__ void wbfm_commit_kernel(const ChainLaunch a)
+{
+    const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= a.n_list) return;
+    const uint32_t ch = a.ch_list[li];
+    const uint32_t vlen = a.vlen_gated ? a.vlen_gated[ch] : a.vlen;
+    if (vlen == 0) return;
+    const uint32_t ntiles = (vlen + a.tile_len - 1) / a.tile_len;
+    const WbfmRecord r = a.records[(size_t)li * a.tiles_per_ch + ntiles - 1];
+    WbfmCarry cy;
+    cy.y = r.y_out; cy.u = r.u_out; cy.back = r.back_out;
+    cy.y_end = r.y_end; cy.u_end = r.u_end;
+    cy.pad[0] = cy.pad[1] = cy.pad[2] = 0;
+    a.wbfm_carry[a.first_ch + ch] = cy;
+}
+
+// New tail = last TAIL samples of [old tail | this call's open blocks] for one family.
+__global__ __launch_bounds__(256) void tail_update_kernel(const ChainLaunch a, int family)
+{
+    const uint32_t li = blockIdx.x;
+    const uint32_t ch = a.ch_list[li];
+    const uint32_t ech = a.first_ch + ch;
+    const uint32_t vlen = a.vlen_gated ? a.vlen_gated[ch] : a.vlen;
+    if (vlen == 0) return;
+    uint8_t *tail = a.tails + ((size_t)ech * FAM_COUNT + family) * TAIL_BYTES;
+    const uint8_t *iq_ch = a.iq + (size_t)ch * a.ch_stride_bytes;
+    const uint32_t *blk_list = a.vlen_gated ? a.blk_lists + (size_t)ch * a.n_blocks : nullptr;
+    // thread i moves 8 samples (16 bytes): new tail samples [8i, 8i+8) = virtual vlen-TAIL+8i
+    const int64_t v = (int64_t)vlen - TAIL + 8 * (int64_t)threadIdx.x;
+    const uint8_t *src;
+    if (v < 0) src = tail + TAIL_BYTES + 2 * v;
+    else if (!blk_list) src = iq_ch + 2 * v;
+    else {
+        const uint32_t blk = (uint32_t)(v / a.block_samples);
+        const uint32_t off = (uint32_t)(v - (int64_t)blk * a.block_samples);
+        src = iq_ch + ((int64_t)blk_list[blk] * a.block_samples + off) * 2;
+    }
+    const uint4 val = *(const uint4 *)src;
+    __syncthreads();
+    ((uint4 *)tail)[threadIdx.x] = val;
+}
+
+// Per-block squelch magnitude sums for channels whose chain kernel does not produce them
+// (mode None, squelch-gated calls).  One workgroup per (block, channel).
+__global__ __launch_bounds__(256) void magnitude_kernel(const uint8_t *iq, size_t ch_stride_bytes,
+                                                        const uint32_t *ch_list, uint32_t block_samples,
+                                                        uint32_t n_blocks, uint32_t *mag_sums)
+{
+    const uint32_t ch = ch_list ? ch_list[blockIdx.y] : blockIdx.y;
+    const uint32_t blk = blockIdx.x;
+    const uint4 *src = (const uint4 *)(iq + (size_t)ch * ch_stride_bytes + (size_t)blk * block_samples * 2);
+    const uint32_t n16 = block_samples / 8;  // 16-byte groups
+    uint32_t m = 0;
+    for (uint32_t i = threadIdx.x; i < n16; i += 256) {
+        uint4 r = src[i];
+        m += magnitude2(r.x ^ 0x80808080u) + magnitude2(r.y ^ 0x80808080u) +
+             magnitude2(r.z ^ 0x80808080u) + magnitude2(r.w ^ 0x80808080u);
+    }
+    for (int off = 32; off > 0; off >>= 1) m += __shfl_down(m, off);
+    __shared__ uint32_t part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) mag_sums[(size_t)ch * n_blocks + blk] = part[0] + part[1] + part[2] + part[3];
+}
+
+// Squelch decisions (SignalDetector.cc:259-271, SignalTracker.cc:104-145, Squelch.cc:240-269)
+// and output bookkeeping; one thread per channel walks its blocks in order.
+__global__ void squelch_kernel(const SquelchLaunch q)
+{
+    const uint32_t ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= q.n_ch) return;
+    const uint32_t ech = q.first_ch + ch;
+    const ChanParams p = q.params[ech];
+    uint32_t tracking = q.tracker[ech];
+    uint32_t open = 0;
+    for (uint32_t b = 0; b < q.n_blocks; b++) {
+        const uint32_t avg = q.mag_sums[(size_t)ch * q.n_blocks + b] / q.block_samples;
+        uint32_t m = avg > 127u ? 127u : avg;  // DbfsCalculator.cc:122-125, full scale 127
+        int32_t dbfs = g_consts.db_table[m] - 42;
+        dbfs = (int32_t)((uint32_t)dbfs - p.rx_gain_db);
+        const uint32_t present = dbfs >= p.threshold ? 1u : 0u;
+        const uint32_t allowed = present | tracking;
+        tracking = present;
+        if (q.magnitude) q.magnitude[(size_t)ch * q.n_blocks + b] = avg;
+        if (q.allowed) q.allowed[(size_t)ch * q.n_blocks + b] = (uint8_t)allowed;
+        if (allowed) {
+            if (q.blk_lists) q.blk_lists[(size_t)ch * q.n_blocks + open] = b;
+            open++;
+        }
+    }
+    q.tracker[ech] = tracking;
+    const uint32_t vlen = (p.mode == 0) ? 0u : open * q.block_samples;
+    if (q.vlen_out) q.vlen_out[ch] = vlen;
+    if (q.pcm_count) q.pcm_count[ch] = vlen / 32u;
+}
+
+// resetDemodulator() for a channel range: histories become zero signal; the WBFM
+// de-emphasis state survives (WbFmDemodulator.cc:304-320) and restarts at the stream end.
+__global__ void reset_kernel(uint8_t *tails, WbfmCarry *wc, DcCarry *dc, uint32_t first_ch, uint32_t n_ch)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n16 = (size_t)n_ch * FAM_COUNT * TAIL_BYTES / 16;
+    uint4 *t = (uint4 *)(tails + (size_t)first_ch * FAM_COUNT * TAIL_BYTES);
+    for (size_t k = i; k < n16; k += (size_t)gridDim.x * blockDim.x)
+        t[k] = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
+    if (i < n_ch) {
+        WbfmCarry c = wc[first_ch + i];
+        c.y = c.y_end; c.u = c.u_end; c.back = 0;
+        wc[first_ch + i] = c;
+        dc[2 * (size_t)(first_ch + i)] = DcCarry{0.f, 0.f};
+        dc[2 * (size_t)(first_ch + i) + 1] = DcCarry{0.f, 0.f};
+    }
+}
+
+// Repeats the first `period` bytes of a buffer over the rest (bench input staging).
+__global__ void tile_fill_kernel(uint8_t *dst, size_t period, size_t total)
+{
+    const size_t n16 = total / 16, p16 = period / 16;
+    for (size_t i = p16 + blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16;
+         i += (size_t)gridDim.x * blockDim.x)
+        ((uint4 *)dst)[i] = ((const uint4 *)dst)[i % p16];
+}
+
+// ---- launch wrappers ---------------------------------------------------------------------
+hipError_t launch_wbfm(const ChainLaunch &a, bool gated, bool mag, uint32_t n_blocks, hipStream_t s)
+{
+    dim3 grid(n_blocks), block(WB_THREADS);
+    if (gated) {
+        if (mag) hipLaunchKernelGGL((wbfm_chain_kernel<true, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((wbfm_chain_kernel<true, false>), grid, block, 0, s, a);
+    } else {
+        if (mag) hipLaunchKernelGGL((wbfm_chain_kernel<false, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((wbfm_chain_kernel<false, false>), grid, block, 0, s, a);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_wbfm_verify(const ChainLaunch &a, hipStream_t s)
+{
+    const uint32_t n = a.n_list * a.tiles_per_ch;
+    hipLaunchKernelGGL(wbfm_verify_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_wbfm_commit(const ChainLaunch &a, hipStream_t s)
+{
+    hipLaunchKernelGGL(wbfm_commit_kernel, dim3((a.n_list + 255) / 256), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_tail_update(const ChainLaunch &a, int family, hipStream_t s)
+{
+    hipLaunchKernelGGL(tail_update_kernel, dim3(a.n_list), dim3(256), 0, s, a, family);
+    return hipGetLastError();
+}
+
+hipError_t launch_magnitude(const uint8_t *iq, size_t ch_stride_bytes, const uint32_t *ch_list, uint32_t n_list,
+                            uint32_t block_samples, uint32_t n_blocks, uint32_t *mag_sums, hipStream_t s)
+{
+    hipLaunchKernelGGL(magnitude_kernel, dim3(n_blocks, n_list), dim3(256), 0, s, iq, ch_stride_bytes, ch_list,
+                       block_samples, n_blocks, mag_sums);
+    return hipGetLastError();
+}
+
+hipError_t launch_squelch(const SquelchLaunch &q, hipStream_t s)
+{
+    hipLaunchKernelGGL(squelch_kernel, dim3((q.n_ch + 63) / 64), dim3(64), 0, s, q);
+    return hipGetLastError();
+}
+
+hipError_t launch_reset(uint8_t *tails, WbfmCarry *wc, DcCarry *dc, uint32_t first_ch, uint32_t n_ch, hipStream_t s)
+{
+    uint32_t blocks = (n_ch + 255) / 256;
+    if (blocks < 64) blocks = 64;
+    hipLaunchKernelGGL(reset_kernel, dim3(blocks), dim3(256), 0, s, tails, wc, dc, first_ch, n_ch);
+    return hipGetLastError();
+}
+
+hipError_t launch_tile_fill(uint8_t *dst, size_t period, size_t total, hipStream_t s)
+{
+    hipLaunchKernelGGL(tile_fill_kernel, dim3(2048), dim3(256), 0, s, dst, period, total);
+    return hipGetLastError();
+}
+
+}  // namespace iqd

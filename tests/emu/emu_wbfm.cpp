@@ -1,0 +1,117 @@
+// tests/emu/emu_wbfm.cpp — TEST INFRASTRUCTURE ONLY.
+//
+// Compiles the WBFM chain's phase functions (rtlsdrdiags_amd/csrc/iqd_wbfm.h) for the host
+// with IQD_HOST_EMU and steps them with a loop over thread ids in place of the SIMT machine,
+// so the tiling / hand-off / history logic of the GPU kernel can be checked against the
+// oracle in the CPU-only test tier.  It mirrors what iqd_engine.cpp does for one channel
+// with the squelch open.  Nothing in the product links or loads this file.
+#define IQD_HOST_EMU 1
+#include <stdint.h>
+#include <string.h>
+
+#include <vector>
+
+#include "iqd_host.h"
+#include "iqd_wbfm.h"
+
+namespace {
+
+struct HostExec {
+    template <class F> void all(F f) { for (int t = 0; t < iqd::WB_THREADS; t++) f(t); }
+    bool in_wave0() const { return true; }
+    template <class F> void wave0(F f) { for (int l = 0; l < 64; l++) f(l); }
+    template <class F> bool wave0_all(F f)
+    {
+        bool ok = true;
+        for (int l = 0; l < 64; l++) ok = f(l) && ok;
+        return ok;
+    }
+    void sync() const {}
+};
+
+}  // namespace
+
+extern "C" {
+
+// One accept call for one WBFM channel (squelch open).  tail/carry are in-out state.
+// guess_bias perturbs the de-emphasis state guess (to force the segment repair path).
+// Returns the number of tile hand-off mismatches; seg_repairs counts repair rounds.
+int emu_wbfm_accept(const uint8_t *iq, uint32_t n_samples, uint32_t tile_len, uint32_t block_samples,
+                    int rotation, float gain, uint8_t *tail, iqd::WbfmCarry *carry,
+                    int16_t *pcm, uint32_t *mag_sums, uint32_t *seg_repairs, float guess_scale)
+{
+    using namespace iqd;
+    static Consts c;
+    static std::vector<float> lut;
+    static bool ready = false;
+    if (!ready) { build_consts(c); build_atan2_lut(lut); ready = true; }
+    Consts cc = c;
+    cc.deemph_c128 *= guess_scale;  // 1.0 = the product's guess
+
+    ChanParams p;
+    default_params(p);
+    p.gain[FAM_WBFM] = gain;
+    p.rotation = rotation;
+    derive_params(p);
+
+    const uint32_t ntiles = (n_samples + tile_len - 1) / tile_len;
+    std::vector<WbfmRecord> recs(ntiles);
+    static WbfmLds lds;
+    uint32_t repairs = 0;
+    for (uint32_t tile = 0; tile < ntiles; tile++) {
+        WbfmTile t;
+        t.iq_ch = iq;
+        t.tail = tail;
+        t.blk_list = nullptr;
+        t.block_samples = block_samples;
+        t.block_magic = block_magic(block_samples);
+        t.v0 = (int64_t)tile * tile_len;
+        t.tlen = (int32_t)((n_samples - t.v0) < tile_len ? (n_samples - t.v0) : tile_len);
+        if (rotation == 0) { t.sel_i = 0x06040200u; t.sel_q = 0x07050301u; t.neg_i = 0; t.neg_q = 0; }
+        else {
+            t.sel_i = 0x07040300u; t.sel_q = 0x06050201u;
+            t.neg_i = rotation > 0 ? 0x00ffff00u : 0xffff0000u;
+            t.neg_q = rotation > 0 ? 0xffff0000u : 0x00ffff00u;
+        }
+        t.k = p.wbfm_k;
+        t.lut = lut.data();
+        t.pcm_row = pcm;
+        t.mag_row = mag_sums;
+        WbfmStart start;
+        if (tile == 0) { start.y = carry->y; start.u = carry->u; start.back = carry->back; start.cold = 0; }
+        else { start.y = 0; start.u = 0; start.back = 0; start.cold = 1; }
+        HostExec ex;
+        memset(&lds, 0xcd, sizeof(lds));  // poison: the kernel must initialise what it reads
+        wbfm_tile<false, true>(ex, t, cc, lds, start, &recs[tile]);
+        repairs += lds.repair_count;
+    }
+    int mismatches = 0;
+    for (uint32_t tile = 1; tile < ntiles; tile++)
+        if (f2u(recs[tile].y_in) != f2u(recs[tile - 1].y_out)) mismatches++;
+    const WbfmRecord &r = recs[ntiles - 1];
+    carry->y = r.y_out; carry->u = r.u_out; carry->back = r.back_out;
+    carry->y_end = r.y_end; carry->u_end = r.u_end;
+    // tail update (tail_update_kernel)
+    std::vector<uint8_t> nt(TAIL_BYTES);
+    for (int i = 0; i < TAIL; i++) {
+        const int64_t v = (int64_t)n_samples - TAIL + i;
+        const uint8_t *src = v < 0 ? tail + TAIL_BYTES + 2 * v : iq + 2 * v;
+        nt[2 * i] = src[0];
+        nt[2 * i + 1] = src[1];
+    }
+    memcpy(tail, nt.data(), TAIL_BYTES);
+    if (seg_repairs) *seg_repairs = repairs;
+    return mismatches;
+}
+
+void emu_wbfm_reset(uint8_t *tail, iqd::WbfmCarry *carry)
+{
+    memset(tail, 0x80, iqd::TAIL_BYTES);
+    carry->y = carry->y_end;
+    carry->u = carry->u_end;
+    carry->back = 0;
+}
+
+uint32_t emu_lds_bytes(void) { return (uint32_t)sizeof(iqd::WbfmLds); }
+
+}  // extern "C"

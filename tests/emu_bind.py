@@ -1,0 +1,55 @@
+"""ctypes binding of tests/emu/libiqd_emu.so (host twin of the GPU kernels' phase functions)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "emu", "libiqd_emu.so")
+
+
+class Carry(C.Structure):
+    _fields_ = [("y", C.c_float), ("u", C.c_float), ("back", C.c_int32), ("y_end", C.c_float),
+                ("u_end", C.c_float), ("pad", C.c_uint32 * 3)]
+
+
+def lib():
+    subprocess.run(["make", "-s", "-C", os.path.join(HERE, "emu")], check=True)
+    L = C.CDLL(SO)
+    L.emu_wbfm_accept.restype = C.c_int
+    L.emu_wbfm_accept.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_float,
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float]
+    L.emu_wbfm_reset.argtypes = [C.c_void_p, C.c_void_p]
+    L.emu_lds_bytes.restype = C.c_uint32
+    return L
+
+
+class WbfmChannel:
+    """One WBFM channel driven through the emulated kernel, call after call."""
+
+    def __init__(self, L, tile_len, block_samples=16384, rotation=1, gain=None, guess_scale=1.0):
+        self.L, self.tile_len, self.block_samples = L, tile_len, block_samples
+        self.rotation = rotation
+        self.gain = np.float32(256000 / (2 * np.pi)) if gain is None else np.float32(gain)
+        self.guess_scale = guess_scale
+        self.tail = np.full(4096, 128, np.uint8)
+        self.carry = Carry()
+        self.hand_off_mismatches = 0
+        self.segment_repairs = 0
+
+    def accept(self, u8):
+        u8 = np.ascontiguousarray(u8, dtype=np.uint8)
+        m = len(u8) // 2
+        pcm = np.zeros(m // 32, np.int16)
+        mag = np.zeros(max(1, (m + self.block_samples - 1) // self.block_samples), np.uint32)
+        rep = C.c_uint32(0)
+        self.hand_off_mismatches += self.L.emu_wbfm_accept(
+            u8.ctypes.data, m, self.tile_len, self.block_samples, self.rotation, self.gain,
+            self.tail.ctypes.data, C.byref(self.carry), pcm.ctypes.data, mag.ctypes.data,
+            C.byref(rep), self.guess_scale)
+        self.segment_repairs += rep.value
+        return pcm, mag
+
+    def reset(self):
+        self.L.emu_wbfm_reset(self.tail.ctypes.data, C.byref(self.carry))

@@ -1,0 +1,81 @@
+"""CPU: the WBFM kernel's phase functions (rtlsdrdiags_amd/csrc/iqd_wbfm.h), stepped on the host
+by tests/emu, against the oracle: tiling, lead-in, exact hand-off, state carried between calls."""
+import numpy as np
+import pytest
+
+from rtlsdrdiags_amd import synth
+from tests import emu_bind
+
+
+@pytest.fixture(scope="module")
+def emu():
+    return emu_bind.lib()
+
+
+def oracle_wbfm(oracle, u8, rotation=1, gain=None):
+    c = oracle.chain()
+    c.set_mode("wbfm")
+    c.set_rotation(rotation)
+    if gain is not None:
+        c.set_gain(3, gain)
+    return c.accept_stream(u8)
+
+
+def test_lds_fits_three_workgroups_per_cu(emu):
+    assert 3 * emu.emu_lds_bytes() <= 160 * 1024
+
+
+@pytest.mark.parametrize("call_samples,tile_len", [(6 * 16384, 61440), (6 * 16384, 16384), (16384, 16384),
+                                                   (16384, 8192), (4096, 7680), (128, 7680), (384, 128)])
+def test_calls_and_tiles(emu, oracle, call_samples, tile_len):
+    u8 = synth.fm_tone(6 * 16384, seed=21)
+    ref, ref_mag, _ = oracle_wbfm(oracle, u8)
+    ch = emu_bind.WbfmChannel(emu, tile_len)
+    out = [ch.accept(u8[2 * o:2 * (o + call_samples)])[0] for o in range(0, len(u8) // 2, call_samples)]
+    assert np.array_equal(np.concatenate(out), ref)
+    assert ch.hand_off_mismatches == 0
+
+
+@pytest.mark.parametrize("kind", ["white", "rails"])
+def test_edge_inputs_and_magnitude(emu, oracle, kind):
+    u8 = synth.white_u8(3 * 16384, seed=3) if kind == "white" else synth.rails_u8(2 * 16384, seed=4)
+    ref, ref_mag, _ = oracle_wbfm(oracle, u8)
+    ch = emu_bind.WbfmChannel(emu, 16384)
+    pcm, mag = ch.accept(u8)
+    assert np.array_equal(pcm, ref)
+    assert np.array_equal(mag // 16384, ref_mag)
+    assert ch.hand_off_mismatches == 0
+
+
+@pytest.mark.parametrize("scale", [0.0, 3.0e4, -1.0e5])
+def test_bad_state_guess_is_repaired_exactly(emu, oracle, scale):
+    """The segment state guess only affects speed: whatever it is, the output is exact."""
+    u8 = synth.fm_tone(2 * 16384, seed=5)
+    ref, _, _ = oracle_wbfm(oracle, u8)
+    ch = emu_bind.WbfmChannel(emu, 16384, guess_scale=scale)
+    pcm, _ = ch.accept(u8)
+    assert np.array_equal(pcm, ref)
+    assert ch.segment_repairs > 5
+
+
+@pytest.mark.parametrize("rotation", [1, 0, -1])
+def test_rotation_and_cast_overflow_gain(emu, oracle, rotation):
+    u8 = synth.fm_tone(2 * 16384, seed=9, amplitude=100.0)
+    ref, _, _ = oracle_wbfm(oracle, u8, rotation=rotation, gain=8.0e6)
+    ch = emu_bind.WbfmChannel(emu, 8192, rotation=rotation, gain=8.0e6)
+    out = [ch.accept(u8[:32768])[0], ch.accept(u8[32768:])[0]]
+    assert np.array_equal(np.concatenate(out), ref)
+
+
+def test_reset_keeps_deemphasis_state(emu, oracle):
+    u8 = synth.fm_tone(2 * 16384, seed=12)
+    c = oracle.chain()
+    c.set_mode("wbfm")
+    a, _, _ = c.accept_stream(u8[:32768])
+    c.reset()
+    b, _, _ = c.accept_stream(u8[32768:])
+    ch = emu_bind.WbfmChannel(emu, 8192)
+    pa, _ = ch.accept(u8[:32768])
+    ch.reset()
+    pb, _ = ch.accept(u8[32768:])
+    assert np.array_equal(pa, a) and np.array_equal(pb, b)

@@ -1,0 +1,76 @@
+"""CPU: host-side logic of the engine and the C-ABI surface (no compute without a GPU)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_wrap_delta_float_only():
+    """iqd_prims.h::wrap_delta == the reference's double-precision branch-cut handling
+    (WbFmDemodulator.cc:472-480) for EVERY float in [pi, 2*pi] and its mirror image."""
+    f32 = np.float32
+    pi_f, hi = f32(np.pi), f32(2 * np.pi)
+    lo = f32(2 * np.pi - float(hi))
+    assert float(hi) / 2 == float(pi_f) and float(pi_f) > np.pi
+    bits = np.arange(np.array([pi_f]).view(np.uint32)[0] - 8, np.array([hi]).view(np.uint32)[0] + 1, dtype=np.uint32)
+    d = bits.view(np.float32)
+    for sign in (1.0, -1.0):
+        x = (d * f32(sign)).astype(np.float32)
+        xd = x.astype(np.float64)
+        ref = x.copy()
+        m = xd > np.pi
+        ref[m] = (xd[m] - 2 * np.pi).astype(np.float32)
+        m = xd < -np.pi
+        ref[m] = (xd[m] + 2 * np.pi).astype(np.float32)
+        assert not np.any(np.abs(ref.astype(np.float64)) > np.pi)          # one step is enough
+        mine = np.where(x >= pi_f, ((x - hi).astype(np.float32) - lo).astype(np.float32),
+                        np.where(x <= -pi_f, ((x + hi).astype(np.float32) + lo).astype(np.float32), x))
+        assert np.array_equal(mine.view(np.uint32), ref.view(np.uint32))
+
+
+def test_library_exports_every_declared_symbol():
+    from rtlsdrdiags_amd import capi
+    header = open(os.path.join(ROOT, "include", "iqdemod.h")).read()
+    declared = set(re.findall(r"\b(iqd_[a-z_0-9]+)\s*\(", header))
+    declared -= {"iqd_t"}
+    lib = C.CDLL(capi.LIB)
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+    assert declared == set(capi.EXPORTS)
+
+
+def test_create_fails_loudly_without_a_gpu_or_with_bad_config():
+    import torch
+    from rtlsdrdiags_amd import capi
+    lib = capi._lib()
+    h = C.c_void_p()
+    cfg = capi.Config(lib.iqd_abi_version(), 0, 0, -1, 0)
+    assert lib.iqd_create(C.byref(cfg), C.byref(h)) == -1            # n_channels == 0
+    cfg = capi.Config(lib.iqd_abi_version() + 1, 1, 0, -1, 0)
+    assert lib.iqd_create(C.byref(cfg), C.byref(h)) == -1            # ABI mismatch
+    cfg = capi.Config(lib.iqd_abi_version(), 1, 1000, -1, 0)
+    assert lib.iqd_create(C.byref(cfg), C.byref(h)) == -1            # block_bytes % 256
+    if not torch.cuda.is_available():
+        with pytest.raises(capi.IqdError):
+            capi.Engine(1)                                           # no CPU fallback exists
+    assert lib.iqd_strerror(-2) == b"no usable HIP device"
+
+
+def test_product_never_touches_the_oracle():
+    """The product tree must not import, link or load anything under oracle/ or tests/."""
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "rtlsdrdiags_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip", ".cc")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f)).read()
+                if re.search(r"(from|import)\s+oracle|oracle/|libiqd_oracle|libiqd_ref|libiqd_emu|tests/emu/", text) \
+                        and "tests/emu" not in text.split("IQD_HOST_EMU")[0][-400:]:
+                    hits = [l for l in text.splitlines()
+                            if re.search(r"(from|import)\s+oracle|libiqd_oracle|libiqd_ref|libiqd_emu|#include.*oracle", l)]
+                    if hits:
+                        bad.append((f, hits))
+    assert not bad, bad
