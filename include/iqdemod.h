@@ -152,6 +152,8 @@ int iqd_dev_download(iqd_t *e, void *dst_host, const void *src_dev, size_t bytes
 /* Fills dst_dev with `total` bytes by repeating the first `period` bytes already there. */
 int iqd_dev_tile(iqd_t *e, void *dst_dev, size_t period, size_t total);
 void *iqd_stream(iqd_t *e); /* the engine's hipStream_t */
+/* Diagnostic builds (-DIQD_STAMPS) only: cycle sums per kernel phase; zeros otherwise. */
+int iqd_debug_stamps(iqd_t *e, unsigned long long *out16);
 
 #ifdef __cplusplus
 }

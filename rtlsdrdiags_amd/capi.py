@@ -9,7 +9,9 @@ import os
 
 import numpy as np
 
-from .build import LIB
+from .build import LIB as _DEFAULT_LIB
+
+LIB = os.environ.get("IQD_LIB", _DEFAULT_LIB)   # experiments: alternative builds of the same ABI
 
 MODE = {"none": 0, "am": 1, "fm": 2, "wbfm": 3, "lsb": 4, "usb": 5}
 DEMOD = {"am": 1, "fm": 2, "wbfm": 3, "ssb": 4}
@@ -38,7 +40,7 @@ EXPORTS = [
     "iqd_set_gain", "iqd_set_squelch", "iqd_set_rx_gain_db", "iqd_set_rotation", "iqd_reset",
     "iqd_accept_iq", "iqd_accept_iq_device", "iqd_synchronize", "iqd_get_stats", "iqd_set_profiling",
     "iqd_get_channel_mode", "iqd_get_channel_gain", "iqd_dev_alloc", "iqd_dev_free", "iqd_dev_upload",
-    "iqd_dev_download", "iqd_dev_tile", "iqd_stream",
+    "iqd_dev_download", "iqd_dev_tile", "iqd_stream", "iqd_debug_stamps",
 ]
 
 _LIB = None
@@ -184,6 +186,12 @@ class Engine:
         g = C.c_float()
         self._check(self._L.iqd_get_channel_gain(self._h, ch, int(DEMOD.get(demod, demod)), C.byref(g)))
         return g.value
+
+    def debug_stamps(self):
+        out = (C.c_ulonglong * 16)()
+        self._L.iqd_debug_stamps.argtypes = [C.c_void_p, C.c_void_p]
+        self._check(self._L.iqd_debug_stamps(self._h, out))
+        return list(out)
 
     def dev_alloc(self, nbytes):
         p = C.c_void_p()

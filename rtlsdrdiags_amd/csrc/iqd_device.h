@@ -15,10 +15,13 @@ constexpr int TAIL_BYTES = 2 * TAIL;
 constexpr int SEG = 128;            // de-emphasis IIR segment (one lane's run)
 constexpr int FORCED_BACK = 768;    // an exact IIR restart point lies this far before a tile
 constexpr int COLD_HALO = 2048;     // zero-state warm-up distance of interior tiles
-constexpr int WBFM_NSEG = 60;       // segments per chunk -> chunk = 7680 samples
+#ifndef IQD_WBFM_NSEG
+#define IQD_WBFM_NSEG 58
+#endif
+constexpr int WBFM_NSEG = IQD_WBFM_NSEG;  // segments per chunk (58 -> 7424 samples, 3 workgroups per CU)
 constexpr int WBFM_CHUNK = WBFM_NSEG * SEG;
 constexpr int TSTRIDE = 132;        // dwords between segments of the IIR input buffer
-constexpr int WSTRIDE = 66;         // dwords between segments of the int16 output buffer
+constexpr int WSTRIDE = 68;         // dwords between segments of the int16 output buffer (16-B aligned)
 
 enum Family { FAM_AM = 0, FAM_FM = 1, FAM_WBFM = 2, FAM_SSB = 3, FAM_COUNT = 4 };
 
@@ -62,7 +65,7 @@ struct Consts {
     int32_t am_s1_lo[2], am_s1_hi[2];
     int32_t db_table[257];
     float deemph_b0, deemph_a1;     // 0.0253863, -0.9492274
-    float deemph_c128;              // (-a1)^128, for the state guess only
+    float deemph_c, deemph_c16, deemph_c127, deemph_c128, deemph_cinv;  // powers of -a1 (state guess only)
     float dc_a1;                    // -0.95
 };
 

@@ -72,10 +72,11 @@ struct iqd_engine {
     uint32_t *d_tracker = nullptr;
     float *d_atan = nullptr, *d_fmlut = nullptr;
     uint32_t *d_counters = nullptr, *d_mismatch = nullptr;
+    unsigned long long *d_stamps = nullptr;
     uint32_t *h_counters = nullptr;  // pinned
 
     // per-call scratch
-    DevBuf lists[FAM_COUNT + 1], mag_sums, blk_lists, vlen, records, base8k;
+    DevBuf lists[FAM_COUNT + 1], mag_sums, blk_lists, vlen, records, base8k, present;
     DevBuf st_iq, st_pcm, st_count, st_mag, st_allowed;  // staging for host-pointer accepts
 
     bool profiling = false;
@@ -177,6 +178,8 @@ int iqd_create(const iqd_config *cfg, iqd_t **out)
     ok = ok && hipMalloc((void **)&e->d_fmlut, fm_lut.size() * sizeof(float)) == hipSuccess;
     ok = ok && hipMalloc((void **)&e->d_counters, CNT_COUNT * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc((void **)&e->d_mismatch, MAX_MISMATCH_LIST * 2 * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMalloc((void **)&e->d_stamps, 16 * sizeof(unsigned long long)) == hipSuccess;
+    ok = ok && hipMemset(e->d_stamps, 0, 16 * sizeof(unsigned long long)) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&e->h_counters, CNT_COUNT * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipEventCreate(&e->ev0) == hipSuccess && hipEventCreate(&e->ev1) == hipSuccess;
     if (ok) {
@@ -205,12 +208,12 @@ void iqd_destroy(iqd_t *e)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     void *ptrs[] = {e->d_params, e->d_tails, e->d_wcarry, e->d_dc, e->d_tracker,
-                    e->d_atan, e->d_fmlut, e->d_counters, e->d_mismatch};
+                    e->d_atan, e->d_fmlut, e->d_counters, e->d_mismatch, e->d_stamps};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (e->h_counters) (void)hipHostFree(e->h_counters);
     for (auto &b : e->lists) b.release();
-    DevBuf *bufs[] = {&e->mag_sums, &e->blk_lists, &e->vlen, &e->records, &e->base8k,
+    DevBuf *bufs[] = {&e->mag_sums, &e->blk_lists, &e->vlen, &e->records, &e->base8k, &e->present,
                       &e->st_iq, &e->st_pcm, &e->st_count, &e->st_mag, &e->st_allowed};
     for (DevBuf *b : bufs) b->release();
     if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -320,6 +323,16 @@ int iqd_synchronize(iqd_t *e)
 }
 
 void *iqd_stream(iqd_t *e) { return e ? (void *)e->stream : nullptr; }
+
+// Diagnostic builds (-DIQD_STAMPS) only: per-phase cycle sums of the chain kernel.
+int iqd_debug_stamps(iqd_t *e, unsigned long long *out16)
+{
+    if (!e || !out16) return IQD_EINVAL;
+    (void)hipSetDevice(e->device);
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    HIP_TRY(e, hipMemcpy(out16, e->d_stamps, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return IQD_OK;
+}
 
 int iqd_dev_alloc(iqd_t *e, size_t bytes, void **out)
 {
@@ -439,9 +452,11 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         HIP_TRY(e, e->vlen.ensure((size_t)n_ch * sizeof(uint32_t)));
         HIP_TRY(e, launch_magnitude((const uint8_t *)iq_dev, bytes_per_ch, nullptr, n_ch, e->block_samples,
                                     n_blocks, e->mag_sums.as<uint32_t>(), s));
+        HIP_TRY(e, e->present.ensure((size_t)n_ch * n_blocks));
         q.blk_lists = e->blk_lists.as<uint32_t>();
         q.vlen_out = e->vlen.as<uint32_t>();
-        HIP_TRY(e, launch_squelch(q, s));
+        q.present = e->present.as<uint8_t>();
+        HIP_TRY(e, launch_squelch(q, false, s));
     }
 
     ChainLaunch base{};
@@ -465,6 +480,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
     base.mag_sums = e->mag_sums.as<uint32_t>();
     base.counters = e->d_counters;
     base.mismatch_list = e->d_mismatch;
+    base.stamps = e->d_stamps;
 
     const bool fused_mag = want_mag && !gated;
     bool timed = false;
@@ -498,7 +514,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         HIP_TRY(e, launch_magnitude((const uint8_t *)iq_dev, bytes_per_ch, e->lists[FAM_COUNT].as<uint32_t>(),
                                     (uint32_t)e->h_lists[FAM_COUNT].size(), e->block_samples, n_blocks,
                                     e->mag_sums.as<uint32_t>(), s));
-    if (!gated && (want_mag || pcm_count_dev || signal_present_dev)) HIP_TRY(e, launch_squelch(q, s));
+    if (!gated && (want_mag || pcm_count_dev || signal_present_dev)) HIP_TRY(e, launch_squelch(q, true, s));
 
     // exact-state verification of the WBFM hand-offs (a mismatch has never been observed;
     // the repair path re-runs the affected tiles from the neighbour's exact state)

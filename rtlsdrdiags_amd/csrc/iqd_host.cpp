@@ -68,7 +68,12 @@ void build_consts(Consts &c)
     c.db_table[0] = c.db_table[1];
     c.deemph_b0 = taps::DEEMPH_B0;
     c.deemph_a1 = taps::DEEMPH_A1;
-    c.deemph_c128 = (float)pow(-(double)taps::DEEMPH_A1, 128.0);
+    const double cc = -(double)taps::DEEMPH_A1;
+    c.deemph_c = (float)cc;
+    c.deemph_c16 = (float)pow(cc, 16.0);
+    c.deemph_c127 = (float)pow(cc, 127.0);
+    c.deemph_c128 = (float)pow(cc, 128.0);
+    c.deemph_cinv = (float)(1.0 / cc);
     c.dc_a1 = taps::DCBLOCK_A1;
 }
 

@@ -42,6 +42,7 @@ struct ChainLaunch {
     uint32_t *counters;           // [CNT_COUNT]
     uint32_t *mismatch_list;      // [MAX_MISMATCH_LIST][2]
     int32_t *base8k;              // [n_ch][pcm_stride] AM/SSB 8 kS/s intermediates
+    unsigned long long *stamps;   // diagnostic builds (IQD_STAMPS): [16] phase cycle sums
 };
 
 struct SquelchLaunch {
@@ -49,6 +50,7 @@ struct SquelchLaunch {
     const ChanParams *params;
     const uint32_t *mag_sums;     // [n_ch][n_blocks]
     uint32_t *tracker;            // [engine ch] SignalTracker state
+    uint8_t *present;             // scratch [n_ch][n_blocks] (squelch-gated calls)
     uint32_t *magnitude;          // out, optional
     uint8_t *allowed;             // out, optional
     uint32_t *blk_lists;          // out, optional
@@ -64,7 +66,7 @@ hipError_t launch_wbfm_commit(const ChainLaunch &a, hipStream_t s);
 hipError_t launch_tail_update(const ChainLaunch &a, int family, hipStream_t s);
 hipError_t launch_magnitude(const uint8_t *iq, size_t ch_stride_bytes, const uint32_t *ch_list, uint32_t n_list,
                             uint32_t block_samples, uint32_t n_blocks, uint32_t *mag_sums, hipStream_t s);
-hipError_t launch_squelch(const SquelchLaunch &q, hipStream_t s);
+hipError_t launch_squelch(const SquelchLaunch &q, bool always_open, hipStream_t s);
 hipError_t launch_tile_fill(uint8_t *dst, size_t period, size_t total, hipStream_t s);
 
 }  // namespace iqd

@@ -32,6 +32,17 @@ struct DeviceExec {
         return __all(ok);
     }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
+#ifdef IQD_STAMPS   // diagnostic build only: cycles per phase, summed over workgroups
+    unsigned long long last = 0, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    __device__ __forceinline__ void stamp(int k)
+    {
+        const unsigned long long now = __builtin_readcyclecounter();
+        if (last) acc[k] += now - last;
+        last = now;
+    }
+#else
+    __device__ __forceinline__ void stamp(int) const {}
+#endif
 };
 
 __device__ __forceinline__ void rotation_selectors(int rotation, WbfmTile &t)
@@ -74,6 +85,7 @@ __global__ __launch_bounds__(WB_THREADS) void wbfm_chain_kernel(const ChainLaunc
     t.tlen = (int32_t)(((int64_t)vlen - v0) < (int64_t)a.tile_len ? ((int64_t)vlen - v0) : (int64_t)a.tile_len);
     rotation_selectors(p.rotation, t);
     t.k = p.wbfm_k;
+    t.bounded = (fabsf(p.wbfm_k) * 3.1730f < 2147483648.0f) ? 1u : 0u;
     t.lut = a.atan_lut;
     t.pcm_row = a.pcm + (size_t)ch * a.pcm_stride;
     t.mag_row = MAG ? a.mag_sums + (size_t)ch * a.n_blocks : nullptr;
@@ -90,6 +102,10 @@ __global__ __launch_bounds__(WB_THREADS) void wbfm_chain_kernel(const ChainLaunc
     DeviceExec ex{(int)threadIdx.x};
     wbfm_tile<GATED, MAG>(ex, t, g_consts, lds, start, &a.records[(size_t)li * a.tiles_per_ch + tile]);
     if (threadIdx.x == 0 && lds.repair_count) atomicAdd(&a.counters[CNT_SEG_REPAIRS], lds.repair_count);
+#ifdef IQD_STAMPS
+    if (a.stamps && (threadIdx.x == 0 || threadIdx.x == 64))
+        for (int k = 0; k < 8; k++) atomicAdd(&a.stamps[(threadIdx.x ? 8 : 0) + k], ex.acc[k]);
+#endif
 }
 
 // Hand-off check between consecutive tiles of a channel: a cold tile's own state at its
@@ -183,34 +199,54 @@ __global__ __launch_bounds__(256) void magnitude_kernel(const uint8_t *iq, size_
     if (threadIdx.x == 0) mag_sums[(size_t)ch * n_blocks + blk] = part[0] + part[1] + part[2] + part[3];
 }
 
-// Squelch decisions (SignalDetector.cc:259-271, SignalTracker.cc:104-145, Squelch.cc:240-269)
-// and output bookkeeping; one thread per channel walks its blocks in order.
-__global__ void squelch_kernel(const SquelchLaunch q)
+// Squelch, part 1 (SignalDetector.cc:249-271): per (channel, block) average magnitude and the
+// "signal present" comparison.  When no channel's squelch can close (always_open) this is the
+// whole squelch: every block is allowed and the tracker ends in its Tracking state.
+__global__ void squelch_block_kernel(const SquelchLaunch q, int always_open)
+{
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= q.n_ch * q.n_blocks) return;
+    const uint32_t ch = idx / q.n_blocks, b = idx - ch * q.n_blocks;
+    const uint32_t ech = q.first_ch + ch;
+    const ChanParams &p = q.params[ech];
+    const uint32_t avg = q.mag_sums[idx] / q.block_samples;
+    const uint32_t m = avg > 127u ? 127u : avg;  // DbfsCalculator.cc:122-125, full scale 127
+    int32_t dbfs = g_consts.db_table[m] - 42;
+    dbfs = (int32_t)((uint32_t)dbfs - p.rx_gain_db);
+    const uint32_t present = dbfs >= p.threshold ? 1u : 0u;
+    if (q.magnitude) q.magnitude[idx] = avg;
+    if (always_open) {
+        if (q.allowed) q.allowed[idx] = 1;
+        if (b == q.n_blocks - 1) q.tracker[ech] = 1u;
+        if (b == 0 && q.pcm_count) q.pcm_count[ch] = p.mode == 0 ? 0u : q.n_blocks * q.block_samples / 32u;
+    } else {
+        q.present[idx] = (uint8_t)present;
+    }
+}
+
+// Squelch, part 2 (SignalTracker.cc:104-145, Squelch.cc:240-269): the two-state tracker with its
+// one-block tail, the list of open blocks and the open length; one thread per channel.
+__global__ void squelch_track_kernel(const SquelchLaunch q)
 {
     const uint32_t ch = blockIdx.x * blockDim.x + threadIdx.x;
     if (ch >= q.n_ch) return;
     const uint32_t ech = q.first_ch + ch;
-    const ChanParams p = q.params[ech];
+    const int32_t mode = q.params[ech].mode;
     uint32_t tracking = q.tracker[ech];
     uint32_t open = 0;
     for (uint32_t b = 0; b < q.n_blocks; b++) {
-        const uint32_t avg = q.mag_sums[(size_t)ch * q.n_blocks + b] / q.block_samples;
-        uint32_t m = avg > 127u ? 127u : avg;  // DbfsCalculator.cc:122-125, full scale 127
-        int32_t dbfs = g_consts.db_table[m] - 42;
-        dbfs = (int32_t)((uint32_t)dbfs - p.rx_gain_db);
-        const uint32_t present = dbfs >= p.threshold ? 1u : 0u;
+        const uint32_t present = q.present[(size_t)ch * q.n_blocks + b];
         const uint32_t allowed = present | tracking;
         tracking = present;
-        if (q.magnitude) q.magnitude[(size_t)ch * q.n_blocks + b] = avg;
         if (q.allowed) q.allowed[(size_t)ch * q.n_blocks + b] = (uint8_t)allowed;
         if (allowed) {
-            if (q.blk_lists) q.blk_lists[(size_t)ch * q.n_blocks + open] = b;
+            q.blk_lists[(size_t)ch * q.n_blocks + open] = b;
             open++;
         }
     }
     q.tracker[ech] = tracking;
-    const uint32_t vlen = (p.mode == 0) ? 0u : open * q.block_samples;
-    if (q.vlen_out) q.vlen_out[ch] = vlen;
+    const uint32_t vlen = (mode == 0) ? 0u : open * q.block_samples;
+    q.vlen_out[ch] = vlen;
     if (q.pcm_count) q.pcm_count[ch] = vlen / 32u;
 }
 
@@ -282,9 +318,12 @@ hipError_t launch_magnitude(const uint8_t *iq, size_t ch_stride_bytes, const uin
     return hipGetLastError();
 }
 
-hipError_t launch_squelch(const SquelchLaunch &q, hipStream_t s)
+hipError_t launch_squelch(const SquelchLaunch &q, bool always_open, hipStream_t s)
 {
-    hipLaunchKernelGGL(squelch_kernel, dim3((q.n_ch + 63) / 64), dim3(64), 0, s, q);
+    const uint32_t n = q.n_ch * q.n_blocks;
+    hipLaunchKernelGGL(squelch_block_kernel, dim3((n + 255) / 256), dim3(256), 0, s, q, always_open ? 1 : 0);
+    if (!always_open)
+        hipLaunchKernelGGL(squelch_track_kernel, dim3((q.n_ch + 63) / 64), dim3(64), 0, s, q);
     return hipGetLastError();
 }
 

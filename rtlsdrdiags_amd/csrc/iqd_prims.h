@@ -23,8 +23,8 @@
 
 namespace iqd {
 
-struct u32x4 { uint32_t x, y, z, w; };
-struct u32x2 { uint32_t x, y; };
+struct alignas(16) u32x4 { uint32_t x, y, z, w; };
+struct alignas(8) u32x2 { uint32_t x, y; };
 
 IQD_DEV uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 IQD_DEV float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
@@ -117,8 +117,10 @@ IQD_DEV float wrap_delta(float d)
     const float PI_F = 3.14159274101257324f;       // smallest float > M_PI
     const float TWO_PI_HI = 6.28318548202514648f;  // (float)(2*M_PI)
     const float TWO_PI_LO = -1.74845553146951715e-7f;  // (float)(2*M_PI - TWO_PI_HI)
-    if (d >= PI_F) d = (d - TWO_PI_HI) - TWO_PI_LO;
-    else if (d <= -PI_F) d = (d + TWO_PI_HI) + TWO_PI_LO;
+    // k = sign(d) when |d| >= pi else 0;  d - k*HI is exact (Sterbenz), then one rounding
+    const float k = (__builtin_fabsf(d) >= PI_F) ? __builtin_copysignf(1.0f, d) : 0.0f;
+    d = __builtin_fmaf(-k, TWO_PI_HI, d);
+    d = __builtin_fmaf(-k, TWO_PI_LO, d);
     return d;
 }
 
@@ -131,5 +133,11 @@ IQD_DEV int32_t cast_i16(float f)
     else wide = (int32_t)0x80000000u;
     return (int32_t)(int16_t)(uint16_t)((uint32_t)wide & 0xffffu);
 }
+
+// The same cast when the caller has proved |f| < 2^31 (v_cvt_i32_f32 truncates toward zero).
+IQD_DEV uint32_t cast_i16_bounded(float f) { return (uint32_t)(int32_t)f; }
+
+// low halves of two dwords -> one dword (a.lo | b.lo << 16), v_perm_b32
+IQD_DEV uint32_t pack_lo16(uint32_t a, uint32_t b) { return perm(b, a, 0x05040100u); }
 
 }  // namespace iqd

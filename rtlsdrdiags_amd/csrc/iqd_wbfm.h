@@ -26,9 +26,16 @@ namespace iqd {
 
 constexpr int WB_THREADS = 256;
 constexpr int WB_BIAS = 16384 + (128 << 15);  // Q15 rounding term + 128 for the table index
+constexpr int TGRAN = TSTRIDE / 4;            // 16-byte granules per segment of the IIR input
+
+// Granule gi (0..31) of a segment sits at gi ^ ((gi >> 3) & 3): phase 1 writes 16 consecutive
+// samples per lane (8 lanes -> 8 different bank groups) and the IIR lanes, one segment each,
+// stay conflict-free because the segment stride is 33 granules.
+IQD_DEV int t_slot(int seg, int gi) { return seg * TGRAN + (gi ^ ((gi >> 3) & 3)); }
 
 struct WbfmLds {
-    float t[WBFM_NSEG * TSTRIDE];          // u[n] = b0 * (K * dtheta[n]), segment-strided
+    u32x4 t4[WBFM_NSEG * TGRAN];           // u[n] = b0 * (K * dtheta[n]) as float bits: per segment
+                                           // 32 granules of 4 samples (XOR-swizzled) + 1 pad
     uint32_t w[WBFM_NSEG * WSTRIDE];       // (int16)y[n], two per dword, segment-strided
     uint32_t y1[(8 + WBFM_CHUNK / 4) / 2];   // stage-1 output with 8 samples of history
     uint32_t y2[(40 + WBFM_CHUNK / 16) / 2]; // stage-2 output with 40 samples of history
@@ -41,6 +48,11 @@ struct WbfmLds {
     uint32_t repair_count;
 };
 
+// Per 16-sample group: sum c^(15-k) u[k], input of the IIR state guess.  Lives in the data part of
+// y1 (dead between the end of a chunk's decimation and the next chunk's stage 1).
+IQD_DEV float *lds_part(WbfmLds &lds) { return (float *)&lds.y1[4]; }
+static_assert(WBFM_NSEG * 8 * 4 <= (WBFM_CHUNK / 4 / 2) * 4, "part[] must fit in y1's data region");
+
 struct WbfmTile {
     const uint8_t *iq_ch;        // the channel's input row (virtual sample 0)
     const uint8_t *tail;         // the channel's WBFM tail: virtual samples [-TAIL, 0)
@@ -51,6 +63,7 @@ struct WbfmTile {
     int32_t tlen;                // tile length
     uint32_t sel_i, sel_q, neg_i, neg_q;  // rotation as byte selectors / negate masks
     float k;                     // (gain / 75000) * 32767
+    uint32_t bounded;            // |k| * pi * 1.01 < 2^31: (int16) casts cannot hit the indefinite value
     const float *lut;            // atan2 table, lut[y * 256 + x]
     int16_t *pcm_row;            // PCM of virtual sample 0
     uint32_t *mag_row;           // per-block magnitude sums of this channel
@@ -157,19 +170,28 @@ IQD_DEV void wbfm_phase1(const WbfmTile &t, const Consts &c, WbfmLds &lds, const
         float th[17];
 #pragma unroll
         for (int k = 0; k < 17; k++) {
-            const uint32_t ix = bfe((uint32_t)ai[k], 15, 8);   // (uint8)((int8)I' + 128)
-            const uint32_t iy = bfe((uint32_t)aq[k], 15, 8);
-            th[k] = t.lut[(iy << 8) | ix];
+            // byte offset of lut[(uint8)(Q'+128)][(uint8)(I'+128)]: bits 15..22 of each accumulator
+            const uint32_t off = (((uint32_t)aq[k] >> 5) & 0x3fc00u) | (((uint32_t)ai[k] >> 13) & 0x3fcu);
+            th[k] = *(const float *)((const char *)t.lut + off);
         }
         const int p = n0 - cstart;  // position inside the chunk
-        float *dst = &lds.t[(p >> 7) * TSTRIDE + (p & 127)];
+        const int seg = p >> 7, gq = (p & 127) >> 4;
+        float u[16];
+        const float cc = c.deemph_c;
+        float part = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             float d = th[k + 1] - th[k];
             d = wrap_delta(d);
             const float v1 = t.k * d;
-            dst[k] = c.deemph_b0 * v1;
+            u[k] = c.deemph_b0 * v1;
+            part = __builtin_fmaf(cc, part, u[k]);
         }
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            lds.t4[t_slot(seg, 4 * gq + q)] =
+                u32x4{f2u(u[4 * q]), f2u(u[4 * q + 1]), f2u(u[4 * q + 2]), f2u(u[4 * q + 3])};
+        lds_part(lds)[8 * seg + gq] = part;
         if (MAG && cstart >= 0) {
             uint32_t m = 0;
 #pragma unroll
@@ -203,26 +225,36 @@ IQD_DEV void wbfm_flush_mag(const WbfmTile &t, WbfmLds &lds, const ChunkBlocks &
 }
 
 // ---- de-emphasis IIR -----------------------------------------------------------------------
+IQD_DEV float t_last(const WbfmLds &lds, int seg) { return u2f(lds.t4[t_slot(seg, 31)].w); }
+
 IQD_DEV float iir_u_before(const WbfmLds &lds, int seg)  // u[n-1] at the start of a segment
 {
-    return seg == 0 ? lds.u_carry : lds.t[(seg - 1) * TSTRIDE + (SEG - 1)];
+    return seg == 0 ? lds.u_carry : t_last(lds, seg - 1);
 }
 
-// lane j: zero-state response of segment j in plain float arithmetic (guess only).
+// lane j: approximate zero-state response of segment j to t[n] = u[n] + u[n-1], from the
+// per-group partial sums phase 1 left (plain float arithmetic: this is only the state GUESS).
+//   S = sum c^(127-i) u[i];  response = S + c^127 u[-1] + (S - u[127]) / c
 IQD_DEV void iir_guess(const Consts &c, WbfmLds &lds, int nseg, int lane)
 {
     if (lane == 0) lds.z[3] = lds.y_carry, lds.z[2] = 0.f, lds.z[1] = 0.f, lds.z[0] = 0.f;
     if (lane >= nseg) return;
-    const float cc = -c.deemph_a1;
-    const float *src = &lds.t[lane * TSTRIDE];
-    float up = iir_u_before(lds, lane), z = 0.f;
-    for (int i = 0; i < SEG; i++) {
-        const float u = src[i];
-        z = cc * z + (u + up);
-        up = u;
-    }
+    float sum = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; g++) sum = __builtin_fmaf(c.deemph_c16, sum, lds_part(lds)[8 * lane + g]);
+    const float z = sum + c.deemph_c127 * iir_u_before(lds, lane) + (sum - t_last(lds, lane)) * c.deemph_cinv;
     lds.z[4 + lane] = z;
 }
+
+// One de-emphasis step, exactly as IirFilter::filterData evaluates it (IirFilter.cc:161-176):
+// y = (b0 x[n] + b1 x[n-1]) - (a1 y[n-1]), every operation rounded to binary32.
+#define IQD_IIR_STEP(U)            \
+    {                              \
+        const float tn_ = (U) + up; \
+        const float r_ = a1 * y;   \
+        y = tn_ - r_;              \
+        up = (U);                  \
+    }
 
 // lane j >= 1: run segment j-1 from the guessed state to get the state entering segment j.
 IQD_DEV void iir_warm(const Consts &c, WbfmLds &lds, int nseg, int lane)
@@ -234,39 +266,58 @@ IQD_DEV void iir_warm(const Consts &c, WbfmLds &lds, int nseg, int lane)
     const float *zz = &lds.z[4 + lane - 2];
     float y = zz[0] + a * (zz[-1] + a * (zz[-2] + a * zz[-3]));
     if (lane == 1) y = lds.y_carry;  // exact
-    const float *src = &lds.t[(lane - 1) * TSTRIDE];
     float up = iir_u_before(lds, lane - 1);
     const float a1 = c.deemph_a1;
-    for (int i = 0; i < SEG; i++) {
-        const float u = src[i];
-        const float tn = u + up;
-        const float r = a1 * y;
-        y = tn - r;
-        up = u;
+#pragma unroll 2
+    for (int gi = 0; gi < 32; gi += 2) {
+        const u32x4 a4 = lds.t4[t_slot(lane - 1, gi)], b4 = lds.t4[t_slot(lane - 1, gi + 1)];
+        IQD_IIR_STEP(u2f(a4.x)) IQD_IIR_STEP(u2f(a4.y)) IQD_IIR_STEP(u2f(a4.z)) IQD_IIR_STEP(u2f(a4.w))
+        IQD_IIR_STEP(u2f(b4.x)) IQD_IIR_STEP(u2f(b4.y)) IQD_IIR_STEP(u2f(b4.z)) IQD_IIR_STEP(u2f(b4.w))
     }
     lds.g[lane] = y;
 }
 
 // lane j: the real pass over segment j from g[j]; writes (int16)y and e[j].
-IQD_DEV void iir_real(const Consts &c, WbfmLds &lds, int nseg, int lane)
+// bounded: the host proved |y| < 2^31 for this launch (|K| pi * 1.01 < 2^31), so the cast needs
+// no "integer indefinite" handling.
+IQD_DEV void iir_real(const Consts &c, WbfmLds &lds, int nseg, int lane, bool bounded)
 {
     if (lane >= nseg) return;
-    const float *src = &lds.t[lane * TSTRIDE];
-    uint32_t *dst = &lds.w[lane * WSTRIDE];
+    u32x4 *dst = (u32x4 *)&lds.w[lane * WSTRIDE];
     float up = iir_u_before(lds, lane), y = lds.g[lane];
     const float a1 = c.deemph_a1;
-    for (int i = 0; i < SEG; i += 2) {
-        const float u0 = src[i], u1 = src[i + 1];
-        const float t0 = u0 + up;
-        const float r0 = a1 * y;
-        y = t0 - r0;
-        const uint32_t w0 = (uint32_t)cast_i16(y) & 0xffffu;
-        const float t1 = u1 + u0;
-        const float r1 = a1 * y;
-        y = t1 - r1;
-        const uint32_t w1 = (uint32_t)cast_i16(y) & 0xffffu;
-        up = u1;
-        dst[i >> 1] = w0 | (w1 << 16);
+    if (bounded) {
+#pragma unroll 2
+        for (int gi = 0; gi < 32; gi += 2) {
+            const u32x4 a4 = lds.t4[t_slot(lane, gi)], b4 = lds.t4[t_slot(lane, gi + 1)];
+            uint32_t w[8];
+            IQD_IIR_STEP(u2f(a4.x)) w[0] = cast_i16_bounded(y);
+            IQD_IIR_STEP(u2f(a4.y)) w[1] = cast_i16_bounded(y);
+            IQD_IIR_STEP(u2f(a4.z)) w[2] = cast_i16_bounded(y);
+            IQD_IIR_STEP(u2f(a4.w)) w[3] = cast_i16_bounded(y);
+            IQD_IIR_STEP(u2f(b4.x)) w[4] = cast_i16_bounded(y);
+            IQD_IIR_STEP(u2f(b4.y)) w[5] = cast_i16_bounded(y);
+            IQD_IIR_STEP(u2f(b4.z)) w[6] = cast_i16_bounded(y);
+            IQD_IIR_STEP(u2f(b4.w)) w[7] = cast_i16_bounded(y);
+            dst[gi >> 1] = u32x4{pack_lo16(w[0], w[1]), pack_lo16(w[2], w[3]),
+                                 pack_lo16(w[4], w[5]), pack_lo16(w[6], w[7])};
+        }
+        lds.e[lane] = y;
+        return;
+    }
+#pragma unroll 2
+    for (int gi = 0; gi < 32; gi += 2) {
+        const u32x4 a4 = lds.t4[t_slot(lane, gi)], b4 = lds.t4[t_slot(lane, gi + 1)];
+        uint32_t w[8];
+        IQD_IIR_STEP(u2f(a4.x)) w[0] = (uint32_t)cast_i16(y) & 0xffffu;
+        IQD_IIR_STEP(u2f(a4.y)) w[1] = (uint32_t)cast_i16(y) << 16;
+        IQD_IIR_STEP(u2f(a4.z)) w[2] = (uint32_t)cast_i16(y) & 0xffffu;
+        IQD_IIR_STEP(u2f(a4.w)) w[3] = (uint32_t)cast_i16(y) << 16;
+        IQD_IIR_STEP(u2f(b4.x)) w[4] = (uint32_t)cast_i16(y) & 0xffffu;
+        IQD_IIR_STEP(u2f(b4.y)) w[5] = (uint32_t)cast_i16(y) << 16;
+        IQD_IIR_STEP(u2f(b4.z)) w[6] = (uint32_t)cast_i16(y) & 0xffffu;
+        IQD_IIR_STEP(u2f(b4.w)) w[7] = (uint32_t)cast_i16(y) << 16;
+        dst[gi >> 1] = u32x4{w[0] | w[1], w[2] | w[3], w[4] | w[5], w[6] | w[7]};
     }
     lds.e[lane] = y;
 }
@@ -420,36 +471,46 @@ IQD_DEV void wbfm_tile(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLds &ld
         const int clen = cstart < 0 ? -cstart : (t.tlen - cstart < WBFM_CHUNK ? t.tlen - cstart : WBFM_CHUNK);
         const int nseg = clen / SEG;
         const ChunkBlocks cb = chunk_blocks(t, cstart);
+        ex.stamp(7);
         ex.all([&](int tid) { wbfm_phase1<GATED, MAG>(t, c, lds, cb, cstart, clen, tid); });
-        if (MAG) ex.all([&](int tid) { wbfm_flush_mag(t, lds, cb, cstart, clen, tid); });
+        ex.stamp(0);
         if (ex.in_wave0()) {
             if (rec_pos == cstart) { rec.y_out = lds.y_carry; rec.u_out = lds.u_carry; }
             ex.wave0([&](int lane) { iir_guess(c, lds, nseg, lane); });
+            ex.stamp(1);
             ex.wave0([&](int lane) { iir_warm(c, lds, nseg, lane); });
+            ex.stamp(2);
             int rounds = 0;
             do {
-                ex.wave0([&](int lane) { iir_real(c, lds, nseg, lane); });
+                ex.wave0([&](int lane) { iir_real(c, lds, nseg, lane, t.bounded != 0); });
                 rounds++;
             } while (!ex.wave0_all([&](int lane) { return iir_check(lds, nseg, lane); }));
+            ex.stamp(3);
             if (rec_pos > cstart && rec_pos < cstart + clen) {
                 const int seg = (rec_pos - cstart) / SEG - 1;
                 rec.y_out = lds.e[seg];
-                rec.u_out = lds.t[seg * TSTRIDE + SEG - 1];
+                rec.u_out = t_last(lds, seg);
             }
             if (start.cold && cstart < 0) rec.y_in = lds.e[(COLD_HALO - FORCED_BACK) / SEG - 1];
             ex.wave0([&](int lane) {
                 if (lane == 0) {
                     lds.y_carry = lds.e[nseg - 1];
-                    lds.u_carry = lds.t[(nseg - 1) * TSTRIDE + SEG - 1];
+                    lds.u_carry = t_last(lds, nseg - 1);
                     lds.repair_count += (uint32_t)(rounds - 1);
                 }
             });
         }
         ex.sync();
-        ex.all([&](int tid) { wbfm_stage1(c, lds, clen, tid); });
+        ex.stamp(4);
+        ex.all([&](int tid) {
+            if (MAG) wbfm_flush_mag(t, lds, cb, cstart, clen, tid);
+            wbfm_stage1(c, lds, clen, tid);
+        });
+        ex.stamp(5);
         ex.all([&](int tid) { wbfm_stage2(c, lds, clen, tid); });
         ex.all([&](int tid) { wbfm_stage3(c, lds, t, cstart, clen, tid); });
         ex.all([&](int tid) { wbfm_shift_history(lds, clen, tid); });
+        ex.stamp(6);
         cstart += clen;
     }
     if (ex.in_wave0() && rec_out) {

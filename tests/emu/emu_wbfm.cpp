@@ -7,6 +7,7 @@
 // with the squelch open.  Nothing in the product links or loads this file.
 #define IQD_HOST_EMU 1
 #include <stdint.h>
+#include <math.h>
 #include <string.h>
 
 #include <vector>
@@ -27,6 +28,7 @@ struct HostExec {
         return ok;
     }
     void sync() const {}
+    void stamp(int) const {}
 };
 
 }  // namespace
@@ -74,6 +76,7 @@ int emu_wbfm_accept(const uint8_t *iq, uint32_t n_samples, uint32_t tile_len, ui
             t.neg_q = rotation > 0 ? 0xffff0000u : 0x00ffff00u;
         }
         t.k = p.wbfm_k;
+        t.bounded = (fabsf(p.wbfm_k) * 3.1730f < 2147483648.0f) ? 1u : 0u;
         t.lut = lut.data();
         t.pcm_row = pcm;
         t.mag_row = mag_sums;

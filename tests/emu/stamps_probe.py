@@ -1,0 +1,15 @@
+import sys, os
+sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT','.'))
+import numpy as np, torch
+from rtlsdrdiags_amd import capi, synth
+n = 1<<28; period = 1<<24
+u8 = synth.fm_tone(period, seed=1234)
+iq = torch.from_numpy(u8).cuda().repeat(n//period)
+pcm = torch.zeros(n//32, dtype=torch.int16, device='cuda'); torch.cuda.synchronize()
+eng = capi.Engine(1); eng.set_mode('wbfm')
+for _ in range(3): eng.accept_device(iq.data_ptr(), 2*n, pcm.data_ptr())
+s = eng.debug_stamps()
+names = ['P1','guess','warm','real+check','finish/wait','S1','S2+S3+shift','loop-top']
+for w in (0,1):
+    tot = sum(s[8*w:8*w+8]) or 1
+    print('wave', w, ' '.join('%s=%.1f%%' % (names[k], 100.0*s[8*w+k]/tot) for k in range(8)), 'total Mcycles', tot/1e6)

@@ -67,6 +67,15 @@ def test_rotation_and_cast_overflow_gain(emu, oracle, rotation):
     assert np.array_equal(np.concatenate(out), ref)
 
 
+def test_unbounded_cast_path(emu, oracle):
+    """A gain so large that y leaves the int32 range: the slow cast with x86 'indefinite' rules."""
+    u8 = synth.fm_tone(16384, seed=10, amplitude=100.0)
+    ref, _, _ = oracle_wbfm(oracle, u8, gain=6.0e9)
+    ch = emu_bind.WbfmChannel(emu, 8192, gain=6.0e9)
+    pcm, _ = ch.accept(u8)
+    assert np.array_equal(pcm, ref)
+
+
 def test_reset_keeps_deemphasis_state(emu, oracle):
     u8 = synth.fm_tone(2 * 16384, seed=12)
     c = oracle.chain()
