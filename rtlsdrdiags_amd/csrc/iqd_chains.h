@@ -1,0 +1,362 @@
+// FM, AM and SSB chains (FmDemodulator.cc:376-560, AmDemodulator.cc:339-504,
+// SsbDemodulator.cc:462-598 behind IqDataProcessor.cc:735-749) as per-thread phase functions,
+// in the same tile / chunk scheme as the WBFM chain (iqd_wbfm.h).
+//
+// Every decimating stage here is a FIR: with the raw tail in front of a tile all histories are
+// rebuilt exactly from bytes, so tiles are independent.  The only recurrence left is the
+// 8 kS/s DC-removal IIR of AM and SSB; the tile kernels stop in front of it (they emit its
+// integer input at 8 kS/s) and dc_kernel runs it with the exact carried state.
+//
+// Overflow: the reference clamps its Q15 accumulators after every MAC.  Fed with int8 samples
+// the AM/SSB stages and the FM tuner can be bounded once and for all (|acc| stays below 2^30:
+// see the bounds next to each stage), so those sums use v_dot4 / v_dot2 in any order; the FM
+// post-demodulation stages see arbitrary int16 values and keep the sequential clamp.
+#pragma once
+#include "iqd_wbfm.h"
+
+namespace iqd {
+
+typedef WbfmTile Tile;
+
+constexpr int CH_CHUNK = 8192;       // samples per chunk of the FM / AM / SSB tile kernels
+constexpr int FIR_HALO = 1280;       // raw history a tile rebuilds its FIR states from
+                                     // (FM needs 684, AM 260, SSB 1220 samples)
+
+// ---- shared front end: raw u8 -> signed -> rotated rail dwords in LDS, + squelch magnitude ----
+template <bool GATED, bool MAG, class Lds>
+IQD_DEV void front_rotate(const Tile &t, Lds &lds, const ChunkBlocks &cb, int cstart, int clen, int tid,
+                          int rail_hist)
+{
+    const int ngroups = clen >> 4;
+    for (int g = tid; g < ngroups; g += WB_THREADS) {
+        const int64_t v = t.v0 + cstart + 16 * g;
+        const u32x4 *po = raw_group<GATED>(t, v);
+        const u32x4 r2 = po[0], r3 = po[1];
+        uint32_t s[8] = {r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
+        uint32_t xi[4], xq[4];
+#pragma unroll
+        for (int j = 0; j < 8; j++) s[j] ^= 0x80808080u;
+#pragma unroll
+        for (int j = 0; j < 4; j++) rotate4(t, s[2 * j], s[2 * j + 1], xi[j], xq[j]);
+        *(u32x4 *)&lds.xi[rail_hist + 4 * g] = u32x4{xi[0], xi[1], xi[2], xi[3]};
+        *(u32x4 *)&lds.xq[rail_hist + 4 * g] = u32x4{xq[0], xq[1], xq[2], xq[3]};
+        if (MAG && cstart >= 0) {
+            uint32_t m = 0;
+#pragma unroll
+            for (int j = 0; j < 8; j++) m += magnitude2(s[j]);
+            const uint32_t slot = div_block(t, cb.in_blk + (uint32_t)(16 * g));
+#if IQD_ON_DEVICE
+            atomicAdd(&lds.mag[slot], m);
+#else
+            lds.mag[slot] += m;
+#endif
+        }
+    }
+}
+
+template <class Lds>
+IQD_DEV void flush_mag(const Tile &t, Lds &lds, const ChunkBlocks &cb, int cstart, int clen, int tid)
+{
+    if (cstart < 0) return;
+    const uint32_t nslots = div_block(t, cb.in_blk + (uint32_t)clen - 1) + 1;
+    if ((uint32_t)tid < nslots) {
+        const uint32_t m = lds.mag[tid];
+        lds.mag[tid] = 0;
+#if IQD_ON_DEVICE
+        if (m) atomicAdd(&t.mag_row[cb.base_blk + tid], m);
+#else
+        t.mag_row[cb.base_blk + tid] += m;
+#endif
+    }
+}
+
+// Q15 dot product without the clamp (only where the bound proves it cannot fire);
+// buf is an int16 array, `newest` the index of x[n], taps newest first.
+template <int L>
+IQD_DEV int q15_free(const int16_t *h, const uint32_t *buf, int newest)
+{
+    int acc = 1 << 14;
+#pragma unroll
+    for (int k = 0; k < L; k++) {
+        const int idx = newest - k;
+        const uint32_t pair = buf[idx >> 1];
+        const uint32_t tap = (idx & 1) ? ((uint32_t)(uint16_t)h[k] << 16) : (uint32_t)(uint16_t)h[k];
+        acc = dot2(pair, tap, acc);
+    }
+    return acc >> 15;
+}
+
+// Moves the last `n_dwords` of a buffer's data region (which holds `used` dwords after a
+// history region of n_dwords) to its front.  Ranges never overlap when used >= n_dwords.
+IQD_DEV void shift_hist(uint32_t *buf, int n_dwords, int used, int tid, int first_tid)
+{
+    const int k = tid - first_tid;
+    if (k < 0 || k >= n_dwords) return;
+    if (used >= n_dwords) buf[k] = buf[used + k];
+}
+IQD_DEV void shift_hist_serial(uint32_t *buf, int n_dwords, int used)  // used < n_dwords
+{
+    for (int k = 0; k < n_dwords; k++) buf[k] = buf[used + k];
+}
+
+// =============================================================================================
+// FM
+// =============================================================================================
+struct FmLds {
+    alignas(16) uint32_t xi[8 + CH_CHUNK / 4];               // rail dwords (4 samples each), 8 of history
+    alignas(16) uint32_t xq[8 + CH_CHUNK / 4];
+    alignas(16) float theta[4 + CH_CHUNK / 4];               // 64 kS/s phase, 4 of history
+    alignas(16) uint32_t e[(12 + CH_CHUNK / 4) / 2];         // int16 (int16)(K*dtheta), 12 of history
+    alignas(16) uint32_t y2[(40 + CH_CHUNK / 16) / 2];       // int16 16 kS/s, 40 of history
+    alignas(16) uint32_t mag[CH_CHUNK / SEG + 2];
+};
+
+// Tuner decimator /4, 32 taps (FmDemodulator.cc:389-419) + phase angle (:476).
+// Bound: |acc| <= 16384 + 35938*128 < 2^23, no clamp; |y| <= 141 -> the theta table.
+IQD_DEV void fm_stage1(const Tile &t, const Consts &c, FmLds &lds, int clen, int tid, const float *fm_lut)
+{
+    const int ngroups = clen >> 4;
+    for (int g = tid; g < ngroups; g += WB_THREADS) {
+        const u32x4 *pi = (const u32x4 *)&lds.xi[4 * g], *pq = (const u32x4 *)&lds.xq[4 * g];
+        const u32x4 a0 = pi[0], a1 = pi[1], a2 = pi[2], b0 = pq[0], b1 = pq[1], b2 = pq[2];
+        const uint32_t di[12] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w};
+        const uint32_t dq[12] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w};
+        float th[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {   // output m = 4g + r uses rail dwords [m-7, m] = d[1+r .. 8+r]
+            int li = 1 << 14, hi = 0, lq = 1 << 14, hq = 0;
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                li = dot4(di[1 + r + q], c.fm_tuner_lo[q], li);
+                hi = dot4(di[1 + r + q], c.fm_tuner_hi[q], hi);
+                lq = dot4(dq[1 + r + q], c.fm_tuner_lo[q], lq);
+                hq = dot4(dq[1 + r + q], c.fm_tuner_hi[q], hq);
+            }
+            const int yi = (li + (int)((uint32_t)hi << 8)) >> 15;
+            const int yq = (lq + (int)((uint32_t)hq << 8)) >> 15;
+            th[r] = fm_lut[(yq + FM_LUT_R) * FM_LUT_W + (yi + FM_LUT_R)];
+        }
+        *(u32x4 *)&lds.theta[4 + 4 * g] = u32x4{f2u(th[0]), f2u(th[1]), f2u(th[2]), f2u(th[3])};
+    }
+    (void)t;
+}
+
+// Differentiator theta[n-2] - theta[n-4] (FmDemodulator.cc:113-122,479), branch cut, scale,
+// (int16) cast (:485-498, :540).
+IQD_DEV void fm_discriminate(const Tile &t, FmLds &lds, int clen, int tid)
+{
+    const int nout = clen >> 2;
+    for (int m = tid; m < nout; m += WB_THREADS) {
+        float d = lds.theta[4 + m - 2] - lds.theta[4 + m - 4];
+        d = wrap_delta(d);
+        const float v = t.k * d;
+        put_i16(lds.e, 12 + m, t.bounded ? (int)cast_i16_bounded(v) : cast_i16(v));
+    }
+}
+
+IQD_DEV void fm_post(const Consts &c, FmLds &lds, int clen, int tid)   // /4, 12 taps (:545)
+{
+    const int nout = clen >> 4;
+    for (int j = tid; j < nout; j += WB_THREADS)
+        put_i16(lds.y2, 40 + j, q15_seq<12>(c.post12, lds.e, 12 + 4 * j + 3));
+}
+
+IQD_DEV void fm_audio(const Consts &c, FmLds &lds, const Tile &t, int cstart, int clen, int tid)  // /2, 40 taps
+{
+    const int nout = clen >> 5;
+    for (int i = tid; i < nout; i += WB_THREADS) {
+        const int y = q15_seq<40>(c.audio40, lds.y2, 40 + 2 * i + 1);
+        if (cstart >= 0) t.pcm_row[((t.v0 + cstart) >> 5) + i] = (int16_t)y;
+    }
+}
+
+IQD_DEV void fm_shift(FmLds &lds, int clen, int tid)
+{
+    const int n4 = clen >> 2;                 // rail dwords and 64 kS/s samples in this chunk
+    shift_hist(lds.xi, 8, n4, tid, 0);
+    shift_hist(lds.xq, 8, n4, tid, 8);
+    shift_hist((uint32_t *)lds.theta, 4, n4, tid, 16);
+    shift_hist(lds.e, 6, n4 >> 1, tid, 24);
+    if ((clen >> 5) >= 20) shift_hist(lds.y2, 20, clen >> 5, tid, 32);
+    else if (tid == 32) shift_hist_serial(lds.y2, 20, clen >> 5);
+}
+
+template <bool GATED, bool MAG, class Exec>
+IQD_DEV void fm_tile(Exec &ex, const Tile &t, const Consts &c, FmLds &lds, const float *fm_lut)
+{
+    ex.all([&](int tid) {
+        if (tid < 8) lds.xi[tid] = 0, lds.xq[tid] = 0;
+        if (tid < 4) lds.theta[tid] = 0.f;
+        if (tid < 6) lds.e[tid] = 0;
+        if (tid < 20) lds.y2[tid] = 0;
+        if (tid < CH_CHUNK / SEG + 2) lds.mag[tid] = 0;
+    });
+    for (int cstart = -FIR_HALO; cstart < t.tlen;) {
+        const int clen = cstart < 0 ? -cstart : (t.tlen - cstart < CH_CHUNK ? t.tlen - cstart : CH_CHUNK);
+        const ChunkBlocks cb = chunk_blocks(t, cstart);
+        ex.all([&](int tid) { front_rotate<GATED, MAG>(t, lds, cb, cstart, clen, tid, 8); });
+        ex.all([&](int tid) {
+            if (MAG) flush_mag(t, lds, cb, cstart, clen, tid);
+            fm_stage1(t, c, lds, clen, tid, fm_lut);
+        });
+        ex.all([&](int tid) { fm_discriminate(t, lds, clen, tid); });
+        ex.all([&](int tid) { fm_post(c, lds, clen, tid); });
+        ex.all([&](int tid) { fm_audio(c, lds, t, cstart, clen, tid); });
+        ex.all([&](int tid) { fm_shift(lds, clen, tid); });
+        cstart += clen;
+    }
+}
+
+// =============================================================================================
+// AM and SSB (shared /32 front end)
+// =============================================================================================
+struct AmLds {
+    alignas(16) uint32_t xi[4 + CH_CHUNK / 4];               // rail dwords, 4 of history (1 needed)
+    alignas(16) uint32_t xq[4 + CH_CHUNK / 4];
+    alignas(16) uint32_t s1i[(12 + CH_CHUNK / 4) / 2];       // int16 64 kS/s, 12 of history (8 needed)
+    alignas(16) uint32_t s1q[(12 + CH_CHUNK / 4) / 2];
+    alignas(16) uint32_t s2i[(16 + CH_CHUNK / 16) / 2];      // int16 16 kS/s, 16 of history (14 needed)
+    alignas(16) uint32_t s2q[(16 + CH_CHUNK / 16) / 2];
+    alignas(16) uint32_t s3i[(32 + CH_CHUNK / 32) / 2];      // int16 8 kS/s, 32 of history (30 needed by SSB)
+    alignas(16) uint32_t s3q[(32 + CH_CHUNK / 32) / 2];
+    alignas(16) uint32_t mag[CH_CHUNK / SEG + 2];
+};
+
+// Stage 1: /4, 8 taps.  |acc| <= 16384 + 29002*128 < 2^22; |y| <= 113.
+IQD_DEV void am_stage1(const Consts &c, AmLds &lds, int clen, int tid)
+{
+    const int ngroups = clen >> 4;
+    for (int g = tid; g < ngroups; g += WB_THREADS) {
+        // outputs m = 4g + r use rail dwords [m-1, m] = indices 4 + m - 1, 4 + m
+        uint32_t di[5], dq[5];
+        di[0] = lds.xi[4 + 4 * g - 1];
+        dq[0] = lds.xq[4 + 4 * g - 1];
+        const u32x4 a = *(const u32x4 *)&lds.xi[4 + 4 * g], b = *(const u32x4 *)&lds.xq[4 + 4 * g];
+        di[1] = a.x; di[2] = a.y; di[3] = a.z; di[4] = a.w;
+        dq[1] = b.x; dq[2] = b.y; dq[3] = b.z; dq[4] = b.w;
+        int yi[4], yq[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            int li = 1 << 14, hi = 0, lq = 1 << 14, hq = 0;
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                li = dot4(di[r + q], c.am_s1_lo[q], li);
+                hi = dot4(di[r + q], c.am_s1_hi[q], hi);
+                lq = dot4(dq[r + q], c.am_s1_lo[q], lq);
+                hq = dot4(dq[r + q], c.am_s1_hi[q], hq);
+            }
+            yi[r] = (li + (int)((uint32_t)hi << 8)) >> 15;
+            yq[r] = (lq + (int)((uint32_t)hq << 8)) >> 15;
+        }
+        *(u32x2 *)&lds.s1i[6 + 2 * g] = u32x2{pack_lo16((uint32_t)yi[0], (uint32_t)yi[1]), pack_lo16((uint32_t)yi[2], (uint32_t)yi[3])};
+        *(u32x2 *)&lds.s1q[6 + 2 * g] = u32x2{pack_lo16((uint32_t)yq[0], (uint32_t)yq[1]), pack_lo16((uint32_t)yq[2], (uint32_t)yq[3])};
+    }
+}
+
+// Stage 2: /4, 12 taps.  |x| <= 113 -> |acc| <= 16384 + 34926*113 < 2^22; |y| <= 121.
+IQD_DEV void am_stage2(const Consts &c, AmLds &lds, int clen, int tid)
+{
+    const int nout = clen >> 4;
+    for (int j = tid; j < nout; j += WB_THREADS) {
+        put_i16(lds.s2i, 16 + j, q15_free<12>(c.am_s2, lds.s1i, 12 + 4 * j + 3));
+        put_i16(lds.s2q, 16 + j, q15_free<12>(c.am_s2, lds.s1q, 12 + 4 * j + 3));
+    }
+}
+
+// Stage 3: /2, 16 taps.  |x| <= 121 -> |acc| <= 16384 + 48394*121 < 2^23; |y| <= 179.
+IQD_DEV void am_stage3(const Consts &c, AmLds &lds, int clen, int tid)
+{
+    const int nout = clen >> 5;
+    for (int i = tid; i < nout; i += WB_THREADS) {
+        put_i16(lds.s3i, 32 + i, q15_free<16>(c.am_s3, lds.s2i, 16 + 2 * i + 1));
+        put_i16(lds.s3q, 32 + i, q15_free<16>(c.am_s3, lds.s2q, 16 + 2 * i + 1));
+    }
+}
+
+// Detector input at 8 kS/s -> global scratch (the DC-removal IIR runs in dc_kernel).
+//   AM  (AmDemodulator.cc:446-459): max(|i|,|q|) + min(|i|,|q|)/2 in int16 arithmetic
+//   SSB (SsbDemodulator.cc:574-588): delayed I (the 1.0 tap is -32768 in Q15, so -i[n-15])
+//       -+ Hilbert-transformed Q.  |x| <= 179 -> Hilbert |acc| <= 16384 + 67250*179 < 2^24.
+IQD_DEV void am_detect(const Consts &c, AmLds &lds, const Tile &t, int cstart, int clen, int tid,
+                       int ssb, int lsb, int32_t *base_row)
+{
+    const int nout = clen >> 5;
+    for (int i = tid; i < nout; i += WB_THREADS) {
+        int x;
+        if (!ssb) {
+            const int iv = get_i16(lds.s3i, 32 + i), qv = get_i16(lds.s3q, 32 + i);
+            const int im = (int)(int16_t)(iv < 0 ? -iv : iv), qm = (int)(int16_t)(qv < 0 ? -qv : qv);
+            x = (int)(int16_t)((im > qm) ? im + (qm >> 1) : qm + (im >> 1));
+        } else {
+            const int idl = q15_free<16>(c.ssb_delay, lds.s3i, 32 + i);
+            const int qh = q15_free<31>(c.ssb_hilbert, lds.s3q, 32 + i);
+            x = lsb ? (int)(int16_t)idl - (int)(int16_t)qh : (int)(int16_t)idl + (int)(int16_t)qh;
+        }
+        if (cstart >= 0) base_row[((t.v0 + cstart) >> 5) + i] = x;
+    }
+}
+
+IQD_DEV void am_shift(AmLds &lds, int clen, int tid)
+{
+    const int n4 = clen >> 2;
+    shift_hist(lds.xi, 4, n4, tid, 0);
+    shift_hist(lds.xq, 4, n4, tid, 4);
+    shift_hist(lds.s1i, 6, n4 >> 1, tid, 8);
+    shift_hist(lds.s1q, 6, n4 >> 1, tid, 16);
+    shift_hist(lds.s2i, 8, clen >> 5, tid, 24);
+    shift_hist(lds.s2q, 8, clen >> 5, tid, 32);
+    if ((clen >> 6) >= 16) {
+        shift_hist(lds.s3i, 16, clen >> 6, tid, 40);
+        shift_hist(lds.s3q, 16, clen >> 6, tid, 56);
+    } else if (tid == 40) {
+        shift_hist_serial(lds.s3i, 16, clen >> 6);
+        shift_hist_serial(lds.s3q, 16, clen >> 6);
+    }
+}
+
+template <bool GATED, bool MAG, class Exec>
+IQD_DEV void am_tile(Exec &ex, const Tile &t, const Consts &c, AmLds &lds, int ssb, int lsb, int32_t *base_row)
+{
+    ex.all([&](int tid) {
+        if (tid < 4) lds.xi[tid] = 0, lds.xq[tid] = 0;
+        if (tid < 6) lds.s1i[tid] = 0, lds.s1q[tid] = 0;
+        if (tid < 8) lds.s2i[tid] = 0, lds.s2q[tid] = 0;
+        if (tid < 16) lds.s3i[tid] = 0, lds.s3q[tid] = 0;
+        if (tid < CH_CHUNK / SEG + 2) lds.mag[tid] = 0;
+    });
+    for (int cstart = -FIR_HALO; cstart < t.tlen;) {
+        const int clen = cstart < 0 ? -cstart : (t.tlen - cstart < CH_CHUNK ? t.tlen - cstart : CH_CHUNK);
+        const ChunkBlocks cb = chunk_blocks(t, cstart);
+        ex.all([&](int tid) { front_rotate<GATED, MAG>(t, lds, cb, cstart, clen, tid, 4); });
+        ex.all([&](int tid) {
+            if (MAG) flush_mag(t, lds, cb, cstart, clen, tid);
+            am_stage1(c, lds, clen, tid);
+        });
+        ex.all([&](int tid) { am_stage2(c, lds, clen, tid); });
+        ex.all([&](int tid) { am_stage3(c, lds, clen, tid); });
+        ex.all([&](int tid) { am_detect(c, lds, t, cstart, clen, tid, ssb, lsb, base_row); });
+        ex.all([&](int tid) { am_shift(lds, clen, tid); });
+        cstart += clen;
+    }
+}
+
+// DC-removal IIR + gain + (int16) cast for one channel (AmDemodulator.cc:462-465,
+// SsbDemodulator.cc:590-592; IirFilter.cc:161-176 with b = {1, -1}, a1 = -0.95):
+//   y[n] = ((0 + 1*x[n]) + (-1)*x[n-1]) - (0 + a1*y[n-1]);  pcm = (int16_t)(gain * y[n])
+IQD_DEV void dc_block_run(const int32_t *x, int n, float gain, float a1, DcCarry &st, int16_t *pcm)
+{
+    float xp = st.x_prev, yp = st.y_prev;
+    for (int i = 0; i < n; i++) {
+        const float xf = (float)x[i];
+        const float tn = xf - xp;        // exact: both are small integers
+        const float r = a1 * yp;
+        const float y = tn - r;
+        pcm[i] = (int16_t)cast_i16(gain * y);
+        xp = xf;
+        yp = y;
+    }
+    st.x_prev = xp;
+    st.y_prev = yp;
+}
+
+}  // namespace iqd

@@ -23,6 +23,9 @@ constexpr int WBFM_CHUNK = WBFM_NSEG * SEG;
 constexpr int TSTRIDE = 132;        // dwords between segments of the IIR input buffer
 constexpr int WSTRIDE = 68;         // dwords between segments of the int16 output buffer (16-B aligned)
 
+constexpr int FM_LUT_R = 141;        // the FM tuner decimator fed with int8 cannot leave [-141, 141]
+constexpr int FM_LUT_W = 2 * FM_LUT_R + 1;
+
 enum Family { FAM_AM = 0, FAM_FM = 1, FAM_WBFM = 2, FAM_SSB = 3, FAM_COUNT = 4 };
 
 // ---- per-channel parameters (host mirror uploaded when dirty) ---------------------------

@@ -495,18 +495,26 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         const TilePlan plan = plan_tiles(vlen, n_list);
         a.tile_len = plan.tile_len;
         a.tiles_per_ch = plan.tiles_per_ch;
+        if (e->profiling && !timed) HIP_TRY(e, hipEventRecord(e->ev0, s));
         if (f == FAM_WBFM) {
             HIP_TRY(e, e->records.ensure((size_t)n_list * a.tiles_per_ch * sizeof(WbfmRecord)));
             a.records = e->records.as<WbfmRecord>();
-            if (e->profiling && !timed) HIP_TRY(e, hipEventRecord(e->ev0, s));
             HIP_TRY(e, launch_wbfm(a, gated, fused_mag, n_list * a.tiles_per_ch, s));
-            if (e->profiling && !timed) { HIP_TRY(e, hipEventRecord(e->ev1, s)); timed = true; }
-            e->stats.kernel_launches++;
+        } else if (f == FAM_FM) {
+            HIP_TRY(e, launch_fm(a, gated, fused_mag, n_list * a.tiles_per_ch, s));
+        } else {
+            HIP_TRY(e, e->base8k.ensure((size_t)n_ch * base.pcm_stride * sizeof(int32_t)));
+            a.base8k = e->base8k.as<int32_t>();
+            HIP_TRY(e, launch_am(a, f, gated, fused_mag, n_list * a.tiles_per_ch, s));
+        }
+        if (e->profiling && !timed) { HIP_TRY(e, hipEventRecord(e->ev1, s)); timed = true; }
+        e->stats.kernel_launches++;
+        if (f == FAM_WBFM) {
             HIP_TRY(e, launch_wbfm_verify(a, s));
             wb = a;
             have_wbfm = true;
         } else {
-            return e->fail(IQD_EINVAL, "demodulator family %d has no kernel yet", f);
+            HIP_TRY(e, launch_tail_update(a, f, s));
         }
     }
     // channels in mode None still report their magnitudes

@@ -18,8 +18,6 @@ void build_consts(Consts &c);
 // WbFmDemodulator.cc:159-170: lut[y*256+x] = (float)atan2(y-128., x-128.)
 void build_atan2_lut(std::vector<float> &lut);
 // FmDemodulator.cc:476 for every (q, i) in [-FM_LUT_R, FM_LUT_R]^2
-constexpr int FM_LUT_R = 141;
-constexpr int FM_LUT_W = 2 * FM_LUT_R + 1;
 void build_fm_lut(std::vector<float> &lut);
 
 void default_params(ChanParams &p);

@@ -60,6 +60,8 @@ struct SquelchLaunch {
 
 hipError_t upload_consts(const Consts &c, hipStream_t s);
 hipError_t launch_wbfm(const ChainLaunch &a, bool gated, bool mag, uint32_t n_blocks, hipStream_t s);
+hipError_t launch_fm(const ChainLaunch &a, bool gated, bool mag, uint32_t n_blocks, hipStream_t s);
+hipError_t launch_am(const ChainLaunch &a, int family, bool gated, bool mag, uint32_t n_blocks, hipStream_t s);
 hipError_t launch_reset(uint8_t *tails, WbfmCarry *wc, DcCarry *dc, uint32_t first_ch, uint32_t n_ch, hipStream_t s);
 hipError_t launch_wbfm_verify(const ChainLaunch &a, hipStream_t s);
 hipError_t launch_wbfm_commit(const ChainLaunch &a, hipStream_t s);

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include "iqd_kernels.h"
+#include "iqd_chains.h"
 #include "iqd_wbfm.h"
 
 namespace iqd {
@@ -106,6 +107,69 @@ __global__ __launch_bounds__(WB_THREADS) void wbfm_chain_kernel(const ChainLaunc
     if (a.stamps && (threadIdx.x == 0 || threadIdx.x == 64))
         for (int k = 0; k < 8; k++) atomicAdd(&a.stamps[(threadIdx.x ? 8 : 0) + k], ex.acc[k]);
 #endif
+}
+
+// Common tile set-up of the FM / AM / SSB kernels (no carried float state: FIR chains only).
+__device__ __forceinline__ bool setup_tile(const ChainLaunch &a, bool gated, int family, Tile &t, uint32_t &ch, uint32_t &ech)
+{
+    const uint32_t li = blockIdx.x / a.tiles_per_ch, tile = blockIdx.x - li * a.tiles_per_ch;
+    ch = a.ch_list[li];
+    ech = a.first_ch + ch;
+    const uint32_t vlen = gated ? a.vlen_gated[ch] : a.vlen;
+    const int64_t v0 = (int64_t)tile * a.tile_len;
+    if (v0 >= (int64_t)vlen) return false;
+    const ChanParams &p = a.params[ech];
+    t.iq_ch = a.iq + (size_t)ch * a.ch_stride_bytes;
+    t.tail = a.tails + ((size_t)ech * FAM_COUNT + family) * TAIL_BYTES;
+    t.blk_list = gated ? a.blk_lists + (size_t)ch * a.n_blocks : nullptr;
+    t.block_samples = a.block_samples;
+    t.block_magic = a.block_magic;
+    t.v0 = v0;
+    t.tlen = (int32_t)(((int64_t)vlen - v0) < (int64_t)a.tile_len ? ((int64_t)vlen - v0) : (int64_t)a.tile_len);
+    rotation_selectors(p.rotation, t);
+    t.k = p.fm_k;
+    t.bounded = (fabsf(p.fm_k) * 6.35f < 2147483648.0f) ? 1u : 0u;   // |K * dtheta| <= |K| * 2 pi
+    t.lut = nullptr;
+    t.pcm_row = a.pcm + (size_t)ch * a.pcm_stride;
+    t.mag_row = a.mag_sums + (size_t)ch * a.n_blocks;
+    return true;
+}
+
+template <bool GATED, bool MAG>
+__global__ __launch_bounds__(WB_THREADS) void fm_chain_kernel(const ChainLaunch a)
+{
+    __shared__ FmLds lds;
+    Tile t;
+    uint32_t ch, ech;
+    if (!setup_tile(a, GATED, FAM_FM, t, ch, ech)) return;
+    DeviceExec ex{(int)threadIdx.x};
+    fm_tile<GATED, MAG>(ex, t, g_consts, lds, a.fm_lut);
+}
+
+template <bool GATED, bool MAG>
+__global__ __launch_bounds__(WB_THREADS) void am_chain_kernel(const ChainLaunch a, int family)
+{
+    __shared__ AmLds lds;
+    Tile t;
+    uint32_t ch, ech;
+    if (!setup_tile(a, GATED, family, t, ch, ech)) return;
+    DeviceExec ex{(int)threadIdx.x};
+    am_tile<GATED, MAG>(ex, t, g_consts, lds, family == FAM_SSB, a.params[ech].ssb_lsb,
+                        a.base8k + (size_t)ch * a.pcm_stride);
+}
+
+// AM / SSB DC-removal IIR with the exact carried state: one lane per channel.
+__global__ void dc_kernel(const ChainLaunch a, int family)
+{
+    const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= a.n_list) return;
+    const uint32_t ch = a.ch_list[li], ech = a.first_ch + ch;
+    const uint32_t vlen = a.vlen_gated ? a.vlen_gated[ch] : a.vlen;
+    const ChanParams &p = a.params[ech];
+    DcCarry st = a.dc_carry[2 * (size_t)ech + (family == FAM_SSB ? 1 : 0)];
+    dc_block_run(a.base8k + (size_t)ch * a.pcm_stride, (int)(vlen / 32), p.gain[family], g_consts.dc_a1, st,
+                 a.pcm + (size_t)ch * a.pcm_stride);
+    a.dc_carry[2 * (size_t)ech + (family == FAM_SSB ? 1 : 0)] = st;
 }
 
 // Hand-off check between consecutive tiles of a channel: a cold tile's own state at its
@@ -288,6 +352,25 @@ hipError_t launch_wbfm(const ChainLaunch &a, bool gated, bool mag, uint32_t n_bl
         if (mag) hipLaunchKernelGGL((wbfm_chain_kernel<false, true>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((wbfm_chain_kernel<false, false>), grid, block, 0, s, a);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_fm(const ChainLaunch &a, bool gated, bool mag, uint32_t n_blocks, hipStream_t s)
+{
+    dim3 grid(n_blocks), block(WB_THREADS);
+    if (gated) hipLaunchKernelGGL((fm_chain_kernel<true, false>), grid, block, 0, s, a);
+    else if (mag) hipLaunchKernelGGL((fm_chain_kernel<false, true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((fm_chain_kernel<false, false>), grid, block, 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_am(const ChainLaunch &a, int family, bool gated, bool mag, uint32_t n_blocks, hipStream_t s)
+{
+    dim3 grid(n_blocks), block(WB_THREADS);
+    if (gated) hipLaunchKernelGGL((am_chain_kernel<true, false>), grid, block, 0, s, a, family);
+    else if (mag) hipLaunchKernelGGL((am_chain_kernel<false, true>), grid, block, 0, s, a, family);
+    else hipLaunchKernelGGL((am_chain_kernel<false, false>), grid, block, 0, s, a, family);
+    hipLaunchKernelGGL(dc_kernel, dim3((a.n_list + 63) / 64), dim3(64), 0, s, a, family);
     return hipGetLastError();
 }
 

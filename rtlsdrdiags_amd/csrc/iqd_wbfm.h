@@ -36,9 +36,9 @@ IQD_DEV int t_slot(int seg, int gi) { return seg * TGRAN + (gi ^ ((gi >> 3) & 3)
 struct WbfmLds {
     u32x4 t4[WBFM_NSEG * TGRAN];           // u[n] = b0 * (K * dtheta[n]) as float bits: per segment
                                            // 32 granules of 4 samples (XOR-swizzled) + 1 pad
-    uint32_t w[WBFM_NSEG * WSTRIDE];       // (int16)y[n], two per dword, segment-strided
-    uint32_t y1[(8 + WBFM_CHUNK / 4) / 2];   // stage-1 output with 8 samples of history
-    uint32_t y2[(40 + WBFM_CHUNK / 16) / 2]; // stage-2 output with 40 samples of history
+    alignas(16) uint32_t w[WBFM_NSEG * WSTRIDE];       // (int16)y[n], two per dword, segment-strided
+    alignas(16) uint32_t y1[(8 + WBFM_CHUNK / 4) / 2];   // stage-1 output with 8 samples of history
+    alignas(16) uint32_t y2[(40 + WBFM_CHUNK / 16) / 2]; // stage-2 output with 40 samples of history
     uint32_t whist[2];                     // the 4 w samples before the chunk
     float z[WBFM_NSEG + 4];                // zero-state segment responses; z[3] = carried y
     float g[WBFM_NSEG];                    // state entering each segment

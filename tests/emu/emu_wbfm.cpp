@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "iqd_host.h"
+#include "iqd_chains.h"
 #include "iqd_wbfm.h"
 
 namespace {
@@ -116,5 +117,64 @@ void emu_wbfm_reset(uint8_t *tail, iqd::WbfmCarry *carry)
 }
 
 uint32_t emu_lds_bytes(void) { return (uint32_t)sizeof(iqd::WbfmLds); }
+
+// One accept call for one FM (family 1), AM (0) or SSB (3) channel with the squelch open.
+// tail and dc are in-out state; base8k is caller scratch of n_samples/32 ints.
+void emu_chain_accept(int family, int lsb, const uint8_t *iq, uint32_t n_samples, uint32_t tile_len,
+                      uint32_t block_samples, int rotation, float gain, uint8_t *tail, iqd::DcCarry *dc,
+                      int16_t *pcm, uint32_t *mag_sums, int32_t *base8k)
+{
+    using namespace iqd;
+    static Consts c;
+    static std::vector<float> fm_lut;
+    static bool ready = false;
+    if (!ready) { build_consts(c); build_fm_lut(fm_lut); ready = true; }
+    ChanParams p;
+    default_params(p);
+    p.gain[family] = gain;
+    p.rotation = rotation;
+    derive_params(p);
+    const uint32_t ntiles = (n_samples + tile_len - 1) / tile_len;
+    static FmLds flds;
+    static AmLds alds;
+    for (uint32_t tile = 0; tile < ntiles; tile++) {
+        Tile t;
+        t.iq_ch = iq;
+        t.tail = tail;
+        t.blk_list = nullptr;
+        t.block_samples = block_samples;
+        t.block_magic = block_magic(block_samples);
+        t.v0 = (int64_t)tile * tile_len;
+        t.tlen = (int32_t)((n_samples - t.v0) < tile_len ? (n_samples - t.v0) : tile_len);
+        if (rotation == 0) { t.sel_i = 0x06040200u; t.sel_q = 0x07050301u; t.neg_i = 0; t.neg_q = 0; }
+        else {
+            t.sel_i = 0x07040300u; t.sel_q = 0x06050201u;
+            t.neg_i = rotation > 0 ? 0x00ffff00u : 0xffff0000u;
+            t.neg_q = rotation > 0 ? 0xffff0000u : 0x00ffff00u;
+        }
+        t.k = p.fm_k;
+        t.bounded = (fabsf(p.fm_k) * 6.35f < 2147483648.0f) ? 1u : 0u;
+        t.lut = nullptr;
+        t.pcm_row = pcm;
+        t.mag_row = mag_sums;
+        HostExec ex;
+        if (family == FAM_FM) {
+            memset(&flds, 0xcd, sizeof(flds));
+            fm_tile<false, true>(ex, t, c, flds, fm_lut.data());
+        } else {
+            memset(&alds, 0xcd, sizeof(alds));
+            am_tile<false, true>(ex, t, c, alds, family == FAM_SSB, lsb, base8k);
+        }
+    }
+    if (family != FAM_FM) dc_block_run(base8k, (int)(n_samples / 32), p.gain[family], c.dc_a1, *dc, pcm);
+    std::vector<uint8_t> nt(TAIL_BYTES);
+    for (int i = 0; i < TAIL; i++) {
+        const int64_t v = (int64_t)n_samples - TAIL + i;
+        const uint8_t *src = v < 0 ? tail + TAIL_BYTES + 2 * v : iq + 2 * v;
+        nt[2 * i] = src[0];
+        nt[2 * i + 1] = src[1];
+    }
+    memcpy(tail, nt.data(), TAIL_BYTES);
+}
 
 }  // extern "C"

@@ -22,6 +22,9 @@ def lib():
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float]
     L.emu_wbfm_reset.argtypes = [C.c_void_p, C.c_void_p]
     L.emu_lds_bytes.restype = C.c_uint32
+    L.emu_chain_accept.restype = None
+    L.emu_chain_accept.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
+                                   C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     return L
 
 
@@ -53,3 +56,34 @@ class WbfmChannel:
 
     def reset(self):
         self.L.emu_wbfm_reset(self.tail.ctypes.data, C.byref(self.carry))
+
+
+FAMILY = {"am": 0, "fm": 1, "lsb": 3, "usb": 3}
+DEFAULT_GAIN = {"am": 300.0, "fm": 64000 / (2 * np.pi), "lsb": 300.0, "usb": 300.0}
+
+
+class FirChannel:
+    """One FM / AM / SSB channel driven through the emulated tile kernel + DC-removal pass."""
+
+    def __init__(self, L, mode, tile_len, block_samples=16384, rotation=1, gain=None):
+        self.L, self.mode, self.tile_len, self.block_samples = L, mode, tile_len, block_samples
+        self.rotation = rotation
+        self.gain = np.float32(DEFAULT_GAIN[mode] if gain is None else gain)
+        self.tail = np.full(4096, 128, np.uint8)
+        self.dc = np.zeros(2, np.float32)
+
+    def accept(self, u8):
+        u8 = np.ascontiguousarray(u8, dtype=np.uint8)
+        m = len(u8) // 2
+        pcm = np.zeros(m // 32, np.int16)
+        mag = np.zeros(max(1, (m + self.block_samples - 1) // self.block_samples), np.uint32)
+        base = np.zeros(m // 32 + 1, np.int32)
+        self.L.emu_chain_accept(FAMILY[self.mode], 1 if self.mode == "lsb" else 0, u8.ctypes.data, m,
+                                self.tile_len, self.block_samples, self.rotation, self.gain,
+                                self.tail.ctypes.data, self.dc.ctypes.data, pcm.ctypes.data,
+                                mag.ctypes.data, base.ctypes.data)
+        return pcm, mag
+
+    def reset(self):
+        self.tail[:] = 128
+        self.dc[:] = 0

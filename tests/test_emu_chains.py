@@ -1,0 +1,64 @@
+"""CPU: the FM / AM / SSB tile kernels' phase functions (rtlsdrdiags_amd/csrc/iqd_chains.h), stepped
+on the host by tests/emu, against the oracle."""
+import numpy as np
+import pytest
+
+from rtlsdrdiags_amd import synth
+from tests import emu_bind
+
+MODES = ["am", "fm", "lsb", "usb"]
+
+
+@pytest.fixture(scope="module")
+def emu():
+    return emu_bind.lib()
+
+
+def oracle_run(oracle, mode, u8, rotation=1, gain=None):
+    c = oracle.chain()
+    c.set_mode(mode)
+    c.set_rotation(rotation)
+    if gain is not None:
+        c.set_gain({"am": 1, "fm": 2, "lsb": 4, "usb": 4}[mode], gain)
+    return c.accept_stream(u8)
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("call_samples,tile_len", [(4 * 16384, 65536), (4 * 16384, 16384), (16384, 8192),
+                                                   (4096, 8192), (128, 8192), (1152, 384)])
+def test_calls_and_tiles(emu, oracle, mode, call_samples, tile_len):
+    u8 = synth.fm_tone(4 * 16384, seed=41) if mode == "fm" else synth.am_tone(4 * 16384, seed=42)
+    ref, ref_mag, _ = oracle_run(oracle, mode, u8)
+    ch = emu_bind.FirChannel(emu, mode, tile_len)
+    out = [ch.accept(u8[2 * o:2 * (o + call_samples)])[0] for o in range(0, len(u8) // 2, call_samples)]
+    assert np.array_equal(np.concatenate(out), ref)
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("kind", ["white", "rails", "ssb"])
+def test_edge_inputs_and_magnitude(emu, oracle, mode, kind):
+    u8 = {"white": synth.white_u8(2 * 16384, seed=3), "rails": synth.rails_u8(2 * 16384, seed=4),
+          "ssb": synth.ssb_tone(2 * 16384, seed=5)}[kind]
+    ref, ref_mag, _ = oracle_run(oracle, mode, u8)
+    ch = emu_bind.FirChannel(emu, mode, 16384)
+    pcm, mag = ch.accept(u8)
+    assert np.array_equal(pcm, ref)
+    assert np.array_equal(mag // 16384, ref_mag)
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("rotation", [0, -1])
+def test_rotation_and_overflowing_gain(emu, oracle, mode, rotation):
+    gain = {"am": 30000.0, "fm": 2.0e6, "lsb": 30000.0, "usb": 30000.0}[mode]
+    u8 = synth.fm_tone(2 * 16384, seed=6, amplitude=100.0)
+    ref, _, _ = oracle_run(oracle, mode, u8, rotation=rotation, gain=gain)
+    ch = emu_bind.FirChannel(emu, mode, 8192, rotation=rotation, gain=gain)
+    out = [ch.accept(u8[:32768])[0], ch.accept(u8[32768:])[0]]
+    assert np.array_equal(np.concatenate(out), ref)
+
+
+def test_fm_unbounded_cast(emu, oracle):
+    u8 = synth.fm_tone(16384, seed=10, amplitude=100.0)
+    ref, _, _ = oracle_run(oracle, "fm", u8, gain=4.0e9)
+    pcm, _ = emu_bind.FirChannel(emu, "fm", 8192, gain=4.0e9).accept(u8)
+    assert np.array_equal(pcm, ref)
