@@ -82,7 +82,7 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from rtlsdrdiags_amd import capi, synth
+    from rtlsdrdiags_amd import capi, shard, synth
 
     n = 1 << args.log2_samples
     n_ch = args.channels
@@ -104,8 +104,7 @@ def main():
     def step():
         eng.accept_device(iq.data_ptr(), 2 * n, pcm.data_ptr(), cnt.data_ptr(), mag.data_ptr())
         if args.gather and dist is not None:
-            gl = [torch.empty_like(pcm) for _ in range(world)] if rank == 0 else None
-            dist.gather(pcm, gl, dst=0)
+            shard.gather_pcm(pcm.view(n_ch, -1), cnt, dst=0)
 
     for _ in range(args.warmup):
         step()
@@ -126,9 +125,7 @@ def main():
     k1 = eng.stats()
     eng.set_profiling(False)
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = shard.max_over_ranks(elapsed, dev)
 
     total_samples = float(n) * n_ch * args.steps * world
     value = total_samples / elapsed / 1e6

@@ -90,6 +90,8 @@ int iqd_set_rotation(iqd_t *e, uint32_t first_ch, uint32_t n_ch, int rotation);
 /* Replaces {Am,Fm,WbFm,Ssb}Demodulator::resetDemodulator() for all four demodulators of the
  * channels (note WbFmDemodulator.cc:304-320 leaves the de-emphasis filter state alone). */
 int iqd_reset(iqd_t *e, uint32_t first_ch, uint32_t n_ch);
+/* The same for one demodulator only (demod = IQD_DEMOD_*), as the reference's per-object call. */
+int iqd_reset_demod(iqd_t *e, uint32_t first_ch, uint32_t n_ch, int demod);
 
 /* Replaces IqDataProcessor::acceptIqData(timeStamp, bufferPtr, byteCount),
  * IqDataProcessor.cc:722-840, for n_ch channels at once, each receiving

@@ -37,7 +37,7 @@ class IqdError(RuntimeError):
 
 EXPORTS = [
     "iqd_abi_version", "iqd_strerror", "iqd_last_error", "iqd_create", "iqd_destroy", "iqd_set_mode",
-    "iqd_set_gain", "iqd_set_squelch", "iqd_set_rx_gain_db", "iqd_set_rotation", "iqd_reset",
+    "iqd_set_gain", "iqd_set_squelch", "iqd_set_rx_gain_db", "iqd_set_rotation", "iqd_reset", "iqd_reset_demod",
     "iqd_accept_iq", "iqd_accept_iq_device", "iqd_synchronize", "iqd_get_stats", "iqd_set_profiling",
     "iqd_get_channel_mode", "iqd_get_channel_gain", "iqd_dev_alloc", "iqd_dev_free", "iqd_dev_upload",
     "iqd_dev_download", "iqd_dev_tile", "iqd_stream", "iqd_debug_stamps",
@@ -69,6 +69,7 @@ def _lib():
     L.iqd_set_rx_gain_db.argtypes = [vp, u32, u32, u32]
     L.iqd_set_rotation.argtypes = [vp, u32, u32, C.c_int]
     L.iqd_reset.argtypes = [vp, u32, u32]
+    L.iqd_reset_demod.argtypes = [vp, u32, u32, C.c_int]
     L.iqd_accept_iq.argtypes = [vp, u32, u32, vp, sz, vp, vp, vp, vp]
     L.iqd_accept_iq_device.argtypes = [vp, u32, u32, vp, sz, vp, vp, vp, vp]
     L.iqd_synchronize.argtypes = [vp]
@@ -143,6 +144,10 @@ class Engine:
     def reset(self, first=0, n=None):
         f, n = self._range(first, n)
         self._check(self._L.iqd_reset(self._h, f, n))
+
+    def reset_demod(self, demod, first=0, n=None):
+        f, n = self._range(first, n)
+        self._check(self._L.iqd_reset_demod(self._h, f, n, int(DEMOD.get(demod, demod))))
 
     # ---- data path ------------------------------------------------------------------------
     def accept(self, iq_u8, first=0, n=None):

@@ -1,0 +1,160 @@
+// Host-side mirror of the reference's IqDataProcessor and demodulator classes over the C ABI.
+#include "IqDataProcessor.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+// ---- demodulator handles ------------------------------------------------------------------
+DemodulatorHandle::DemodulatorHandle(int demod, float defaultGain, PcmCallback cb)
+    : demod(demod), demodulatorGain(defaultGain), pcmCallbackPtr(cb), engine(0)
+{
+}
+
+void DemodulatorHandle::setDemodulatorGain(float gain)
+{
+  demodulatorGain = gain;
+  if (engine != 0) iqd_set_gain(engine, 0, 1, demod, gain);
+}
+
+void DemodulatorHandle::resetDemodulator(void)
+{
+  if (engine != 0) iqd_reset_demod(engine, 0, 1, demod);
+}
+
+void DemodulatorHandle::displayInternalInformation(void)
+{
+  static const char *names[] = {"", "AM", "FM", "Wideband FM", "SSB"};
+  fprintf(stderr, "\n%s Demodulator Internal Information\n", names[demod]);
+  fprintf(stderr, "Demodulator Gain         : %f\n", demodulatorGain);
+}
+
+// default gains: AmDemodulator.cc:104, FmDemodulator.cc:158, WbFmDemodulator.cc:173, SsbDemodulator.cc:147
+AmDemodulator::AmDemodulator(PcmCallback cb) : DemodulatorHandle(IQD_DEMOD_AM, 300, cb) {}
+FmDemodulator::FmDemodulator(PcmCallback cb) : DemodulatorHandle(IQD_DEMOD_FM, 64000 / (2 * M_PI), cb) {}
+WbFmDemodulator::WbFmDemodulator(PcmCallback cb) : DemodulatorHandle(IQD_DEMOD_WBFM, 256000 / (2 * M_PI), cb) {}
+SsbDemodulator::SsbDemodulator(PcmCallback cb) : DemodulatorHandle(IQD_DEMOD_SSB, 300, cb), lsbDemodulationMode(true) {}
+
+void SsbDemodulator::setLsbDemodulationMode(void) { lsbDemodulationMode = true; }
+void SsbDemodulator::setUsbDemodulationMode(void) { lsbDemodulationMode = false; }
+
+// ---- IqDataProcessor ------------------------------------------------------------------------
+IqDataProcessor::IqDataProcessor(char *hostIpAddress, int hostPort)
+    : engine(0), demodulatorMode(None), signalDetectThreshold(-200), blockBytes(32768),
+      amDemodulatorPtr(0), fmDemodulatorPtr(0), wbFmDemodulatorPtr(0), ssbDemodulatorPtr(0),
+      signalNotificationEnabled(false), signalCallbackContextPtr(0), signalCallbackPtr(0),
+      signalMagnitudeNotificationEnabled(false), signalMagnitudeCallbackContextPtr(0),
+      signalMagnitudeCallbackPtr(0), lastStatus(IQD_OK), receiveBlockCount(0)
+{
+  (void)hostIpAddress;
+  (void)hostPort;
+  iqd_config cfg;
+  memset(&cfg, 0, sizeof(cfg));
+  cfg.abi_version = IQD_ABI_VERSION;
+  cfg.n_channels = 1;
+  cfg.block_bytes = blockBytes;
+  cfg.device = -1;
+  lastStatus = iqd_create(&cfg, &engine);
+  if (lastStatus != IQD_OK) engine = 0;   // every accept then reports the failure; no CPU path
+}
+
+IqDataProcessor::~IqDataProcessor(void)
+{
+  DemodulatorHandle *all[4] = {amDemodulatorPtr, fmDemodulatorPtr, wbFmDemodulatorPtr, ssbDemodulatorPtr};
+  for (int i = 0; i < 4; i++)
+    if (all[i] != 0) all[i]->engine = 0;
+  if (engine != 0) iqd_destroy(engine);
+}
+
+const char *IqDataProcessor::lastError(void) const
+{
+  return engine != 0 ? iqd_last_error(engine) : iqd_strerror(lastStatus);
+}
+
+void IqDataProcessor::attach(DemodulatorHandle *h)
+{
+  if (h == 0 || engine == 0) return;
+  h->engine = engine;
+  iqd_set_gain(engine, 0, 1, h->demod, h->demodulatorGain);
+}
+
+void IqDataProcessor::setAmDemodulator(AmDemodulator *p) { amDemodulatorPtr = p; attach(p); }
+void IqDataProcessor::setFmDemodulator(FmDemodulator *p) { fmDemodulatorPtr = p; attach(p); }
+void IqDataProcessor::setWbFmDemodulator(WbFmDemodulator *p) { wbFmDemodulatorPtr = p; attach(p); }
+void IqDataProcessor::setSsbDemodulator(SsbDemodulator *p) { ssbDemodulatorPtr = p; attach(p); }
+
+void IqDataProcessor::setDemodulatorMode(demodulatorType mode)
+{
+  demodulatorMode = mode;
+  if (ssbDemodulatorPtr != 0) {   // IqDataProcessor.cc:244-256
+    if (mode == Lsb) ssbDemodulatorPtr->setLsbDemodulationMode();
+    if (mode == Usb) ssbDemodulatorPtr->setUsbDemodulationMode();
+  }
+  if (engine != 0) iqd_set_mode(engine, 0, 1, (int)mode);
+}
+
+void IqDataProcessor::setSignalDetectThreshold(int32_t threshold)
+{
+  signalDetectThreshold = threshold;
+  if (engine != 0) iqd_set_squelch(engine, 0, 1, threshold);
+}
+
+void IqDataProcessor::setReceiveGainInDb(uint32_t gainInDb)
+{
+  if (engine != 0) iqd_set_rx_gain_db(engine, 0, 1, gainInDb);
+}
+
+void IqDataProcessor::enableSignalNotification(void) { signalNotificationEnabled = true; }
+void IqDataProcessor::disableSignalNotification(void) { signalNotificationEnabled = false; }
+void IqDataProcessor::registerSignalStateCallback(void (*cb)(bool, void *), void *contextPtr)
+{
+  signalCallbackContextPtr = contextPtr;
+  signalCallbackPtr = cb;
+}
+void IqDataProcessor::enableSignalMagnitudeNotification(void) { signalMagnitudeNotificationEnabled = true; }
+void IqDataProcessor::disableSignalMagnitudeNotification(void) { signalMagnitudeNotificationEnabled = false; }
+void IqDataProcessor::registerSignalMagnitudeCallback(void (*cb)(uint32_t, void *), void *contextPtr)
+{
+  signalMagnitudeCallbackContextPtr = contextPtr;
+  signalMagnitudeCallbackPtr = cb;
+}
+
+// IqDataProcessor.cc:722-840: squelch, the two notifications, then the selected demodulator,
+// whose PCM goes to that demodulator's callback (e.g. WbFmDemodulator.cc:582-591).
+void IqDataProcessor::acceptIqData(unsigned long timeStamp, unsigned char *bufferPtr, unsigned long byteCount)
+{
+  (void)timeStamp;
+  if (engine == 0 || byteCount != blockBytes) {
+    lastStatus = engine == 0 ? lastStatus : IQD_EINVAL;
+    return;
+  }
+  uint32_t pcmCount = 0, magnitude = 0;
+  uint8_t allowed = 0;
+  lastStatus = iqd_accept_iq(engine, 0, 1, bufferPtr, byteCount, pcmData, &pcmCount, &magnitude, &allowed);
+  if (lastStatus != IQD_OK) return;
+  receiveBlockCount++;
+  if (signalNotificationEnabled && signalCallbackPtr != 0)
+    signalCallbackPtr(allowed != 0, signalCallbackContextPtr);
+  if (signalMagnitudeNotificationEnabled && signalMagnitudeCallbackPtr != 0)
+    signalMagnitudeCallbackPtr(magnitude, signalMagnitudeCallbackContextPtr);
+  if (allowed == 0 || pcmCount == 0) return;
+  DemodulatorHandle *h = 0;
+  switch (demodulatorMode) {
+    case Am: h = amDemodulatorPtr; break;
+    case Fm: h = fmDemodulatorPtr; break;
+    case WbFm: h = wbFmDemodulatorPtr; break;
+    case Lsb: case Usb: h = ssbDemodulatorPtr; break;
+    default: break;
+  }
+  if (h != 0 && h->pcmCallbackPtr != 0) h->pcmCallbackPtr(pcmData, pcmCount);
+}
+
+void IqDataProcessor::displayInternalInformation(void)
+{
+  static const char *modes[] = {"None", "AM", "FM", "WBFM", "LSB", "USB"};
+  fprintf(stderr, "\nIq Data Processor Internal Information\n");
+  fprintf(stderr, "Demodulator Mode         : %s\n", modes[(int)demodulatorMode]);
+  fprintf(stderr, "Signal Detect Threshold  : %d dBFs\n", (int)signalDetectThreshold);
+  fprintf(stderr, "Receive Block Count      : %lu\n", receiveBlockCount);
+  fprintf(stderr, "Engine                   : %s\n", engine != 0 ? "MI355X (HIP)" : "unavailable");
+}

@@ -1,0 +1,123 @@
+// C++ host surface of the engine with the reference's class and method names, so that code
+// written against RtlSdrDiags' IqDataProcessor (hdr_diags/IqDataProcessor.h:16-58) and its four
+// demodulator classes ({Am,Fm,WbFm,Ssb}Demodulator.h) compiles and behaves the same while
+// the arithmetic runs on the GPU through the C ABI (include/iqdemod.h).
+//
+// One IqDataProcessor owns one single-channel engine.  Differences from the reference, all on
+// the host side: acceptIqData() does not modify the caller's buffer, byteCount must be the
+// engine's block size (32768 by default, as Radio.cc:1895 always passes), the UDP IQ dump
+// (IqDataProcessor.cc:756-760) is not provided.
+#pragma once
+#include <stdint.h>
+
+#include "iqdemod.h"
+
+class IqDataProcessor;
+
+// Common part of the four demodulator handles: a PCM sink and a gain, bound to an engine
+// channel once the handle is given to an IqDataProcessor (set*Demodulator()).
+class DemodulatorHandle
+{
+  public:
+  typedef void (*PcmCallback)(int16_t *bufferPtr, uint32_t bufferLength);
+
+  void resetDemodulator(void);
+  void setDemodulatorGain(float gain);
+  void displayInternalInformation(void);
+
+  protected:
+  DemodulatorHandle(int demod, float defaultGain, PcmCallback pcmCallbackPtr);
+
+  int demod;                 // IQD_DEMOD_*
+  float demodulatorGain;
+  PcmCallback pcmCallbackPtr;
+  iqd_t *engine;             // null until attached
+
+  friend class IqDataProcessor;
+};
+
+class AmDemodulator : public DemodulatorHandle
+{
+  public:
+  AmDemodulator(PcmCallback pcmCallbackPtr);      // AmDemodulator.h:24-26
+};
+
+class FmDemodulator : public DemodulatorHandle
+{
+  public:
+  FmDemodulator(PcmCallback pcmCallbackPtr);      // FmDemodulator.h:24-26
+};
+
+class WbFmDemodulator : public DemodulatorHandle
+{
+  public:
+  WbFmDemodulator(PcmCallback pcmCallbackPtr);    // WbFmDemodulator.h:24-26
+};
+
+class SsbDemodulator : public DemodulatorHandle
+{
+  public:
+  SsbDemodulator(PcmCallback pcmCallbackPtr);     // SsbDemodulator.h:27-28
+  void setLsbDemodulationMode(void);              // SsbDemodulator.h:30
+  void setUsbDemodulationMode(void);              // SsbDemodulator.h:31
+
+  private:
+  bool lsbDemodulationMode;
+  friend class IqDataProcessor;
+};
+
+class IqDataProcessor
+{
+  public:
+  enum demodulatorType {None = 0, Am = 1, Fm = 2, WbFm = 3, Lsb = 4, Usb = 5};
+
+  IqDataProcessor(char *hostIpAddress, int hostPort);   // the UDP peer is accepted and ignored
+  ~IqDataProcessor(void);
+
+  void setDemodulatorMode(demodulatorType mode);
+  void setAmDemodulator(AmDemodulator *demodulatorPtr);
+  void setFmDemodulator(FmDemodulator *demodulatorPtr);
+  void setWbFmDemodulator(WbFmDemodulator *demodulatorPtr);
+  void setSsbDemodulator(SsbDemodulator *demodulatorPtr);
+  void setSignalDetectThreshold(int32_t threshold);
+
+  void acceptIqData(unsigned long timeStamp, unsigned char *bufferPtr, unsigned long byteCount);
+
+  void enableSignalNotification(void);
+  void disableSignalNotification(void);
+  void registerSignalStateCallback(void (*signalCallbackPtr)(bool signalPresent, void *contextPtr),
+                                   void *contextPtr);
+  void enableSignalMagnitudeNotification(void);
+  void disableSignalMagnitudeNotification(void);
+  void registerSignalMagnitudeCallback(void (*callbackPtr)(uint32_t signalMagnitude, void *contextPtr),
+                                       void *contextPtr);
+
+  // radio_adjustableReceiveGainInDb is a global in the reference (Radio.cc:19); here it is a
+  // property of the processor.
+  void setReceiveGainInDb(uint32_t gainInDb);
+
+  void displayInternalInformation(void);
+  bool isOperational(void) const { return engine != 0; }   // false when no HIP device was found
+  const char *lastError(void) const;
+
+  private:
+  void attach(DemodulatorHandle *h);
+
+  iqd_t *engine;
+  demodulatorType demodulatorMode;
+  int32_t signalDetectThreshold;
+  uint32_t blockBytes;
+  AmDemodulator *amDemodulatorPtr;
+  FmDemodulator *fmDemodulatorPtr;
+  WbFmDemodulator *wbFmDemodulatorPtr;
+  SsbDemodulator *ssbDemodulatorPtr;
+  bool signalNotificationEnabled;
+  void *signalCallbackContextPtr;
+  void (*signalCallbackPtr)(bool signalPresent, void *contextPtr);
+  bool signalMagnitudeNotificationEnabled;
+  void *signalMagnitudeCallbackContextPtr;
+  void (*signalMagnitudeCallbackPtr)(uint32_t signalMagnitude, void *contextPtr);
+  int16_t pcmData[512];      // one block's PCM (32768 / 64)
+  int lastStatus;
+  unsigned long receiveBlockCount;
+};

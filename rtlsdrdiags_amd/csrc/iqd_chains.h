@@ -278,7 +278,7 @@ IQD_DEV void am_stage3(const Consts &c, AmLds &lds, int clen, int tid)
 //   SSB (SsbDemodulator.cc:574-588): delayed I (the 1.0 tap is -32768 in Q15, so -i[n-15])
 //       -+ Hilbert-transformed Q.  |x| <= 179 -> Hilbert |acc| <= 16384 + 67250*179 < 2^24.
 IQD_DEV void am_detect(const Consts &c, AmLds &lds, const Tile &t, int cstart, int clen, int tid,
-                       int ssb, int lsb, int32_t *base_row)
+                       int ssb, int lsb, int32_t *base_row, int base_stride_t)
 {
     const int nout = clen >> 5;
     for (int i = tid; i < nout; i += WB_THREADS) {
@@ -292,7 +292,7 @@ IQD_DEV void am_detect(const Consts &c, AmLds &lds, const Tile &t, int cstart, i
             const int qh = q15_free<31>(c.ssb_hilbert, lds.s3q, 32 + i);
             x = lsb ? (int)(int16_t)idl - (int)(int16_t)qh : (int)(int16_t)idl + (int)(int16_t)qh;
         }
-        if (cstart >= 0) base_row[((t.v0 + cstart) >> 5) + i] = x;
+        if (cstart >= 0) base_row[(size_t)(((t.v0 + cstart) >> 5) + i) * base_stride_t] = x;
     }
 }
 
@@ -315,7 +315,8 @@ IQD_DEV void am_shift(AmLds &lds, int clen, int tid)
 }
 
 template <bool GATED, bool MAG, class Exec>
-IQD_DEV void am_tile(Exec &ex, const Tile &t, const Consts &c, AmLds &lds, int ssb, int lsb, int32_t *base_row)
+IQD_DEV void am_tile(Exec &ex, const Tile &t, const Consts &c, AmLds &lds, int ssb, int lsb, int32_t *base_row,
+                     int base_stride_t)
 {
     ex.all([&](int tid) {
         if (tid < 4) lds.xi[tid] = 0, lds.xq[tid] = 0;
@@ -334,7 +335,7 @@ IQD_DEV void am_tile(Exec &ex, const Tile &t, const Consts &c, AmLds &lds, int s
         });
         ex.all([&](int tid) { am_stage2(c, lds, clen, tid); });
         ex.all([&](int tid) { am_stage3(c, lds, clen, tid); });
-        ex.all([&](int tid) { am_detect(c, lds, t, cstart, clen, tid, ssb, lsb, base_row); });
+        ex.all([&](int tid) { am_detect(c, lds, t, cstart, clen, tid, ssb, lsb, base_row, base_stride_t); });
         ex.all([&](int tid) { am_shift(lds, clen, tid); });
         cstart += clen;
     }
@@ -357,6 +358,125 @@ IQD_DEV void dc_block_run(const int32_t *x, int n, float gain, float a1, DcCarry
     }
     st.x_prev = xp;
     st.y_prev = yp;
+}
+
+
+// ---- the same IIR for long streams: one wave per channel, 64 segments of SEG samples at a time ----
+// Same scheme as the WBFM de-emphasis (iqd_wbfm.h): every lane warms up over the previous
+// segment from a guessed state and is accepted only if it reproduces its left neighbour's exact
+// end state bit for bit; otherwise it restarts from that state.
+constexpr int DC_SUPER = 64 * SEG;          // PCM samples per pass of the wave
+struct DcLds {
+    int32_t x[64 * (SEG + 1)];              // detector input, one padded row per segment
+    float z[64 + 4], g[64], e[64];
+    float x_carry, y_carry;                 // state entering the pass
+};
+
+IQD_DEV float dc_x_before(const DcLds &lds, int seg)
+{
+    return seg == 0 ? lds.x_carry : (float)lds.x[(seg - 1) * (SEG + 1) + SEG - 1];
+}
+
+IQD_DEV void dc_guess(const Consts &c, DcLds &lds, int nseg, int lane)
+{
+    if (lane == 0) lds.z[3] = lds.y_carry, lds.z[2] = 0.f, lds.z[1] = 0.f, lds.z[0] = 0.f;
+    if (lane >= nseg) return;
+    const float cc = -c.dc_a1;
+    const int32_t *src = &lds.x[lane * (SEG + 1)];
+    float xp = dc_x_before(lds, lane), z = 0.f;
+    for (int i = 0; i < SEG; i++) {
+        const float xf = (float)src[i];
+        z = __builtin_fmaf(cc, z, xf - xp);
+        xp = xf;
+    }
+    lds.z[4 + lane] = z;
+}
+
+IQD_DEV void dc_warm(const Consts &c, DcLds &lds, int nseg, int lane)
+{
+    if (lane >= nseg) return;
+    if (lane == 0) { lds.g[0] = lds.y_carry; return; }
+    const float a = c.dc_c128;
+    const float *zz = &lds.z[4 + lane - 2];
+    float y = zz[0] + a * (zz[-1] + a * (zz[-2] + a * zz[-3]));
+    if (lane == 1) y = lds.y_carry;
+    const int32_t *src = &lds.x[(lane - 1) * (SEG + 1)];
+    float xp = dc_x_before(lds, lane - 1);
+    const float a1 = c.dc_a1;
+    for (int i = 0; i < SEG; i++) {
+        const float xf = (float)src[i];
+        const float tn = xf - xp;
+        const float r = a1 * y;
+        y = tn - r;
+        xp = xf;
+    }
+    lds.g[lane] = y;
+}
+
+IQD_DEV void dc_real(const Consts &c, DcLds &lds, int nseg, int lane, float gain, int16_t *pcm /* of the pass */)
+{
+    if (lane >= nseg) return;
+    const int32_t *src = &lds.x[lane * (SEG + 1)];
+    float xp = dc_x_before(lds, lane), y = lds.g[lane];
+    const float a1 = c.dc_a1;
+    for (int i = 0; i < SEG; i++) {
+        const float xf = (float)src[i];
+        const float tn = xf - xp;
+        const float r = a1 * y;
+        y = tn - r;
+        pcm[lane * SEG + i] = (int16_t)cast_i16(gain * y);
+        xp = xf;
+    }
+    lds.e[lane] = y;
+}
+
+IQD_DEV bool dc_check(DcLds &lds, int nseg, int lane)
+{
+    if (lane == 0 || lane >= nseg) return true;
+    const float want = lds.e[lane - 1];
+    if (f2u(want) == f2u(lds.g[lane])) return true;
+    lds.g[lane] = want;
+    return false;
+}
+
+// One channel, n PCM samples (multiple of 4; the last pass may be partial, its last segment too).
+template <class Exec>
+IQD_DEV void dc_block_wave(Exec &ex, const Consts &c, DcLds &lds, const int32_t *x, int n, float gain,
+                           DcCarry &st, int16_t *pcm)
+{
+    ex.wave0([&](int lane) { if (lane == 0) { lds.x_carry = st.x_prev; lds.y_carry = st.y_prev; } });
+    for (int base = 0; base < n; base += DC_SUPER) {
+        const int len = n - base < DC_SUPER ? n - base : DC_SUPER;
+        const int nfull = len / SEG;              // whole segments: the segmented scheme
+        ex.wave0([&](int lane) {
+            for (int i = lane; i < nfull * SEG; i += 64) lds.x[(i / SEG) * (SEG + 1) + (i % SEG)] = x[base + i];
+        });
+        if (nfull > 0) {
+            ex.wave0([&](int lane) { dc_guess(c, lds, nfull, lane); });
+            ex.wave0([&](int lane) { dc_warm(c, lds, nfull, lane); });
+            do {
+                ex.wave0([&](int lane) { dc_real(c, lds, nfull, lane, gain, pcm + base); });
+            } while (!ex.wave0_all([&](int lane) { return dc_check(lds, nfull, lane); }));
+            ex.wave0([&](int lane) {
+                if (lane == 0) {
+                    lds.y_carry = lds.e[nfull - 1];
+                    lds.x_carry = (float)lds.x[(nfull - 1) * (SEG + 1) + SEG - 1];
+                }
+            });
+        }
+        const int rest = len - nfull * SEG;       // a tail shorter than a segment: one lane, serial
+        if (rest > 0) {
+            ex.wave0([&](int lane) {
+                if (lane != 0) return;
+                DcCarry t2{lds.x_carry, lds.y_carry};
+                dc_block_run(x + base + nfull * SEG, rest, gain, c.dc_a1, t2, pcm + base + nfull * SEG);
+                lds.x_carry = t2.x_prev;
+                lds.y_carry = t2.y_prev;
+            });
+        }
+    }
+    st.x_prev = lds.x_carry;
+    st.y_prev = lds.y_carry;
 }
 
 }  // namespace iqd

@@ -279,7 +279,16 @@ int iqd_reset(iqd_t *e, uint32_t first_ch, uint32_t n_ch)
 {
     if (!range_ok(e, first_ch, n_ch)) return IQD_EINVAL;
     (void)hipSetDevice(e->device);
-    HIP_TRY(e, launch_reset(e->d_tails, e->d_wcarry, e->d_dc, first_ch, n_ch, e->stream));
+    HIP_TRY(e, launch_reset(e->d_tails, e->d_wcarry, e->d_dc, first_ch, n_ch, 0xfu, e->stream));
+    return IQD_OK;
+}
+
+int iqd_reset_demod(iqd_t *e, uint32_t first_ch, uint32_t n_ch, int demod)
+{
+    if (!range_ok(e, first_ch, n_ch) || demod < IQD_DEMOD_AM || demod > IQD_DEMOD_SSB) return IQD_EINVAL;
+    static const int fam[5] = {0, FAM_AM, FAM_FM, FAM_WBFM, FAM_SSB};
+    (void)hipSetDevice(e->device);
+    HIP_TRY(e, launch_reset(e->d_tails, e->d_wcarry, e->d_dc, first_ch, n_ch, 1u << fam[demod], e->stream));
     return IQD_OK;
 }
 
@@ -481,6 +490,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
     base.counters = e->d_counters;
     base.mismatch_list = e->d_mismatch;
     base.stamps = e->d_stamps;
+    base.n_ch_call = n_ch;
 
     const bool fused_mag = want_mag && !gated;
     bool timed = false;

@@ -41,7 +41,9 @@ struct ChainLaunch {
     const uint32_t *tile_sel;     // optional (list index, tile) pairs for a repair launch
     uint32_t *counters;           // [CNT_COUNT]
     uint32_t *mismatch_list;      // [MAX_MISMATCH_LIST][2]
-    int32_t *base8k;              // [n_ch][pcm_stride] AM/SSB 8 kS/s intermediates
+    int32_t *base8k;              // AM/SSB detector input at 8 kS/s, n_ch_call * pcm_stride ints
+    size_t base_stride_ch, base_stride_t;   // its layout: channel-major or time-major
+    uint32_t n_ch_call;           // channels in this accept call
     unsigned long long *stamps;   // diagnostic builds (IQD_STAMPS): [16] phase cycle sums
 };
 
@@ -62,7 +64,8 @@ hipError_t upload_consts(const Consts &c, hipStream_t s);
 hipError_t launch_wbfm(const ChainLaunch &a, bool gated, bool mag, uint32_t n_blocks, hipStream_t s);
 hipError_t launch_fm(const ChainLaunch &a, bool gated, bool mag, uint32_t n_blocks, hipStream_t s);
 hipError_t launch_am(const ChainLaunch &a, int family, bool gated, bool mag, uint32_t n_blocks, hipStream_t s);
-hipError_t launch_reset(uint8_t *tails, WbfmCarry *wc, DcCarry *dc, uint32_t first_ch, uint32_t n_ch, hipStream_t s);
+hipError_t launch_reset(uint8_t *tails, WbfmCarry *wc, DcCarry *dc, uint32_t first_ch, uint32_t n_ch,
+                        uint32_t family_mask, hipStream_t s);
 hipError_t launch_wbfm_verify(const ChainLaunch &a, hipStream_t s);
 hipError_t launch_wbfm_commit(const ChainLaunch &a, hipStream_t s);
 hipError_t launch_tail_update(const ChainLaunch &a, int family, hipStream_t s);

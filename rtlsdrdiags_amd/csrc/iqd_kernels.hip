@@ -155,21 +155,79 @@ __global__ __launch_bounds__(WB_THREADS) void am_chain_kernel(const ChainLaunch 
     if (!setup_tile(a, GATED, family, t, ch, ech)) return;
     DeviceExec ex{(int)threadIdx.x};
     am_tile<GATED, MAG>(ex, t, g_consts, lds, family == FAM_SSB, a.params[ech].ssb_lsb,
-                        a.base8k + (size_t)ch * a.pcm_stride);
+                        a.base8k + (size_t)ch * a.base_stride_ch, (int)a.base_stride_t);
 }
 
-// AM / SSB DC-removal IIR with the exact carried state: one lane per channel.
-__global__ void dc_kernel(const ChainLaunch a, int family)
+// AM / SSB DC-removal IIR with the exact carried state for batches of short streams: one lane per
+// channel, 64 channels per wave.  The detector input was written time-major ([t][channel]) by
+// am_chain_kernel, so a wave reads one coalesced row per step (8 steps in flight); PCM goes
+// through a 64 x 64 LDS tile so that the channel-major output rows are written coalesced too.
+__global__ __launch_bounds__(64) void dc_kernel(const ChainLaunch a, int family)
 {
-    const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
-    if (li >= a.n_list) return;
+    __shared__ __attribute__((aligned(16))) uint32_t pout[64][34];  // int16 pairs, row stride 136 B
+    const int lane = threadIdx.x;
+    const uint32_t li0 = blockIdx.x * 64;
+    const uint32_t n_rows = a.n_list - li0 < 64 ? a.n_list - li0 : 64;
+    const uint32_t which = family == FAM_SSB ? 1 : 0;
+    const bool mine = (uint32_t)lane < n_rows;
+    const uint32_t ch = a.ch_list[li0 + (mine ? lane : 0)];
+    const uint32_t ech = a.first_ch + ch;
+    const uint32_t n_mine = mine ? (a.vlen_gated ? a.vlen_gated[ch] : a.vlen) / 32 : 0;
+    const float gain = a.params[ech].gain[family];
+    DcCarry st = a.dc_carry[2 * (size_t)ech + which];
+    uint32_t n_max = n_mine;
+    for (int off = 32; off > 0; off >>= 1) {
+        const uint32_t o = __shfl_xor(n_max, off);
+        n_max = o > n_max ? o : n_max;
+    }
+    const float a1 = g_consts.dc_a1;
+    const int32_t *src = a.base8k + ch;                 // + t * base_stride_t
+    for (uint32_t t0 = 0; t0 < n_max; t0 += 64) {
+        int32_t xs[64];                                 // 64 coalesced row loads in flight
+#pragma unroll
+        for (int k = 0; k < 64; k++) {                  // rows beyond n_mine are clamped, results unused
+            const uint32_t t = t0 + k < a.pcm_stride ? t0 + k : (uint32_t)a.pcm_stride - 1;
+            xs[k] = src[(size_t)t * a.base_stride_t];
+        }
+#pragma unroll
+        for (int i = 0; i < 64; i += 8) {
+            uint32_t w[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const float xf = (float)xs[i + k];
+                const float tn = xf - st.x_prev;
+                const float r = a1 * st.y_prev;
+                const float y = tn - r;
+                w[k] = (uint32_t)cast_i16(gain * y);
+                if (t0 + i + k < n_mine) { st.x_prev = xf; st.y_prev = y; }
+            }
+            *(u32x4 *)&pout[lane][i >> 1] = u32x4{pack_lo16(w[0], w[1]), pack_lo16(w[2], w[3]),
+                                                 pack_lo16(w[4], w[5]), pack_lo16(w[6], w[7])};
+        }
+        __syncthreads();
+        for (uint32_t r = 0; r < n_rows; r++) {        // row r's channel and length live in lane r
+            const uint32_t chr = __shfl(ch, (int)r);
+            const uint32_t n_r = __shfl(n_mine, (int)r);
+            if (t0 + lane < n_r) a.pcm[(size_t)chr * a.pcm_stride + t0 + lane] = ((const int16_t *)pout[r])[lane];
+        }
+        __syncthreads();
+    }
+    if (mine) a.dc_carry[2 * (size_t)ech + which] = st;
+}
+
+// The same for long streams: one wave per channel, segmented with exact verification.
+__global__ __launch_bounds__(64) void dc_wave_kernel(const ChainLaunch a, int family)
+{
+    __shared__ DcLds lds;
+    const uint32_t li = blockIdx.x;
     const uint32_t ch = a.ch_list[li], ech = a.first_ch + ch;
     const uint32_t vlen = a.vlen_gated ? a.vlen_gated[ch] : a.vlen;
     const ChanParams &p = a.params[ech];
     DcCarry st = a.dc_carry[2 * (size_t)ech + (family == FAM_SSB ? 1 : 0)];
-    dc_block_run(a.base8k + (size_t)ch * a.pcm_stride, (int)(vlen / 32), p.gain[family], g_consts.dc_a1, st,
-                 a.pcm + (size_t)ch * a.pcm_stride);
-    a.dc_carry[2 * (size_t)ech + (family == FAM_SSB ? 1 : 0)] = st;
+    DeviceExec ex{(int)threadIdx.x};
+    dc_block_wave(ex, g_consts, lds, a.base8k + (size_t)ch * a.base_stride_ch, (int)(vlen / 32), p.gain[family], st,
+                  a.pcm + (size_t)ch * a.pcm_stride);
+    if (threadIdx.x == 0) a.dc_carry[2 * (size_t)ech + (family == FAM_SSB ? 1 : 0)] = st;
 }
 
 // Hand-off check between consecutive tiles of a channel: a cold tile's own state at its
@@ -316,19 +374,25 @@ __global__ void squelch_track_kernel(const SquelchLaunch q)
 
 // resetDemodulator() for a channel range: histories become zero signal; the WBFM
 // de-emphasis state survives (WbFmDemodulator.cc:304-320) and restarts at the stream end.
-__global__ void reset_kernel(uint8_t *tails, WbfmCarry *wc, DcCarry *dc, uint32_t first_ch, uint32_t n_ch)
+__global__ void reset_kernel(uint8_t *tails, WbfmCarry *wc, DcCarry *dc, uint32_t first_ch, uint32_t n_ch,
+                             uint32_t family_mask)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t n16 = (size_t)n_ch * FAM_COUNT * TAIL_BYTES / 16;
+    const size_t per_tail = TAIL_BYTES / 16;
+    const size_t n16 = (size_t)n_ch * FAM_COUNT * per_tail;
     uint4 *t = (uint4 *)(tails + (size_t)first_ch * FAM_COUNT * TAIL_BYTES);
-    for (size_t k = i; k < n16; k += (size_t)gridDim.x * blockDim.x)
-        t[k] = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
+    for (size_t k = i; k < n16; k += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t fam = (uint32_t)((k / per_tail) % FAM_COUNT);
+        if (family_mask & (1u << fam)) t[k] = make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
+    }
     if (i < n_ch) {
-        WbfmCarry c = wc[first_ch + i];
-        c.y = c.y_end; c.u = c.u_end; c.back = 0;
-        wc[first_ch + i] = c;
-        dc[2 * (size_t)(first_ch + i)] = DcCarry{0.f, 0.f};
-        dc[2 * (size_t)(first_ch + i) + 1] = DcCarry{0.f, 0.f};
+        if (family_mask & (1u << FAM_WBFM)) {
+            WbfmCarry c = wc[first_ch + i];
+            c.y = c.y_end; c.u = c.u_end; c.back = 0;
+            wc[first_ch + i] = c;
+        }
+        if (family_mask & (1u << FAM_AM)) dc[2 * (size_t)(first_ch + i)] = DcCarry{0.f, 0.f};
+        if (family_mask & (1u << FAM_SSB)) dc[2 * (size_t)(first_ch + i) + 1] = DcCarry{0.f, 0.f};
     }
 }
 
@@ -364,13 +428,19 @@ hipError_t launch_fm(const ChainLaunch &a, bool gated, bool mag, uint32_t n_bloc
     return hipGetLastError();
 }
 
-hipError_t launch_am(const ChainLaunch &a, int family, bool gated, bool mag, uint32_t n_blocks, hipStream_t s)
+hipError_t launch_am(const ChainLaunch &a_in, int family, bool gated, bool mag, uint32_t n_blocks, hipStream_t s)
 {
     dim3 grid(n_blocks), block(WB_THREADS);
+    ChainLaunch a = a_in;
+    const bool batch = a.vlen / 32 <= 2048;      // short streams: lane-per-channel DC pass
+    a.base_stride_ch = batch ? 1 : a.pcm_stride; // time-major scratch for it, channel-major otherwise
+    a.base_stride_t = batch ? a.n_ch_call : 1;
     if (gated) hipLaunchKernelGGL((am_chain_kernel<true, false>), grid, block, 0, s, a, family);
     else if (mag) hipLaunchKernelGGL((am_chain_kernel<false, true>), grid, block, 0, s, a, family);
     else hipLaunchKernelGGL((am_chain_kernel<false, false>), grid, block, 0, s, a, family);
-    hipLaunchKernelGGL(dc_kernel, dim3((a.n_list + 63) / 64), dim3(64), 0, s, a, family);
+    // short streams: one lane per channel; long streams: one wave per channel, segmented
+    if (batch) hipLaunchKernelGGL(dc_kernel, dim3((a.n_list + 63) / 64), dim3(64), 0, s, a, family);
+    else hipLaunchKernelGGL(dc_wave_kernel, dim3(a.n_list), dim3(64), 0, s, a, family);
     return hipGetLastError();
 }
 
@@ -410,11 +480,12 @@ hipError_t launch_squelch(const SquelchLaunch &q, bool always_open, hipStream_t 
     return hipGetLastError();
 }
 
-hipError_t launch_reset(uint8_t *tails, WbfmCarry *wc, DcCarry *dc, uint32_t first_ch, uint32_t n_ch, hipStream_t s)
+hipError_t launch_reset(uint8_t *tails, WbfmCarry *wc, DcCarry *dc, uint32_t first_ch, uint32_t n_ch,
+                        uint32_t family_mask, hipStream_t s)
 {
     uint32_t blocks = (n_ch + 255) / 256;
     if (blocks < 64) blocks = 64;
-    hipLaunchKernelGGL(reset_kernel, dim3(blocks), dim3(256), 0, s, tails, wc, dc, first_ch, n_ch);
+    hipLaunchKernelGGL(reset_kernel, dim3(blocks), dim3(256), 0, s, tails, wc, dc, first_ch, n_ch, family_mask);
     return hipGetLastError();
 }
 

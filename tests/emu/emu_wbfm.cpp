@@ -163,10 +163,19 @@ void emu_chain_accept(int family, int lsb, const uint8_t *iq, uint32_t n_samples
             fm_tile<false, true>(ex, t, c, flds, fm_lut.data());
         } else {
             memset(&alds, 0xcd, sizeof(alds));
-            am_tile<false, true>(ex, t, c, alds, family == FAM_SSB, lsb, base8k);
+            am_tile<false, true>(ex, t, c, alds, family == FAM_SSB, lsb, base8k, 1);
         }
     }
-    if (family != FAM_FM) dc_block_run(base8k, (int)(n_samples / 32), p.gain[family], c.dc_a1, *dc, pcm);
+    if (family != FAM_FM) {
+        if (n_samples / 32 <= 256) {
+            dc_block_run(base8k, (int)(n_samples / 32), p.gain[family], c.dc_a1, *dc, pcm);
+        } else {   // the segmented wave-per-channel variant
+            static DcLds dlds;
+            memset(&dlds, 0xcd, sizeof(dlds));
+            HostExec ex;
+            dc_block_wave(ex, c, dlds, base8k, (int)(n_samples / 32), p.gain[family], *dc, pcm);
+        }
+    }
     std::vector<uint8_t> nt(TAIL_BYTES);
     for (int i = 0; i < TAIL; i++) {
         const int64_t v = (int64_t)n_samples - TAIL + i;

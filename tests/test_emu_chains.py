@@ -62,3 +62,18 @@ def test_fm_unbounded_cast(emu, oracle):
     ref, _, _ = oracle_run(oracle, "fm", u8, gain=4.0e9)
     pcm, _ = emu_bind.FirChannel(emu, "fm", 8192, gain=4.0e9).accept(u8)
     assert np.array_equal(pcm, ref)
+
+
+@pytest.mark.parametrize("mode", ["am", "usb"])
+@pytest.mark.parametrize("n_samples", [278528, 266368])
+def test_long_stream_segmented_dc_blocker(emu, oracle, mode, n_samples):
+    """More than one pass of the wave-per-channel DC-removal kernel, with a partial last pass and a
+    last segment shorter than 128 PCM samples."""
+    u8 = synth.am_tone(n_samples, seed=51, depth=0.8)
+    c = oracle.chain()
+    c.set_mode(mode)
+    ref = np.concatenate([c.accept_stream(u8[o:o + 32768])[0] for o in range(0, len(u8) - 32767, 32768)]
+                         + ([c.accept_stream(u8[len(u8) // 32768 * 32768:], 256)[0]] if len(u8) % 32768 else []))
+    ch = emu_bind.FirChannel(emu, mode, 65536)
+    pcm, _ = ch.accept(u8)
+    assert np.array_equal(pcm, ref)

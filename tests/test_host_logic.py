@@ -74,3 +74,13 @@ def test_product_never_touches_the_oracle():
                     if hits:
                         bad.append((f, hits))
     assert not bad, bad
+
+
+def test_file_tool_fails_loudly_without_gpu():
+    import subprocess
+    import torch
+    tool = os.path.join(ROOT, "rtlsdrdiags_amd", "bin", "iqdemod_file")
+    assert os.path.exists(tool)
+    if not torch.cuda.is_available():
+        r = subprocess.run([tool, "3"], input=b"\x80" * 32768, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 1 and b"no usable HIP device" in r.stderr and r.stdout == b""
