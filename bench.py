@@ -53,6 +53,16 @@ def cpu_baseline(period_u8, seconds_target=12.0):
                       "IqDataProcessor::acceptIqData in 32768-byte blocks, 1 thread" % reps}
 
 
+def measured_traffic(mode, n_ch, log2_samples):
+    """HBM bytes per launch of the chain kernel from the committed rocprofv3 PMC summary of the same
+    workload (profiles/), or None: bench.py itself cannot collect PMC counters."""
+    path = os.path.join(ROOT, "profiles", "r1_wbfm_2p28_pmc.json")
+    if mode == "wbfm" and n_ch == 1 and log2_samples == 28 and os.path.exists(path):
+        with open(path) as f:
+            return json.load(f).get("traffic_bytes_per_launch")
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -145,8 +155,9 @@ def main():
                        "sharding": "independent channels, one per rank, no data-path collective"
                                    + ("; PCM gathered to rank 0 over RCCL" if args.gather else "")},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "wbfm_chain_kernel", "kernel_ms": round(kern_ms, 4),
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": measured_traffic(args.mode, n_ch, args.log2_samples),
+                         "kernel": "%s_chain_kernel" % ("am" if args.mode in ("am", "lsb", "usb") else args.mode), "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_SAMPLE * n * n_ch},
             "state_checks": k1["state_checks"] - k0["state_checks"],
             "state_repairs": k1["state_repairs"] - k0["state_repairs"],
