@@ -41,9 +41,7 @@ IQD_DEV void front_rotate(const Tile &t, Lds &lds, const ChunkBlocks &cb, int cs
         *(u32x4 *)&lds.xi[rail_hist + 4 * g] = u32x4{xi[0], xi[1], xi[2], xi[3]};
         *(u32x4 *)&lds.xq[rail_hist + 4 * g] = u32x4{xq[0], xq[1], xq[2], xq[3]};
         if (MAG && cstart >= 0) {
-            uint32_t m = 0;
-#pragma unroll
-            for (int j = 0; j < 8; j++) m += magnitude2(s[j]);
+            const uint32_t m = magnitude16(s);
             const uint32_t slot = div_block(t, cb.in_blk + (uint32_t)(16 * g));
 #if IQD_ON_DEVICE
             atomicAdd(&lds.mag[slot], m);
@@ -109,6 +107,7 @@ struct FmLds {
     alignas(16) uint32_t e[(12 + CH_CHUNK / 4) / 2];         // int16 (int16)(K*dtheta), 12 of history
     alignas(16) uint32_t y2[(40 + CH_CHUNK / 16) / 2];       // int16 16 kS/s, 40 of history
     alignas(16) uint32_t mag[CH_CHUNK / SEG + 2];
+    uint32_t e_peak, e_peak_hist, y2_peak, y2_peak_hist;   // loudness flags for the clamp-free fast paths
 };
 
 // Tuner decimator /4, 32 taps (FmDemodulator.cc:389-419) + phase angle (:476).
@@ -146,32 +145,54 @@ IQD_DEV void fm_stage1(const Tile &t, const Consts &c, FmLds &lds, int clen, int
 IQD_DEV void fm_discriminate(const Tile &t, FmLds &lds, int clen, int tid)
 {
     const int nout = clen >> 2;
+    uint32_t peak = 0;
     for (int m = tid; m < nout; m += WB_THREADS) {
         float d = lds.theta[4 + m - 2] - lds.theta[4 + m - 4];
         d = wrap_delta(d);
         const float v = t.k * d;
-        put_i16(lds.e, 12 + m, t.bounded ? (int)cast_i16_bounded(v) : cast_i16(v));
+        const int e = (int)(int16_t)(uint16_t)(t.bounded ? cast_i16_bounded(v) : (uint32_t)cast_i16(v));
+        put_i16(lds.e, 12 + m, e);
+        const uint32_t a = (uint32_t)(e < 0 ? -e : e);
+        peak = a > peak ? a : peak;
     }
+    if (peak > (uint32_t)POST12_SAFE) lds_max(&lds.e_peak, peak);
 }
 
 IQD_DEV void fm_post(const Consts &c, FmLds &lds, int clen, int tid)   // /4, 12 taps (:545)
 {
     const int nout = clen >> 4;
-    for (int j = tid; j < nout; j += WB_THREADS)
-        put_i16(lds.y2, 40 + j, q15_seq<12>(c.post12, lds.e, 12 + 4 * j + 3));
+    const bool quiet = lds.e_peak <= (uint32_t)POST12_SAFE && lds.e_peak_hist <= (uint32_t)POST12_SAFE;
+    uint32_t peak = 0;
+    for (int j = tid; j < nout; j += WB_THREADS) {
+        const int y = quiet ? q15_pairs<12>(c.post12, lds.e, 12 + 4 * j + 3) : q15_seq<12>(c.post12, lds.e, 12 + 4 * j + 3);
+        put_i16(lds.y2, 40 + j, y);
+        const uint32_t a = (uint32_t)(y < 0 ? -y : y);
+        peak = a > peak ? a : peak;
+    }
+    if (peak > (uint32_t)AUDIO40_SAFE) lds_max(&lds.y2_peak, peak);
 }
 
 IQD_DEV void fm_audio(const Consts &c, FmLds &lds, const Tile &t, int cstart, int clen, int tid)  // /2, 40 taps
 {
     const int nout = clen >> 5;
+    const bool quiet = lds.y2_peak <= (uint32_t)AUDIO40_SAFE && lds.y2_peak_hist <= (uint32_t)AUDIO40_SAFE;
     for (int i = tid; i < nout; i += WB_THREADS) {
-        const int y = q15_seq<40>(c.audio40, lds.y2, 40 + 2 * i + 1);
+        const int y = quiet ? q15_pairs<40>(c.audio40, lds.y2, 40 + 2 * i + 1)
+                            : q15_seq<40>(c.audio40, lds.y2, 40 + 2 * i + 1);
         if (cstart >= 0) t.pcm_row[((t.v0 + cstart) >> 5) + i] = (int16_t)y;
     }
 }
 
 IQD_DEV void fm_shift(FmLds &lds, int clen, int tid)
 {
+    if (tid == 64) {   // conservative loudness flags for what stays in reach of the next chunk
+        const uint32_t keep_e = (clen >> 2) >= 12 ? 0u : lds.e_peak_hist;
+        lds.e_peak_hist = lds.e_peak > keep_e ? lds.e_peak : keep_e;
+        lds.e_peak = 0;
+        const uint32_t keep_y = (clen >> 4) >= 40 ? 0u : lds.y2_peak_hist;
+        lds.y2_peak_hist = lds.y2_peak > keep_y ? lds.y2_peak : keep_y;
+        lds.y2_peak = 0;
+    }
     const int n4 = clen >> 2;                 // rail dwords and 64 kS/s samples in this chunk
     shift_hist(lds.xi, 8, n4, tid, 0);
     shift_hist(lds.xq, 8, n4, tid, 8);
@@ -190,6 +211,7 @@ IQD_DEV void fm_tile(Exec &ex, const Tile &t, const Consts &c, FmLds &lds, const
         if (tid < 6) lds.e[tid] = 0;
         if (tid < 20) lds.y2[tid] = 0;
         if (tid < CH_CHUNK / SEG + 2) lds.mag[tid] = 0;
+        if (tid == 0) lds.e_peak = lds.e_peak_hist = lds.y2_peak = lds.y2_peak_hist = 0;
     });
     for (int cstart = -FIR_HALO; cstart < t.tlen;) {
         const int clen = cstart < 0 ? -cstart : (t.tlen - cstart < CH_CHUNK ? t.tlen - cstart : CH_CHUNK);

@@ -55,8 +55,8 @@ struct VerifyRec { float y_in, y_out, u_out; uint32_t flags; };
 
 // ---- constants (taps, packed the way the kernels consume them) ----------------------------
 struct Consts {
-    // WBFM pre-demod 16-tap FIR split into low/high tap bytes for v_dot4_i32_i8;
-    // dword q covers window bytes 4q..4q+3 (oldest sample first).
+    // WBFM pre-demod 16-tap FIR for v_dot4_i32_i8, accumulator DOUBLED: pre_lo holds 2*lo with
+    // h = 128*hi + lo; dword q covers window bytes 4q..4q+3 (oldest sample first).
     int32_t pre_lo[4], pre_hi[4];
     // Q15 taps of the decimators, as int16 (index = k, newest sample first)
     int16_t wbfm_d1[8], post12[12], audio40[40];

@@ -43,12 +43,32 @@ static void pack_dot4(const int16_t *hq, int L, int32_t *lo, int32_t *hi)
     }
 }
 
+// The WBFM pre-demod FIR wants its accumulator doubled, so that the 8 bits the atan2 table is
+// indexed with (bits 15..22 of the Q15 sum) land on a byte boundary (bits 16..23):
+// h = 128*hi + lo with lo in [-64,63];  2*sum(h*x) = sum((2*lo)*x) + 256*sum(hi*x).
+static void pack_dot4_doubled(const int16_t *hq, int L, int32_t *lo2, int32_t *hi)
+{
+    for (int q = 0; q < L / 4; q++) {
+        uint32_t l = 0, h = 0;
+        for (int b = 0; b < 4; b++) {
+            const int tap = hq[L - 1 - (4 * q + b)];
+            int tl = tap & 0x7f;
+            if (tl >= 64) tl -= 128;
+            const int th = (tap - tl) / 128;     // |tap| <= 15933 -> |th| <= 125
+            l |= (uint32_t)(uint8_t)(int8_t)(2 * tl) << (8 * b);
+            h |= (uint32_t)(uint8_t)(int8_t)th << (8 * b);
+        }
+        lo2[q] = (int32_t)l;
+        hi[q] = (int32_t)h;
+    }
+}
+
 void build_consts(Consts &c)
 {
     memset(&c, 0, sizeof(c));
     int16_t pre[16];
     quantize_q15(taps::WBFM_PRE, 16, pre);
-    pack_dot4(pre, 16, c.pre_lo, c.pre_hi);
+    pack_dot4_doubled(pre, 16, c.pre_lo, c.pre_hi);
     quantize_q15(taps::WBFM_D1, 8, c.wbfm_d1);
     quantize_q15(taps::POST12, 12, c.post12);
     quantize_q15(taps::AUDIO40, 40, c.audio40);

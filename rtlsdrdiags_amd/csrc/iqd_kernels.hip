@@ -33,6 +33,8 @@ struct DeviceExec {
         return __all(ok);
     }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
+    // the single-wave IIR phase is the workgroup's critical path: let it win VALU arbitration
+    __device__ __forceinline__ void critical(bool on) const { if (on) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
 #ifdef IQD_STAMPS   // diagnostic build only: cycles per phase, summed over workgroups
     unsigned long long last = 0, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     __device__ __forceinline__ void stamp(int k)

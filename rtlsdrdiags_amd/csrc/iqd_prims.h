@@ -41,6 +41,30 @@ IQD_DEV int dot4(uint32_t a, int32_t b, int acc)
 #endif
 }
 
+// First link of a dot4 chain: c + dot4(a, b) with c in a VGPR / as the constant 0, written to a
+// fresh register (VOP3P form).  The compiler would otherwise spend a v_mov per chain on the
+// destructive v_dot4c form.
+IQD_DEV int dot4_first(uint32_t a, int32_t b, int c_vgpr)
+{
+#if IQD_ON_DEVICE
+    int r;
+    asm("v_dot4_i32_i8 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c_vgpr));
+    return r;
+#else
+    return dot4(a, b, c_vgpr);
+#endif
+}
+IQD_DEV int dot4_first0(uint32_t a, int32_t b)
+{
+#if IQD_ON_DEVICE
+    int r;
+    asm("v_dot4_i32_i8 %0, %1, %2, 0" : "=v"(r) : "v"(a), "s"(b));
+    return r;
+#else
+    return dot4(a, b, 0);
+#endif
+}
+
 // acc + a.lo*b.lo + a.hi*b.hi on signed 16-bit halves (v_dot2_i32_i16)
 IQD_DEV int dot2(uint32_t a, uint32_t b, int acc)
 {

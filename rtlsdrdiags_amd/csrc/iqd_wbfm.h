@@ -25,7 +25,7 @@
 namespace iqd {
 
 constexpr int WB_THREADS = 256;
-constexpr int WB_BIAS = 16384 + (128 << 15);  // Q15 rounding term + 128 for the table index
+constexpr int WB_BIAS = 2 * (16384 + (128 << 15));  // doubled: Q15 rounding term + 128 for the table index
 constexpr int TGRAN = TSTRIDE / 4;            // 16-byte granules per segment of the IIR input
 
 // Granule gi (0..31) of a segment sits at gi ^ ((gi >> 3) & 3): phase 1 writes 16 consecutive
@@ -46,6 +46,7 @@ struct WbfmLds {
     float y_carry, u_carry;                // state entering the chunk
     uint32_t mag[WBFM_CHUNK / SEG + 2];    // squelch magnitude partial sums per block slot
     uint32_t repair_count;
+    uint32_t y2_peak, y2_peak_hist;        // max |y2| of this chunk (if loud) / reaching into the next
 };
 
 // Per 16-sample group: sum c^(15-k) u[k], input of the IIR state guess.  Lives in the data part of
@@ -89,9 +90,11 @@ IQD_DEV void rotate4(const WbfmTile &t, uint32_t w0, uint32_t w1, uint32_t &xi, 
 }
 
 // 17 outputs (samples -1 .. 15 of the group) of the 16-tap FIR over 32 bytes of one rail.
-// Output idx uses window bytes idx .. idx+15; the result carries WB_BIAS.
+// Output idx uses window bytes idx .. idx+15.  The result is TWICE the Q15 accumulator plus WB_BIAS, so
+// that byte 2 of it is (uint8)((int8)(acc >> 15) + 128), the atan2 table index.
 IQD_DEV void fir16_window(const uint32_t (&x)[8], const Consts &c, int (&acc)[17])
 {
+    const int bias = WB_BIAS;   // lives in one VGPR for all chains
     uint32_t y[3][7];
 #pragma unroll
     for (int j = 0; j < 7; j++) {
@@ -102,12 +105,12 @@ IQD_DEV void fir16_window(const uint32_t (&x)[8], const Consts &c, int (&acc)[17
 #pragma unroll
     for (int idx = 0; idx < 17; idx++) {
         const int s = idx & 3, j0 = idx >> 2;
-        int lo = WB_BIAS, hi = 0;
+        int lo, hi;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const uint32_t d = (s == 0) ? x[j0 + q] : y[s - 1][j0 + q];
-            lo = dot4(d, c.pre_lo[q], lo);
-            hi = dot4(d, c.pre_hi[q], hi);
+            lo = q == 0 ? dot4_first(d, c.pre_lo[0], bias) : dot4(d, c.pre_lo[q], lo);
+            hi = q == 0 ? dot4_first0(d, c.pre_hi[0]) : dot4(d, c.pre_hi[q], hi);
         }
         acc[idx] = lo + (int)((uint32_t)hi << 8);
     }
@@ -127,6 +130,33 @@ IQD_DEV uint32_t magnitude2(uint32_t s)
     return sum;
 }
 
+// The same for 8 dwords (16 samples) with packed 16-bit arithmetic: two samples per instruction.
+// Per lane of 16 bits the partial sums stay below 8 * 192, so they cannot carry into the neighbour.
+IQD_DEV uint32_t magnitude16(const uint32_t (&s)[8])
+{
+#if IQD_ON_DEVICE
+    typedef short s2 __attribute__((ext_vector_type(2)));
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    us2 acc = {0, 0};
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const s2 w = __builtin_bit_cast(s2, s[j]);
+        const s2 q = w >> 8;                       // sign-extended high bytes (Q)
+        const s2 i = (s2)(w << 8) >> 8;            // sign-extended low bytes (I)
+        const us2 a = __builtin_bit_cast(us2, __builtin_elementwise_max(i, (s2)(-i)));
+        const us2 b = __builtin_bit_cast(us2, __builtin_elementwise_max(q, (s2)(-q)));
+        const us2 mx = __builtin_elementwise_max(a, b), mn = __builtin_elementwise_min(a, b);
+        acc += mx + (mn >> 1);
+    }
+    const uint32_t r = __builtin_bit_cast(uint32_t, acc);
+    return (r & 0xffffu) + (r >> 16);
+#else
+    uint32_t m = 0;
+    for (int j = 0; j < 8; j++) m += magnitude2(s[j]);
+    return m;
+#endif
+}
+
 IQD_DEV uint32_t div_block(const WbfmTile &t, uint32_t x)  // x / block_samples, x < 65536
 {
     return (uint32_t)(((uint64_t)x * t.block_magic) >> 32);
@@ -144,65 +174,136 @@ IQD_DEV ChunkBlocks chunk_blocks(const WbfmTile &t, int cstart)
     return cb;
 }
 
+// ---- phase 1, split so that two 16-sample groups per lane can be interleaved: the second
+// group's FIR arithmetic runs while the first group's table gathers are in flight ----------
+struct P1Raw { u32x4 r0, r1, r2, r3; };   // 16 lead-in samples + the group's own 16
+
+template <bool GATED>
+IQD_DEV P1Raw p1_load(const WbfmTile &t, int64_t v)
+{
+    const u32x4 *ph = raw_group<GATED>(t, v - 16);
+    const u32x4 *po = raw_group<GATED>(t, v);
+    return P1Raw{ph[0], ph[1], po[0], po[1]};
+}
+
+// raw -> signed -> rotated rails -> 17 FIR outputs per rail -> byte offsets into the atan2 table
+IQD_DEV void p1_front(const WbfmTile &t, const Consts &c, const P1Raw &r, uint32_t (&off)[17])
+{
+    uint32_t s[16] = {r.r0.x, r.r0.y, r.r0.z, r.r0.w, r.r1.x, r.r1.y, r.r1.z, r.r1.w,
+                      r.r2.x, r.r2.y, r.r2.z, r.r2.w, r.r3.x, r.r3.y, r.r3.z, r.r3.w};
+    uint32_t xi[8], xq[8];
+#pragma unroll
+    for (int j = 0; j < 16; j++) s[j] ^= 0x80808080u;  // offset binary -> signed (:735-738)
+#pragma unroll
+    for (int j = 0; j < 8; j++) rotate4(t, s[2 * j], s[2 * j + 1], xi[j], xq[j]);
+    int ai[17], aq[17];
+#ifdef IQD_ABL_NOFIR   // diagnostic build: skip the FIR arithmetic, keep its inputs alive
+#pragma unroll
+    for (int k = 0; k < 17; k++) { ai[k] = (int)(xi[k & 7] + k); aq[k] = (int)(xq[k & 7] ^ k); }
+#else
+    fir16_window(xi, c, ai);
+    fir16_window(xq, c, aq);
+#endif
+#pragma unroll
+    for (int k = 0; k < 17; k++)  // float index of lut[(uint8)(Q'+128)][(uint8)(I'+128)]: byte 2 of each sum
+        off[k] = perm((uint32_t)aq[k], (uint32_t)ai[k], 0x0c0c0602u);
+}
+
+IQD_DEV void p1_gather(const WbfmTile &t, const uint32_t (&off)[17], float (&th)[17])
+{
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+#ifdef IQD_ABL_NOLUT   // diagnostic build: no table gather
+        th[k] = u2f(0x3f000000u | (off[k] & 0x3fffffu));
+#else
+        th[k] = t.lut[off[k]];
+#endif
+    }
+}
+
+IQD_DEV uint32_t p1_magnitude(const P1Raw &r)
+{
+    const uint32_t k = 0x80808080u;
+    const uint32_t own[8] = {r.r2.x ^ k, r.r2.y ^ k, r.r2.z ^ k, r.r2.w ^ k, r.r3.x ^ k, r.r3.y ^ k, r.r3.z ^ k, r.r3.w ^ k};
+    return magnitude16(own);
+}
+
+// theta -> delta theta, branch cut, K*d, b0*v -> LDS (+ the partial sum for the IIR state guess)
+IQD_DEV void p1_finish(const WbfmTile &t, const Consts &c, WbfmLds &lds, const float (&th)[17], int p, bool valid)
+{
+    const int seg = p >> 7, gq = (p & 127) >> 4;
+    float u[16];
+    const float c2 = c.deemph_c * c.deemph_c;
+    float pe = 0.f, po = 0.f;   // sum c^(15-k) u[k] as two interleaved chains (even / odd k)
+#pragma unroll
+    for (int k = 0; k < 16; k += 2) {
+        float d0 = th[k + 1] - th[k], d1 = th[k + 2] - th[k + 1];
+        d0 = wrap_delta(d0);
+        d1 = wrap_delta(d1);
+        const float v0 = t.k * d0, v1 = t.k * d1;
+        u[k] = c.deemph_b0 * v0;
+        u[k + 1] = c.deemph_b0 * v1;
+        pe = __builtin_fmaf(c2, pe, u[k]);
+        po = __builtin_fmaf(c2, po, u[k + 1]);
+    }
+    const float part = __builtin_fmaf(c.deemph_c, pe, po);
+    if (!valid) return;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        lds.t4[t_slot(seg, 4 * gq + q)] =
+            u32x4{f2u(u[4 * q]), f2u(u[4 * q + 1]), f2u(u[4 * q + 2]), f2u(u[4 * q + 3])};
+    lds_part(lds)[8 * seg + gq] = part;
+}
+
+IQD_DEV void p1_add_mag(const WbfmTile &t, WbfmLds &lds, const ChunkBlocks &cb, int p, uint32_t m)
+{
+    const uint32_t slot = div_block(t, cb.in_blk + (uint32_t)p);  // block slot relative to the chunk's first block
+#if IQD_ON_DEVICE
+    atomicAdd(&lds.mag[slot], m);
+#else
+    lds.mag[slot] += m;
+#endif
+}
+
 template <bool GATED, bool MAG>
 IQD_DEV void wbfm_phase1(const WbfmTile &t, const Consts &c, WbfmLds &lds, const ChunkBlocks &cb,
                          int cstart, int clen, int tid)
 {
     const int ngroups = clen >> 4;
-    for (int g = tid; g < ngroups; g += WB_THREADS) {
-        const int n0 = cstart + 16 * g;
-        const int64_t v = t.v0 + n0;
-        const u32x4 *ph = raw_group<GATED>(t, v - 16);
-        const u32x4 *po = raw_group<GATED>(t, v);
-        const u32x4 r0 = ph[0], r1 = ph[1], r2 = po[0], r3 = po[1];
-        uint32_t s[16] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w,
-                          r2.x, r2.y, r2.z, r2.w, r3.x, r3.y, r3.z, r3.w};
-        uint32_t xi[8], xq[8];
-#pragma unroll
-        for (int j = 0; j < 16; j++) s[j] ^= 0x80808080u;  // offset binary -> signed (:735-738)
-#pragma unroll
-        for (int j = 0; j < 8; j++) rotate4(t, s[2 * j], s[2 * j + 1], xi[j], xq[j]);
-
-        int ai[17], aq[17];
-        fir16_window(xi, c, ai);
-        fir16_window(xq, c, aq);
-
-        float th[17];
-#pragma unroll
-        for (int k = 0; k < 17; k++) {
-            // byte offset of lut[(uint8)(Q'+128)][(uint8)(I'+128)]: bits 15..22 of each accumulator
-            const uint32_t off = (((uint32_t)aq[k] >> 5) & 0x3fc00u) | (((uint32_t)ai[k] >> 13) & 0x3fcu);
-            th[k] = *(const float *)((const char *)t.lut + off);
-        }
-        const int p = n0 - cstart;  // position inside the chunk
-        const int seg = p >> 7, gq = (p & 127) >> 4;
-        float u[16];
-        const float cc = c.deemph_c;
-        float part = 0.f;
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            float d = th[k + 1] - th[k];
-            d = wrap_delta(d);
-            const float v1 = t.k * d;
-            u[k] = c.deemph_b0 * v1;
-            part = __builtin_fmaf(cc, part, u[k]);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-            lds.t4[t_slot(seg, 4 * gq + q)] =
-                u32x4{f2u(u[4 * q]), f2u(u[4 * q + 1]), f2u(u[4 * q + 2]), f2u(u[4 * q + 3])};
-        lds_part(lds)[8 * seg + gq] = part;
-        if (MAG && cstart >= 0) {
-            uint32_t m = 0;
-#pragma unroll
-            for (int j = 8; j < 16; j++) m += magnitude2(s[j]);
-            // block slot relative to the block holding the chunk's first sample
-            const uint32_t slot = div_block(t, cb.in_blk + (uint32_t)p);
-#if IQD_ON_DEVICE
-            atomicAdd(&lds.mag[slot], m);
+#ifdef IQD_ABL_NOMAG
+    const bool want_mag = false;
 #else
-            lds.mag[slot] += m;
+    const bool want_mag = MAG && cstart >= 0;
 #endif
+    for (int g0 = tid; (g0 & ~63) < ngroups; g0 += 2 * WB_THREADS) {   // wave-uniform trip count
+        // lanes past the end redo the chunk's last group and drop the result (no divergence)
+        const int ga = g0 < ngroups ? g0 : ngroups - 1;
+        const bool va = g0 < ngroups;
+        const bool wave_has_b = ((g0 & ~63) + WB_THREADS) < ngroups;
+        const int gb = g0 + WB_THREADS < ngroups ? g0 + WB_THREADS : ngroups - 1;
+        const bool vb = g0 + WB_THREADS < ngroups;
+        const P1Raw ra = p1_load<GATED>(t, t.v0 + cstart + 16 * ga);
+        uint32_t off[17];
+        float tha[17];
+        if (wave_has_b) {
+            const P1Raw rb = p1_load<GATED>(t, t.v0 + cstart + 16 * gb);
+            float thb[17];
+            p1_front(t, c, ra, off);
+            p1_gather(t, off, tha);
+            const uint32_t ma = want_mag ? p1_magnitude(ra) : 0u;
+            p1_front(t, c, rb, off);
+            p1_gather(t, off, thb);
+            const uint32_t mb = want_mag ? p1_magnitude(rb) : 0u;
+            p1_finish(t, c, lds, tha, 16 * ga, va);
+            p1_finish(t, c, lds, thb, 16 * gb, vb);
+            if (want_mag && va) p1_add_mag(t, lds, cb, 16 * ga, ma);
+            if (want_mag && vb) p1_add_mag(t, lds, cb, 16 * gb, mb);
+        } else {
+            p1_front(t, c, ra, off);
+            p1_gather(t, off, tha);
+            const uint32_t ma = want_mag ? p1_magnitude(ra) : 0u;
+            p1_finish(t, c, lds, tha, 16 * ga, va);
+            if (want_mag && va) p1_add_mag(t, lds, cb, 16 * ga, ma);
         }
     }
 }
@@ -386,20 +487,55 @@ IQD_DEV int q15_seq(const int16_t *h, const uint32_t *buf, int newest)
     return acc >> 15;
 }
 
-// /4, 12 taps (WbFmDemodulator.cc:541)
+// The same dot product when the bound proves that no clamp can fire: whole pairs per v_dot2,
+// any order.  L even, `newest` odd (the window then starts and ends on dword boundaries).
+template <int L>
+IQD_DEV int q15_pairs(const int16_t *h, const uint32_t *buf, int newest)
+{
+    int acc = 1 << 14;
+    const uint32_t *p = buf + (newest >> 1);
+#pragma unroll
+    for (int q = 0; q < L / 2; q++)
+        acc = dot2(p[-q], (uint32_t)(uint16_t)h[2 * q + 1] | ((uint32_t)(uint16_t)h[2 * q] << 16), acc);
+    return acc >> 15;
+}
+
+constexpr int AUDIO40_SAFE = 16061;   // (2^30 - 16384) / 66852: below it the 40-tap sum cannot clamp
+constexpr int POST12_SAFE = 29210;    // (2^30 - 16384) / 36758
+
+IQD_DEV void lds_max(uint32_t *slot, uint32_t v)
+{
+#if IQD_ON_DEVICE
+    atomicMax(slot, v);
+#else
+    if (v > *slot) *slot = v;
+#endif
+}
+
+// /4, 12 taps (WbFmDemodulator.cc:541).  Its input is stage 1's output, |y1| <= 29126 whatever the
+// data (sum|h1| = 29126 < 2^15), and 16384 + 36758 * 29126 < 2^30: the clamp can never fire here.
 IQD_DEV void wbfm_stage2(const Consts &c, WbfmLds &lds, int clen, int tid)
 {
     const int nout = clen >> 4;
-    for (int j = tid; j < nout; j += WB_THREADS)
-        put_i16(lds.y2, 40 + j, q15_seq<12>(c.post12, lds.y1, 8 + 4 * j + 3));
+    uint32_t peak = 0;
+    for (int j = tid; j < nout; j += WB_THREADS) {
+        const int y = q15_pairs<12>(c.post12, lds.y1, 8 + 4 * j + 3);
+        put_i16(lds.y2, 40 + j, y);
+        const uint32_t a = (uint32_t)(y < 0 ? -y : y);
+        peak = a > peak ? a : peak;
+    }
+    if (peak > (uint32_t)AUDIO40_SAFE) lds_max(&lds.y2_peak, peak);   // rare: loud audio only
 }
 
 // /2, 40 taps (WbFmDemodulator.cc:546) -> PCM
 IQD_DEV void wbfm_stage3(const Consts &c, WbfmLds &lds, const WbfmTile &t, int cstart, int clen, int tid)
 {
     const int nout = clen >> 5;
+    // the reference's per-MAC clamp matters only when some |y2| in reach exceeds AUDIO40_SAFE
+    const bool quiet = lds.y2_peak <= (uint32_t)AUDIO40_SAFE && lds.y2_peak_hist <= (uint32_t)AUDIO40_SAFE;
     for (int i = tid; i < nout; i += WB_THREADS) {
-        const int y = q15_seq<40>(c.audio40, lds.y2, 40 + 2 * i + 1);
+        const int y = quiet ? q15_pairs<40>(c.audio40, lds.y2, 40 + 2 * i + 1)
+                            : q15_seq<40>(c.audio40, lds.y2, 40 + 2 * i + 1);
         if (cstart >= 0) t.pcm_row[((t.v0 + cstart) >> 5) + i] = (int16_t)y;
     }
 }
@@ -419,6 +555,10 @@ IQD_DEV void wbfm_shift_history(WbfmLds &lds, int clen, int tid)
         const u32x2 last = w_group(lds, n1 - 1);
         lds.whist[0] = last.x;
         lds.whist[1] = last.y;
+    } else if (tid == 129) {   // conservative: the 40 samples kept may contain this chunk's peak
+        const uint32_t keep = n2 >= 40 ? 0u : lds.y2_peak_hist;
+        lds.y2_peak_hist = lds.y2_peak > keep ? lds.y2_peak : keep;
+        lds.y2_peak = 0;
     }
 }
 
@@ -455,6 +595,8 @@ IQD_DEV void wbfm_tile(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLds &ld
             lds.y_carry = start.cold ? 0.f : start.y;
             lds.u_carry = start.cold ? 0.f : start.u;
             lds.repair_count = 0;
+            lds.y2_peak = 0;
+            lds.y2_peak_hist = 0;
         }
     });
     // restart point for whoever continues this stream: FORCED_BACK before the end when the
@@ -475,6 +617,7 @@ IQD_DEV void wbfm_tile(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLds &ld
         ex.all([&](int tid) { wbfm_phase1<GATED, MAG>(t, c, lds, cb, cstart, clen, tid); });
         ex.stamp(0);
         if (ex.in_wave0()) {
+            ex.critical(true);
             if (rec_pos == cstart) { rec.y_out = lds.y_carry; rec.u_out = lds.u_carry; }
             ex.wave0([&](int lane) { iir_guess(c, lds, nseg, lane); });
             ex.stamp(1);
@@ -499,6 +642,7 @@ IQD_DEV void wbfm_tile(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLds &ld
                     lds.repair_count += (uint32_t)(rounds - 1);
                 }
             });
+            ex.critical(false);
         }
         ex.sync();
         ex.stamp(4);

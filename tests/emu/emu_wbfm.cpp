@@ -30,6 +30,7 @@ struct HostExec {
     }
     void sync() const {}
     void stamp(int) const {}
+    void critical(bool) const {}
 };
 
 }  // namespace

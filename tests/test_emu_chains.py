@@ -77,3 +77,22 @@ def test_long_stream_segmented_dc_blocker(emu, oracle, mode, n_samples):
     ch = emu_bind.FirChannel(emu, mode, 65536)
     pcm, _ = ch.accept(u8)
     assert np.array_equal(pcm, ref)
+
+
+def _loud_quiet(seed, tone=3000.0):
+    """Alternating wide- and narrow-deviation FM so that the audio decimators switch between their
+    clamp-capable and clamp-free evaluation inside and across chunks."""
+    parts = []
+    for k, dev in enumerate([70000.0, 1500.0, 74000.0, 800.0, 1500.0, 72000.0]):
+        parts.append(synth.fm_tone(5632 + 1024 * k, seed=seed + k, deviation=dev, tone=tone, amplitude=110.0, sigma=0.5))
+    u8 = np.concatenate(parts)
+    return u8[: (len(u8) // 256) * 256]
+
+
+def test_fm_loud_and_quiet_sections(emu, oracle):
+    u8 = _loud_quiet(60)
+    ref, _, _ = oracle_run(oracle, "fm", u8, gain=20000.0)
+    pcm, _ = emu_bind.FirChannel(emu, "fm", 16384, gain=20000.0).accept(u8)
+    assert np.array_equal(pcm, ref)
+    a = np.abs(ref.astype(np.int32))
+    assert a.max() > 8000 and min(a[k:k + 40].max() for k in range(0, len(a) - 40, 20)) < 8000

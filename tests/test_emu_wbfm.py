@@ -88,3 +88,16 @@ def test_reset_keeps_deemphasis_state(emu, oracle):
     ch.reset()
     pb, _ = ch.accept(u8[32768:])
     assert np.array_equal(pa, a) and np.array_equal(pb, b)
+
+
+def test_loud_and_quiet_sections(emu, oracle):
+    """The 40-tap audio decimator switches between the clamp-capable and the clamp-free evaluation."""
+    from tests.test_emu_chains import _loud_quiet
+    u8 = _loud_quiet(70, tone=700.0)
+    for gain in (90000.0, None):
+        ref, _, _ = oracle_wbfm(oracle, u8, gain=gain)
+        ch = emu_bind.WbfmChannel(emu, 8192, gain=gain)
+        pcm, _ = ch.accept(u8)
+        assert np.array_equal(pcm, ref)
+    a = np.abs(ref.astype(np.int32))
+    assert a.max() > 17000 and min(a[k:k + 40].max() for k in range(0, len(a) - 40, 20)) < 3000
