@@ -116,8 +116,10 @@ int iqd_accept_iq(iqd_t *e, uint32_t first_ch, uint32_t n_ch,
                   uint32_t *magnitude, uint8_t *signal_present);
 
 /* Device-pointer form: every pointer is HIP device memory (same layouts); the work is
- * enqueued on the engine's stream and the call returns without waiting unless a state
- * repair is needed.  Use iqd_synchronize() before reading results. */
+ * enqueued on the engine's stream.  Calls that involve WBFM channels wait for the kernels
+ * (they read the hand-off verification counter and, if ever needed, repair); calls without
+ * WBFM channels return as soon as the work is queued.  Use iqd_synchronize() before reading
+ * results. */
 int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch,
                          const void *iq_dev, size_t bytes_per_ch,
                          void *pcm_dev, void *pcm_count_dev,

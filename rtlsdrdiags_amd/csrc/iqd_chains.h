@@ -103,7 +103,7 @@ IQD_DEV void shift_hist_serial(uint32_t *buf, int n_dwords, int used)  // used <
 struct FmLds {
     alignas(16) uint32_t xi[8 + CH_CHUNK / 4];               // rail dwords (4 samples each), 8 of history
     alignas(16) uint32_t xq[8 + CH_CHUNK / 4];
-    alignas(16) float theta[4 + CH_CHUNK / 4];               // 64 kS/s phase, 4 of history
+    alignas(16) uint32_t theta[4 + CH_CHUNK / 4];            // 64 kS/s phase (float bits), 4 of history
     alignas(16) uint32_t e[(12 + CH_CHUNK / 4) / 2];         // int16 (int16)(K*dtheta), 12 of history
     alignas(16) uint32_t y2[(40 + CH_CHUNK / 16) / 2];       // int16 16 kS/s, 40 of history
     alignas(16) uint32_t mag[CH_CHUNK / SEG + 2];
@@ -147,7 +147,7 @@ IQD_DEV void fm_discriminate(const Tile &t, FmLds &lds, int clen, int tid)
     const int nout = clen >> 2;
     uint32_t peak = 0;
     for (int m = tid; m < nout; m += WB_THREADS) {
-        float d = lds.theta[4 + m - 2] - lds.theta[4 + m - 4];
+        float d = u2f(lds.theta[4 + m - 2]) - u2f(lds.theta[4 + m - 4]);
         d = wrap_delta(d);
         const float v = t.k * d;
         const int e = (int)(int16_t)(uint16_t)(t.bounded ? cast_i16_bounded(v) : (uint32_t)cast_i16(v));
@@ -196,7 +196,7 @@ IQD_DEV void fm_shift(FmLds &lds, int clen, int tid)
     const int n4 = clen >> 2;                 // rail dwords and 64 kS/s samples in this chunk
     shift_hist(lds.xi, 8, n4, tid, 0);
     shift_hist(lds.xq, 8, n4, tid, 8);
-    shift_hist((uint32_t *)lds.theta, 4, n4, tid, 16);
+    shift_hist(lds.theta, 4, n4, tid, 16);
     shift_hist(lds.e, 6, n4 >> 1, tid, 24);
     if ((clen >> 5) >= 20) shift_hist(lds.y2, 20, clen >> 5, tid, 32);
     else if (tid == 32) shift_hist_serial(lds.y2, 20, clen >> 5);
@@ -207,7 +207,7 @@ IQD_DEV void fm_tile(Exec &ex, const Tile &t, const Consts &c, FmLds &lds, const
 {
     ex.all([&](int tid) {
         if (tid < 8) lds.xi[tid] = 0, lds.xq[tid] = 0;
-        if (tid < 4) lds.theta[tid] = 0.f;
+        if (tid < 4) lds.theta[tid] = 0;
         if (tid < 6) lds.e[tid] = 0;
         if (tid < 20) lds.y2[tid] = 0;
         if (tid < CH_CHUNK / SEG + 2) lds.mag[tid] = 0;

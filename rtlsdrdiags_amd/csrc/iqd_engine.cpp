@@ -536,8 +536,10 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
 
     // exact-state verification of the WBFM hand-offs (a mismatch has never been observed;
     // the repair path re-runs the affected tiles from the neighbour's exact state)
-    HIP_TRY(e, hipMemcpyAsync(e->h_counters, e->d_counters, CNT_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    HIP_TRY(e, hipStreamSynchronize(s));
+    if (have_wbfm || timed) {
+        HIP_TRY(e, hipMemcpyAsync(e->h_counters, e->d_counters, CNT_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(e, hipStreamSynchronize(s));
+    }
     if (have_wbfm) {
         e->stats.state_checks += e->h_counters[CNT_TILE_CHECKS];
         if (e->h_counters[CNT_TILE_MISMATCH]) {

@@ -105,7 +105,7 @@ IQD_DEV void fir16_window(const uint32_t (&x)[8], const Consts &c, int (&acc)[17
 #pragma unroll
     for (int idx = 0; idx < 17; idx++) {
         const int s = idx & 3, j0 = idx >> 2;
-        int lo, hi;
+        int lo = 0, hi = 0;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const uint32_t d = (s == 0) ? x[j0 + q] : y[s - 1][j0 + q];
@@ -275,11 +275,19 @@ IQD_DEV void wbfm_phase1(const WbfmTile &t, const Consts &c, WbfmLds &lds, const
 #else
     const bool want_mag = MAG && cstart >= 0;
 #endif
+#ifdef IQD_P1_SINGLE
+    for (int g0 = tid; (g0 & ~63) < ngroups; g0 += WB_THREADS) {
+#else
     for (int g0 = tid; (g0 & ~63) < ngroups; g0 += 2 * WB_THREADS) {   // wave-uniform trip count
+#endif
         // lanes past the end redo the chunk's last group and drop the result (no divergence)
         const int ga = g0 < ngroups ? g0 : ngroups - 1;
         const bool va = g0 < ngroups;
+#ifdef IQD_P1_SINGLE   // experiment: one group per lane and pass (fewer VGPRs)
+        const bool wave_has_b = false;
+#else
         const bool wave_has_b = ((g0 & ~63) + WB_THREADS) < ngroups;
+#endif
         const int gb = g0 + WB_THREADS < ngroups ? g0 + WB_THREADS : ngroups - 1;
         const bool vb = g0 + WB_THREADS < ngroups;
         const P1Raw ra = p1_load<GATED>(t, t.v0 + cstart + 16 * ga);
