@@ -115,6 +115,7 @@ struct FmLds {
 IQD_DEV void fm_stage1(const Tile &t, const Consts &c, FmLds &lds, int clen, int tid, const float *fm_lut)
 {
     const int ngroups = clen >> 4;
+    const int round = 1 << 14;   // Q15 rounding term, kept in one VGPR for every chain head
     for (int g = tid; g < ngroups; g += WB_THREADS) {
         const u32x4 *pi = (const u32x4 *)&lds.xi[4 * g], *pq = (const u32x4 *)&lds.xq[4 * g];
         const u32x4 a0 = pi[0], a1 = pi[1], a2 = pi[2], b0 = pq[0], b1 = pq[1], b2 = pq[2];
@@ -123,13 +124,13 @@ IQD_DEV void fm_stage1(const Tile &t, const Consts &c, FmLds &lds, int clen, int
         float th[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) {   // output m = 4g + r uses rail dwords [m-7, m] = d[1+r .. 8+r]
-            int li = 1 << 14, hi = 0, lq = 1 << 14, hq = 0;
+            int li = 0, hi = 0, lq = 0, hq = 0;
 #pragma unroll
             for (int q = 0; q < 8; q++) {
-                li = dot4(di[1 + r + q], c.fm_tuner_lo[q], li);
-                hi = dot4(di[1 + r + q], c.fm_tuner_hi[q], hi);
-                lq = dot4(dq[1 + r + q], c.fm_tuner_lo[q], lq);
-                hq = dot4(dq[1 + r + q], c.fm_tuner_hi[q], hq);
+                li = q == 0 ? dot4_first(di[1 + r], c.fm_tuner_lo[0], round) : dot4(di[1 + r + q], c.fm_tuner_lo[q], li);
+                hi = q == 0 ? dot4_first0(di[1 + r], c.fm_tuner_hi[0]) : dot4(di[1 + r + q], c.fm_tuner_hi[q], hi);
+                lq = q == 0 ? dot4_first(dq[1 + r], c.fm_tuner_lo[0], round) : dot4(dq[1 + r + q], c.fm_tuner_lo[q], lq);
+                hq = q == 0 ? dot4_first0(dq[1 + r], c.fm_tuner_hi[0]) : dot4(dq[1 + r + q], c.fm_tuner_hi[q], hq);
             }
             const int yi = (li + (int)((uint32_t)hi << 8)) >> 15;
             const int yq = (lq + (int)((uint32_t)hq << 8)) >> 15;
@@ -248,6 +249,7 @@ struct AmLds {
 IQD_DEV void am_stage1(const Consts &c, AmLds &lds, int clen, int tid)
 {
     const int ngroups = clen >> 4;
+    const int round = 1 << 14;
     for (int g = tid; g < ngroups; g += WB_THREADS) {
         // outputs m = 4g + r use rail dwords [m-1, m] = indices 4 + m - 1, 4 + m
         uint32_t di[5], dq[5];
@@ -259,14 +261,12 @@ IQD_DEV void am_stage1(const Consts &c, AmLds &lds, int clen, int tid)
         int yi[4], yq[4];
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            int li = 1 << 14, hi = 0, lq = 1 << 14, hq = 0;
-#pragma unroll
-            for (int q = 0; q < 2; q++) {
-                li = dot4(di[r + q], c.am_s1_lo[q], li);
-                hi = dot4(di[r + q], c.am_s1_hi[q], hi);
-                lq = dot4(dq[r + q], c.am_s1_lo[q], lq);
-                hq = dot4(dq[r + q], c.am_s1_hi[q], hq);
-            }
+            int li = dot4_first(di[r], c.am_s1_lo[0], round), hi = dot4_first0(di[r], c.am_s1_hi[0]);
+            int lq = dot4_first(dq[r], c.am_s1_lo[0], round), hq = dot4_first0(dq[r], c.am_s1_hi[0]);
+            li = dot4(di[r + 1], c.am_s1_lo[1], li);
+            hi = dot4(di[r + 1], c.am_s1_hi[1], hi);
+            lq = dot4(dq[r + 1], c.am_s1_lo[1], lq);
+            hq = dot4(dq[r + 1], c.am_s1_hi[1], hq);
             yi[r] = (li + (int)((uint32_t)hi << 8)) >> 15;
             yq[r] = (lq + (int)((uint32_t)hq << 8)) >> 15;
         }

@@ -161,60 +161,51 @@ __global__ __launch_bounds__(WB_THREADS) void am_chain_kernel(const ChainLaunch 
 }
 
 // AM / SSB DC-removal IIR with the exact carried state for batches of short streams: one lane per
-// channel, 64 channels per wave.  The detector input was written time-major ([t][channel]) by
-// am_chain_kernel, so a wave reads one coalesced row per step (8 steps in flight); PCM goes
-// through a 64 x 64 LDS tile so that the channel-major output rows are written coalesced too.
+// channel.  The detector input was written time-major ([t][channel]) by am_chain_kernel, so a wave
+// reads one coalesced row per step; the next 8 rows are fetched while the current 8 are filtered.
+// Each lane writes its PCM 4 samples (8 bytes) at a time straight into its channel's row.
 __global__ __launch_bounds__(64) void dc_kernel(const ChainLaunch a, int family)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t pout[64][34];  // int16 pairs, row stride 136 B
-    const int lane = threadIdx.x;
-    const uint32_t li0 = blockIdx.x * 64;
-    const uint32_t n_rows = a.n_list - li0 < 64 ? a.n_list - li0 : 64;
+    const uint32_t li = blockIdx.x * 64 + threadIdx.x;
+    if (li >= a.n_list) return;
     const uint32_t which = family == FAM_SSB ? 1 : 0;
-    const bool mine = (uint32_t)lane < n_rows;
-    const uint32_t ch = a.ch_list[li0 + (mine ? lane : 0)];
+    const uint32_t ch = a.ch_list[li];
     const uint32_t ech = a.first_ch + ch;
-    const uint32_t n_mine = mine ? (a.vlen_gated ? a.vlen_gated[ch] : a.vlen) / 32 : 0;
+    const uint32_t n = (a.vlen_gated ? a.vlen_gated[ch] : a.vlen) / 32;   // multiple of 4
     const float gain = a.params[ech].gain[family];
     DcCarry st = a.dc_carry[2 * (size_t)ech + which];
-    uint32_t n_max = n_mine;
-    for (int off = 32; off > 0; off >>= 1) {
-        const uint32_t o = __shfl_xor(n_max, off);
-        n_max = o > n_max ? o : n_max;
-    }
     const float a1 = g_consts.dc_a1;
     const int32_t *src = a.base8k + ch;                 // + t * base_stride_t
-    for (uint32_t t0 = 0; t0 < n_max; t0 += 64) {
-        int32_t xs[64];                                 // 64 coalesced row loads in flight
+    u32x2 *dst = (u32x2 *)(a.pcm + (size_t)ch * a.pcm_stride);
+    const size_t last = a.pcm_stride - 1;
+    constexpr int B = 32;                               // steps per batch; one batch of row loads in flight
+    int32_t cur[B], nxt[B];
 #pragma unroll
-        for (int k = 0; k < 64; k++) {                  // rows beyond n_mine are clamped, results unused
-            const uint32_t t = t0 + k < a.pcm_stride ? t0 + k : (uint32_t)a.pcm_stride - 1;
-            xs[k] = src[(size_t)t * a.base_stride_t];
+    for (int k = 0; k < B; k++) cur[k] = src[(size_t)((size_t)k < last ? k : last) * a.base_stride_t];
+    for (uint32_t t0 = 0; t0 < n; t0 += B) {
+#pragma unroll
+        for (int k = 0; k < B; k++) {                   // rows past the end are clamped and unused
+            const size_t t = (size_t)t0 + B + k;
+            nxt[k] = src[(t < last ? t : last) * a.base_stride_t];
         }
 #pragma unroll
-        for (int i = 0; i < 64; i += 8) {
-            uint32_t w[8];
+        for (int q = 0; q < B; q += 4) {
+            uint32_t w[4];
 #pragma unroll
-            for (int k = 0; k < 8; k++) {
-                const float xf = (float)xs[i + k];
+            for (int k = 0; k < 4; k++) {
+                const float xf = (float)cur[q + k];
                 const float tn = xf - st.x_prev;
                 const float r = a1 * st.y_prev;
                 const float y = tn - r;
                 w[k] = (uint32_t)cast_i16(gain * y);
-                if (t0 + i + k < n_mine) { st.x_prev = xf; st.y_prev = y; }
+                if (t0 + q + k < n) { st.x_prev = xf; st.y_prev = y; }
             }
-            *(u32x4 *)&pout[lane][i >> 1] = u32x4{pack_lo16(w[0], w[1]), pack_lo16(w[2], w[3]),
-                                                 pack_lo16(w[4], w[5]), pack_lo16(w[6], w[7])};
+            if (t0 + q < n) dst[(t0 + q) / 4] = u32x2{pack_lo16(w[0], w[1]), pack_lo16(w[2], w[3])};
         }
-        __syncthreads();
-        for (uint32_t r = 0; r < n_rows; r++) {        // row r's channel and length live in lane r
-            const uint32_t chr = __shfl(ch, (int)r);
-            const uint32_t n_r = __shfl(n_mine, (int)r);
-            if (t0 + lane < n_r) a.pcm[(size_t)chr * a.pcm_stride + t0 + lane] = ((const int16_t *)pout[r])[lane];
-        }
-        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < B; k++) cur[k] = nxt[k];
     }
-    if (mine) a.dc_carry[2 * (size_t)ech + which] = st;
+    a.dc_carry[2 * (size_t)ech + which] = st;
 }
 
 // The same for long streams: one wave per channel, segmented with exact verification.

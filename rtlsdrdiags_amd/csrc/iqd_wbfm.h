@@ -466,16 +466,47 @@ IQD_DEV int get_i16(const uint32_t *buf, int idx)
 // so the sum is formed with v_dot2 in any order.
 IQD_DEV void wbfm_stage1(const Consts &c, WbfmLds &lds, int clen, int tid)
 {
-    const int nout = clen >> 2;
-    for (int m = tid; m < nout; m += WB_THREADS) {
-        const u32x2 a = w_group(lds, m - 1), b = w_group(lds, m);
-        // window ascending x[4m-4 .. 4m+3] <-> taps h[7 .. 0]
-        int acc = 1 << 14;
-        acc = dot2(a.x, ((uint32_t)(uint16_t)c.wbfm_d1[7]) | ((uint32_t)(uint16_t)c.wbfm_d1[6] << 16), acc);
-        acc = dot2(a.y, ((uint32_t)(uint16_t)c.wbfm_d1[5]) | ((uint32_t)(uint16_t)c.wbfm_d1[4] << 16), acc);
-        acc = dot2(b.x, ((uint32_t)(uint16_t)c.wbfm_d1[3]) | ((uint32_t)(uint16_t)c.wbfm_d1[2] << 16), acc);
-        acc = dot2(b.y, ((uint32_t)(uint16_t)c.wbfm_d1[1]) | ((uint32_t)(uint16_t)c.wbfm_d1[0] << 16), acc);
-        put_i16(lds.y1, 8 + m, acc >> 15);
+    // Four consecutive outputs per lane and pass: w groups m0-1 .. m0+3 (a group = 4 samples = 2 dwords;
+    // 32 groups per segment, so groups m0 .. m0+3 never straddle segments), two passes issued together
+    // so that the LDS latency is paid once.
+    const int nquad = clen >> 4;
+    const uint32_t t76 = ((uint32_t)(uint16_t)c.wbfm_d1[7]) | ((uint32_t)(uint16_t)c.wbfm_d1[6] << 16);
+    const uint32_t t54 = ((uint32_t)(uint16_t)c.wbfm_d1[5]) | ((uint32_t)(uint16_t)c.wbfm_d1[4] << 16);
+    const uint32_t t32 = ((uint32_t)(uint16_t)c.wbfm_d1[3]) | ((uint32_t)(uint16_t)c.wbfm_d1[2] << 16);
+    const uint32_t t10 = ((uint32_t)(uint16_t)c.wbfm_d1[1]) | ((uint32_t)(uint16_t)c.wbfm_d1[0] << 16);
+    for (int k0 = tid; k0 < nquad; k0 += 2 * WB_THREADS) {
+        u32x2 prev[2];
+        u32x4 lo[2], hi[2];
+        bool ok[2];
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const int k = k0 + r * WB_THREADS;
+            ok[r] = k < nquad;
+            const int m0 = 4 * (ok[r] ? k : k0);
+            prev[r] = w_group(lds, m0 - 1);
+            const u32x4 *p = (const u32x4 *)&lds.w[(m0 >> 5) * WSTRIDE + 2 * (m0 & 31)];
+            lo[r] = p[0];
+            hi[r] = p[1];
+        }
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            if (!ok[r]) continue;
+            const int m0 = 4 * (k0 + r * WB_THREADS);
+            // window of output m: x[4m-4 .. 4m+3] ascending <-> taps h[7 .. 0]
+            const uint32_t g[10] = {prev[r].x, prev[r].y, lo[r].x, lo[r].y, lo[r].z, lo[r].w,
+                                    hi[r].x, hi[r].y, hi[r].z, hi[r].w};
+            uint32_t y[4];
+#pragma unroll
+            for (int o = 0; o < 4; o++) {
+                int acc = 1 << 14;
+                acc = dot2(g[2 * o], t76, acc);
+                acc = dot2(g[2 * o + 1], t54, acc);
+                acc = dot2(g[2 * o + 2], t32, acc);
+                acc = dot2(g[2 * o + 3], t10, acc);
+                y[o] = (uint32_t)(acc >> 15);
+            }
+            *(u32x2 *)&lds.y1[(8 + m0) >> 1] = u32x2{pack_lo16(y[0], y[1]), pack_lo16(y[2], y[3])};
+        }
     }
 }
 
@@ -524,13 +555,28 @@ IQD_DEV void lds_max(uint32_t *slot, uint32_t v)
 // data (sum|h1| = 29126 < 2^15), and 16384 + 36758 * 29126 < 2^30: the clamp can never fire here.
 IQD_DEV void wbfm_stage2(const Consts &c, WbfmLds &lds, int clen, int tid)
 {
-    const int nout = clen >> 4;
+    // two consecutive outputs per lane: y1 dwords 2*j0 .. 2*j0+7 (j0 even -> 16-byte aligned)
+    const int npair = clen >> 5;
+    uint32_t taps[6];
+#pragma unroll
+    for (int q = 0; q < 6; q++)   // pair q counts back from the newest dword: (lo: h[2q+1], hi: h[2q])
+        taps[q] = (uint32_t)(uint16_t)c.post12[2 * q + 1] | ((uint32_t)(uint16_t)c.post12[2 * q] << 16);
     uint32_t peak = 0;
-    for (int j = tid; j < nout; j += WB_THREADS) {
-        const int y = q15_pairs<12>(c.post12, lds.y1, 8 + 4 * j + 3);
-        put_i16(lds.y2, 40 + j, y);
-        const uint32_t a = (uint32_t)(y < 0 ? -y : y);
-        peak = a > peak ? a : peak;
+    for (int k = tid; k < npair; k += WB_THREADS) {
+        const u32x4 *p = (const u32x4 *)&lds.y1[4 * k];
+        const u32x4 a = p[0], b = p[1];
+        const uint32_t d[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        int y[2];
+#pragma unroll
+        for (int o = 0; o < 2; o++) {   // output j = 2k + o: newest dword = 2j + 5 = d[2*o + 5]
+            int acc = 1 << 14;
+#pragma unroll
+            for (int q = 0; q < 6; q++) acc = dot2(d[2 * o + 5 - q], taps[q], acc);
+            y[o] = acc >> 15;
+            const uint32_t m = (uint32_t)(y[o] < 0 ? -y[o] : y[o]);
+            peak = m > peak ? m : peak;
+        }
+        lds.y2[20 + k] = pack_lo16((uint32_t)y[0], (uint32_t)y[1]);
     }
     if (peak > (uint32_t)AUDIO40_SAFE) lds_max(&lds.y2_peak, peak);   // rare: loud audio only
 }
@@ -549,27 +595,36 @@ IQD_DEV void wbfm_stage3(const Consts &c, WbfmLds &lds, const WbfmTile &t, int c
 }
 
 // Histories for the next chunk (call after a barrier that follows stage3).
-IQD_DEV void wbfm_shift_history(WbfmLds &lds, int clen, int tid)
+// Histories for the next chunk.  Part A (y1 tail, last w group) runs beside stage 3, which touches
+// neither; part B (y2 tail, loudness flags) runs at the head of the next chunk's phase 1, when
+// stage 3 has finished reading y2.
+IQD_DEV void wbfm_shift_a(WbfmLds &lds, int clen, int tid)
 {
-    const int n1 = clen >> 2, n2 = clen >> 4;
-    if (tid < 4) {  // 8 int16 = 4 dwords
-        lds.y1[tid] = lds.y1[(n1 >> 1) + tid];
-    } else if (tid >= 64 && tid < 64 + 20 && (n2 >> 1) >= 20) {  // 40 int16 = 20 dwords
+    const int n1 = clen >> 2;
+    if (tid >= 192 && tid < 196) {  // 8 int16 = 4 dwords
+        const int k = tid - 192;
+        lds.y1[k] = lds.y1[(n1 >> 1) + k];
+    } else if (tid == 200) {
+        const u32x2 last = w_group(lds, n1 - 1);
+        lds.whist[0] = last.x;
+        lds.whist[1] = last.y;
+    }
+}
+
+IQD_DEV void wbfm_shift_b(WbfmLds &lds, int clen, int tid)
+{
+    const int n2 = clen >> 4;
+    if (tid >= 64 && tid < 64 + 20 && (n2 >> 1) >= 20) {  // 40 int16 = 20 dwords
         const int k = tid - 64;
         lds.y2[k] = lds.y2[(n2 >> 1) + k];
     } else if (tid == 96 && (n2 >> 1) < 20) {  // short chunk: ranges overlap, move in order
         for (int k = 0; k < 20; k++) lds.y2[k] = lds.y2[(n2 >> 1) + k];
-    } else if (tid == 128) {
-        const u32x2 last = w_group(lds, n1 - 1);
-        lds.whist[0] = last.x;
-        lds.whist[1] = last.y;
     } else if (tid == 129) {   // conservative: the 40 samples kept may contain this chunk's peak
         const uint32_t keep = n2 >= 40 ? 0u : lds.y2_peak_hist;
         lds.y2_peak_hist = lds.y2_peak > keep ? lds.y2_peak : keep;
         lds.y2_peak = 0;
     }
 }
-
 
 // ---- tile driver ----------------------------------------------------------------------------
 // Exec abstracts the SIMT machine: all(f) runs f(tid) for the 256 threads and then barriers;
@@ -617,12 +672,16 @@ IQD_DEV void wbfm_tile(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLds &ld
     rec.u_out = start.u;
     rec.back_out = t.tlen - rec_pos;
 
+    int prev_clen = 0;
     for (int cstart = -halo; cstart < t.tlen;) {
         const int clen = cstart < 0 ? -cstart : (t.tlen - cstart < WBFM_CHUNK ? t.tlen - cstart : WBFM_CHUNK);
         const int nseg = clen / SEG;
         const ChunkBlocks cb = chunk_blocks(t, cstart);
         ex.stamp(7);
-        ex.all([&](int tid) { wbfm_phase1<GATED, MAG>(t, c, lds, cb, cstart, clen, tid); });
+        ex.all([&](int tid) {
+            if (prev_clen) wbfm_shift_b(lds, prev_clen, tid);
+            wbfm_phase1<GATED, MAG>(t, c, lds, cb, cstart, clen, tid);
+        });
         ex.stamp(0);
         if (ex.in_wave0()) {
             ex.critical(true);
@@ -660,8 +719,11 @@ IQD_DEV void wbfm_tile(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLds &ld
         });
         ex.stamp(5);
         ex.all([&](int tid) { wbfm_stage2(c, lds, clen, tid); });
-        ex.all([&](int tid) { wbfm_stage3(c, lds, t, cstart, clen, tid); });
-        ex.all([&](int tid) { wbfm_shift_history(lds, clen, tid); });
+        ex.all([&](int tid) {
+            wbfm_stage3(c, lds, t, cstart, clen, tid);
+            wbfm_shift_a(lds, clen, tid);
+        });
+        prev_clen = clen;
         ex.stamp(6);
         cstart += clen;
     }
