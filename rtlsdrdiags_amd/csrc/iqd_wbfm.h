@@ -24,7 +24,10 @@
 
 namespace iqd {
 
-constexpr int WB_THREADS = 256;
+#ifndef IQD_WB_THREADS
+#define IQD_WB_THREADS 256
+#endif
+constexpr int WB_THREADS = IQD_WB_THREADS;   // threads per workgroup of the tile kernels
 constexpr int WB_BIAS = 2 * (16384 + (128 << 15));  // doubled: Q15 rounding term + 128 for the table index
 constexpr int TGRAN = TSTRIDE / 4;            // 16-byte granules per segment of the IIR input
 
@@ -601,10 +604,10 @@ IQD_DEV void wbfm_stage3(const Consts &c, WbfmLds &lds, const WbfmTile &t, int c
 IQD_DEV void wbfm_shift_a(WbfmLds &lds, int clen, int tid)
 {
     const int n1 = clen >> 2;
-    if (tid >= 192 && tid < 196) {  // 8 int16 = 4 dwords
-        const int k = tid - 192;
+    if (tid >= 100 && tid < 104) {  // 8 int16 = 4 dwords
+        const int k = tid - 100;
         lds.y1[k] = lds.y1[(n1 >> 1) + k];
-    } else if (tid == 200) {
+    } else if (tid == 110) {
         const u32x2 last = w_group(lds, n1 - 1);
         lds.whist[0] = last.x;
         lds.whist[1] = last.y;
@@ -619,7 +622,7 @@ IQD_DEV void wbfm_shift_b(WbfmLds &lds, int clen, int tid)
         lds.y2[k] = lds.y2[(n2 >> 1) + k];
     } else if (tid == 96 && (n2 >> 1) < 20) {  // short chunk: ranges overlap, move in order
         for (int k = 0; k < 20; k++) lds.y2[k] = lds.y2[(n2 >> 1) + k];
-    } else if (tid == 129) {   // conservative: the 40 samples kept may contain this chunk's peak
+    } else if (tid == 97) {   // conservative: the 40 samples kept may contain this chunk's peak
         const uint32_t keep = n2 >= 40 ? 0u : lds.y2_peak_hist;
         lds.y2_peak_hist = lds.y2_peak > keep ? lds.y2_peak : keep;
         lds.y2_peak = 0;
