@@ -33,6 +33,12 @@ struct DeviceExec {
         return __all(ok);
     }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
+    template <class F> __device__ __forceinline__ void others(F f) { if (tid >= 64) f(tid); }
+    template <class F> __device__ __forceinline__ void all_nosync(F f) { f(tid); }
+    template <class T> struct Local {   // per-thread values that live across phases: registers here
+        T v;
+        __device__ __forceinline__ T &at(int) { return v; }
+    };
     // the single-wave IIR phase is the workgroup's critical path: let it win VALU arbitration
     __device__ __forceinline__ void critical(bool on) const { if (on) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
 #ifdef IQD_STAMPS   // diagnostic build only: cycles per phase, summed over workgroups
@@ -103,7 +109,11 @@ __global__ __launch_bounds__(WB_THREADS) void wbfm_chain_kernel(const ChainLaunc
         start.y = 0.f; start.u = 0.f; start.back = 0; start.cold = 1;
     }
     DeviceExec ex{(int)threadIdx.x};
+#ifdef IQD_WBFM_SERIAL_PHASES   // the first driver: IIR phase not overlapped (kept for A/B measurements)
     wbfm_tile<GATED, MAG>(ex, t, g_consts, lds, start, &a.records[(size_t)li * a.tiles_per_ch + tile]);
+#else
+    wbfm_tile_pipe<GATED, MAG>(ex, t, g_consts, lds, start, &a.records[(size_t)li * a.tiles_per_ch + tile]);
+#endif
     if (threadIdx.x == 0 && lds.repair_count) atomicAdd(&a.counters[CNT_SEG_REPAIRS], lds.repair_count);
 #ifdef IQD_STAMPS
     if (a.stamps && (threadIdx.x == 0 || threadIdx.x == 64))

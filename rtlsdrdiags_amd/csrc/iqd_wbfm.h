@@ -42,7 +42,7 @@ struct WbfmLds {
     alignas(16) uint32_t w[WBFM_NSEG * WSTRIDE];       // (int16)y[n], two per dword, segment-strided
     alignas(16) uint32_t y1[(8 + WBFM_CHUNK / 4) / 2];   // stage-1 output with 8 samples of history
     alignas(16) uint32_t y2[(40 + WBFM_CHUNK / 16) / 2]; // stage-2 output with 40 samples of history
-    uint32_t whist[2];                     // the 4 w samples before the chunk
+    uint32_t whist[4];                     // the 4 w samples before the chunk, two alternating slots
     float z[WBFM_NSEG + 4];                // zero-state segment responses; z[3] = carried y
     float g[WBFM_NSEG];                    // state entering each segment
     float e[WBFM_NSEG];                    // state leaving each segment
@@ -231,11 +231,18 @@ IQD_DEV uint32_t p1_magnitude(const P1Raw &r)
     return magnitude16(own);
 }
 
-// theta -> delta theta, branch cut, K*d, b0*v -> LDS (+ the partial sum for the IIR state guess)
-IQD_DEV void p1_finish(const WbfmTile &t, const Consts &c, WbfmLds &lds, const float (&th)[17], int p, bool valid)
+// What phase 1 produces for one 16-sample group, held in registers until it may be stored.
+struct P1Out {
+    float u[16];     // b0 * (K * dtheta)
+    float part;      // sum c^(15-k) u[k], for the IIR state guess
+    uint32_t mag;    // squelch magnitude sum of the group
+    int p;           // position of the group inside its chunk
+    int valid;
+};
+
+// theta -> delta theta, branch cut, K*d, b0*v (+ the partial sum for the IIR state guess)
+IQD_DEV void p1_make(const WbfmTile &t, const Consts &c, const float (&th)[17], P1Out &o)
 {
-    const int seg = p >> 7, gq = (p & 127) >> 4;
-    float u[16];
     const float c2 = c.deemph_c * c.deemph_c;
     float pe = 0.f, po = 0.f;   // sum c^(15-k) u[k] as two interleaved chains (even / odd k)
 #pragma unroll
@@ -244,18 +251,37 @@ IQD_DEV void p1_finish(const WbfmTile &t, const Consts &c, WbfmLds &lds, const f
         d0 = wrap_delta(d0);
         d1 = wrap_delta(d1);
         const float v0 = t.k * d0, v1 = t.k * d1;
-        u[k] = c.deemph_b0 * v0;
-        u[k + 1] = c.deemph_b0 * v1;
-        pe = __builtin_fmaf(c2, pe, u[k]);
-        po = __builtin_fmaf(c2, po, u[k + 1]);
+        o.u[k] = c.deemph_b0 * v0;
+        o.u[k + 1] = c.deemph_b0 * v1;
+        pe = __builtin_fmaf(c2, pe, o.u[k]);
+        po = __builtin_fmaf(c2, po, o.u[k + 1]);
     }
-    const float part = __builtin_fmaf(c.deemph_c, pe, po);
-    if (!valid) return;
+    o.part = __builtin_fmaf(c.deemph_c, pe, po);
+}
+
+IQD_DEV void p1_store_t(WbfmLds &lds, const P1Out &o)
+{
+    if (!o.valid) return;
+    const int seg = o.p >> 7, gq = (o.p & 127) >> 4;
 #pragma unroll
     for (int q = 0; q < 4; q++)
         lds.t4[t_slot(seg, 4 * gq + q)] =
-            u32x4{f2u(u[4 * q]), f2u(u[4 * q + 1]), f2u(u[4 * q + 2]), f2u(u[4 * q + 3])};
-    lds_part(lds)[8 * seg + gq] = part;
+            u32x4{f2u(o.u[4 * q]), f2u(o.u[4 * q + 1]), f2u(o.u[4 * q + 2]), f2u(o.u[4 * q + 3])};
+}
+
+IQD_DEV void p1_store_part(float *part, const P1Out &o)
+{
+    if (o.valid) part[8 * (o.p >> 7) + ((o.p & 127) >> 4)] = o.part;
+}
+
+IQD_DEV void p1_finish(const WbfmTile &t, const Consts &c, WbfmLds &lds, const float (&th)[17], int p, bool valid)
+{
+    P1Out o;
+    o.p = p;
+    o.valid = valid;
+    p1_make(t, c, th, o);
+    p1_store_t(lds, o);
+    p1_store_part(lds_part(lds), o);
 }
 
 IQD_DEV void p1_add_mag(const WbfmTile &t, WbfmLds &lds, const ChunkBlocks &cb, int p, uint32_t m)
@@ -347,13 +373,14 @@ IQD_DEV float iir_u_before(const WbfmLds &lds, int seg)  // u[n-1] at the start 
 // lane j: approximate zero-state response of segment j to t[n] = u[n] + u[n-1], from the
 // per-group partial sums phase 1 left (plain float arithmetic: this is only the state GUESS).
 //   S = sum c^(127-i) u[i];  response = S + c^127 u[-1] + (S - u[127]) / c
-IQD_DEV void iir_guess(const Consts &c, WbfmLds &lds, int nseg, int lane)
+IQD_DEV void iir_guess(const Consts &c, WbfmLds &lds, int nseg, int lane, const float *part = nullptr)
 {
+    if (!part) part = lds_part(lds);
     if (lane == 0) lds.z[3] = lds.y_carry, lds.z[2] = 0.f, lds.z[1] = 0.f, lds.z[0] = 0.f;
     if (lane >= nseg) return;
     float sum = 0.f;
 #pragma unroll
-    for (int g = 0; g < 8; g++) sum = __builtin_fmaf(c.deemph_c16, sum, lds_part(lds)[8 * lane + g]);
+    for (int g = 0; g < 8; g++) sum = __builtin_fmaf(c.deemph_c16, sum, part[8 * lane + g]);
     const float z = sum + c.deemph_c127 * iir_u_before(lds, lane) + (sum - t_last(lds, lane)) * c.deemph_cinv;
     lds.z[4 + lane] = z;
 }
@@ -446,9 +473,9 @@ IQD_DEV bool iir_check(WbfmLds &lds, int nseg, int lane)
 }
 
 // ---- decimators ----------------------------------------------------------------------------
-IQD_DEV u32x2 w_group(const WbfmLds &lds, int g)  // 4 consecutive w samples, group index g
+IQD_DEV u32x2 w_group(const WbfmLds &lds, int g, int hslot = 0)  // 4 consecutive w samples, group index g
 {
-    if (g < 0) return u32x2{lds.whist[0], lds.whist[1]};
+    if (g < 0) return u32x2{lds.whist[2 * hslot], lds.whist[2 * hslot + 1]};
     const uint32_t *p = &lds.w[(g >> 5) * WSTRIDE + 2 * (g & 31)];
     return u32x2{p[0], p[1]};
 }
@@ -467,7 +494,7 @@ IQD_DEV int get_i16(const uint32_t *buf, int idx)
 
 // /4, 8 taps (WbFmDemodulator.cc:535-537).  sum|hq| = 29126 < 2^15: no clamp can fire,
 // so the sum is formed with v_dot2 in any order.
-IQD_DEV void wbfm_stage1(const Consts &c, WbfmLds &lds, int clen, int tid)
+IQD_DEV void wbfm_stage1(const Consts &c, WbfmLds &lds, int clen, int tid, int hslot = 0)
 {
     // Four consecutive outputs per lane and pass: w groups m0-1 .. m0+3 (a group = 4 samples = 2 dwords;
     // 32 groups per segment, so groups m0 .. m0+3 never straddle segments), two passes issued together
@@ -486,7 +513,7 @@ IQD_DEV void wbfm_stage1(const Consts &c, WbfmLds &lds, int clen, int tid)
             const int k = k0 + r * WB_THREADS;
             ok[r] = k < nquad;
             const int m0 = 4 * (ok[r] ? k : k0);
-            prev[r] = w_group(lds, m0 - 1);
+            prev[r] = w_group(lds, m0 - 1, hslot);
             const u32x4 *p = (const u32x4 *)&lds.w[(m0 >> 5) * WSTRIDE + 2 * (m0 & 31)];
             lo[r] = p[0];
             hi[r] = p[1];
@@ -655,7 +682,7 @@ IQD_DEV void wbfm_tile(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLds &ld
     ex.all([&](int tid) {
         if (tid < 4) lds.y1[tid] = 0;
         if (tid < 20) lds.y2[tid] = 0;
-        if (tid < 2) lds.whist[tid] = 0;
+        if (tid < 4) lds.whist[tid] = 0;
         if (tid < WBFM_CHUNK / SEG + 2) lds.mag[tid] = 0;
         if (tid == 0) {
             lds.y_carry = start.cold ? 0.f : start.y;
@@ -730,6 +757,207 @@ IQD_DEV void wbfm_tile(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLds &ld
         ex.stamp(6);
         cstart += clen;
     }
+    if (ex.in_wave0() && rec_out) {
+        rec.y_end = lds.y_carry;
+        rec.u_end = lds.u_carry;
+        rec.pad[0] = rec.pad[1] = 0;
+        ex.wave0([&](int lane) { if (lane == 0) *rec_out = rec; });
+    }
+}
+
+
+// ---- pipelined tile driver -------------------------------------------------------------------
+// The serial IIR phase of chunk k (wave 0) runs beside phase 1 of chunk k+1 (waves 1-3, then wave 0
+// too), whose results wait in registers until the IIR has released the LDS input buffer:
+//
+//   X   wave 0: IIR(k), then phase 1 of groups 384.. of chunk k+1      waves 1-3: phase 1 of
+//       groups p and p+192 of chunk k+1 (two groups per lane, interleaved)          | barrier
+//   Y1  store u(k+1) -> t4, magnitude sums; stage 1(k)                                | barrier
+//   Y2  flush magnitudes(k+1); store guess sums(k+1) into the w region (stage 1 has
+//       consumed w(k)); stage 2(k)                                                     | barrier
+//   Y3  stage 3(k) -> PCM, y1 history                      (runs into the next X: nothing it
+//       touches is touched there)
+struct P1Pair { P1Out a, b; };
+
+template <bool GATED>
+IQD_DEV void p1_compute(const WbfmTile &t, const Consts &c, int cstart, int clen, int ga_raw, int gb_raw,
+                        bool wave_has_b, bool want_mag, P1Pair &r)
+{
+    const int ngroups = clen >> 4;
+    const int ga = ga_raw < ngroups ? ga_raw : ngroups - 1;   // lanes past the end redo the last group
+    const int gb = gb_raw < ngroups ? gb_raw : ngroups - 1;
+    r.a.valid = ga_raw < ngroups;
+    r.b.valid = wave_has_b && gb_raw < ngroups;
+    r.a.p = 16 * ga;
+    r.b.p = 16 * gb;
+    r.a.mag = r.b.mag = 0;
+    const P1Raw ra = p1_load<GATED>(t, t.v0 + cstart + 16 * ga);
+    uint32_t off[17];
+    float tha[17];
+    if (wave_has_b) {
+        const P1Raw rb = p1_load<GATED>(t, t.v0 + cstart + 16 * gb);
+        float thb[17];
+        p1_front(t, c, ra, off);
+        p1_gather(t, off, tha);
+        if (want_mag) r.a.mag = p1_magnitude(ra);
+        p1_front(t, c, rb, off);
+        p1_gather(t, off, thb);
+        if (want_mag) r.b.mag = p1_magnitude(rb);
+        p1_make(t, c, tha, r.a);
+        p1_make(t, c, thb, r.b);
+    } else {
+        p1_front(t, c, ra, off);
+        p1_gather(t, off, tha);
+        if (want_mag) r.a.mag = p1_magnitude(ra);
+        p1_make(t, c, tha, r.a);
+    }
+}
+
+constexpr int PIPE_OTHERS = WB_THREADS - 64;   // lanes of waves 1-3
+static_assert(WBFM_CHUNK / 16 <= 2 * PIPE_OTHERS + 64, "a chunk must fit two groups per lane of waves 1-3 plus one of wave 0");
+
+template <bool GATED, bool MAG, class Exec>
+IQD_DEV void wbfm_tile_pipe(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLds &lds,
+                            const WbfmStart &start, WbfmRecord *rec_out)
+{
+    const int halo = start.cold ? COLD_HALO : start.back;
+    ex.all([&](int tid) {
+        if (tid < 4) lds.y1[tid] = 0;
+        if (tid < 20) lds.y2[tid] = 0;
+        if (tid < 4) lds.whist[tid] = 0;
+        if (tid < WBFM_CHUNK / SEG + 2) lds.mag[tid] = 0;
+        if (tid == 0) {
+            lds.y_carry = start.cold ? 0.f : start.y;
+            lds.u_carry = start.cold ? 0.f : start.u;
+            lds.repair_count = 0;
+            lds.y2_peak = 0;
+            lds.y2_peak_hist = 0;
+        }
+    });
+    int rec_pos = t.tlen - FORCED_BACK;
+    if (rec_pos < -halo) rec_pos = -halo;
+    WbfmRecord rec;
+    rec.y_in = start.y;
+    rec.y_out = start.y;
+    rec.u_out = start.u;
+    rec.back_out = t.tlen - rec_pos;
+
+    float *part = (float *)lds.w;   // guess sums live at the head of the w region between stage 1 and the IIR
+    typename Exec::template Local<P1Pair> regs;
+    auto chunk_len = [&](int cs) { return cs < 0 ? -cs : (t.tlen - cs < WBFM_CHUNK ? t.tlen - cs : WBFM_CHUNK); };
+#ifdef IQD_ABL_NOMAG
+    const bool mag_on = false;
+#else
+    const bool mag_on = MAG;
+#endif
+
+    // iteration -1 only produces chunk 0; iteration k consumes chunk k and produces chunk k+1
+    int cstart = -halo - 1, clen = 0;          // "no current chunk"
+    int next_cstart = -halo, next_clen = chunk_len(-halo);
+    int prev_clen = 0, parity = 0;
+    bool has_cur = false, has_next = true;
+    while (has_cur || has_next) {
+        const int nseg = clen / SEG;
+        const ChunkBlocks ncb = chunk_blocks(t, next_cstart);
+        const bool next_mag = mag_on && next_cstart >= 0;
+        // ---- X ----
+        if (ex.in_wave0()) {
+            if (has_cur) {
+                if (rec_pos == cstart) { rec.y_out = lds.y_carry; rec.u_out = lds.u_carry; }
+                ex.wave0([&](int lane) { iir_guess(c, lds, nseg, lane, part); });
+                ex.wave0([&](int lane) { iir_warm(c, lds, nseg, lane); });
+                int rounds = 0;
+                do {
+                    ex.wave0([&](int lane) { iir_real(c, lds, nseg, lane, t.bounded != 0); });
+                    rounds++;
+                } while (!ex.wave0_all([&](int lane) { return iir_check(lds, nseg, lane); }));
+                if (rec_pos > cstart && rec_pos < cstart + clen) {
+                    const int seg = (rec_pos - cstart) / SEG - 1;
+                    rec.y_out = lds.e[seg];
+                    rec.u_out = t_last(lds, seg);
+                }
+                if (start.cold && cstart < 0) rec.y_in = lds.e[(COLD_HALO - FORCED_BACK) / SEG - 1];
+                ex.wave0([&](int lane) {
+                    if (lane == 0) {
+                        lds.y_carry = lds.e[nseg - 1];
+                        lds.u_carry = t_last(lds, nseg - 1);
+                        lds.repair_count += (uint32_t)(rounds - 1);
+                    }
+                });
+            }
+            if (has_next && (next_clen >> 4) > 2 * PIPE_OTHERS)   // wave 0's share: groups 384 ..
+                ex.wave0([&](int lane) {
+                    p1_compute<GATED>(t, c, next_cstart, next_clen, 2 * PIPE_OTHERS + lane, 0, false, next_mag,
+                                      regs.at(lane));
+                });
+        }
+        if (has_next)
+            ex.others([&](int tid) {
+                const int p = tid - 64;
+                const int ng = next_clen >> 4;
+                if ((p & ~63) >= ng) { regs.at(tid).a.valid = 0; regs.at(tid).b.valid = 0; return; }   // idle wave
+                const bool wave_has_b = ((p & ~63) + PIPE_OTHERS) < ng;
+                p1_compute<GATED>(t, c, next_cstart, next_clen, p, p + PIPE_OTHERS, wave_has_b, next_mag, regs.at(tid));
+            });
+        ex.sync();
+        // ---- Y1 ----
+        ex.all([&](int tid) {
+            if (prev_clen) wbfm_shift_b(lds, prev_clen, tid);
+            if (has_next) {
+                const bool w0 = tid < 64;
+                const bool mine = !w0 || (next_clen >> 4) > 2 * PIPE_OTHERS;
+                if (mine) {
+                    P1Pair &r = regs.at(tid);
+                    p1_store_t(lds, r.a);
+                    if (next_mag && r.a.valid) p1_add_mag(t, lds, ncb, r.a.p, r.a.mag);
+                    if (!w0) {
+                        p1_store_t(lds, r.b);
+                        if (next_mag && r.b.valid) p1_add_mag(t, lds, ncb, r.b.p, r.b.mag);
+                    }
+                }
+            }
+            if (has_cur) {
+                wbfm_stage1(c, lds, clen, tid, parity ^ 1);
+                if (tid == 110) {   // the last w group of this chunk, for the next chunk's stage 1
+                    const u32x2 last = w_group(lds, (clen >> 2) - 1);
+                    lds.whist[2 * parity] = last.x;
+                    lds.whist[2 * parity + 1] = last.y;
+                }
+            }
+        });
+        // ---- Y2 ----
+        ex.all([&](int tid) {
+            if (has_next) {
+                if (next_mag) wbfm_flush_mag(t, lds, ncb, next_cstart, next_clen, tid);
+                const bool w0 = tid < 64;
+                const bool mine = !w0 || (next_clen >> 4) > 2 * PIPE_OTHERS;
+                if (mine) {
+                    p1_store_part(part, regs.at(tid).a);
+                    if (!w0) p1_store_part(part, regs.at(tid).b);
+                }
+            }
+            if (has_cur) wbfm_stage2(c, lds, clen, tid);
+        });
+        // ---- Y3 (no barrier behind it: see the table above) ----
+        if (has_cur) {
+            ex.all_nosync([&](int tid) {
+                wbfm_stage3(c, lds, t, cstart, clen, tid);
+                const int n1 = clen >> 2;
+                if (tid >= 100 && tid < 104) lds.y1[tid - 100] = lds.y1[(n1 >> 1) + tid - 100];
+            });
+            prev_clen = clen;
+            parity ^= 1;
+        }
+        // advance
+        has_cur = has_next;
+        cstart = next_cstart;
+        clen = next_clen;
+        next_cstart = cstart + clen;
+        has_next = has_cur && next_cstart < t.tlen;
+        next_clen = has_next ? chunk_len(next_cstart) : 0;
+        if (!has_cur) break;
+    }
+    ex.sync();
     if (ex.in_wave0() && rec_out) {
         rec.y_end = lds.y_carry;
         rec.u_end = lds.u_carry;

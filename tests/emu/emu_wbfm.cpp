@@ -29,13 +29,23 @@ struct HostExec {
         return ok;
     }
     void sync() const {}
+    template <class F> void others(F f) { for (int t = 64; t < iqd::WB_THREADS; t++) f(t); }
+    template <class F> void all_nosync(F f) { for (int t = 0; t < iqd::WB_THREADS; t++) f(t); }
+    template <class T> struct Local {
+        std::vector<T> v = std::vector<T>(iqd::WB_THREADS);
+        T &at(int tid) { return v[tid]; }
+    };
     void stamp(int) const {}
     void critical(bool) const {}
 };
 
 }  // namespace
 
+static int g_serial_phases = 0;
+
 extern "C" {
+
+void emu_wbfm_driver(int serial_phases) { g_serial_phases = serial_phases; }
 
 // One accept call for one WBFM channel (squelch open).  tail/carry are in-out state.
 // guess_bias perturbs the de-emphasis state guess (to force the segment repair path).
@@ -87,7 +97,8 @@ int emu_wbfm_accept(const uint8_t *iq, uint32_t n_samples, uint32_t tile_len, ui
         else { start.y = 0; start.u = 0; start.back = 0; start.cold = 1; }
         HostExec ex;
         memset(&lds, 0xcd, sizeof(lds));  // poison: the kernel must initialise what it reads
-        wbfm_tile<false, true>(ex, t, cc, lds, start, &recs[tile]);
+        if (g_serial_phases) wbfm_tile<false, true>(ex, t, cc, lds, start, &recs[tile]);
+        else wbfm_tile_pipe<false, true>(ex, t, cc, lds, start, &recs[tile]);
         repairs += lds.repair_count;
     }
     int mismatches = 0;

@@ -7,9 +7,13 @@ from rtlsdrdiags_amd import synth
 from tests import emu_bind
 
 
-@pytest.fixture(scope="module")
-def emu():
-    return emu_bind.lib()
+@pytest.fixture(scope="module", params=["pipelined", "serial_phases"])
+def emu(request):
+    """Both tile drivers: the pipelined one the kernel uses and the first, phase-by-phase one."""
+    L = emu_bind.lib()
+    L.emu_wbfm_driver(1 if request.param == "serial_phases" else 0)
+    yield L
+    L.emu_wbfm_driver(0)
 
 
 def oracle_wbfm(oracle, u8, rotation=1, gain=None):
