@@ -861,6 +861,7 @@ IQD_DEV void wbfm_tile_pipe(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLd
         const ChunkBlocks ncb = chunk_blocks(t, next_cstart);
         const bool next_mag = mag_on && next_cstart >= 0;
         // ---- X ----
+        ex.stamp(7);
         if (ex.in_wave0()) {
             if (has_cur) {
                 if (rec_pos == cstart) { rec.y_out = lds.y_carry; rec.u_out = lds.u_carry; }
@@ -885,6 +886,7 @@ IQD_DEV void wbfm_tile_pipe(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLd
                     }
                 });
             }
+            ex.stamp(1);
             if (has_next && (next_clen >> 4) > 2 * PIPE_OTHERS)   // wave 0's share: groups 384 ..
                 ex.wave0([&](int lane) {
                     p1_compute<GATED>(t, c, next_cstart, next_clen, 2 * PIPE_OTHERS + lane, 0, false, next_mag,
@@ -899,7 +901,9 @@ IQD_DEV void wbfm_tile_pipe(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLd
                 const bool wave_has_b = ((p & ~63) + PIPE_OTHERS) < ng;
                 p1_compute<GATED>(t, c, next_cstart, next_clen, p, p + PIPE_OTHERS, wave_has_b, next_mag, regs.at(tid));
             });
+        ex.stamp(2);
         ex.sync();
+        ex.stamp(3);
         // ---- Y1 ----
         ex.all([&](int tid) {
             if (prev_clen) wbfm_shift_b(lds, prev_clen, tid);
@@ -925,6 +929,7 @@ IQD_DEV void wbfm_tile_pipe(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLd
                 }
             }
         });
+        ex.stamp(4);
         // ---- Y2 ----
         ex.all([&](int tid) {
             if (has_next) {
@@ -938,6 +943,7 @@ IQD_DEV void wbfm_tile_pipe(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLd
             }
             if (has_cur) wbfm_stage2(c, lds, clen, tid);
         });
+        ex.stamp(5);
         // ---- Y3 (no barrier behind it: see the table above) ----
         if (has_cur) {
             ex.all_nosync([&](int tid) {
@@ -948,6 +954,7 @@ IQD_DEV void wbfm_tile_pipe(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLd
             prev_clen = clen;
             parity ^= 1;
         }
+        ex.stamp(6);
         // advance
         has_cur = has_next;
         cstart = next_cstart;
