@@ -813,6 +813,23 @@ IQD_DEV void p1_compute(const WbfmTile &t, const Consts &c, int cstart, int clen
     }
 }
 
+// One group whose raw bytes were fetched earlier (wave 0 issues the loads before its IIR phase).
+IQD_DEV void p1_compute_one(const WbfmTile &t, const Consts &c, const P1Raw &ra, int ngroups, int g_raw,
+                            bool want_mag, P1Pair &r)
+{
+    const int g = g_raw < ngroups ? g_raw : ngroups - 1;
+    r.a.valid = g_raw < ngroups;
+    r.b.valid = 0;
+    r.a.p = 16 * g;
+    r.a.mag = 0;
+    uint32_t off[17];
+    float th[17];
+    p1_front(t, c, ra, off);
+    p1_gather(t, off, th);
+    if (want_mag) r.a.mag = p1_magnitude(ra);
+    p1_make(t, c, th, r.a);
+}
+
 constexpr int PIPE_OTHERS = WB_THREADS - 64;   // lanes of waves 1-3
 static_assert(WBFM_CHUNK / 16 <= 2 * PIPE_OTHERS + 64, "a chunk must fit two groups per lane of waves 1-3 plus one of wave 0");
 
@@ -844,6 +861,7 @@ IQD_DEV void wbfm_tile_pipe(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLd
 
     float *part = (float *)lds.w;   // guess sums live at the head of the w region between stage 1 and the IIR
     typename Exec::template Local<P1Pair> regs;
+    typename Exec::template Local<P1Raw> raw0;   // wave 0's prefetched group
     auto chunk_len = [&](int cs) { return cs < 0 ? -cs : (t.tlen - cs < WBFM_CHUNK ? t.tlen - cs : WBFM_CHUNK); };
 #ifdef IQD_ABL_NOMAG
     const bool mag_on = false;
@@ -863,6 +881,12 @@ IQD_DEV void wbfm_tile_pipe(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLd
         // ---- X ----
         ex.stamp(7);
         if (ex.in_wave0()) {
+            const bool w0_share = has_next && (next_clen >> 4) > 2 * PIPE_OTHERS;   // groups 384 ..
+            if (w0_share)   // fetch the raw bytes now: the loads fly during the IIR
+                ex.wave0([&](int lane) {
+                    const int ng = next_clen >> 4, g = 2 * PIPE_OTHERS + lane;
+                    raw0.at(lane) = p1_load<GATED>(t, t.v0 + next_cstart + 16 * (g < ng ? g : ng - 1));
+                });
             if (has_cur) {
                 if (rec_pos == cstart) { rec.y_out = lds.y_carry; rec.u_out = lds.u_carry; }
                 ex.wave0([&](int lane) { iir_guess(c, lds, nseg, lane, part); });
@@ -887,10 +911,9 @@ IQD_DEV void wbfm_tile_pipe(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLd
                 });
             }
             ex.stamp(1);
-            if (has_next && (next_clen >> 4) > 2 * PIPE_OTHERS)   // wave 0's share: groups 384 ..
+            if (w0_share)
                 ex.wave0([&](int lane) {
-                    p1_compute<GATED>(t, c, next_cstart, next_clen, 2 * PIPE_OTHERS + lane, 0, false, next_mag,
-                                      regs.at(lane));
+                    p1_compute_one(t, c, raw0.at(lane), next_clen >> 4, 2 * PIPE_OTHERS + lane, next_mag, regs.at(lane));
                 });
         }
         if (has_next)
