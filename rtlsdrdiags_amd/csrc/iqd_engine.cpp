@@ -521,10 +521,12 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         e->stats.kernel_launches++;
         if (f == FAM_WBFM) {
             HIP_TRY(e, launch_wbfm_verify(a, s));
+            // state commit + tail, skipped on the device if the verification flagged anything
+            HIP_TRY(e, launch_tail_update(a, FAM_WBFM, true, s));
             wb = a;
             have_wbfm = true;
         } else {
-            HIP_TRY(e, launch_tail_update(a, f, s));
+            HIP_TRY(e, launch_tail_update(a, f, false, s));
         }
     }
     // channels in mode None still report their magnitudes
@@ -545,9 +547,8 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         if (e->h_counters[CNT_TILE_MISMATCH]) {
             int rc = run_wbfm_repairs(e, wb, gated, e->h_counters[CNT_TILE_MISMATCH]);
             if (rc != IQD_OK) return rc;
+            HIP_TRY(e, launch_tail_update(wb, FAM_WBFM, false, s));   // the guarded launch did nothing
         }
-        HIP_TRY(e, launch_wbfm_commit(wb, s));
-        HIP_TRY(e, launch_tail_update(wb, FAM_WBFM, s));
     }
     if (timed) {
         float ms = 0.f;

@@ -67,8 +67,7 @@ hipError_t launch_am(const ChainLaunch &a, int family, bool gated, bool mag, uin
 hipError_t launch_reset(uint8_t *tails, WbfmCarry *wc, DcCarry *dc, uint32_t first_ch, uint32_t n_ch,
                         uint32_t family_mask, hipStream_t s);
 hipError_t launch_wbfm_verify(const ChainLaunch &a, hipStream_t s);
-hipError_t launch_wbfm_commit(const ChainLaunch &a, hipStream_t s);
-hipError_t launch_tail_update(const ChainLaunch &a, int family, hipStream_t s);
+hipError_t launch_tail_update(const ChainLaunch &a, int family, bool guarded, hipStream_t s);
 hipError_t launch_magnitude(const uint8_t *iq, size_t ch_stride_bytes, const uint32_t *ch_list, uint32_t n_list,
                             uint32_t block_samples, uint32_t n_blocks, uint32_t *mag_sums, hipStream_t s);
 hipError_t launch_squelch(const SquelchLaunch &q, bool always_open, hipStream_t s);

@@ -65,8 +65,11 @@ __device__ __forceinline__ void rotation_selectors(int rotation, WbfmTile &t)
     }
 }
 
+#ifndef IQD_WBFM_MIN_WAVES
+#define IQD_WBFM_MIN_WAVES 1
+#endif
 template <bool GATED, bool MAG>
-__global__ __launch_bounds__(WB_THREADS) void wbfm_chain_kernel(const ChainLaunch a)
+__global__ __launch_bounds__(WB_THREADS, IQD_WBFM_MIN_WAVES) void wbfm_chain_kernel(const ChainLaunch a)
 {
     __shared__ WbfmLds lds;
     uint32_t li, tile;
@@ -258,31 +261,26 @@ __global__ void wbfm_verify_kernel(const ChainLaunch a)
     }
 }
 
-// Commits the restart state of each channel's last tile (after verification / repair).
-__global__ void wbfm_commit_kernel(const ChainLaunch a)
+// New tail = last TAIL samples of [old tail | this call's open blocks] for one family.  For WBFM the
+// same launch commits the restart state of each channel's last tile; with `guarded` it does nothing
+// when the hand-off verification has flagged a mismatch (the host then repairs and launches it again).
+__global__ __launch_bounds__(256) void tail_update_kernel(const ChainLaunch a, int family, int guarded)
 {
-    const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
-    if (li >= a.n_list) return;
-    const uint32_t ch = a.ch_list[li];
-    const uint32_t vlen = a.vlen_gated ? a.vlen_gated[ch] : a.vlen;
-    if (vlen == 0) return;
-    const uint32_t ntiles = (vlen + a.tile_len - 1) / a.tile_len;
-    const WbfmRecord r = a.records[(size_t)li * a.tiles_per_ch + ntiles - 1];
-    WbfmCarry cy;
-    cy.y = r.y_out; cy.u = r.u_out; cy.back = r.back_out;
-    cy.y_end = r.y_end; cy.u_end = r.u_end;
-    cy.pad[0] = cy.pad[1] = cy.pad[2] = 0;
-    a.wbfm_carry[a.first_ch + ch] = cy;
-}
-
-// New tail = last TAIL samples of [old tail | this call's open blocks] for one family.
-__global__ __launch_bounds__(256) void tail_update_kernel(const ChainLaunch a, int family)
-{
+    if (guarded && a.counters[CNT_TILE_MISMATCH] != 0) return;
     const uint32_t li = blockIdx.x;
     const uint32_t ch = a.ch_list[li];
     const uint32_t ech = a.first_ch + ch;
     const uint32_t vlen = a.vlen_gated ? a.vlen_gated[ch] : a.vlen;
     if (vlen == 0) return;
+    if (family == FAM_WBFM && threadIdx.x == 0) {
+        const uint32_t ntiles = (vlen + a.tile_len - 1) / a.tile_len;
+        const WbfmRecord r = a.records[(size_t)li * a.tiles_per_ch + ntiles - 1];
+        WbfmCarry cy;
+        cy.y = r.y_out; cy.u = r.u_out; cy.back = r.back_out;
+        cy.y_end = r.y_end; cy.u_end = r.u_end;
+        cy.pad[0] = cy.pad[1] = cy.pad[2] = 0;
+        a.wbfm_carry[ech] = cy;
+    }
     uint8_t *tail = a.tails + ((size_t)ech * FAM_COUNT + family) * TAIL_BYTES;
     const uint8_t *iq_ch = a.iq + (size_t)ch * a.ch_stride_bytes;
     const uint32_t *blk_list = a.vlen_gated ? a.blk_lists + (size_t)ch * a.n_blocks : nullptr;
@@ -454,15 +452,9 @@ hipError_t launch_wbfm_verify(const ChainLaunch &a, hipStream_t s)
     return hipGetLastError();
 }
 
-hipError_t launch_wbfm_commit(const ChainLaunch &a, hipStream_t s)
+hipError_t launch_tail_update(const ChainLaunch &a, int family, bool guarded, hipStream_t s)
 {
-    hipLaunchKernelGGL(wbfm_commit_kernel, dim3((a.n_list + 255) / 256), dim3(256), 0, s, a);
-    return hipGetLastError();
-}
-
-hipError_t launch_tail_update(const ChainLaunch &a, int family, hipStream_t s)
-{
-    hipLaunchKernelGGL(tail_update_kernel, dim3(a.n_list), dim3(256), 0, s, a, family);
+    hipLaunchKernelGGL(tail_update_kernel, dim3(a.n_list), dim3(256), 0, s, a, family, guarded ? 1 : 0);
     return hipGetLastError();
 }
 
