@@ -1,5 +1,7 @@
+"""Diagnostic: per-phase cycle shares of the WBFM chain kernel.  Needs a library built with -DIQD_STAMPS:
+   IQD_LIB=.../libiqdemod_stamps.so python tools/stamps_probe.py"""
 import sys, os
-sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT','.'))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from rtlsdrdiags_amd import capi, synth
 n = 1<<28; period = 1<<24
