@@ -16,10 +16,10 @@ constexpr int SEG = 128;            // de-emphasis IIR segment (one lane's run)
 constexpr int FORCED_BACK = 768;    // an exact IIR restart point lies this far before a tile
 constexpr int COLD_HALO = 2048;     // zero-state warm-up distance of interior tiles
 #ifndef IQD_WBFM_NSEG
-#define IQD_WBFM_NSEG 56
+#define IQD_WBFM_NSEG 55
 #endif
-constexpr int WBFM_NSEG = IQD_WBFM_NSEG;  // segments per chunk (56 -> 7168 samples = 448 groups of 16:
-                                          // 2 x 192 for waves 1-3 + 64 for wave 0; 3 workgroups per CU)
+constexpr int WBFM_NSEG = IQD_WBFM_NSEG;  // segments per chunk (55 -> 7040 samples = 440 groups of 16:
+                                          // seven wave passes of 63 groups; 3 workgroups per CU)
 constexpr int WBFM_CHUNK = WBFM_NSEG * SEG;
 constexpr int TSTRIDE = 132;        // dwords between segments of the IIR input buffer
 constexpr int WSTRIDE = 68;         // dwords between segments of the int16 output buffer (16-B aligned)

@@ -35,6 +35,11 @@ struct DeviceExec {
     __device__ __forceinline__ void sync() const { __syncthreads(); }
     template <class F> __device__ __forceinline__ void others(F f) { if (tid >= 64) f(tid); }
     template <class F> __device__ __forceinline__ void all_nosync(F f) { f(tid); }
+    // value held by the lane below (undefined in lane 0 of a wave): v_mov_b32_dpp wave_shr:1
+    template <int SLOT> __device__ __forceinline__ uint32_t shr1(int, uint32_t v) const
+    {
+        return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, false);
+    }
     template <class T> struct Local {   // per-thread values that live across phases: registers here
         T v;
         __device__ __forceinline__ T &at(int) { return v; }
@@ -111,16 +116,27 @@ __global__ __launch_bounds__(WB_THREADS, IQD_WBFM_MIN_WAVES) void wbfm_chain_ker
     } else {
         start.y = 0.f; start.u = 0.f; start.back = 0; start.cold = 1;
     }
-    DeviceExec ex{(int)threadIdx.x};
+#ifndef IQD_ROT_MODE
+#define IQD_ROT_MODE 0
+#endif
+    // Which hardware wave plays "wave 0" (the serial IIR) rotates from workgroup to workgroup, so that the
+    // workgroups sharing a CU do not stack their IIR waves on one SIMD and their FIR waves on the other three.
+    uint32_t rot = 0;
+    if (IQD_ROT_MODE == 1) rot = blockIdx.x;
+    if (IQD_ROT_MODE == 2) rot = blockIdx.x >> 3;
+    if (IQD_ROT_MODE == 3) rot = blockIdx.x >> 8;
+    if (IQD_ROT_MODE == 4) rot = (blockIdx.x * 2654435761u) >> 16;
+    if (IQD_ROT_MODE == 5) rot = (blockIdx.x >> 3) + (blockIdx.x >> 8);
+    DeviceExec ex{(int)((threadIdx.x + 64u * (rot & 3u)) & (WB_THREADS - 1))};
 #ifdef IQD_WBFM_SERIAL_PHASES   // the first driver: IIR phase not overlapped (kept for A/B measurements)
     wbfm_tile<GATED, MAG>(ex, t, g_consts, lds, start, &a.records[(size_t)li * a.tiles_per_ch + tile]);
 #else
     wbfm_tile_pipe<GATED, MAG>(ex, t, g_consts, lds, start, &a.records[(size_t)li * a.tiles_per_ch + tile]);
 #endif
-    if (threadIdx.x == 0 && lds.repair_count) atomicAdd(&a.counters[CNT_SEG_REPAIRS], lds.repair_count);
+    if (ex.tid == 0 && lds.repair_count) atomicAdd(&a.counters[CNT_SEG_REPAIRS], lds.repair_count);
 #ifdef IQD_STAMPS
-    if (a.stamps && (threadIdx.x == 0 || threadIdx.x == 64))
-        for (int k = 0; k < 8; k++) atomicAdd(&a.stamps[(threadIdx.x ? 8 : 0) + k], ex.acc[k]);
+    if (a.stamps && (ex.tid == 0 || ex.tid == 64))
+        for (int k = 0; k < 8; k++) atomicAdd(&a.stamps[(ex.tid ? 8 : 0) + k], ex.acc[k]);
 #endif
 }
 

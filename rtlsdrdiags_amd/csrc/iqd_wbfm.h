@@ -95,6 +95,7 @@ IQD_DEV void rotate4(const WbfmTile &t, uint32_t w0, uint32_t w1, uint32_t &xi, 
 // 17 outputs (samples -1 .. 15 of the group) of the 16-tap FIR over 32 bytes of one rail.
 // Output idx uses window bytes idx .. idx+15.  The result is TWICE the Q15 accumulator plus WB_BIAS, so
 // that byte 2 of it is (uint8)((int8)(acc >> 15) + 128), the atan2 table index.
+template <int FIRST = 0>
 IQD_DEV void fir16_window(const uint32_t (&x)[8], const Consts &c, int (&acc)[17])
 {
     const int bias = WB_BIAS;   // lives in one VGPR for all chains
@@ -106,7 +107,7 @@ IQD_DEV void fir16_window(const uint32_t (&x)[8], const Consts &c, int (&acc)[17
         y[2][j] = alignbyte(x[j + 1], x[j], 3);
     }
 #pragma unroll
-    for (int idx = 0; idx < 17; idx++) {
+    for (int idx = FIRST; idx < 17; idx++) {
         const int s = idx & 3, j0 = idx >> 2;
         int lo = 0, hi = 0;
 #pragma unroll
@@ -217,7 +218,7 @@ IQD_DEV void p1_gather(const WbfmTile &t, const uint32_t (&off)[17], float (&th)
 #pragma unroll
     for (int k = 0; k < 17; k++) {
 #ifdef IQD_ABL_NOLUT   // diagnostic build: no table gather
-        th[k] = u2f(0x3f000000u | (off[k] & 0x3fffffu));
+        th[k] = u2f(0x3f000000u | (off[k] & 0xffu));
 #else
         th[k] = t.lut[off[k]];
 #endif
@@ -813,6 +814,105 @@ IQD_DEV void p1_compute(const WbfmTile &t, const Consts &c, int cstart, int clen
     }
 }
 
+// ---- phase 1 with neighbour sharing ------------------------------------------------------------
+// Consecutive lanes hold consecutive groups, so a lane's 16-sample lead-in is its left neighbour's
+// own rotated data and its theta[-1] the neighbour's theta[15]: both arrive by one DPP wave shift
+// instead of being recomputed.  Lane 0 of a wave has no neighbour; it therefore redoes the group
+// before the wave's first one (1/64 redundancy) purely as a donor: its rotated bytes and theta[15]
+// need no lead-in, everything else it computes is dropped.
+struct P1Own { u32x4 r2, r3; };   // a group's own 32 raw bytes
+
+constexpr int P1S_PER_WAVE = 63;                       // useful groups per wave and pass
+IQD_DEV int p1s_group(int slot, int lane) { return P1S_PER_WAVE * slot + lane - 1; }
+
+template <bool GATED>
+IQD_DEV P1Own p1s_load(const WbfmTile &t, int cstart, int ngroups, int g_raw)
+{
+    const int g = g_raw < ngroups ? g_raw : ngroups - 1;      // g = -1 is the lead-in of the chunk
+    const u32x4 *po = raw_group<GATED>(t, t.v0 + cstart + 16 * g);
+    return P1Own{po[0], po[1]};
+}
+
+template <int SLOT0, class Exec>
+IQD_DEV void p1s_front(Exec &ex, int tid, const WbfmTile &t, const Consts &c, const P1Own &r, uint32_t (&off)[17])
+{
+    uint32_t s[8] = {r.r2.x, r.r2.y, r.r2.z, r.r2.w, r.r3.x, r.r3.y, r.r3.z, r.r3.w};
+    uint32_t xi[8], xq[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) s[j] ^= 0x80808080u;
+#pragma unroll
+    for (int j = 0; j < 4; j++) rotate4(t, s[2 * j], s[2 * j + 1], xi[4 + j], xq[4 + j]);
+    xi[0] = ex.template shr1<SLOT0 + 0>(tid, xi[4]);
+    xi[1] = ex.template shr1<SLOT0 + 1>(tid, xi[5]);
+    xi[2] = ex.template shr1<SLOT0 + 2>(tid, xi[6]);
+    xi[3] = ex.template shr1<SLOT0 + 3>(tid, xi[7]);
+    xq[0] = ex.template shr1<SLOT0 + 4>(tid, xq[4]);
+    xq[1] = ex.template shr1<SLOT0 + 5>(tid, xq[5]);
+    xq[2] = ex.template shr1<SLOT0 + 6>(tid, xq[6]);
+    xq[3] = ex.template shr1<SLOT0 + 7>(tid, xq[7]);
+    int ai[17], aq[17];
+#ifdef IQD_ABL_NOFIR   // diagnostic build: skip the FIR arithmetic, keep its inputs alive
+#pragma unroll
+    for (int k = 1; k < 17; k++) { ai[k] = (int)(xi[k & 7] + k); aq[k] = (int)(xq[k & 7] ^ k); }
+#else
+    fir16_window<1>(xi, c, ai);
+    fir16_window<1>(xq, c, aq);
+#endif
+#pragma unroll
+    for (int k = 1; k < 17; k++) off[k] = perm((uint32_t)aq[k], (uint32_t)ai[k], 0x0c0c0602u);
+}
+
+IQD_DEV void p1s_gather(const WbfmTile &t, const uint32_t (&off)[17], float (&th)[17])
+{
+#pragma unroll
+    for (int k = 1; k < 17; k++) {
+#ifdef IQD_ABL_NOLUT   // diagnostic build: no table gather
+        th[k] = u2f(0x3f000000u | (off[k] & 0xffu));
+#else
+        th[k] = t.lut[off[k]];
+#endif
+    }
+}
+
+IQD_DEV uint32_t p1s_magnitude(const P1Own &r)
+{
+    const uint32_t k = 0x80808080u;
+    const uint32_t own[8] = {r.r2.x ^ k, r.r2.y ^ k, r.r2.z ^ k, r.r2.w ^ k, r.r3.x ^ k, r.r3.y ^ k, r.r3.z ^ k, r.r3.w ^ k};
+    return magnitude16(own);
+}
+
+// Two passes (slots sa, sb) of one wave, interleaved like p1_compute.  lane = tid & 63.
+template <class Exec>
+IQD_DEV void p1s_compute(Exec &ex, int tid, const WbfmTile &t, const Consts &c, const P1Own &ra, const P1Own &rb,
+                         int ngroups, int sa, int sb, bool wave_has_b, bool want_mag, P1Pair &r)
+{
+    const int lane = tid & 63;
+    const int ga = p1s_group(sa, lane), gb = p1s_group(sb, lane);
+    r.a.valid = lane > 0 && ga < ngroups;
+    r.b.valid = wave_has_b && lane > 0 && gb < ngroups;
+    r.a.p = 16 * (ga < 0 ? 0 : ga);
+    r.b.p = 16 * (gb < 0 ? 0 : gb);
+    r.a.mag = r.b.mag = 0;
+    uint32_t off[17];
+    float tha[17];
+    p1s_front<0>(ex, tid, t, c, ra, off);
+    p1s_gather(t, off, tha);
+    if (want_mag) r.a.mag = p1s_magnitude(ra);
+    if (wave_has_b) {
+        float thb[17];
+        p1s_front<9>(ex, tid, t, c, rb, off);
+        p1s_gather(t, off, thb);
+        if (want_mag) r.b.mag = p1s_magnitude(rb);
+        tha[0] = u2f(ex.template shr1<8>(tid, f2u(tha[16])));
+        p1_make(t, c, tha, r.a);
+        thb[0] = u2f(ex.template shr1<17>(tid, f2u(thb[16])));
+        p1_make(t, c, thb, r.b);
+    } else {
+        tha[0] = u2f(ex.template shr1<8>(tid, f2u(tha[16])));
+        p1_make(t, c, tha, r.a);
+    }
+}
+
 // One group whose raw bytes were fetched earlier (wave 0 issues the loads before its IIR phase).
 IQD_DEV void p1_compute_one(const WbfmTile &t, const Consts &c, const P1Raw &ra, int ngroups, int g_raw,
                             bool want_mag, P1Pair &r)
@@ -831,7 +931,9 @@ IQD_DEV void p1_compute_one(const WbfmTile &t, const Consts &c, const P1Raw &ra,
 }
 
 constexpr int PIPE_OTHERS = WB_THREADS - 64;   // lanes of waves 1-3
-static_assert(WBFM_CHUNK / 16 <= 2 * PIPE_OTHERS + 64, "a chunk must fit two groups per lane of waves 1-3 plus one of wave 0");
+// chunks of up to 6 x 63 groups leave wave 0 to the IIR alone; longer ones give it a seventh pass
+constexpr bool W0_CAN_SHARE = WBFM_CHUNK / 16 > 6 * P1S_PER_WAVE;
+static_assert(WBFM_CHUNK / 16 <= 7 * P1S_PER_WAVE, "a chunk must fit seven wave passes of 63 groups");
 
 template <bool GATED, bool MAG, class Exec>
 IQD_DEV void wbfm_tile_pipe(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLds &lds,
@@ -861,7 +963,7 @@ IQD_DEV void wbfm_tile_pipe(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLd
 
     float *part = (float *)lds.w;   // guess sums live at the head of the w region between stage 1 and the IIR
     typename Exec::template Local<P1Pair> regs;
-    typename Exec::template Local<P1Raw> raw0;   // wave 0's prefetched group
+    typename Exec::template Local<P1Own> raw0;   // wave 0's prefetched group
     auto chunk_len = [&](int cs) { return cs < 0 ? -cs : (t.tlen - cs < WBFM_CHUNK ? t.tlen - cs : WBFM_CHUNK); };
 #ifdef IQD_ABL_NOMAG
     const bool mag_on = false;
@@ -881,12 +983,9 @@ IQD_DEV void wbfm_tile_pipe(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLd
         // ---- X ----
         ex.stamp(7);
         if (ex.in_wave0()) {
-            const bool w0_share = has_next && (next_clen >> 4) > 2 * PIPE_OTHERS;   // groups 384 ..
+            const bool w0_share = W0_CAN_SHARE && has_next && (next_clen >> 4) > P1S_PER_WAVE * 6;   // slot 6: groups 378 ..
             if (w0_share)   // fetch the raw bytes now: the loads fly during the IIR
-                ex.wave0([&](int lane) {
-                    const int ng = next_clen >> 4, g = 2 * PIPE_OTHERS + lane;
-                    raw0.at(lane) = p1_load<GATED>(t, t.v0 + next_cstart + 16 * (g < ng ? g : ng - 1));
-                });
+                ex.wave0([&](int lane) { raw0.at(lane) = p1s_load<GATED>(t, next_cstart, next_clen >> 4, p1s_group(6, lane)); });
             if (has_cur) {
                 if (rec_pos == cstart) { rec.y_out = lds.y_carry; rec.u_out = lds.u_carry; }
                 ex.wave0([&](int lane) { iir_guess(c, lds, nseg, lane, part); });
@@ -913,16 +1012,18 @@ IQD_DEV void wbfm_tile_pipe(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLd
             ex.stamp(1);
             if (w0_share)
                 ex.wave0([&](int lane) {
-                    p1_compute_one(t, c, raw0.at(lane), next_clen >> 4, 2 * PIPE_OTHERS + lane, next_mag, regs.at(lane));
+                    p1s_compute(ex, lane, t, c, raw0.at(lane), raw0.at(lane), next_clen >> 4, 6, 6, false, next_mag, regs.at(lane));
                 });
         }
         if (has_next)
             ex.others([&](int tid) {
-                const int p = tid - 64;
+                const int w = (tid - 64) >> 6, lane = tid & 63;    // waves 1-3 take slots w and w+3
                 const int ng = next_clen >> 4;
-                if ((p & ~63) >= ng) { regs.at(tid).a.valid = 0; regs.at(tid).b.valid = 0; return; }   // idle wave
-                const bool wave_has_b = ((p & ~63) + PIPE_OTHERS) < ng;
-                p1_compute<GATED>(t, c, next_cstart, next_clen, p, p + PIPE_OTHERS, wave_has_b, next_mag, regs.at(tid));
+                if (P1S_PER_WAVE * w >= ng) { regs.at(tid).a.valid = 0; regs.at(tid).b.valid = 0; return; }   // idle wave
+                const bool wave_has_b = P1S_PER_WAVE * (w + 3) < ng;
+                const P1Own ra = p1s_load<GATED>(t, next_cstart, ng, p1s_group(w, lane));
+                const P1Own rb = wave_has_b ? p1s_load<GATED>(t, next_cstart, ng, p1s_group(w + 3, lane)) : ra;
+                p1s_compute(ex, tid, t, c, ra, rb, ng, w, w + 3, wave_has_b, next_mag, regs.at(tid));
             });
         ex.stamp(2);
         ex.sync();
@@ -932,7 +1033,7 @@ IQD_DEV void wbfm_tile_pipe(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLd
             if (prev_clen) wbfm_shift_b(lds, prev_clen, tid);
             if (has_next) {
                 const bool w0 = tid < 64;
-                const bool mine = !w0 || (next_clen >> 4) > 2 * PIPE_OTHERS;
+                const bool mine = !w0 || (W0_CAN_SHARE && (next_clen >> 4) > P1S_PER_WAVE * 6);
                 if (mine) {
                     P1Pair &r = regs.at(tid);
                     p1_store_t(lds, r.a);
@@ -958,7 +1059,7 @@ IQD_DEV void wbfm_tile_pipe(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLd
             if (has_next) {
                 if (next_mag) wbfm_flush_mag(t, lds, ncb, next_cstart, next_clen, tid);
                 const bool w0 = tid < 64;
-                const bool mine = !w0 || (next_clen >> 4) > 2 * PIPE_OTHERS;
+                const bool mine = !w0 || (W0_CAN_SHARE && (next_clen >> 4) > P1S_PER_WAVE * 6);
                 if (mine) {
                     p1_store_part(part, regs.at(tid).a);
                     if (!w0) p1_store_part(part, regs.at(tid).b);

@@ -31,6 +31,13 @@ struct HostExec {
     void sync() const {}
     template <class F> void others(F f) { for (int t = 64; t < iqd::WB_THREADS; t++) f(t); }
     template <class F> void all_nosync(F f) { for (int t = 0; t < iqd::WB_THREADS; t++) f(t); }
+    // wave shift by one lane: lanes run in ascending order here, so the lane below has already published
+    uint32_t pub[18][iqd::WB_THREADS];
+    template <int SLOT> uint32_t shr1(int tid, uint32_t v)
+    {
+        pub[SLOT][tid] = v;
+        return (tid & 63) ? pub[SLOT][tid - 1] : 0xdeadbeefu;
+    }
     template <class T> struct Local {
         std::vector<T> v = std::vector<T>(iqd::WB_THREADS);
         T &at(int tid) { return v[tid]; }
