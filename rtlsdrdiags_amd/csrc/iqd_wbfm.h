@@ -613,12 +613,13 @@ IQD_DEV void wbfm_stage2(const Consts &c, WbfmLds &lds, int clen, int tid)
 }
 
 // /2, 40 taps (WbFmDemodulator.cc:546) -> PCM
-IQD_DEV void wbfm_stage3(const Consts &c, WbfmLds &lds, const WbfmTile &t, int cstart, int clen, int tid)
+IQD_DEV void wbfm_stage3(const Consts &c, WbfmLds &lds, const WbfmTile &t, int cstart, int clen, int tid,
+                         int nthreads = WB_THREADS)
 {
     const int nout = clen >> 5;
     // the reference's per-MAC clamp matters only when some |y2| in reach exceeds AUDIO40_SAFE
     const bool quiet = lds.y2_peak <= (uint32_t)AUDIO40_SAFE && lds.y2_peak_hist <= (uint32_t)AUDIO40_SAFE;
-    for (int i = tid; i < nout; i += WB_THREADS) {
+    for (int i = tid; i < nout; i += nthreads) {
         const int y = quiet ? q15_pairs<40>(c.audio40, lds.y2, 40 + 2 * i + 1)
                             : q15_seq<40>(c.audio40, lds.y2, 40 + 2 * i + 1);
         if (cstart >= 0) t.pcm_row[((t.v0 + cstart) >> 5) + i] = (int16_t)y;
@@ -1070,8 +1071,8 @@ IQD_DEV void wbfm_tile_pipe(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLd
         ex.stamp(5);
         // ---- Y3 (no barrier behind it: see the table above) ----
         if (has_cur) {
-            ex.all_nosync([&](int tid) {
-                wbfm_stage3(c, lds, t, cstart, clen, tid);
+            ex.others([&](int tid) {   // wave 0 goes straight on to the next chunk's IIR, the critical path
+                wbfm_stage3(c, lds, t, cstart, clen, tid - 64, PIPE_OTHERS);
                 const int n1 = clen >> 2;
                 if (tid >= 100 && tid < 104) lds.y1[tid - 100] = lds.y1[(n1 >> 1) + tid - 100];
             });
