@@ -35,6 +35,18 @@ struct DeviceExec {
     __device__ __forceinline__ void sync() const { __syncthreads(); }
     template <class F> __device__ __forceinline__ void others(F f) { if (tid >= 64) f(tid); }
     template <class F> __device__ __forceinline__ void all_nosync(F f) { f(tid); }
+    // Rendezvous of waves 1-3 only (wave 0 is elsewhere, in its serial phase): a monotonic arrival counter in
+    // LDS.  All waves of a workgroup are resident, so spinning cannot starve the ones being waited for.
+    uint32_t sync_epoch = 0;
+    __device__ __forceinline__ void others_sync(uint32_t *ctr)
+    {
+        if (tid < 64) return;
+        sync_epoch += 3;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if ((tid & 63) == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < sync_epoch) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
     // value held by the lane below (undefined in lane 0 of a wave): v_mov_b32_dpp wave_shr:1
     template <int SLOT> __device__ __forceinline__ uint32_t shr1(int, uint32_t v) const
     {
@@ -47,10 +59,10 @@ struct DeviceExec {
     // the single-wave IIR phase is the workgroup's critical path: let it win VALU arbitration
     __device__ __forceinline__ void critical(bool on) const { if (on) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
 #ifdef IQD_STAMPS   // diagnostic build only: cycles per phase, summed over workgroups
-    unsigned long long last = 0, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t last = 0, acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // 32-bit: a workgroup lives far less than 2^32 cycles
     __device__ __forceinline__ void stamp(int k)
     {
-        const unsigned long long now = __builtin_readcyclecounter();
+        const uint32_t now = (uint32_t)__builtin_readcyclecounter() | 1u;
         if (last) acc[k] += now - last;
         last = now;
     }
@@ -136,7 +148,7 @@ __global__ __launch_bounds__(WB_THREADS, IQD_WBFM_MIN_WAVES) void wbfm_chain_ker
     if (ex.tid == 0 && lds.repair_count) atomicAdd(&a.counters[CNT_SEG_REPAIRS], lds.repair_count);
 #ifdef IQD_STAMPS
     if (a.stamps && (ex.tid == 0 || ex.tid == 64))
-        for (int k = 0; k < 8; k++) atomicAdd(&a.stamps[(ex.tid ? 8 : 0) + k], ex.acc[k]);
+        for (int k = 0; k < 8; k++) atomicAdd(&a.stamps[(ex.tid ? 8 : 0) + k], (unsigned long long)ex.acc[k]);
 #endif
 }
 

@@ -49,6 +49,8 @@ struct WbfmLds {
     float y_carry, u_carry;                // state entering the chunk
     uint32_t mag[WBFM_CHUNK / SEG + 2];    // squelch magnitude partial sums per block slot
     uint32_t repair_count;
+    uint32_t sync_ctr;                     // arrivals at the waves-1-3 rendezvous (monotonic)
+    float part[WBFM_CHUNK / 16];           // per 16-sample group: sum c^(15-k) u[k], input of the IIR state guess
     uint32_t y2_peak, y2_peak_hist;        // max |y2| of this chunk (if loud) / reaching into the next
 };
 
@@ -584,7 +586,7 @@ IQD_DEV void lds_max(uint32_t *slot, uint32_t v)
 
 // /4, 12 taps (WbFmDemodulator.cc:541).  Its input is stage 1's output, |y1| <= 29126 whatever the
 // data (sum|h1| = 29126 < 2^15), and 16384 + 36758 * 29126 < 2^30: the clamp can never fire here.
-IQD_DEV void wbfm_stage2(const Consts &c, WbfmLds &lds, int clen, int tid)
+IQD_DEV void wbfm_stage2(const Consts &c, WbfmLds &lds, int clen, int tid, int nthreads = WB_THREADS)
 {
     // two consecutive outputs per lane: y1 dwords 2*j0 .. 2*j0+7 (j0 even -> 16-byte aligned)
     const int npair = clen >> 5;
@@ -593,7 +595,7 @@ IQD_DEV void wbfm_stage2(const Consts &c, WbfmLds &lds, int clen, int tid)
     for (int q = 0; q < 6; q++)   // pair q counts back from the newest dword: (lo: h[2q+1], hi: h[2q])
         taps[q] = (uint32_t)(uint16_t)c.post12[2 * q + 1] | ((uint32_t)(uint16_t)c.post12[2 * q] << 16);
     uint32_t peak = 0;
-    for (int k = tid; k < npair; k += WB_THREADS) {
+    for (int k = tid; k < npair; k += nthreads) {
         const u32x4 *p = (const u32x4 *)&lds.y1[4 * k];
         const u32x4 a = p[0], b = p[1];
         const uint32_t d[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
@@ -769,16 +771,18 @@ IQD_DEV void wbfm_tile(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLds &ld
 
 
 // ---- pipelined tile driver -------------------------------------------------------------------
-// The serial IIR phase of chunk k (wave 0) runs beside phase 1 of chunk k+1 (waves 1-3, then wave 0
-// too), whose results wait in registers until the IIR has released the LDS input buffer:
+// Two workgroup barriers per chunk.  The serial IIR of chunk k (wave 0) runs beside the last two
+// decimation stages of chunk k-1 and phase 1 of chunk k+1 (waves 1-3), whose results wait in registers
+// until the IIR has released the LDS input buffer:
 //
-//   X   wave 0: IIR(k), then phase 1 of groups 384.. of chunk k+1      waves 1-3: phase 1 of
-//       groups p and p+192 of chunk k+1 (two groups per lane, interleaved)          | barrier
-//   Y1  store u(k+1) -> t4, magnitude sums; stage 1(k)                                | barrier
-//   Y2  flush magnitudes(k+1); store guess sums(k+1) into the w region (stage 1 has
-//       consumed w(k)); stage 2(k)                                                     | barrier
-//   Y3  stage 3(k) -> PCM, y1 history                      (runs into the next X: nothing it
-//       touches is touched there)
+//   X   wave 0:    IIR(k): t4, part -> w; then phase 1 of groups 378.. of chunk k+1
+//       waves 1-3: flush magnitudes(k); stage 2(k-1); rendezvous of these three waves;
+//                  stage 3(k-1) -> PCM, y1 history; phase 1 of two groups per lane of chunk k+1     | barrier
+//   Y   all:       y2 history(k-1); store u(k+1) -> t4, guess sums -> part, magnitude sums;
+//                  stage 1(k): w -> y1                                                              | barrier
+//
+// Nothing one side of X writes is read by the other side before the barrier: the IIR touches t4, part, w,
+// z/g/e and the carries; stages 2 and 3 touch y1, y2 and the loudness flags; phase 1 lives in registers.
 struct P1Pair { P1Out a, b; };
 
 template <bool GATED>
@@ -950,6 +954,7 @@ IQD_DEV void wbfm_tile_pipe(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLd
             lds.y_carry = start.cold ? 0.f : start.y;
             lds.u_carry = start.cold ? 0.f : start.u;
             lds.repair_count = 0;
+            lds.sync_ctr = 0;
             lds.y2_peak = 0;
             lds.y2_peak_hist = 0;
         }
@@ -962,7 +967,6 @@ IQD_DEV void wbfm_tile_pipe(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLd
     rec.u_out = start.u;
     rec.back_out = t.tlen - rec_pos;
 
-    float *part = (float *)lds.w;   // guess sums live at the head of the w region between stage 1 and the IIR
     typename Exec::template Local<P1Pair> regs;
     typename Exec::template Local<P1Own> raw0;   // wave 0's prefetched group
     auto chunk_len = [&](int cs) { return cs < 0 ? -cs : (t.tlen - cs < WBFM_CHUNK ? t.tlen - cs : WBFM_CHUNK); };
@@ -972,24 +976,27 @@ IQD_DEV void wbfm_tile_pipe(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLd
     const bool mag_on = MAG;
 #endif
 
-    // iteration -1 only produces chunk 0; iteration k consumes chunk k and produces chunk k+1
+    // iteration -1 only produces chunk 0; iteration k runs the IIR of chunk k, phase 1 of chunk k+1 and the
+    // last two decimation stages of chunk k-1; one more iteration drains the last chunk's decimation
     int cstart = -halo - 1, clen = 0;          // "no current chunk"
     int next_cstart = -halo, next_clen = chunk_len(-halo);
-    int prev_clen = 0, parity = 0;
+    int st_cstart = 0, st_clen = 0;            // chunk whose stage-1 output awaits stages 2 and 3
+    int parity = 0;
     bool has_cur = false, has_next = true;
-    while (has_cur || has_next) {
+    while (has_cur || has_next || st_clen) {
         const int nseg = clen / SEG;
-        const ChunkBlocks ncb = chunk_blocks(t, next_cstart);
-        const bool next_mag = mag_on && next_cstart >= 0;
+        const ChunkBlocks ccb = chunk_blocks(t, cstart), ncb = chunk_blocks(t, next_cstart);
+        const bool cur_mag = mag_on && has_cur && cstart >= 0;
+        const bool next_mag = mag_on && has_next && next_cstart >= 0;
+        const bool w0_share = W0_CAN_SHARE && has_next && (next_clen >> 4) > P1S_PER_WAVE * 6;   // slot 6: groups 378 ..
         // ---- X ----
         ex.stamp(7);
         if (ex.in_wave0()) {
-            const bool w0_share = W0_CAN_SHARE && has_next && (next_clen >> 4) > P1S_PER_WAVE * 6;   // slot 6: groups 378 ..
             if (w0_share)   // fetch the raw bytes now: the loads fly during the IIR
                 ex.wave0([&](int lane) { raw0.at(lane) = p1s_load<GATED>(t, next_cstart, next_clen >> 4, p1s_group(6, lane)); });
             if (has_cur) {
                 if (rec_pos == cstart) { rec.y_out = lds.y_carry; rec.u_out = lds.u_carry; }
-                ex.wave0([&](int lane) { iir_guess(c, lds, nseg, lane, part); });
+                ex.wave0([&](int lane) { iir_guess(c, lds, nseg, lane, lds.part); });
                 ex.wave0([&](int lane) { iir_warm(c, lds, nseg, lane); });
                 int rounds = 0;
                 do {
@@ -1016,6 +1023,20 @@ IQD_DEV void wbfm_tile_pipe(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLd
                     p1s_compute(ex, lane, t, c, raw0.at(lane), raw0.at(lane), next_clen >> 4, 6, 6, false, next_mag, regs.at(lane));
                 });
         }
+        if (cur_mag || st_clen)
+            ex.others([&](int tid) {
+                if (cur_mag) wbfm_flush_mag(t, lds, ccb, cstart, clen, tid - 64);
+                if (st_clen) wbfm_stage2(c, lds, st_clen, tid - 64, PIPE_OTHERS);
+            });
+        if (st_clen) {
+            ex.others_sync(&lds.sync_ctr);   // stage 3 reads what all three waves' stage 2 wrote
+            ex.others([&](int tid) {
+                wbfm_stage3(c, lds, t, st_cstart, st_clen, tid - 64, PIPE_OTHERS);
+                const int n1 = st_clen >> 2;
+                if (tid >= 100 && tid < 104) lds.y1[tid - 100] = lds.y1[(n1 >> 1) + tid - 100];
+            });
+        }
+        ex.stamp(0);
         if (has_next)
             ex.others([&](int tid) {
                 const int w = (tid - 64) >> 6, lane = tid & 63;    // waves 1-3 take slots w and w+3
@@ -1029,18 +1050,19 @@ IQD_DEV void wbfm_tile_pipe(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLd
         ex.stamp(2);
         ex.sync();
         ex.stamp(3);
-        // ---- Y1 ----
+        // ---- Y ----
         ex.all([&](int tid) {
-            if (prev_clen) wbfm_shift_b(lds, prev_clen, tid);
+            if (st_clen) wbfm_shift_b(lds, st_clen, tid);   // that chunk's stage 3 finished in X
             if (has_next) {
                 const bool w0 = tid < 64;
-                const bool mine = !w0 || (W0_CAN_SHARE && (next_clen >> 4) > P1S_PER_WAVE * 6);
-                if (mine) {
+                if (!w0 || w0_share) {
                     P1Pair &r = regs.at(tid);
                     p1_store_t(lds, r.a);
+                    p1_store_part(lds.part, r.a);
                     if (next_mag && r.a.valid) p1_add_mag(t, lds, ncb, r.a.p, r.a.mag);
                     if (!w0) {
                         p1_store_t(lds, r.b);
+                        p1_store_part(lds.part, r.b);
                         if (next_mag && r.b.valid) p1_add_mag(t, lds, ncb, r.b.p, r.b.mag);
                     }
                 }
@@ -1055,39 +1077,16 @@ IQD_DEV void wbfm_tile_pipe(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLd
             }
         });
         ex.stamp(4);
-        // ---- Y2 ----
-        ex.all([&](int tid) {
-            if (has_next) {
-                if (next_mag) wbfm_flush_mag(t, lds, ncb, next_cstart, next_clen, tid);
-                const bool w0 = tid < 64;
-                const bool mine = !w0 || (W0_CAN_SHARE && (next_clen >> 4) > P1S_PER_WAVE * 6);
-                if (mine) {
-                    p1_store_part(part, regs.at(tid).a);
-                    if (!w0) p1_store_part(part, regs.at(tid).b);
-                }
-            }
-            if (has_cur) wbfm_stage2(c, lds, clen, tid);
-        });
-        ex.stamp(5);
-        // ---- Y3 (no barrier behind it: see the table above) ----
-        if (has_cur) {
-            ex.others([&](int tid) {   // wave 0 goes straight on to the next chunk's IIR, the critical path
-                wbfm_stage3(c, lds, t, cstart, clen, tid - 64, PIPE_OTHERS);
-                const int n1 = clen >> 2;
-                if (tid >= 100 && tid < 104) lds.y1[tid - 100] = lds.y1[(n1 >> 1) + tid - 100];
-            });
-            prev_clen = clen;
-            parity ^= 1;
-        }
-        ex.stamp(6);
         // advance
+        st_cstart = cstart;
+        st_clen = has_cur ? clen : 0;
+        if (has_cur) parity ^= 1;
         has_cur = has_next;
         cstart = next_cstart;
         clen = next_clen;
         next_cstart = cstart + clen;
         has_next = has_cur && next_cstart < t.tlen;
         next_clen = has_next ? chunk_len(next_cstart) : 0;
-        if (!has_cur) break;
     }
     ex.sync();
     if (ex.in_wave0() && rec_out) {

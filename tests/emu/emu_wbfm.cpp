@@ -31,6 +31,7 @@ struct HostExec {
     void sync() const {}
     template <class F> void others(F f) { for (int t = 64; t < iqd::WB_THREADS; t++) f(t); }
     template <class F> void all_nosync(F f) { for (int t = 0; t < iqd::WB_THREADS; t++) f(t); }
+    void others_sync(uint32_t *) {}   // phases run one after the other here
     // wave shift by one lane: lanes run in ascending order here, so the lane below has already published
     uint32_t pub[18][iqd::WB_THREADS];
     template <int SLOT> uint32_t shr1(int tid, uint32_t v)

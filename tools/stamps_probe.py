@@ -11,7 +11,7 @@ pcm = torch.zeros(n//32, dtype=torch.int16, device='cuda'); torch.cuda.synchroni
 eng = capi.Engine(1); eng.set_mode('wbfm')
 for _ in range(3): eng.accept_device(iq.data_ptr(), 2*n, pcm.data_ptr())
 s = eng.debug_stamps()
-names = ['-','IIR(k)','P1(k+1) compute','wait at B1','Y1 store+S1','Y2 part+S2','Y3 S3','loop-top']
+names = ['st2+sync+st3 | w0 slot','IIR(k)','P1(k+1)','wait at B1','Y: store+S1','-','-','loop-top']
 for w in (0,1):
     tot = sum(s[8*w:8*w+8]) or 1
     print('wave', w, ' '.join('%s=%.1f%%' % (names[k], 100.0*s[8*w+k]/tot) for k in range(8)), 'total Mcycles', tot/1e6)
