@@ -53,6 +53,25 @@ def cpu_baseline(period_u8, seconds_target=12.0):
                       "IqDataProcessor::acceptIqData in 32768-byte blocks, 1 thread" % reps}
 
 
+def host_path(eng, iq_dev, n, n_ch, reps=3):
+    """The same workload through the host-pointer entry point (iqd_accept_iq): IQ in page-locked host memory,
+    uploaded in slices that overlap the kernels, PCM downloaded.  Reported beside `value`, never as it."""
+    iq = eng.host_array((n_ch, 2 * n))
+    pcm = eng.host_array((n_ch, n // 32), np.int16)
+    iq[:] = iq_dev.view(n_ch, -1).cpu().numpy()
+    cnt = np.zeros(n_ch, np.uint32)
+    eng.accept_into(iq, pcm, cnt)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        eng.accept_into(iq, pcm, cnt)
+    dt = (time.perf_counter() - t0) / reps
+    eng.host_free(iq)
+    eng.host_free(pcm)
+    return {"value": round(n * n_ch / dt / 1e6, 1), "unit": "MSamples/s", "ms_per_step": round(1e3 * dt, 3),
+            "GB_per_s_over_pcie": round(2.0625 * n * n_ch / dt / 1e9, 2),
+            "what": "iqd_accept_iq from page-locked host buffers (upload, kernels, PCM download), %d calls" % reps}
+
+
 def measured_traffic(mode, n_ch, log2_samples):
     """HBM bytes per launch of the chain kernel from the committed rocprofv3 PMC summary of the same
     workload (profiles/), or None: bench.py itself cannot collect PMC counters."""
@@ -74,6 +93,7 @@ def main():
     ap.add_argument("--signal", default="fm_tone", choices=["fm_tone", "white"],
                     help="synthetic input: the FM test tone of SURVEY 8(d) (default) or uniform random bytes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive iqd_accept_iq measurement")
     ap.add_argument("--gather", action="store_true", help="also gather the PCM to rank 0 over RCCL each step")
     args = ap.parse_args()
 
@@ -164,6 +184,8 @@ def main():
             "state_checks": k1["state_checks"] - k0["state_checks"],
             "state_repairs": k1["state_repairs"] - k0["state_repairs"],
         }
+        if world == 1 and not args.no_host_path:
+            out["host_path"] = host_path(eng, iq, n, n_ch)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(period_u8)
         print(json.dumps(out))

@@ -109,7 +109,8 @@ int iqd_reset_demod(iqd_t *e, uint32_t first_ch, uint32_t n_ch, int demod);
  *   signal_present [n_ch][bytes_per_ch/block_bytes] Squelch::run() result per block = what
  *                  registerSignalStateCallback would deliver (may be NULL).
  *
- * Host-pointer form: copies in, runs, copies out, returns when done. */
+ * Host-pointer form: copies in, runs, copies out, returns when done (large calls are sliced and
+ * double-buffered so that the copies overlap the kernels; the result is the same). */
 int iqd_accept_iq(iqd_t *e, uint32_t first_ch, uint32_t n_ch,
                   const uint8_t *iq, size_t bytes_per_ch,
                   int16_t *pcm, uint32_t *pcm_count,
@@ -153,6 +154,11 @@ int iqd_dev_alloc(iqd_t *e, size_t bytes, void **out);
 int iqd_dev_free(iqd_t *e, void *p);
 int iqd_dev_upload(iqd_t *e, void *dst_dev, const void *src_host, size_t bytes);
 int iqd_dev_download(iqd_t *e, void *dst_host, const void *src_dev, size_t bytes);
+/* Page-locked host memory for iqd_accept_iq: with it the uploads are true DMA and, for calls of 64 MiB and more,
+ * overlap the kernels (the call is cut into ~32 MiB slices through two device staging sets; this stands in for
+ * the reference's ring of receive buffers, DataConsumer.cc:220-352).  Pageable buffers work too, more slowly. */
+int iqd_host_alloc(iqd_t *e, size_t bytes, void **out);
+int iqd_host_free(iqd_t *e, void *p);
 /* Fills dst_dev with `total` bytes by repeating the first `period` bytes already there. */
 int iqd_dev_tile(iqd_t *e, void *dst_dev, size_t period, size_t total);
 void *iqd_stream(iqd_t *e); /* the engine's hipStream_t */

@@ -40,7 +40,7 @@ EXPORTS = [
     "iqd_set_gain", "iqd_set_squelch", "iqd_set_rx_gain_db", "iqd_set_rotation", "iqd_reset", "iqd_reset_demod",
     "iqd_accept_iq", "iqd_accept_iq_device", "iqd_synchronize", "iqd_get_stats", "iqd_set_profiling",
     "iqd_get_channel_mode", "iqd_get_channel_gain", "iqd_dev_alloc", "iqd_dev_free", "iqd_dev_upload",
-    "iqd_dev_download", "iqd_dev_tile", "iqd_stream", "iqd_debug_stamps",
+    "iqd_dev_download", "iqd_dev_tile", "iqd_stream", "iqd_debug_stamps", "iqd_host_alloc", "iqd_host_free",
 ]
 
 _LIB = None
@@ -82,6 +82,8 @@ def _lib():
     L.iqd_dev_upload.argtypes = [vp, vp, vp, sz]
     L.iqd_dev_download.argtypes = [vp, vp, vp, sz]
     L.iqd_dev_tile.argtypes = [vp, vp, sz, sz]
+    L.iqd_host_alloc.argtypes = [vp, sz, C.POINTER(vp)]
+    L.iqd_host_free.argtypes = [vp, vp]
     L.iqd_stream.argtypes = [vp]
     L.iqd_stream.restype = vp
     _LIB = L
@@ -214,6 +216,29 @@ class Engine:
         out = np.zeros(nbytes // np.dtype(dtype).itemsize, dtype=dtype)
         self._check(self._L.iqd_dev_download(self._h, _np_ptr(out), C.c_void_p(src), nbytes))
         return out
+
+    def host_array(self, shape, dtype=np.uint8):
+        """A page-locked numpy array (iqd_host_alloc); free it with host_free(array)."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        self._check(self._L.iqd_host_alloc(self._h, n, C.byref(p)))
+        buf = (C.c_uint8 * n).from_address(p.value)
+        a = np.frombuffer(buf, dtype=dtype).reshape(shape)
+        self._pinned = getattr(self, "_pinned", {})
+        self._pinned[a.ctypes.data] = p.value
+        return a
+
+    def host_free(self, a):
+        p = getattr(self, "_pinned", {}).pop(a.ctypes.data, None)
+        if p is not None:
+            self._check(self._L.iqd_host_free(self._h, C.c_void_p(p)))
+
+    def accept_into(self, iq_u8, pcm, cnt=None, mag=None, allowed=None, first=0, n=None):
+        """iqd_accept_iq on caller-owned host arrays (e.g. page-locked ones from host_array)."""
+        f, n = self._range(first, n)
+        bpc = iq_u8.size // n
+        self._check(self._L.iqd_accept_iq(self._h, f, n, _np_ptr(iq_u8), bpc, _np_ptr(pcm), _np_ptr(cnt),
+                                          _np_ptr(mag), _np_ptr(allowed)))
 
     def dev_tile(self, dst, period, total):
         self._check(self._L.iqd_dev_tile(self._h, C.c_void_p(dst), period, total))

@@ -13,6 +13,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -78,6 +79,12 @@ struct iqd_engine {
     // per-call scratch
     DevBuf lists[FAM_COUNT + 1], mag_sums, blk_lists, vlen, records, base8k, present;
     DevBuf st_iq, st_pcm, st_count, st_mag, st_allowed;  // staging for host-pointer accepts
+    // sliced host-pointer accepts: two staging sets, so that slice k+1 crosses PCIe while slice k runs
+    DevBuf sl_iq[2], sl_pcm[2], sl_count[2], sl_mag[2], sl_allowed[2];
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
+    uint32_t *h_slice_counts = nullptr;  // pinned, [2][n_ch of a slice]
+    size_t h_slice_counts_cap = 0;
 
     bool profiling = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -216,6 +223,14 @@ void iqd_destroy(iqd_t *e)
     DevBuf *bufs[] = {&e->mag_sums, &e->blk_lists, &e->vlen, &e->records, &e->base8k, &e->present,
                       &e->st_iq, &e->st_pcm, &e->st_count, &e->st_mag, &e->st_allowed};
     for (DevBuf *b : bufs) b->release();
+    for (int b = 0; b < 2; b++) {
+        e->sl_iq[b].release(); e->sl_pcm[b].release(); e->sl_count[b].release();
+        e->sl_mag[b].release(); e->sl_allowed[b].release();
+        if (e->ev_in[b]) (void)hipEventDestroy(e->ev_in[b]);
+        if (e->ev_free[b]) (void)hipEventDestroy(e->ev_free[b]);
+    }
+    if (e->h_slice_counts) (void)hipHostFree(e->h_slice_counts);
+    if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -375,6 +390,24 @@ int iqd_dev_download(iqd_t *e, void *dst, const void *src, size_t bytes)
     (void)hipSetDevice(e->device);
     HIP_TRY(e, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return IQD_OK;
+}
+
+int iqd_host_alloc(iqd_t *e, size_t bytes, void **out)
+{
+    if (!e || !out || bytes == 0) return IQD_EINVAL;
+    (void)hipSetDevice(e->device);
+    if (hipHostMalloc(out, bytes, hipHostMallocDefault) != hipSuccess) {
+        *out = nullptr;
+        return e->fail(IQD_ENOMEM, "hipHostMalloc(%zu) failed", bytes);
+    }
+    return IQD_OK;
+}
+
+int iqd_host_free(iqd_t *e, void *p)
+{
+    if (!e) return IQD_EINVAL;
+    if (p) (void)hipHostFree(p);
     return IQD_OK;
 }
 
@@ -613,6 +646,125 @@ static int run_wbfm_repairs(iqd_t *e, ChainLaunch a, bool gated, uint32_t n_bad)
     return IQD_OK;
 }
 
+// Large host-pointer accepts are cut into slices of about SLICE_BYTES that go through two sets of device
+// staging buffers: the upload of slice k+1 (copy stream) overlaps the kernels and the download of slice k
+// (engine stream).  A slice is either a time range of every channel of the call (few long rows) or a range of
+// whole rows (many channels).  Per-channel state is carried from slice to slice exactly as from one accept call
+// to the next, so the result equals the unsliced call; squelch-gated rows are compacted on the host at the end.
+static const size_t SLICE_BYTES = (size_t)32 << 20;
+
+static int accept_sliced(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const uint8_t *iq, size_t bytes_per_ch,
+                         int16_t *pcm, uint32_t *pcm_count, uint32_t *magnitude, uint8_t *signal_present)
+{
+    hipStream_t s = e->stream;
+    if (!e->copy_stream) {
+        HIP_TRY(e, hipStreamCreateWithFlags(&e->copy_stream, hipStreamNonBlocking));
+        for (int b = 0; b < 2; b++) {
+            HIP_TRY(e, hipEventCreateWithFlags(&e->ev_in[b], hipEventDisableTiming));
+            HIP_TRY(e, hipEventCreateWithFlags(&e->ev_free[b], hipEventDisableTiming));
+        }
+    }
+    const size_t bb = e->block_bytes;
+    const size_t row_blocks = bytes_per_ch / bb;
+    // slice shape: sc channels x st bytes of each row
+    size_t sc, st;
+    if ((size_t)n_ch * bb <= SLICE_BYTES && row_blocks > 1) {   // time slices of all channels
+        sc = n_ch;
+        st = std::max<size_t>(1, SLICE_BYTES / ((size_t)n_ch * bb)) * bb;
+        if (st > bytes_per_ch) st = bytes_per_ch;
+    } else {                                                    // ranges of whole rows
+        st = bytes_per_ch;
+        sc = std::max<size_t>(1, SLICE_BYTES / bytes_per_ch);
+        if (sc > n_ch) sc = n_ch;
+    }
+    const size_t n_tslices = (bytes_per_ch + st - 1) / st, n_cslices = (n_ch + sc - 1) / sc;
+    const size_t n_slices = n_tslices * n_cslices;
+    const size_t st_blocks = st / bb;
+    if (e->h_slice_counts_cap < 2 * sc) {
+        if (e->h_slice_counts) (void)hipHostFree(e->h_slice_counts);
+        e->h_slice_counts = nullptr;
+        e->h_slice_counts_cap = 0;
+        HIP_TRY(e, hipHostMalloc((void **)&e->h_slice_counts, 2 * sc * sizeof(uint32_t), hipHostMallocDefault));
+        e->h_slice_counts_cap = 2 * sc;
+    }
+    for (int b = 0; b < 2; b++) {
+        HIP_TRY(e, e->sl_iq[b].ensure(sc * st));
+        HIP_TRY(e, e->sl_pcm[b].ensure(sc * (st / 64) * sizeof(int16_t)));
+        HIP_TRY(e, e->sl_count[b].ensure(sc * sizeof(uint32_t)));
+        HIP_TRY(e, e->sl_mag[b].ensure(sc * st_blocks * sizeof(uint32_t)));
+        HIP_TRY(e, e->sl_allowed[b].ensure(sc * st_blocks));
+    }
+    std::vector<uint32_t> filled(n_ch, 0);   // PCM samples already in place at the front of each row
+    const size_t row_pcm = bytes_per_ch / 64;
+
+    struct Slice { size_t c0, nc, t0, tb; };
+    auto slice_at = [&](size_t k) {
+        Slice x;
+        const size_t ci = k / n_tslices, ti = k % n_tslices;
+        x.c0 = ci * sc; x.nc = std::min(sc, (size_t)n_ch - x.c0);
+        x.t0 = ti * st; x.tb = std::min(st, bytes_per_ch - x.t0);
+        return x;
+    };
+    auto upload = [&](size_t k) -> int {
+        const Slice x = slice_at(k);
+        const int b = (int)(k & 1);
+        if (k >= 2) HIP_TRY(e, hipStreamWaitEvent(e->copy_stream, e->ev_free[b], 0));
+        HIP_TRY(e, hipMemcpy2DAsync(e->sl_iq[b].p, x.tb, iq + x.c0 * bytes_per_ch + x.t0, bytes_per_ch, x.tb, x.nc,
+                                    hipMemcpyHostToDevice, e->copy_stream));
+        HIP_TRY(e, hipEventRecord(e->ev_in[b], e->copy_stream));
+        return IQD_OK;
+    };
+    // what slice k-1 left in the pinned count buffer: compact its PCM behind what the rows already hold
+    auto settle = [&](size_t k) {
+        const Slice x = slice_at(k);
+        const uint32_t *cnt = e->h_slice_counts + (k & 1) * sc;
+        for (size_t c = 0; c < x.nc; c++) {
+            int16_t *row = pcm + (x.c0 + c) * row_pcm;
+            uint32_t &have = filled[x.c0 + c];
+            const size_t landed = x.t0 / 64;
+            if (cnt[c] && have != landed) memmove(row + have, row + landed, cnt[c] * sizeof(int16_t));
+            have += cnt[c];
+        }
+    };
+
+    int rc = upload(0);
+    if (rc != IQD_OK) return rc;
+    for (size_t k = 0; k < n_slices; k++) {
+        const Slice x = slice_at(k);
+        const int b = (int)(k & 1);
+        if (k + 1 < n_slices && (rc = upload(k + 1)) != IQD_OK) return rc;
+        HIP_TRY(e, hipStreamWaitEvent(s, e->ev_in[b], 0));
+        HIP_TRY(e, hipMemsetAsync(e->sl_pcm[b].p, 0, x.nc * (x.tb / 64) * sizeof(int16_t), s));
+        rc = iqd_accept_iq_device(e, first_ch + (uint32_t)x.c0, (uint32_t)x.nc, e->sl_iq[b].p, x.tb, e->sl_pcm[b].p,
+                                  e->sl_count[b].p, magnitude ? e->sl_mag[b].p : nullptr,
+                                  signal_present ? e->sl_allowed[b].p : nullptr);
+        if (rc != IQD_OK) return rc;
+        if (k >= 1) {   // the previous slice's downloads are complete once its count copy is
+            HIP_TRY(e, hipEventSynchronize(e->ev_free[b ^ 1]));
+            settle(k - 1);
+        }
+        const size_t tpcm = x.tb / 64, tblk = x.tb / bb;
+        HIP_TRY(e, hipMemcpy2DAsync(pcm + x.c0 * row_pcm + x.t0 / 64, row_pcm * sizeof(int16_t), e->sl_pcm[b].p,
+                                    tpcm * sizeof(int16_t), tpcm * sizeof(int16_t), x.nc, hipMemcpyDeviceToHost, s));
+        if (magnitude)
+            HIP_TRY(e, hipMemcpy2DAsync(magnitude + x.c0 * row_blocks + x.t0 / bb, row_blocks * sizeof(uint32_t),
+                                        e->sl_mag[b].p, tblk * sizeof(uint32_t), tblk * sizeof(uint32_t), x.nc,
+                                        hipMemcpyDeviceToHost, s));
+        if (signal_present)
+            HIP_TRY(e, hipMemcpy2DAsync(signal_present + x.c0 * row_blocks + x.t0 / bb, row_blocks, e->sl_allowed[b].p,
+                                        tblk, tblk, x.nc, hipMemcpyDeviceToHost, s));
+        HIP_TRY(e, hipMemcpyAsync(e->h_slice_counts + b * sc, e->sl_count[b].p, x.nc * sizeof(uint32_t),
+                                  hipMemcpyDeviceToHost, s));
+        HIP_TRY(e, hipEventRecord(e->ev_free[b], s));
+    }
+    HIP_TRY(e, hipStreamSynchronize(s));
+    settle(n_slices - 1);
+    for (uint32_t c = 0; c < n_ch; c++)   // like the unsliced path: zeros behind the valid samples
+        if (filled[c] < row_pcm) memset(pcm + c * row_pcm + filled[c], 0, (row_pcm - filled[c]) * sizeof(int16_t));
+    if (pcm_count) memcpy(pcm_count, filled.data(), n_ch * sizeof(uint32_t));
+    return IQD_OK;
+}
+
 int iqd_accept_iq(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const uint8_t *iq, size_t bytes_per_ch,
                   int16_t *pcm, uint32_t *pcm_count, uint32_t *magnitude, uint8_t *signal_present)
 {
@@ -625,6 +777,8 @@ int iqd_accept_iq(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const uint8_t *iq,
     const size_t in_bytes = (size_t)n_ch * bytes_per_ch;
     const size_t pcm_bytes = (size_t)n_ch * (bytes_per_ch / 64) * sizeof(int16_t);
     const size_t nb = (size_t)n_ch * (bytes_per_ch / e->block_bytes);
+    if (in_bytes >= 2 * SLICE_BYTES)
+        return accept_sliced(e, first_ch, n_ch, iq, bytes_per_ch, pcm, pcm_count, magnitude, signal_present);
     HIP_TRY(e, e->st_iq.ensure(in_bytes));
     HIP_TRY(e, e->st_pcm.ensure(pcm_bytes));
     HIP_TRY(e, e->st_count.ensure(n_ch * sizeof(uint32_t)));
