@@ -105,6 +105,14 @@ class Oracle:
         _sig(L.iqo_set_squelch, None, [vp, C.c_int32])
         _sig(L.iqo_set_rx_gain_db, None, [vp, C.c_uint32])
         _sig(L.iqo_set_rotation, None, [vp, C.c_int])
+        _sig(L.iqo_agc_set_type, C.c_int, [vp, C.c_uint32])
+        _sig(L.iqo_agc_set_deadband, C.c_int, [vp, C.c_uint32])
+        _sig(L.iqo_agc_set_blanking_limit, C.c_int, [vp, C.c_uint32])
+        _sig(L.iqo_agc_set_operating_point, None, [vp, C.c_int32])
+        _sig(L.iqo_agc_set_filter_coefficient, C.c_int, [vp, C.c_float])
+        _sig(L.iqo_agc_enable, C.c_int, [vp, C.c_int])
+        _sig(L.iqo_agc_feed, None, [vp, C.c_uint32])
+        _sig(L.iqo_get_rx_gain_db, C.c_uint32, [vp])
         _sig(L.iqo_accept_stream, C.c_long, [vp, vp, sz, sz, vp, sz, vp, vp])
         _sig(L.iqo_demod_accept, C.c_long, [vp, C.c_int, vp, sz, vp, sz])
         _sig(L.iqo_quantize_taps, None, [vp, C.c_int, vp])
@@ -124,9 +132,19 @@ class Oracle:
         _sig(L.iqo_wbfm_stages, None, [vp, sz, C.c_float, vp, vp, vp, vp, vp, vp])
 
     def chain(self):
-        c = _Chain(self.lib, "iqo_")
-        c.set_rx_gain_db = lambda g: self.lib.iqo_set_rx_gain_db(c._h, int(g))
-        c.set_rotation = lambda r: self.lib.iqo_set_rotation(c._h, int(r))
+        L = self.lib
+        c = _Chain(L, "iqo_")
+        c.set_rx_gain_db = lambda g: L.iqo_set_rx_gain_db(c._h, int(g))
+        c.set_rotation = lambda r: L.iqo_set_rotation(c._h, int(r))
+        # AutomaticGainControl: the setters return the reference's success flag
+        c.agc_set_type = lambda t: bool(L.iqo_agc_set_type(c._h, int(t)))
+        c.agc_set_deadband = lambda d: bool(L.iqo_agc_set_deadband(c._h, int(d)))
+        c.agc_set_blanking_limit = lambda n: bool(L.iqo_agc_set_blanking_limit(c._h, int(n)))
+        c.agc_set_operating_point = lambda p: L.iqo_agc_set_operating_point(c._h, int(p))
+        c.agc_set_filter_coefficient = lambda a: bool(L.iqo_agc_set_filter_coefficient(c._h, C.c_float(a)))
+        c.agc_enable = lambda on=True: bool(L.iqo_agc_enable(c._h, 1 if on else 0))
+        c.agc_feed = lambda m: L.iqo_agc_feed(c._h, int(m))
+        c.rx_gain_db = lambda: int(L.iqo_get_rx_gain_db(c._h))
         return c
 
     # ---- primitives ----
@@ -238,10 +256,29 @@ class Reference:
         _sig(L.ref_squelch_destroy, None, [vp])
         _sig(L.ref_squelch_run, C.c_int, [vp, C.c_uint32, vp, C.c_uint32, vp])
         _sig(L.ref_dbfs, C.c_int32, [C.c_uint32])
+        _sig(L.ref_agc_attach, None, [vp, C.c_int32])
+        _sig(L.ref_agc_set, C.c_int, [vp, C.c_int, C.c_float])
+        _sig(L.ref_agc_run, None, [vp, C.c_uint32])
+        _sig(L.ref_agc_if_gain, C.c_uint32, [vp])
 
-    def chain(self):
-        c = _Chain(self.lib, "ref_")
-        c.set_rx_gain_db = lambda g: self.lib.ref_set_rx_gain_db(int(g))  # a process global
+    def chain(self, agc=False, operating_point=-12):
+        """agc=True attaches the reference's AutomaticGainControl the way Radio.cc:184 does; the chain then has
+        its own IF gain (the harness' Radio double) instead of the process-global one, and per-block magnitudes
+        read 0xffffffff (the AGC owns the single magnitude-callback slot)."""
+        L = self.lib
+        c = _Chain(L, "ref_")
+        c.set_rx_gain_db = lambda g: L.ref_set_rx_gain_db(int(g))  # a process global
+        if agc:
+            L.ref_agc_attach(c._h, int(operating_point))
+            c.set_rx_gain_db = lambda g: bool(L.ref_agc_set(c._h, 6, C.c_float(g)))
+            c.agc_set_type = lambda t: bool(L.ref_agc_set(c._h, 0, C.c_float(t)))
+            c.agc_set_deadband = lambda d: bool(L.ref_agc_set(c._h, 1, C.c_float(d)))
+            c.agc_set_blanking_limit = lambda n: bool(L.ref_agc_set(c._h, 2, C.c_float(n)))
+            c.agc_set_filter_coefficient = lambda a: bool(L.ref_agc_set(c._h, 3, C.c_float(a)))
+            c.agc_set_operating_point = lambda p: L.ref_agc_set(c._h, 4, C.c_float(p)) and None
+            c.agc_enable = lambda on=True: bool(L.ref_agc_set(c._h, 5, C.c_float(1.0 if on else 0.0)))
+            c.agc_feed = lambda m: L.ref_agc_run(c._h, int(m))
+            c.rx_gain_db = lambda: int(L.ref_agc_if_gain(c._h))
         return c
 
     def decimate_q15(self, taps, factor, x):

@@ -394,6 +394,7 @@ struct iqo_chain {
     int32_t threshold;
     uint32_t rx_gain_db;
     int tracking; /* SignalTracker state: 0 NoSignal, 1 Tracking */
+    iqo_agc agc;
     wbfm_t wbfm;
     fm_t fm;
     am_t am;
@@ -612,6 +613,133 @@ static size_t ssb_run(iqo_chain *c, ssb_t *s, const int8_t *iq, size_t n, int16_
 /* ------------------------------------------------------------------------ */
 /* Chain = IqDataProcessor                                                    */
 /* ------------------------------------------------------------------------ */
+/* ------------------------------------------------------------------------ */
+/* AutomaticGainControl (src_diags/AutomaticGainControl.cc)                   */
+/* ------------------------------------------------------------------------ */
+#define AGC_MAX_GAIN 46 /* MAX_ADJUSTIBLE_GAIN, AutomaticGainControl.cc:23 */
+
+/* Constructor defaults, AutomaticGainControl.cc:113-189 (operating point -12: Radio.cc:184) */
+static void agc_init(iqo_agc *a)
+{
+    a->type = IQO_AGC_HARRIS;
+    a->deadband_db = 1;
+    a->signal_magnitude = 64;
+    a->enabled = 0;
+    a->blanking_counter = 0;
+    a->blanking_limit = 1;
+    a->gain_was_adjusted = 0;
+    a->if_gain_db = 24;
+    a->normalized_level_dbfs = -24;
+    a->filtered_if_gain_db = 24;
+    a->alpha = 0.8;
+    a->operating_point_dbfs = -12;
+}
+
+static void agc_reset_blanking(iqo_agc *a) /* :625-634 */
+{
+    a->blanking_counter = 0;
+    a->gain_was_adjusted = 0;
+}
+
+/* runLowpass :743-889 / runHarris :935-1062.  `gain` is the radio's IF gain
+ * (Radio::receiveIfGainInDb == radio_adjustableReceiveGainInDb); returns it updated. */
+static uint32_t agc_adjust(iqo_agc *a, uint32_t magnitude, uint32_t gain)
+{
+    int32_t signal_dbfs, error;
+    a->signal_magnitude = magnitude;
+    signal_dbfs = iqo_dbfs(magnitude);
+    a->normalized_level_dbfs = (int32_t)((uint32_t)signal_dbfs - a->if_gain_db);
+    error = a->operating_point_dbfs - signal_dbfs;
+    if (a->if_gain_db == AGC_MAX_GAIN) {
+        if (error > 0) error = 0;
+    } else if (a->if_gain_db == 0) {
+        if (error < 0) error = 0;
+    }
+    if (abs(error) <= a->deadband_db) error = 0;
+    if (a->type == IQO_AGC_LOWPASS) {
+        int32_t adjusted = (int32_t)(a->if_gain_db + (uint32_t)error);
+        a->filtered_if_gain_db = (a->alpha * (float)adjusted) + ((1 - a->alpha) * a->filtered_if_gain_db);
+    } else {
+        a->filtered_if_gain_db = a->filtered_if_gain_db + (a->alpha * (float)error);
+    }
+    if (a->filtered_if_gain_db > AGC_MAX_GAIN) a->filtered_if_gain_db = AGC_MAX_GAIN;
+    else if (a->filtered_if_gain_db < 0) a->filtered_if_gain_db = 0;
+    a->if_gain_db = (uint32_t)a->filtered_if_gain_db;
+    if (error != 0) {
+        gain = a->if_gain_db;      /* Radio::setReceiveIfGainInDb(0, ifGainInDb) */
+        a->gain_was_adjusted = 1;
+    }
+    return gain;
+}
+
+/* run() :663-741: follows external gain changes, blanks after an adjustment. */
+uint32_t iqo_agc_run(iqo_agc *a, uint32_t magnitude, uint32_t gain)
+{
+    int allowed = 0;
+    if (a->if_gain_db != gain) a->if_gain_db = gain;
+    if (a->gain_was_adjusted) {
+        if (a->blanking_counter < a->blanking_limit) {
+            a->blanking_counter++;
+        } else {
+            agc_reset_blanking(a);
+            allowed = 1;
+        }
+    } else {
+        allowed = 1;
+    }
+    if (allowed) gain = agc_adjust(a, magnitude, gain);
+    return gain;
+}
+
+iqo_agc *iqo_agc_of(iqo_chain *c) { return &c->agc; }
+/* signalMagnitudeCallback, AutomaticGainControl.cc:47-64 */
+void iqo_agc_feed(iqo_chain *c, uint32_t magnitude)
+{
+    if (c->agc.enabled) c->rx_gain_db = iqo_agc_run(&c->agc, magnitude, c->rx_gain_db);
+}
+uint32_t iqo_get_rx_gain_db(const iqo_chain *c) { return c->rx_gain_db; }
+
+int iqo_agc_set_type(iqo_chain *c, uint32_t type) /* :287-320 */
+{
+    if (type != IQO_AGC_LOWPASS && type != IQO_AGC_HARRIS) return 0;
+    c->agc.type = type;
+    return 1;
+}
+int iqo_agc_set_deadband(iqo_chain *c, uint32_t db) /* :351-369 */
+{
+    if (db > 10) return 0;
+    c->agc.deadband_db = (int32_t)db;
+    return 1;
+}
+int iqo_agc_set_blanking_limit(iqo_chain *c, uint32_t limit) /* :399-420 */
+{
+    if (limit > 10) return 0;
+    c->agc.blanking_limit = limit;
+    agc_reset_blanking(&c->agc);
+    return 1;
+}
+void iqo_agc_set_operating_point(iqo_chain *c, int32_t dbfs) { c->agc.operating_point_dbfs = dbfs; } /* :440-448 */
+int iqo_agc_set_filter_coefficient(iqo_chain *c, float coefficient) /* :475-493, double compares */
+{
+    if ((coefficient >= 0.001) && (coefficient < 0.999)) {
+        c->agc.alpha = coefficient;
+        return 1;
+    }
+    return 0;
+}
+int iqo_agc_enable(iqo_chain *c, int on) /* enable :516-548 (the radio is receiving), disable :571-595 */
+{
+    if (on) {
+        if (c->agc.enabled) return 0;
+        agc_reset_blanking(&c->agc);
+        c->agc.enabled = 1;
+        return 1;
+    }
+    if (!c->agc.enabled) return 0;
+    c->agc.enabled = 0;
+    return 1;
+}
+
 iqo_chain *iqo_create(void)
 {
     iqo_chain *c = (iqo_chain *)calloc(1, sizeof(*c));
@@ -622,6 +750,7 @@ iqo_chain *iqo_create(void)
     c->threshold = -200;      /* IqDataProcessor.cc:41 */
     c->rx_gain_db = 24;       /* Radio.cc:325-328 */
     c->tracking = 0;
+    agc_init(&c->agc);
     wbfm_init(&c->wbfm);
     fm_init(&c->fm);
     am_init(&c->am);
@@ -695,6 +824,9 @@ long iqo_accept(iqo_chain *c, const uint8_t *iq, size_t bytes, int16_t *pcm, siz
     c->tracking = present;
     if (magnitude) *magnitude = mag;
     if (allowed_out) *allowed_out = (uint8_t)allowed;
+    /* signalMagnitudeCallback (:781-790 -> AutomaticGainControl.cc:47-64): after the squelch, before the
+     * demodulator; a gain change is seen by the next block's squelch */
+    if (c->agc.enabled) c->rx_gain_db = iqo_agc_run(&c->agc, mag, c->rx_gain_db);
     if (!allowed) return 0; /* :793 */
     produced = run_demod(c, c->mode, c->s8, n, tmp);
     for (i = 0; i < produced && i < cap; i++) pcm[i] = tmp[i];

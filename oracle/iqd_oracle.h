@@ -36,6 +36,34 @@ void iqo_set_rx_gain_db(iqo_chain *c, uint32_t gain_db);
 /* +1: +Fs/4 (what acceptIqData applies), -1: -Fs/4, 0: none (extension knob) */
 void iqo_set_rotation(iqo_chain *c, int rotation);
 
+/* AutomaticGainControl (src_diags/AutomaticGainControl.cc): one per chain, constructed like Radio.cc:184
+ * (operating point -12 dBFS), disabled.  Setters return the reference's success flag. */
+enum { IQO_AGC_LOWPASS = 0, IQO_AGC_HARRIS = 1 };
+typedef struct iqo_agc {
+    uint32_t type;
+    uint32_t blanking_counter, blanking_limit;
+    int gain_was_adjusted;
+    int32_t deadband_db;
+    int enabled;
+    int32_t operating_point_dbfs;
+    float alpha;
+    uint32_t if_gain_db;
+    float filtered_if_gain_db;
+    uint32_t signal_magnitude;
+    int32_t normalized_level_dbfs;
+} iqo_agc;
+iqo_agc *iqo_agc_of(iqo_chain *c);
+void iqo_agc_feed(iqo_chain *c, uint32_t magnitude);   /* one magnitude callback */
+uint32_t iqo_get_rx_gain_db(const iqo_chain *c);
+int iqo_agc_set_type(iqo_chain *c, uint32_t type);
+int iqo_agc_set_deadband(iqo_chain *c, uint32_t deadband_db);
+int iqo_agc_set_blanking_limit(iqo_chain *c, uint32_t limit);
+void iqo_agc_set_operating_point(iqo_chain *c, int32_t dbfs);
+int iqo_agc_set_filter_coefficient(iqo_chain *c, float coefficient);
+int iqo_agc_enable(iqo_chain *c, int on);
+/* One AutomaticGainControl::run(magnitude) with the radio's IF gain `gain`; returns the gain afterwards. */
+uint32_t iqo_agc_run(iqo_agc *a, uint32_t magnitude, uint32_t gain);
+
 /* One acceptIqData() call.  bytes must be a multiple of 8 and <= 32768.
  * Returns the number of PCM samples produced (0 when squelched / mode None). */
 long iqo_accept(iqo_chain *c, const uint8_t *iq, size_t bytes,

@@ -14,6 +14,17 @@
 // They are part of this harness (like demodulatorResearch/demodulators/demod.cc
 // is a harness), not stand-ins for a missing library: Radio.cc / diagUi.cc need
 // librtlsdr + libusb and are outside the hot path.
+//
+// For the AGC row src_diags/AutomaticGainControl.cc is compiled
+// unmodified as well.  It talks to its owner through four accessors of class
+// Radio (hdr_diags/Radio.h: getIqProcessor, isReceiving, getReceiveIfGainInDb,
+// setReceiveIfGainInDb).  Radio.cc itself cannot be built here (it is the
+// librtlsdr device driver front end), so the harness plays the owner: it
+// defines those four accessors as a recording test double that does what
+// Radio.cc does when no device is open (Radio.cc:851-861, :1223-1229,
+// :1301-1305, :1472-1476: store the gain, mirror it into
+// radio_adjustableReceiveGainInDb, hand back the processor).  No librtlsdr or
+// libusb header, function or type is declared or imitated anywhere.
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
@@ -26,6 +37,18 @@
 #include "IirFilter.h"
 #include "Squelch.h"
 #include "DbfsCalculator.h"
+#include "AutomaticGainControl.h"
+#include "DataConsumer.h"
+#include <stdlib.h>
+#include <errno.h>
+#include <unistd.h>
+#include <pthread.h>
+#include <math.h>
+// Radio's data members are private and its constructor lives in Radio.cc: the harness fills the three
+// fields its accessors read directly (everything Radio.h includes has been included above already).
+#define private public
+#include "Radio.h"
+#undef private
 
 uint32_t radio_adjustableReceiveGainInDb = 24;  // default: Radio.cc:325-328
 
@@ -35,6 +58,19 @@ void nprintf(FILE *s, const char *formatPtr, ...)
   va_start(args, formatPtr);
   vfprintf(s, formatPtr, args);
   va_end(args);
+}
+
+// ---- the AGC's owner, as a test double (see the header comment) -----------
+IqDataProcessor *Radio::getIqProcessor(void) { return receiveDataProcessorPtr; }
+bool Radio::isReceiving(void) { return receiveEnabled; }
+uint32_t Radio::getReceiveIfGainInDb(void) { return receiveIfGainInDb; }
+bool Radio::setReceiveIfGainInDb(uint8_t stage, uint32_t gain)
+{
+  (void)stage;
+  receiveIfGainInDb = gain;                        // Radio.cc:854
+  radio_adjustableReceiveGainInDb = receiveIfGainInDb;   // Radio.cc:857
+  receiveBlockCount++;                             // harness only: counts the adjustments
+  return true;
 }
 
 namespace {
@@ -70,6 +106,8 @@ struct RefChain
   SsbDemodulator *ssb;
   int lastAllowed;
   uint32_t lastMagnitude;
+  Radio *radio;                 // test double, only with an AGC attached
+  AutomaticGainControl *agc;
 };
 
 void signalStateCb(bool present, void *ctx)
@@ -105,12 +143,16 @@ void *ref_create(void)
   c->proc->enableSignalMagnitudeNotification();
   c->lastAllowed = 0;
   c->lastMagnitude = 0;
+  c->radio = 0;
+  c->agc = 0;
   return c;
 }
 
 void ref_destroy(void *h)
 {
   RefChain *c = (RefChain *)h;
+  if (c->agc) delete c->agc;
+  if (c->radio) free(c->radio);
   delete c->proc;
   delete c->am;
   delete c->fm;
@@ -169,11 +211,61 @@ long ref_accept(void *h, const uint8_t *iq, size_t byteCount,
   memcpy(scratch, iq, byteCount);
   PcmSink sink = {pcm, pcmCapacity, 0};
   g_sink = &sink;
+  if (c->radio) radio_adjustableReceiveGainInDb = c->radio->getReceiveIfGainInDb();  // this chain's receiver
   c->proc->acceptIqData(0, scratch, byteCount);
   g_sink = 0;
+  if (c->agc) c->lastMagnitude = 0xffffffffu;   // the AGC owns the magnitude callback slot
   if (magnitude) *magnitude = c->lastMagnitude;
   if (allowed) *allowed = (uint8_t)c->lastAllowed;
   return (long)sink.count;
+}
+
+// ---- AGC (src_diags/AutomaticGainControl.cc, unmodified) ---------------------
+// Attaches an AutomaticGainControl to the chain the way Radio.cc:184 does
+// (it registers itself for the magnitude callback, AutomaticGainControl.cc:170-186).
+void ref_agc_attach(void *h, int32_t operatingPointInDbFs)
+{
+  RefChain *c = (RefChain *)h;
+  if (c->agc) return;
+  // raw storage: the real constructor lives in Radio.cc; only the fields the accessors above touch are used
+  c->radio = (Radio *)calloc(1, sizeof(Radio));
+  c->radio->receiveDataProcessorPtr = c->proc;
+  c->radio->receiveEnabled = true;
+  c->radio->receiveIfGainInDb = 24;                // Radio.cc:325-328 default
+  c->agc = new AutomaticGainControl(c->radio, operatingPointInDbFs);
+}
+
+// what: 0 setType, 1 setDeadband, 2 setBlankingLimit, 3 setAgcFilterCoefficient,
+// 4 setOperatingPoint, 5 enable(1)/disable(0), 6 Radio::setReceiveIfGainInDb (the user's
+// manual gain command, diagUi.cc:778).  Returns the reference's success flag.
+int ref_agc_set(void *h, int what, float value)
+{
+  RefChain *c = (RefChain *)h;
+  if (!c->agc) return 0;
+  switch (what)
+  {
+    case 0: return c->agc->setType((uint32_t)value) ? 1 : 0;
+    case 1: return c->agc->setDeadband((uint32_t)value) ? 1 : 0;
+    case 2: return c->agc->setBlankingLimit((uint32_t)value) ? 1 : 0;
+    case 3: return c->agc->setAgcFilterCoefficient(value) ? 1 : 0;
+    case 4: c->agc->setOperatingPoint((int32_t)value); return 1;
+    case 5: return (value != 0.0f ? c->agc->enable() : c->agc->disable()) ? 1 : 0;
+    case 6: return c->radio->setReceiveIfGainInDb(0, (uint32_t)value) ? 1 : 0;
+  }
+  return 0;
+}
+
+// One magnitude straight into the AGC, as signalMagnitudeCallback does (AutomaticGainControl.cc:47-64).
+void ref_agc_run(void *h, uint32_t magnitude)
+{
+  RefChain *c = (RefChain *)h;
+  if (c->agc && c->agc->isEnabled()) c->agc->run(magnitude);
+}
+
+uint32_t ref_agc_if_gain(void *h)
+{
+  RefChain *c = (RefChain *)h;
+  return c->radio ? c->radio->getReceiveIfGainInDb() : radio_adjustableReceiveGainInDb;
 }
 
 // Stream helper: feeds `total` bytes in blocks of `blockBytes`, appending PCM.

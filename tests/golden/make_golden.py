@@ -129,6 +129,32 @@ def main():
     prim["rot_down"] = R.rotate(s8, -1)
     np.savez_compressed(os.path.join(OUT, "primitives.npz"), **prim)
 
+    # AutomaticGainControl (src_diags/AutomaticGainControl.cc compiled unmodified; see oracle/ref_shim.cc):
+    # operator commands + magnitudes straight into the AGC, and the AGC inside the acceptIqData flow
+    sys.path.insert(0, os.path.dirname(OUT))
+    import agc_script as A                      # noqa: E402
+    agc = {}
+    for seed in (1, 2, 3):
+        codes, values = A.random_script(seed, 500)
+        flags, gains = A.replay(R.chain(agc=True), codes, values)
+        agc.update({"script%d_codes" % seed: codes, "script%d_values" % seed: values,
+                    "script%d_flags" % seed: flags, "script%d_gains" % seed: gains})
+    # magnitudes 5x8, 100x6, 20x4 with every default
+    c = R.chain(agc=True)
+    c.agc_enable(True)
+    ka = []
+    for m in [5] * 8 + [100] * 6 + [20] * 4:
+        c.agc_feed(m)
+        ka.append(c.rx_gain_db())
+    agc["defaults_gains"] = np.array(ka, np.uint32)
+    for name, amps, cfg in A.STREAM_CASES:
+        u8 = synth.stepped_amplitude(amps, block_samples=2048, seed=21)
+        c = R.chain(agc=True)
+        A.configure(c, cfg)
+        pcm, allowed, gains = A.stream(c, u8, 4096)
+        agc.update({name + "_iq": u8, name + "_pcm": pcm, name + "_allowed": allowed, name + "_gains": gains})
+    np.savez_compressed(os.path.join(OUT, "agc.npz"), **agc)
+
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT) if f.endswith(".npz"))
     print("golden fixtures written: %.1f KiB" % (total / 1024.0))
 

@@ -134,3 +134,43 @@ def test_fm_theta_lut_covers_tuner_range(oracle):
     assert lut.shape == (283, 283)
     assert lut[141, 141] == 0.0                            # atan2(0, 0)
     assert lut[141, 0] == np.float32(np.pi)                # atan2(+0, -141)
+
+
+# ---- AutomaticGainControl -----------------------------------------------------------
+import agc_script as A  # noqa: E402
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_agc_command_scripts(oracle, golden, seed):
+    """Operator commands (valid and rejected values) and block magnitudes straight into the AGC."""
+    g = golden["agc"]
+    flags, gains = A.replay(oracle.chain(), g["script%d_codes" % seed], g["script%d_values" % seed])
+    assert np.array_equal(flags, g["script%d_flags" % seed])
+    assert np.array_equal(gains, g["script%d_gains" % seed])
+    assert len(set(gains.tolist())) > 10 and 0 < flags.sum() < len(flags)
+
+
+def test_agc_defaults_known_answer(oracle, golden):
+    """The survey's own anchor: magnitudes 5x8, 100x6, 20x4 with every default."""
+    c = oracle.chain()
+    c.agc_enable(True)
+    out = []
+    for m in [5] * 8 + [100] * 6 + [20] * 4:
+        c.agc_feed(m)
+        out.append(c.rx_gain_db())
+    assert out == [37, 37, 46, 46, 46, 46, 46, 46, 38, 38, 30, 30, 22, 22, 25, 25, 28, 28]
+    assert np.array_equal(np.array(out, np.uint32), golden["agc"]["defaults_gains"])
+
+
+@pytest.mark.parametrize("case", [c[0] for c in A.STREAM_CASES])
+def test_agc_inside_the_block_flow(oracle, golden, case):
+    """The AGC fed by acceptIqData's magnitude callback: its gain moves the next block's squelch decision."""
+    g = golden["agc"]
+    cfg = dict((c[0], c[2]) for c in A.STREAM_CASES)[case]
+    c = oracle.chain()
+    A.configure(c, cfg)
+    pcm, allowed, gains = A.stream(c, g[case + "_iq"], 4096)
+    assert np.array_equal(gains, g[case + "_gains"])
+    assert np.array_equal(allowed, g[case + "_allowed"])
+    assert np.array_equal(pcm, g[case + "_pcm"])
+    assert len(set(gains.tolist())) > 4

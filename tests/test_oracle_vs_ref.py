@@ -63,3 +63,31 @@ def test_demod_level_entry(oracle, reference):
     s8 = rng.integers(-128, 128, 32768).astype(np.int8)
     for mode in MODES:
         assert np.array_equal(reference.chain().demod_accept(mode, s8), oracle.chain().demod_accept(mode, s8))
+
+
+# ---- AutomaticGainControl ---------------------------------------------------------------------------
+import agc_script as A  # noqa: E402
+
+
+@pytest.mark.parametrize("seed", range(100, 140))
+def test_agc_random_command_scripts(oracle, reference, seed):
+    codes, values = A.random_script(seed)
+    fr, gr = A.replay(reference.chain(agc=True), codes, values)
+    fo, go = A.replay(oracle.chain(), codes, values)
+    assert np.array_equal(fr, fo) and np.array_equal(gr, go)
+
+
+@pytest.mark.parametrize("seed", [31, 32, 33, 34])
+def test_agc_inside_random_streams(oracle, reference, seed):
+    rng = np.random.default_rng(seed)
+    amps = [int(a) for a in np.clip(np.repeat(rng.integers(1, 128, 10), rng.integers(1, 6, 10)), 0, 127)]
+    u8 = synth.stepped_amplitude(amps, block_samples=1024, seed=seed)
+    cfg = dict(mode=["am", "fm", "wbfm", "lsb"][seed % 4], threshold=int(rng.integers(-60, -40)),
+               type=int(seed % 2), alpha=float(rng.choice([0.2, 0.5, 0.8])), deadband=int(rng.integers(0, 4)),
+               blanking=int(rng.integers(0, 4)), operating_point=int(rng.integers(-20, -5)))
+    r, o = reference.chain(agc=True), oracle.chain()
+    A.configure(r, cfg)
+    A.configure(o, cfg)
+    pr, ar, gr = A.stream(r, u8, 2048)
+    po, ao, go = A.stream(o, u8, 2048)
+    assert np.array_equal(gr, go) and np.array_equal(ar, ao) and np.array_equal(pr, po)
