@@ -43,7 +43,8 @@ enum iqd_status {
     IQD_ENODEV = -2,      /* no usable HIP device / HIP runtime error at create */
     IQD_ENOMEM = -3,      /* host or device allocation failed */
     IQD_EHIP = -4,        /* a HIP call failed during accept (see iqd_last_error) */
-    IQD_ESTATE = -5       /* exact-state verification could not be repaired (never expected) */
+    IQD_ESTATE = -5,      /* exact-state verification could not be repaired (never expected) */
+    IQD_EALREADY = -6     /* iqd_agc_enable: every channel of the range already was in that state */
 };
 
 typedef struct iqd_engine iqd_t;
@@ -82,6 +83,46 @@ int iqd_set_squelch(iqd_t *e, uint32_t first_ch, uint32_t n_ch, int32_t threshol
 /* Replaces the global radio_adjustableReceiveGainInDb read at IqDataProcessor.cc:765
  * (per channel here, because each channel stands for its own receiver). */
 int iqd_set_rx_gain_db(iqd_t *e, uint32_t first_ch, uint32_t n_ch, uint32_t gain_db);
+
+/* Reads the IF gain in force for a channel (it differs from the last value set once the channel's AGC has run). */
+int iqd_get_rx_gain_db(iqd_t *e, uint32_t ch, uint32_t *gain_db);
+
+/* Replaces AutomaticGainControl (hdr_diags/AutomaticGainControl.h:22-47, src_diags/AutomaticGainControl.cc), one
+ * per channel, constructed as Radio.cc:184 does (operating point -12 dBFS, Harris type, alpha 0.8, deadband 1,
+ * blanking limit 1, disabled).  An enabled AGC receives the channel's block magnitudes in block order - the
+ * reference's signalMagnitudeCallback, IqDataProcessor.cc:781-790 -> AutomaticGainControl.cc:47-64 - and moves
+ * the channel's IF gain (Radio::setReceiveIfGainInDb, Radio.cc:817-868), which the squelch of the NEXT block
+ * compares with (IqDataProcessor.cc:765).  The recorded samples themselves do not change with the gain: there
+ * is no tuner behind a channel here.  Each setter mirrors the reference method of the same name and returns
+ * IQD_EINVAL where that method returns false (setType :287-320, setDeadband :351-369, setBlankingLimit :399-420,
+ * setOperatingPoint :440-448, setAgcFilterCoefficient :475-493, enable/disable :516-595). */
+enum iqd_agc_type { IQD_AGC_LOWPASS = 0, IQD_AGC_HARRIS = 1 };
+int iqd_agc_set_type(iqd_t *e, uint32_t first_ch, uint32_t n_ch, uint32_t type);
+int iqd_agc_set_deadband(iqd_t *e, uint32_t first_ch, uint32_t n_ch, uint32_t deadband_db);     /* 0..10 */
+int iqd_agc_set_blanking_limit(iqd_t *e, uint32_t first_ch, uint32_t n_ch, uint32_t limit);      /* 0..10 */
+int iqd_agc_set_operating_point(iqd_t *e, uint32_t first_ch, uint32_t n_ch, int32_t dbfs);
+int iqd_agc_set_filter_coefficient(iqd_t *e, uint32_t first_ch, uint32_t n_ch, float coefficient); /* [0.001, 0.999) */
+int iqd_agc_enable(iqd_t *e, uint32_t first_ch, uint32_t n_ch, int enabled);   /* IQD_EALREADY where enable()/disable() return false */
+
+/* displayInternalInformation() (AutomaticGainControl.cc:1082-1149) as values. */
+typedef struct iqd_agc_state {
+    uint32_t enabled, type;
+    int32_t operating_point_dbfs;
+    uint32_t deadband_db, blanking_limit;
+    float alpha;
+    uint32_t rx_gain_db;            /* the receiver's IF gain in force */
+    uint32_t if_gain_db;            /* the AGC's own copy (ifGainInDb) */
+    float filtered_if_gain_db;
+    uint32_t blanking_counter, gain_was_adjusted;
+    int32_t normalized_level_dbfs;
+    uint32_t signal_magnitude;      /* last magnitude the AGC acted on */
+} iqd_agc_state;
+int iqd_agc_get_state(iqd_t *e, uint32_t ch, iqd_agc_state *out);
+
+/* Optional record of the IF gain each block's squelch compared with, for the channels and blocks of the last
+ * accept call: [n_ch][n_blocks], host memory. */
+int iqd_set_gain_trace(iqd_t *e, int enabled);
+int iqd_get_gain_trace(iqd_t *e, uint32_t first_ch, uint32_t n_ch, uint32_t *gain_db, size_t n_blocks);
 
 /* Front-end rotation selector: +1 = upconvertByFsOver4 (what acceptIqData applies,
  * IqDataProcessor.cc:749, the default), -1 = downconvertByFsOver4 (:496-540), 0 = none. */

@@ -29,6 +29,14 @@ class Stats(C.Structure):
                 ("chain_kernel_ms", C.c_double), ("chain_kernel_count", C.c_uint64)]
 
 
+class AgcState(C.Structure):
+    _fields_ = [("enabled", C.c_uint32), ("type", C.c_uint32), ("operating_point_dbfs", C.c_int32),
+                ("deadband_db", C.c_uint32), ("blanking_limit", C.c_uint32), ("alpha", C.c_float),
+                ("rx_gain_db", C.c_uint32), ("if_gain_db", C.c_uint32), ("filtered_if_gain_db", C.c_float),
+                ("blanking_counter", C.c_uint32), ("gain_was_adjusted", C.c_uint32),
+                ("normalized_level_dbfs", C.c_int32), ("signal_magnitude", C.c_uint32)]
+
+
 class IqdError(RuntimeError):
     def __init__(self, status, detail):
         super().__init__("libiqdemod: %s (%d): %s" % (_lib().iqd_strerror(status).decode(), status, detail))
@@ -41,6 +49,9 @@ EXPORTS = [
     "iqd_accept_iq", "iqd_accept_iq_device", "iqd_synchronize", "iqd_get_stats", "iqd_set_profiling",
     "iqd_get_channel_mode", "iqd_get_channel_gain", "iqd_dev_alloc", "iqd_dev_free", "iqd_dev_upload",
     "iqd_dev_download", "iqd_dev_tile", "iqd_stream", "iqd_debug_stamps", "iqd_host_alloc", "iqd_host_free",
+    "iqd_get_rx_gain_db", "iqd_agc_set_type", "iqd_agc_set_deadband", "iqd_agc_set_blanking_limit",
+    "iqd_agc_set_operating_point", "iqd_agc_set_filter_coefficient", "iqd_agc_enable", "iqd_agc_get_state",
+    "iqd_set_gain_trace", "iqd_get_gain_trace",
 ]
 
 _LIB = None
@@ -84,6 +95,16 @@ def _lib():
     L.iqd_dev_tile.argtypes = [vp, vp, sz, sz]
     L.iqd_host_alloc.argtypes = [vp, sz, C.POINTER(vp)]
     L.iqd_host_free.argtypes = [vp, vp]
+    L.iqd_get_rx_gain_db.argtypes = [vp, u32, C.POINTER(u32)]
+    L.iqd_agc_set_type.argtypes = [vp, u32, u32, u32]
+    L.iqd_agc_set_deadband.argtypes = [vp, u32, u32, u32]
+    L.iqd_agc_set_blanking_limit.argtypes = [vp, u32, u32, u32]
+    L.iqd_agc_set_operating_point.argtypes = [vp, u32, u32, C.c_int32]
+    L.iqd_agc_set_filter_coefficient.argtypes = [vp, u32, u32, C.c_float]
+    L.iqd_agc_enable.argtypes = [vp, u32, u32, C.c_int]
+    L.iqd_agc_get_state.argtypes = [vp, u32, C.POINTER(AgcState)]
+    L.iqd_set_gain_trace.argtypes = [vp, C.c_int]
+    L.iqd_get_gain_trace.argtypes = [vp, u32, u32, vp, sz]
     L.iqd_stream.argtypes = [vp]
     L.iqd_stream.restype = vp
     _LIB = L
@@ -150,6 +171,52 @@ class Engine:
     def reset_demod(self, demod, first=0, n=None):
         f, n = self._range(first, n)
         self._check(self._L.iqd_reset_demod(self._h, f, n, int(DEMOD.get(demod, demod))))
+
+    # ---- AutomaticGainControl: True/False like the reference's setters -----------------------
+    def _agc(self, fn, value, first, n):
+        f, n = self._range(first, n)
+        rc = fn(self._h, f, n, value)
+        if rc in (-1, -6):   # IQD_EINVAL / IQD_EALREADY: the reference method returns false
+            return False
+        self._check(rc)
+        return True
+
+    def agc_set_type(self, t, first=0, n=None):
+        return self._agc(self._L.iqd_agc_set_type, int(t), first, n)
+
+    def agc_set_deadband(self, db, first=0, n=None):
+        return self._agc(self._L.iqd_agc_set_deadband, int(db), first, n)
+
+    def agc_set_blanking_limit(self, limit, first=0, n=None):
+        return self._agc(self._L.iqd_agc_set_blanking_limit, int(limit), first, n)
+
+    def agc_set_operating_point(self, dbfs, first=0, n=None):
+        return self._agc(self._L.iqd_agc_set_operating_point, int(dbfs), first, n)
+
+    def agc_set_filter_coefficient(self, a, first=0, n=None):
+        return self._agc(self._L.iqd_agc_set_filter_coefficient, C.c_float(a), first, n)
+
+    def agc_enable(self, on=True, first=0, n=None):
+        return self._agc(self._L.iqd_agc_enable, 1 if on else 0, first, n)
+
+    def agc_state(self, ch):
+        st = AgcState()
+        self._check(self._L.iqd_agc_get_state(self._h, ch, C.byref(st)))
+        return {k: getattr(st, k) for k, _ in AgcState._fields_}
+
+    def rx_gain_db(self, ch=0):
+        g = C.c_uint32()
+        self._check(self._L.iqd_get_rx_gain_db(self._h, ch, C.byref(g)))
+        return g.value
+
+    def set_gain_trace(self, on=True):
+        self._check(self._L.iqd_set_gain_trace(self._h, 1 if on else 0))
+
+    def gain_trace(self, n_blocks, first=0, n=None):
+        f, n = self._range(first, n)
+        out = np.zeros((n, n_blocks), np.uint32)
+        self._check(self._L.iqd_get_gain_trace(self._h, f, n, _np_ptr(out), n_blocks))
+        return out
 
     # ---- data path ------------------------------------------------------------------------
     def accept(self, iq_u8, first=0, n=None):

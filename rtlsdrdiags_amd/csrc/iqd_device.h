@@ -52,6 +52,27 @@ struct WbfmCarry {          // exact de-emphasis state `back` samples before the
 };
 struct DcCarry { float x_prev, y_prev; };   // AM / SSB DC-removal IIR
 
+// AutomaticGainControl (hdr_diags/AutomaticGainControl.h:57-89), one per channel.  The configuration is written
+// by the host; the state lives on the device and moves once per block, in block order.
+struct AgcConfig {
+    uint32_t enabled, type;          // AGC_TYPE_LOWPASS 0 / AGC_TYPE_HARRIS 1
+    int32_t operating_point, deadband;
+    float alpha;
+    uint32_t blanking_limit;
+    uint32_t reset_blanking;         // one-shot: resetBlankingSystem() before the next block
+    uint32_t set_gain;               // one-shot: Radio::setReceiveIfGainInDb (0xffffffff = none)
+};
+struct AgcState {
+    uint32_t rx_gain;                // the receiver's IF gain = radio_adjustableReceiveGainInDb (the squelch reads it)
+    uint32_t if_gain;                // AutomaticGainControl::ifGainInDb
+    float filtered;                  // filteredIfGainInDb
+    uint32_t blank_ctr, adjusted;    // blankingCounter, receiveGainWasAdjusted
+    int32_t normalized;              // normalizedSignalLevelInDbFs
+    uint32_t signal_magnitude;
+    uint32_t pad;
+};
+constexpr uint32_t AGC_MAX_GAIN = 46;   // MAX_ADJUSTIBLE_GAIN, AutomaticGainControl.cc:23
+
 struct VerifyRec { float y_in, y_out, u_out; uint32_t flags; };
 
 // ---- constants (taps, packed the way the kernels consume them) ----------------------------

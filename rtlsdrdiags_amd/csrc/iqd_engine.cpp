@@ -63,7 +63,12 @@ struct iqd_engine {
     bool lists_dirty = true;
     uint32_t list_first = 0, list_n = 0;
     std::vector<uint32_t> h_lists[FAM_COUNT + 1];  // per family; [FAM_COUNT] = mode None
-    bool any_gated = false;
+    bool any_gated = false, any_agc = false;
+    std::vector<AgcConfig> h_agc;           // per channel; the one-shot fields are cleared once applied
+    std::vector<uint8_t> agc_touched;       // the device may have moved this channel's IF gain
+    bool agc_dirty = true;
+    bool trace_on = false;
+    uint32_t trace_first = 0, trace_n = 0, trace_blocks = 0;   // what gain_trace holds
 
     // persistent device state
     ChanParams *d_params = nullptr;
@@ -71,13 +76,15 @@ struct iqd_engine {
     WbfmCarry *d_wcarry = nullptr;
     DcCarry *d_dc = nullptr;
     uint32_t *d_tracker = nullptr;
+    AgcConfig *d_agc_cfg = nullptr;
+    AgcState *d_agc = nullptr;
     float *d_atan = nullptr, *d_fmlut = nullptr;
     uint32_t *d_counters = nullptr, *d_mismatch = nullptr;
     unsigned long long *d_stamps = nullptr;
     uint32_t *h_counters = nullptr;  // pinned
 
     // per-call scratch
-    DevBuf lists[FAM_COUNT + 1], mag_sums, blk_lists, vlen, records, base8k, present;
+    DevBuf lists[FAM_COUNT + 1], mag_sums, blk_lists, vlen, records, base8k, gain_trace;
     DevBuf st_iq, st_pcm, st_count, st_mag, st_allowed;  // staging for host-pointer accepts
     // sliced host-pointer accepts: two staging sets, so that slice k+1 crosses PCIe while slice k runs
     DevBuf sl_iq[2], sl_pcm[2], sl_count[2], sl_mag[2], sl_allowed[2];
@@ -135,6 +142,7 @@ const char *iqd_strerror(int status)
 {
     switch (status) {
     case IQD_OK: return "ok";
+    case IQD_EALREADY: return "already in the requested state";
     case IQD_EINVAL: return "invalid argument";
     case IQD_ENODEV: return "no usable HIP device";
     case IQD_ENOMEM: return "out of memory";
@@ -169,6 +177,15 @@ int iqd_create(const iqd_config *cfg, iqd_t **out)
     build_consts(e->consts);
     e->h_params.resize(e->n_ch);
     for (auto &p : e->h_params) default_params(p);
+    // AutomaticGainControl constructor defaults (AutomaticGainControl.cc:113-189; operating point: Radio.cc:184)
+    AgcConfig agc0{};
+    agc0.enabled = 0; agc0.type = 1; agc0.operating_point = -12; agc0.deadband = 1; agc0.alpha = 0.8f;
+    agc0.blanking_limit = 1; agc0.reset_blanking = 0; agc0.set_gain = 0xffffffffu;
+    e->h_agc.assign(e->n_ch, agc0);
+    e->agc_touched.assign(e->n_ch, 0);
+    AgcState st0{};
+    st0.rx_gain = 24; st0.if_gain = 24; st0.filtered = 24.f; st0.normalized = -24; st0.signal_magnitude = 64;
+    std::vector<AgcState> agc_states(e->n_ch, st0);
 
     std::vector<float> atan_lut, fm_lut;
     build_atan2_lut(atan_lut);
@@ -181,6 +198,8 @@ int iqd_create(const iqd_config *cfg, iqd_t **out)
     ok = ok && hipMalloc((void **)&e->d_wcarry, n * sizeof(WbfmCarry)) == hipSuccess;
     ok = ok && hipMalloc((void **)&e->d_dc, n * 2 * sizeof(DcCarry)) == hipSuccess;
     ok = ok && hipMalloc((void **)&e->d_tracker, n * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMalloc((void **)&e->d_agc_cfg, n * sizeof(AgcConfig)) == hipSuccess;
+    ok = ok && hipMalloc((void **)&e->d_agc, n * sizeof(AgcState)) == hipSuccess;
     ok = ok && hipMalloc((void **)&e->d_atan, atan_lut.size() * sizeof(float)) == hipSuccess;
     ok = ok && hipMalloc((void **)&e->d_fmlut, fm_lut.size() * sizeof(float)) == hipSuccess;
     ok = ok && hipMalloc((void **)&e->d_counters, CNT_COUNT * sizeof(uint32_t)) == hipSuccess;
@@ -194,6 +213,8 @@ int iqd_create(const iqd_config *cfg, iqd_t **out)
         ok = ok && hipMemsetAsync(e->d_wcarry, 0, n * sizeof(WbfmCarry), e->stream) == hipSuccess;
         ok = ok && hipMemsetAsync(e->d_dc, 0, n * 2 * sizeof(DcCarry), e->stream) == hipSuccess;
         ok = ok && hipMemsetAsync(e->d_tracker, 0, n * sizeof(uint32_t), e->stream) == hipSuccess;
+        ok = ok && hipMemcpyAsync(e->d_agc, agc_states.data(), n * sizeof(AgcState), hipMemcpyHostToDevice,
+                                  e->stream) == hipSuccess;
         ok = ok && hipMemcpyAsync(e->d_atan, atan_lut.data(), atan_lut.size() * sizeof(float),
                                   hipMemcpyHostToDevice, e->stream) == hipSuccess;
         ok = ok && hipMemcpyAsync(e->d_fmlut, fm_lut.data(), fm_lut.size() * sizeof(float),
@@ -214,13 +235,13 @@ void iqd_destroy(iqd_t *e)
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    void *ptrs[] = {e->d_params, e->d_tails, e->d_wcarry, e->d_dc, e->d_tracker,
+    void *ptrs[] = {e->d_params, e->d_tails, e->d_wcarry, e->d_dc, e->d_tracker, e->d_agc_cfg, e->d_agc,
                     e->d_atan, e->d_fmlut, e->d_counters, e->d_mismatch, e->d_stamps};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (e->h_counters) (void)hipHostFree(e->h_counters);
     for (auto &b : e->lists) b.release();
-    DevBuf *bufs[] = {&e->mag_sums, &e->blk_lists, &e->vlen, &e->records, &e->base8k, &e->present,
+    DevBuf *bufs[] = {&e->mag_sums, &e->blk_lists, &e->vlen, &e->records, &e->base8k, &e->gain_trace,
                       &e->st_iq, &e->st_pcm, &e->st_count, &e->st_mag, &e->st_allowed};
     for (DevBuf *b : bufs) b->release();
     for (int b = 0; b < 2; b++) {
@@ -276,8 +297,140 @@ int iqd_set_rx_gain_db(iqd_t *e, uint32_t first_ch, uint32_t n_ch, uint32_t gain
 {
     if (!range_ok(e, first_ch, n_ch)) return IQD_EINVAL;
     std::lock_guard<std::mutex> lk(e->mu);
-    for (uint32_t c = first_ch; c < first_ch + n_ch; c++) e->h_params[c].rx_gain_db = gain_db;
-    e->params_dirty = e->lists_dirty = true;
+    for (uint32_t c = first_ch; c < first_ch + n_ch; c++) {
+        e->h_params[c].rx_gain_db = gain_db;
+        e->h_agc[c].set_gain = gain_db;                      // the device holds the gain in force
+        if (!e->h_agc[c].enabled) e->agc_touched[c] = 0;     // and nothing there will move it
+    }
+    e->params_dirty = e->lists_dirty = e->agc_dirty = true;
+    return IQD_OK;
+}
+
+// ---- AutomaticGainControl: the reference's setters one to one (they validate like the reference does) ----
+extern "C++" {
+template <class F>
+static int agc_update(iqd_t *e, uint32_t first_ch, uint32_t n_ch, bool valid, F f)
+{
+    if (!range_ok(e, first_ch, n_ch)) return IQD_EINVAL;
+    if (!valid) return e->fail(IQD_EINVAL, "AGC parameter out of range");
+    std::lock_guard<std::mutex> lk(e->mu);
+    for (uint32_t c = first_ch; c < first_ch + n_ch; c++) f(e->h_agc[c], c);
+    e->agc_dirty = e->lists_dirty = true;
+    return IQD_OK;
+}
+}  // extern "C++"
+
+int iqd_agc_set_type(iqd_t *e, uint32_t first_ch, uint32_t n_ch, uint32_t type)
+{
+    return agc_update(e, first_ch, n_ch, type == IQD_AGC_LOWPASS || type == IQD_AGC_HARRIS,
+                      [&](AgcConfig &a, uint32_t) { a.type = type; });
+}
+
+int iqd_agc_set_deadband(iqd_t *e, uint32_t first_ch, uint32_t n_ch, uint32_t deadband_db)
+{
+    return agc_update(e, first_ch, n_ch, deadband_db <= 10, [&](AgcConfig &a, uint32_t) { a.deadband = (int32_t)deadband_db; });
+}
+
+int iqd_agc_set_blanking_limit(iqd_t *e, uint32_t first_ch, uint32_t n_ch, uint32_t limit)
+{
+    return agc_update(e, first_ch, n_ch, limit <= 10, [&](AgcConfig &a, uint32_t) {
+        a.blanking_limit = limit;
+        a.reset_blanking = 1;   // setBlankingLimit() also resets the blanking system
+    });
+}
+
+int iqd_agc_set_operating_point(iqd_t *e, uint32_t first_ch, uint32_t n_ch, int32_t dbfs)
+{
+    return agc_update(e, first_ch, n_ch, true, [&](AgcConfig &a, uint32_t) { a.operating_point = dbfs; });
+}
+
+int iqd_agc_set_filter_coefficient(iqd_t *e, uint32_t first_ch, uint32_t n_ch, float coefficient)
+{
+    // the reference compares the float against double literals
+    return agc_update(e, first_ch, n_ch, (coefficient >= 0.001) && (coefficient < 0.999),
+                      [&](AgcConfig &a, uint32_t) { a.alpha = coefficient; });
+}
+
+int iqd_agc_enable(iqd_t *e, uint32_t first_ch, uint32_t n_ch, int enabled)
+{
+    uint32_t changed = 0;
+    int rc = agc_update(e, first_ch, n_ch, true, [&](AgcConfig &a, uint32_t c) {
+        if (enabled && !a.enabled) {
+            a.reset_blanking = 1;   // enable() of a disabled AGC resets the blanking system
+            a.enabled = 1;
+            e->agc_touched[c] = 1;
+            changed++;
+        } else if (!enabled && a.enabled) {
+            a.enabled = 0;
+            changed++;
+        }
+    });
+    if (rc == IQD_OK && !changed) return IQD_EALREADY;   // enable()/disable() return false
+    return rc;
+}
+
+// Uploads the AGC configuration and applies the pending one-shot commands.  Call with e->mu held.
+static int agc_sync(iqd_t *e)
+{
+    if (!e->agc_dirty) return IQD_OK;
+    hipStream_t s = e->stream;
+    HIP_TRY(e, hipMemcpyAsync(e->d_agc_cfg, e->h_agc.data(), e->n_ch * sizeof(AgcConfig), hipMemcpyHostToDevice, s));
+    HIP_TRY(e, launch_agc_apply(e->d_agc_cfg, e->d_agc, e->n_ch, s));
+    HIP_TRY(e, hipStreamSynchronize(s));
+    for (auto &a : e->h_agc) { a.reset_blanking = 0; a.set_gain = 0xffffffffu; }
+    e->agc_dirty = false;
+    return IQD_OK;
+}
+
+int iqd_agc_get_state(iqd_t *e, uint32_t ch, iqd_agc_state *out)
+{
+    if (!e || ch >= e->n_ch || !out) return IQD_EINVAL;
+    (void)hipSetDevice(e->device);
+    AgcState st;
+    AgcConfig cfg;
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        int rc = agc_sync(e);
+        if (rc != IQD_OK) return rc;
+        cfg = e->h_agc[ch];
+    }
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    HIP_TRY(e, hipMemcpy(&st, e->d_agc + ch, sizeof(st), hipMemcpyDeviceToHost));
+    out->enabled = cfg.enabled; out->type = cfg.type; out->operating_point_dbfs = cfg.operating_point;
+    out->deadband_db = (uint32_t)cfg.deadband; out->blanking_limit = cfg.blanking_limit; out->alpha = cfg.alpha;
+    out->rx_gain_db = st.rx_gain; out->if_gain_db = st.if_gain; out->filtered_if_gain_db = st.filtered;
+    out->blanking_counter = st.blank_ctr; out->gain_was_adjusted = st.adjusted;
+    out->normalized_level_dbfs = st.normalized; out->signal_magnitude = st.signal_magnitude;
+    return IQD_OK;
+}
+
+int iqd_get_rx_gain_db(iqd_t *e, uint32_t ch, uint32_t *gain_db)
+{
+    iqd_agc_state st;
+    if (!gain_db) return IQD_EINVAL;
+    int rc = iqd_agc_get_state(e, ch, &st);
+    if (rc == IQD_OK) *gain_db = st.rx_gain_db;
+    return rc;
+}
+
+int iqd_set_gain_trace(iqd_t *e, int enabled)
+{
+    if (!e) return IQD_EINVAL;
+    e->trace_on = enabled != 0;
+    if (!e->trace_on) e->trace_n = 0;
+    return IQD_OK;
+}
+
+int iqd_get_gain_trace(iqd_t *e, uint32_t first_ch, uint32_t n_ch, uint32_t *out, size_t n_blocks)
+{
+    if (!e || !out) return IQD_EINVAL;
+    if (!e->trace_n || first_ch < e->trace_first || n_ch == 0 || first_ch + n_ch > e->trace_first + e->trace_n ||
+        n_blocks != e->trace_blocks)
+        return e->fail(IQD_EINVAL, "no gain trace for that range (tracing on? same channels and block count as the last accept?)");
+    (void)hipSetDevice(e->device);
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    HIP_TRY(e, hipMemcpy(out, e->gain_trace.as<uint32_t>() + (size_t)(first_ch - e->trace_first) * n_blocks,
+                         (size_t)n_ch * n_blocks * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return IQD_OK;
 }
 
@@ -424,11 +577,14 @@ int iqd_dev_tile(iqd_t *e, void *dst, size_t period, size_t total)
 static void rebuild_lists(iqd_t *e, uint32_t first_ch, uint32_t n_ch)
 {
     for (auto &l : e->h_lists) l.clear();
-    e->any_gated = false;
+    e->any_gated = e->any_agc = false;
     for (uint32_t c = 0; c < n_ch; c++) {
         const ChanParams &p = e->h_params[first_ch + c];
         e->h_lists[family_of_mode(p.mode)].push_back(c);
-        if (!squelch_always_open(p, e->consts)) e->any_gated = true;
+        ChanParams worst = p;   // a channel whose AGC runs (or ran) may sit at any gain up to the maximum
+        if (e->agc_touched[first_ch + c] && worst.rx_gain_db < AGC_MAX_GAIN) worst.rx_gain_db = AGC_MAX_GAIN;
+        if (!squelch_always_open(worst, e->consts)) e->any_gated = true;
+        if (e->h_agc[first_ch + c].enabled) e->any_agc = true;
     }
     e->list_first = first_ch;
     e->list_n = n_ch;
@@ -451,7 +607,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
 
     const uint32_t n_blocks = (uint32_t)(bytes_per_ch / e->block_bytes);
     const uint32_t vlen = (uint32_t)(bytes_per_ch / 2);
-    bool gated;
+    bool gated, any_agc;
     {
         std::lock_guard<std::mutex> lk(e->mu);
         if (e->params_dirty) {
@@ -471,9 +627,12 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
             }
             HIP_TRY(e, hipStreamSynchronize(s));
         }
+        int rc = agc_sync(e);
+        if (rc != IQD_OK) return rc;
         gated = e->any_gated;
+        any_agc = e->any_agc;
     }
-    const bool want_mag = gated || !(e->flags & IQD_F_NO_MAGNITUDE) || magnitude_dev;
+    const bool want_mag = gated || any_agc || !(e->flags & IQD_F_NO_MAGNITUDE) || magnitude_dev;
 
     HIP_TRY(e, e->mag_sums.ensure((size_t)n_ch * n_blocks * sizeof(uint32_t)));
     HIP_TRY(e, hipMemsetAsync(e->d_counters, 0, CNT_COUNT * sizeof(uint32_t), s));
@@ -487,6 +646,14 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
     q.magnitude = (uint32_t *)magnitude_dev;
     q.allowed = (uint8_t *)signal_present_dev;
     q.pcm_count = (uint32_t *)pcm_count_dev;
+    q.agc_cfg = e->d_agc_cfg;
+    q.agc = e->d_agc;
+    q.any_agc = any_agc ? 1u : 0u;
+    if (e->trace_on) {
+        HIP_TRY(e, e->gain_trace.ensure((size_t)n_ch * n_blocks * sizeof(uint32_t)));
+        q.gain_trace = e->gain_trace.as<uint32_t>();
+        e->trace_first = first_ch; e->trace_n = n_ch; e->trace_blocks = n_blocks;
+    }
 
     if (gated) {
         // pass 1: magnitudes of every block, then the squelch decisions and open-block lists
@@ -494,10 +661,8 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         HIP_TRY(e, e->vlen.ensure((size_t)n_ch * sizeof(uint32_t)));
         HIP_TRY(e, launch_magnitude((const uint8_t *)iq_dev, bytes_per_ch, nullptr, n_ch, e->block_samples,
                                     n_blocks, e->mag_sums.as<uint32_t>(), s));
-        HIP_TRY(e, e->present.ensure((size_t)n_ch * n_blocks));
         q.blk_lists = e->blk_lists.as<uint32_t>();
         q.vlen_out = e->vlen.as<uint32_t>();
-        q.present = e->present.as<uint8_t>();
         HIP_TRY(e, launch_squelch(q, false, s));
     }
 
@@ -567,7 +732,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         HIP_TRY(e, launch_magnitude((const uint8_t *)iq_dev, bytes_per_ch, e->lists[FAM_COUNT].as<uint32_t>(),
                                     (uint32_t)e->h_lists[FAM_COUNT].size(), e->block_samples, n_blocks,
                                     e->mag_sums.as<uint32_t>(), s));
-    if (!gated && (want_mag || pcm_count_dev || signal_present_dev)) HIP_TRY(e, launch_squelch(q, true, s));
+    if (!gated && (want_mag || pcm_count_dev || signal_present_dev || e->trace_on)) HIP_TRY(e, launch_squelch(q, true, s));
 
     // exact-state verification of the WBFM hand-offs (a mismatch has never been observed;
     // the repair path re-runs the affected tiles from the neighbour's exact state)

@@ -52,12 +52,15 @@ struct SquelchLaunch {
     const ChanParams *params;
     const uint32_t *mag_sums;     // [n_ch][n_blocks]
     uint32_t *tracker;            // [engine ch] SignalTracker state
-    uint8_t *present;             // scratch [n_ch][n_blocks] (squelch-gated calls)
     uint32_t *magnitude;          // out, optional
     uint8_t *allowed;             // out, optional
     uint32_t *blk_lists;          // out, optional
     uint32_t *vlen_out;           // out, optional
     uint32_t *pcm_count;          // out, optional
+    const AgcConfig *agc_cfg;     // [engine ch]
+    AgcState *agc;                // [engine ch]: the IF gain the squelch uses, and the AGC behind it
+    uint32_t any_agc;             // some channel of the call has its AGC enabled
+    uint32_t *gain_trace;         // out, optional [n_ch][n_blocks]: the IF gain each block's squelch saw
 };
 
 hipError_t upload_consts(const Consts &c, hipStream_t s);
@@ -67,6 +70,7 @@ hipError_t launch_am(const ChainLaunch &a, int family, bool gated, bool mag, uin
 hipError_t launch_reset(uint8_t *tails, WbfmCarry *wc, DcCarry *dc, uint32_t first_ch, uint32_t n_ch,
                         uint32_t family_mask, hipStream_t s);
 hipError_t launch_wbfm_verify(const ChainLaunch &a, hipStream_t s);
+hipError_t launch_agc_apply(const AgcConfig *cfg, AgcState *st, uint32_t n_ch, hipStream_t s);
 hipError_t launch_tail_update(const ChainLaunch &a, int family, bool guarded, hipStream_t s);
 hipError_t launch_magnitude(const uint8_t *iq, size_t ch_stride_bytes, const uint32_t *ch_list, uint32_t n_list,
                             uint32_t block_samples, uint32_t n_blocks, uint32_t *mag_sums, hipStream_t s);

@@ -350,9 +350,9 @@ __global__ __launch_bounds__(256) void magnitude_kernel(const uint8_t *iq, size_
     if (threadIdx.x == 0) mag_sums[(size_t)ch * n_blocks + blk] = part[0] + part[1] + part[2] + part[3];
 }
 
-// Squelch, part 1 (SignalDetector.cc:249-271): per (channel, block) average magnitude and the
-// "signal present" comparison.  When no channel's squelch can close (always_open) this is the
-// whole squelch: every block is allowed and the tracker ends in its Tracking state.
+// Squelch, part 1 (SignalDetector.cc:249-271): per (channel, block) average magnitude.  When no channel's
+// squelch can close (always_open) this is the whole squelch: every block is allowed and the tracker ends in its
+// Tracking state.  Otherwise the decisions are taken per channel in block order by squelch_track_kernel.
 __global__ void squelch_block_kernel(const SquelchLaunch q, int always_open)
 {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -360,45 +360,114 @@ __global__ void squelch_block_kernel(const SquelchLaunch q, int always_open)
     const uint32_t ch = idx / q.n_blocks, b = idx - ch * q.n_blocks;
     const uint32_t ech = q.first_ch + ch;
     const ChanParams &p = q.params[ech];
-    const uint32_t avg = q.mag_sums[idx] / q.block_samples;
-    const uint32_t m = avg > 127u ? 127u : avg;  // DbfsCalculator.cc:122-125, full scale 127
-    int32_t dbfs = g_consts.db_table[m] - 42;
-    dbfs = (int32_t)((uint32_t)dbfs - p.rx_gain_db);
-    const uint32_t present = dbfs >= p.threshold ? 1u : 0u;
-    if (q.magnitude) q.magnitude[idx] = avg;
+    if (q.magnitude) q.magnitude[idx] = q.mag_sums[idx] / q.block_samples;
+    if (q.gain_trace) q.gain_trace[idx] = q.agc[ech].rx_gain;   // channels with a running AGC overwrite theirs
     if (always_open) {
         if (q.allowed) q.allowed[idx] = 1;
         if (b == q.n_blocks - 1) q.tracker[ech] = 1u;
         if (b == 0 && q.pcm_count) q.pcm_count[ch] = p.mode == 0 ? 0u : q.n_blocks * q.block_samples / 32u;
-    } else {
-        q.present[idx] = (uint8_t)present;
     }
 }
 
-// Squelch, part 2 (SignalTracker.cc:104-145, Squelch.cc:240-269): the two-state tracker with its
-// one-block tail, the list of open blocks and the open length; one thread per channel.
-__global__ void squelch_track_kernel(const SquelchLaunch q)
+// AutomaticGainControl::run (AutomaticGainControl.cc:663-741) with runLowpass (:743-889) / runHarris
+// (:935-1062): one block magnitude in, the receiver's IF gain out.  binary32 arithmetic in the reference's order.
+__device__ __forceinline__ uint32_t agc_run(const AgcConfig &cfg, AgcState &st, uint32_t magnitude, uint32_t gain)
+{
+    if (st.if_gain != gain) st.if_gain = gain;   // follow the operator's manual changes
+    bool allowed = false;
+    if (st.adjusted) {   // blank the measurements that follow an adjustment
+        if (st.blank_ctr < cfg.blanking_limit) {
+            st.blank_ctr++;
+        } else {
+            st.blank_ctr = 0;
+            st.adjusted = 0;
+            allowed = true;
+        }
+    } else {
+        allowed = true;
+    }
+    if (!allowed) return gain;
+    st.signal_magnitude = magnitude;
+    const uint32_t m = magnitude > 127u ? 127u : magnitude;   // DbfsCalculator.cc:122-125
+    const int32_t signal = g_consts.db_table[m] - 42;
+    st.normalized = (int32_t)((uint32_t)signal - st.if_gain);
+    int32_t error = cfg.operating_point - signal;
+    if (st.if_gain == AGC_MAX_GAIN) {
+        if (error > 0) error = 0;
+    } else if (st.if_gain == 0) {
+        if (error < 0) error = 0;
+    }
+    if ((error < 0 ? -error : error) <= cfg.deadband) error = 0;
+    if (cfg.type == 0) {
+        const int32_t adjusted = (int32_t)(st.if_gain + (uint32_t)error);
+        st.filtered = (cfg.alpha * (float)adjusted) + ((1 - cfg.alpha) * st.filtered);
+    } else {
+        st.filtered = st.filtered + (cfg.alpha * (float)error);
+    }
+    if (st.filtered > (float)AGC_MAX_GAIN) st.filtered = (float)AGC_MAX_GAIN;
+    else if (st.filtered < 0) st.filtered = 0;
+    st.if_gain = (uint32_t)st.filtered;
+    if (error != 0) {
+        gain = st.if_gain;   // Radio::setReceiveIfGainInDb(0, ifGainInDb), Radio.cc:851-861
+        st.adjusted = 1;
+    }
+    return gain;
+}
+
+// Squelch, part 2, one thread per channel, blocks in order: the "signal present" comparison
+// (SignalDetector.cc:259-266) with the IF gain in force, the two-state tracker with its one-block tail
+// (SignalTracker.cc:104-145, Squelch.cc:240-269), the list of open blocks - and the magnitude callback into the
+// channel's AGC (IqDataProcessor.cc:781-790), whose gain the NEXT block's comparison sees.
+__global__ void squelch_track_kernel(const SquelchLaunch q, int always_open)
 {
     const uint32_t ch = blockIdx.x * blockDim.x + threadIdx.x;
     if (ch >= q.n_ch) return;
     const uint32_t ech = q.first_ch + ch;
-    const int32_t mode = q.params[ech].mode;
+    const AgcConfig cfg = q.agc_cfg[ech];
+    if (always_open && !cfg.enabled) return;   // squelch_block_kernel did everything
+    const ChanParams &p = q.params[ech];
+    AgcState st = q.agc[ech];
+    uint32_t gain = st.rx_gain;
     uint32_t tracking = q.tracker[ech];
     uint32_t open = 0;
     for (uint32_t b = 0; b < q.n_blocks; b++) {
-        const uint32_t present = q.present[(size_t)ch * q.n_blocks + b];
-        const uint32_t allowed = present | tracking;
-        tracking = present;
-        if (q.allowed) q.allowed[(size_t)ch * q.n_blocks + b] = (uint8_t)allowed;
-        if (allowed) {
-            q.blk_lists[(size_t)ch * q.n_blocks + open] = b;
-            open++;
+        const size_t idx = (size_t)ch * q.n_blocks + b;
+        const uint32_t avg = q.mag_sums[idx] / q.block_samples;
+        if (!always_open) {
+            const uint32_t m = avg > 127u ? 127u : avg;  // DbfsCalculator.cc:122-125, full scale 127
+            int32_t dbfs = g_consts.db_table[m] - 42;
+            dbfs = (int32_t)((uint32_t)dbfs - gain);
+            const uint32_t present = dbfs >= p.threshold ? 1u : 0u;
+            const uint32_t allowed = present | tracking;
+            tracking = present;
+            if (q.allowed) q.allowed[idx] = (uint8_t)allowed;
+            if (allowed) {
+                q.blk_lists[(size_t)ch * q.n_blocks + open] = b;
+                open++;
+            }
         }
+        if (q.gain_trace) q.gain_trace[idx] = gain;
+        if (cfg.enabled) gain = agc_run(cfg, st, avg, gain);
     }
-    q.tracker[ech] = tracking;
-    const uint32_t vlen = (mode == 0) ? 0u : open * q.block_samples;
-    q.vlen_out[ch] = vlen;
-    if (q.pcm_count) q.pcm_count[ch] = vlen / 32u;
+    st.rx_gain = gain;
+    q.agc[ech] = st;
+    if (!always_open) {
+        q.tracker[ech] = tracking;
+        const uint32_t vlen = (p.mode == 0) ? 0u : open * q.block_samples;
+        q.vlen_out[ch] = vlen;
+        if (q.pcm_count) q.pcm_count[ch] = vlen / 32u;
+    }
+}
+
+// The operator's one-shot commands, applied before the next block: a manual IF gain
+// (Radio::setReceiveIfGainInDb) and resetBlankingSystem() (AutomaticGainControl.cc:625-634).
+__global__ void agc_apply_kernel(const AgcConfig *cfg, AgcState *st, uint32_t n_ch)
+{
+    const uint32_t ch = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ch >= n_ch) return;
+    const AgcConfig c = cfg[ch];
+    if (c.set_gain != 0xffffffffu) st[ch].rx_gain = c.set_gain;
+    if (c.reset_blanking) { st[ch].blank_ctr = 0; st[ch].adjusted = 0; }
 }
 
 // resetDemodulator() for a channel range: histories become zero signal; the WBFM
@@ -498,8 +567,14 @@ hipError_t launch_squelch(const SquelchLaunch &q, bool always_open, hipStream_t 
 {
     const uint32_t n = q.n_ch * q.n_blocks;
     hipLaunchKernelGGL(squelch_block_kernel, dim3((n + 255) / 256), dim3(256), 0, s, q, always_open ? 1 : 0);
-    if (!always_open)
-        hipLaunchKernelGGL(squelch_track_kernel, dim3((q.n_ch + 63) / 64), dim3(64), 0, s, q);
+    if (!always_open || q.any_agc)
+        hipLaunchKernelGGL(squelch_track_kernel, dim3((q.n_ch + 63) / 64), dim3(64), 0, s, q, always_open ? 1 : 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_agc_apply(const AgcConfig *cfg, AgcState *st, uint32_t n_ch, hipStream_t s)
+{
+    hipLaunchKernelGGL(agc_apply_kernel, dim3((n_ch + 255) / 256), dim3(256), 0, s, cfg, st, n_ch);
     return hipGetLastError();
 }
 

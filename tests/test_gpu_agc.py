@@ -1,0 +1,191 @@
+"""GPU (MI355X): the per-channel AutomaticGainControl of the engine against the oracle and the golden vectors the
+unmodified reference produced: operator commands, magnitudes arriving block by block inside one
+accept call, the gain moving the next block's squelch decision, thousands of channels with their own AGC."""
+import numpy as np
+import pytest
+
+import agc_script as A
+from rtlsdrdiags_amd import synth
+
+pytestmark = pytest.mark.gpu
+BB = 256            # bytes per block in the magnitude scripts: 128 samples
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from rtlsdrdiags_amd import capi as c
+    return c
+
+
+def block_with_magnitude(m):
+    """128 samples whose SignalDetector average is exactly m (0..191): I = +m, or |I| = 128 with Q = 2(m-128)."""
+    blk = np.empty((BB // 2, 2), np.uint8)
+    if m <= 127:
+        blk[:, 0], blk[:, 1] = 128 + m, 128
+    else:
+        blk[:, 0], blk[:, 1] = 0, 128 + 2 * (m - 128)
+    return blk.reshape(-1)
+
+
+class EngineChain:
+    """Drives channel `ch` of an engine with agc_script.replay: runs of magnitudes become ONE multi-block accept
+    call, so the gains after each block come from the in-kernel block loop (read back through the gain trace)."""
+
+    def __init__(self, eng, ch=0):
+        self.e, self.ch, self.pending = eng, ch, []
+        for name in ("agc_set_type", "agc_set_deadband", "agc_set_blanking_limit", "agc_set_filter_coefficient",
+                     "agc_set_operating_point", "agc_enable"):
+            setattr(self, name, self._command(getattr(eng, name)))
+        eng.set_gain_trace(True)
+
+    def _command(self, fn):
+        def call(v):
+            self.flush()
+            return fn(v, first=self.ch, n=1)
+        return call
+
+    def set_rx_gain_db(self, g):
+        self.flush()
+        self.e.set_rx_gain_db(g, first=self.ch, n=1)
+
+    def agc_feed(self, m):
+        self.pending.append(int(m))
+
+    def flush(self):
+        if not self.pending:
+            return []
+        iq = np.concatenate([block_with_magnitude(m) for m in self.pending])
+        n = len(self.pending)
+        _, _, mag, _ = self.e.accept(iq, first=self.ch, n=1)
+        assert mag[0].tolist() == self.pending
+        trace = self.e.gain_trace(n, first=self.ch, n=1)[0]
+        after = list(trace[1:]) + [self.e.rx_gain_db(self.ch)]
+        self.pending = []
+        return after
+
+    def rx_gain_db(self):
+        return self.e.rx_gain_db(self.ch)
+
+
+def replay_engine(eng, codes, values, ch=0):
+    """agc_script.replay semantics, but with consecutive magnitudes batched into one accept call."""
+    chain = EngineChain(eng, ch)
+    flags = np.ones(len(codes), np.uint8)
+    gains = np.zeros(len(codes), np.uint32)
+    run_start = None
+    for k, (code, v) in enumerate(zip(codes, values)):
+        if int(code) == A.FEED:
+            if run_start is None:
+                run_start = k
+            chain.agc_feed(min(int(v), 191))
+            continue
+        if run_start is not None:
+            gains[run_start:k] = chain.flush()
+            run_start = None
+        f, g = A.replay(chain, [code], [v])
+        flags[k], gains[k] = f[0], g[0]
+    if run_start is not None:
+        gains[run_start:] = chain.flush()
+    return flags, gains
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_command_scripts_match_the_reference(capi, golden, seed):
+    g = golden["agc"]
+    codes, values = g["script%d_codes" % seed], g["script%d_values" % seed]
+    eng = capi.Engine(1, block_bytes=BB)
+    flags, gains = replay_engine(eng, codes, values)
+    assert np.array_equal(flags, g["script%d_flags" % seed])
+    assert np.array_equal(gains, g["script%d_gains" % seed])
+
+
+@pytest.mark.parametrize("seed", range(200, 206))
+def test_random_scripts_match_the_oracle(capi, oracle, seed):
+    codes, values = A.random_script(seed, 400)
+    values = np.where(codes == A.FEED, np.minimum(values, 191), values).astype(np.float32)
+    fo, go = A.replay(oracle.chain(), codes, values)
+    eng = capi.Engine(3, block_bytes=BB)
+    flags, gains = replay_engine(eng, codes, values, ch=1)     # the neighbours must stay untouched
+    assert np.array_equal(flags, fo) and np.array_equal(gains, go)
+    for other in (0, 2):
+        st = eng.agc_state(other)
+        assert st["rx_gain_db"] == 24 and st["filtered_if_gain_db"] == 24.0 and not st["enabled"]
+
+
+@pytest.mark.parametrize("case", [c[0] for c in A.STREAM_CASES])
+@pytest.mark.parametrize("one_call", [True, False])
+def test_agc_moves_the_squelch_inside_the_block_flow(capi, golden, case, one_call):
+    g = golden["agc"]
+    cfg = dict((c[0], c[2]) for c in A.STREAM_CASES)[case]
+    iq = g[case + "_iq"]
+    eng = capi.Engine(1, block_bytes=4096)
+    eng.set_gain_trace(True)
+
+    class Ch:
+        set_mode = staticmethod(eng.set_mode)
+        set_squelch = staticmethod(eng.set_squelch)
+        set_rx_gain_db = staticmethod(eng.set_rx_gain_db)
+    ch = Ch()
+    for name in ("agc_set_type", "agc_set_deadband", "agc_set_blanking_limit", "agc_set_filter_coefficient",
+                 "agc_set_operating_point", "agc_enable"):
+        setattr(ch, name, getattr(eng, name))
+    A.configure(ch, cfg)
+    nblk = len(iq) // 4096
+    if one_call:
+        pcm, cnt, _, allowed = eng.accept(iq)
+        trace = eng.gain_trace(nblk)[0]
+        gains = np.array(list(trace[1:]) + [eng.rx_gain_db(0)], np.uint32)
+        pcm, allowed = pcm[0, :cnt[0]], allowed[0]
+    else:
+        parts, allowed, gains = [], [], []
+        for b in range(nblk):
+            p, c, _, a = eng.accept(iq[b * 4096:(b + 1) * 4096])
+            parts.append(p[0, :c[0]])
+            allowed.append(a[0, 0])
+            gains.append(eng.rx_gain_db(0))
+        pcm, allowed, gains = np.concatenate(parts), np.array(allowed, np.uint8), np.array(gains, np.uint32)
+    assert np.array_equal(gains, g[case + "_gains"])
+    assert np.array_equal(allowed, g[case + "_allowed"])
+    assert np.array_equal(pcm, g[case + "_pcm"])
+
+
+def test_thousands_of_channels_each_with_its_own_agc(capi, oracle):
+    """BASELINE configs[4] flavour: SSB channels, squelch raised, per-channel AGC settings; a sample of channels
+    against the oracle (PCM, decisions, final AGC state)."""
+    n_ch, bb, nblk = 2048, 2048, 24
+    rng = np.random.default_rng(77)
+    base = [synth.stepped_amplitude([int(a) for a in rng.integers(1, 120, nblk)], block_samples=bb // 2, seed=60 + k)
+            for k in range(8)]
+    iq = np.stack([base[c % 8] for c in range(n_ch)])
+    eng = capi.Engine(n_ch, block_bytes=bb)
+    eng.set_squelch(-50)
+    cfgs = []
+    for c in range(n_ch):
+        cfg = dict(mode="lsb" if c % 2 else "usb", type=c % 2, alpha=[0.2, 0.5, 0.8][c % 3], deadband=c % 4,
+                   blanking=c % 3, operating_point=-8 - (c % 9), enabled=(c % 5 != 0))
+        cfgs.append(cfg)
+    for c in range(n_ch):
+        cfg = cfgs[c]
+        eng.set_mode(cfg["mode"], first=c, n=1)
+        eng.agc_set_type(cfg["type"], first=c, n=1)
+        eng.agc_set_filter_coefficient(cfg["alpha"], first=c, n=1)
+        eng.agc_set_deadband(cfg["deadband"], first=c, n=1)
+        eng.agc_set_blanking_limit(cfg["blanking"], first=c, n=1)
+        eng.agc_set_operating_point(cfg["operating_point"], first=c, n=1)
+        eng.agc_enable(cfg["enabled"], first=c, n=1)
+    pcm, cnt, mag, allowed = eng.accept(iq)
+    for c in list(range(0, n_ch, 97)) + [5, 10, n_ch - 1]:
+        cfg = cfgs[c]
+        o = oracle.chain()
+        o.set_mode(cfg["mode"])
+        o.set_squelch(-50)
+        o.agc_set_type(cfg["type"]); o.agc_set_filter_coefficient(cfg["alpha"]); o.agc_set_deadband(cfg["deadband"])
+        o.agc_set_blanking_limit(cfg["blanking"]); o.agc_set_operating_point(cfg["operating_point"])
+        if cfg["enabled"]:
+            o.agc_enable(True)
+        ref, rmag, rallowed = o.accept_stream(iq[c], bb)
+        assert np.array_equal(allowed[c], rallowed), c
+        assert np.array_equal(mag[c], rmag), c
+        assert cnt[c] == len(ref) and np.array_equal(pcm[c, :cnt[c]], ref), c
+        assert eng.rx_gain_db(c) == o.rx_gain_db(), c
+    assert 0 < allowed.sum() < allowed.size
