@@ -158,3 +158,89 @@ void IqDataProcessor::displayInternalInformation(void)
   fprintf(stderr, "Receive Block Count      : %lu\n", receiveBlockCount);
   fprintf(stderr, "Engine                   : %s\n", engine != 0 ? "MI355X (HIP)" : "unavailable");
 }
+
+// ---- AutomaticGainControl ---------------------------------------------------------------------------
+AutomaticGainControl::AutomaticGainControl(IqDataProcessor *processorPtr, int32_t operatingPointInDbFs)
+{
+  this->processorPtr = processorPtr;
+  setOperatingPoint(operatingPointInDbFs);
+}
+
+AutomaticGainControl::~AutomaticGainControl(void) { disable(); }
+
+void AutomaticGainControl::setOperatingPoint(int32_t operatingPointInDbFs)
+{
+  if (processorPtr->engine != 0) iqd_agc_set_operating_point(processorPtr->engine, 0, 1, operatingPointInDbFs);
+}
+
+bool AutomaticGainControl::setAgcFilterCoefficient(float coefficient)
+{
+  return processorPtr->engine != 0 && iqd_agc_set_filter_coefficient(processorPtr->engine, 0, 1, coefficient) == IQD_OK;
+}
+
+bool AutomaticGainControl::setType(uint32_t type)
+{
+  return processorPtr->engine != 0 && iqd_agc_set_type(processorPtr->engine, 0, 1, type) == IQD_OK;
+}
+
+bool AutomaticGainControl::setDeadband(uint32_t deadbandInDb)
+{
+  return processorPtr->engine != 0 && iqd_agc_set_deadband(processorPtr->engine, 0, 1, deadbandInDb) == IQD_OK;
+}
+
+bool AutomaticGainControl::setBlankingLimit(uint32_t blankingLimit)
+{
+  return processorPtr->engine != 0 && iqd_agc_set_blanking_limit(processorPtr->engine, 0, 1, blankingLimit) == IQD_OK;
+}
+
+bool AutomaticGainControl::enable(void)
+{
+  return processorPtr->engine != 0 && iqd_agc_enable(processorPtr->engine, 0, 1, 1) == IQD_OK;
+}
+
+bool AutomaticGainControl::disable(void)
+{
+  return processorPtr->engine != 0 && iqd_agc_enable(processorPtr->engine, 0, 1, 0) == IQD_OK;
+}
+
+bool AutomaticGainControl::isEnabled(void)
+{
+  iqd_agc_state st;
+  return processorPtr->engine != 0 && iqd_agc_get_state(processorPtr->engine, 0, &st) == IQD_OK && st.enabled != 0;
+}
+
+uint32_t AutomaticGainControl::getSignalMagnitude(void)
+{
+  iqd_agc_state st;
+  if (processorPtr->engine == 0 || iqd_agc_get_state(processorPtr->engine, 0, &st) != IQD_OK) return 0;
+  return st.signal_magnitude;
+}
+
+uint32_t AutomaticGainControl::getReceiveIfGainInDb(void)
+{
+  uint32_t gain = 0;
+  if (processorPtr->engine != 0) iqd_get_rx_gain_db(processorPtr->engine, 0, &gain);
+  return gain;
+}
+
+// AutomaticGainControl.cc:1082-1149
+void AutomaticGainControl::displayInternalInformation(void)
+{
+  iqd_agc_state st;
+  if (processorPtr->engine == 0 || iqd_agc_get_state(processorPtr->engine, 0, &st) != IQD_OK) return;
+  fprintf(stderr, "\n--------------------------------------------\n");
+  fprintf(stderr, "AGC Internal Information\n");
+  fprintf(stderr, "--------------------------------------------\n");
+  fprintf(stderr, "AGC Enabled               : %s\n", st.enabled ? "Yes" : "No");
+  fprintf(stderr, "AGC Type                  : %s\n", st.type == AGC_TYPE_LOWPASS ? "Lowpass" : "Harris");
+  fprintf(stderr, "Blanking Counter          : %u ticks\n", st.blanking_counter);
+  fprintf(stderr, "Blanking Limit            : %u ticks\n", st.blanking_limit);
+  fprintf(stderr, "Lowpass Filter Coefficient: %0.3f\n", st.alpha);
+  fprintf(stderr, "Deadband                  : %u dB\n", st.deadband_db);
+  fprintf(stderr, "Operating Point           : %d dBFs\n", st.operating_point_dbfs);
+  fprintf(stderr, "IF Gain                   : %u dB\n", st.rx_gain_db);
+  fprintf(stderr, "/------------------------\n");
+  fprintf(stderr, "Signal Magnitude          : %u\n", st.signal_magnitude);
+  fprintf(stderr, "RSSI (Before Amp)         : %d dBFs\n", st.normalized_level_dbfs);
+  fprintf(stderr, "/------------------------\n");
+}

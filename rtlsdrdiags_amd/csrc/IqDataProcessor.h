@@ -101,6 +101,7 @@ class IqDataProcessor
   const char *lastError(void) const;
 
   private:
+  friend class AutomaticGainControl;
   void attach(DemodulatorHandle *h);
 
   iqd_t *engine;
@@ -120,4 +121,33 @@ class IqDataProcessor
   int16_t pcmData[512];      // one block's PCM (32768 / 64)
   int lastStatus;
   unsigned long receiveBlockCount;
+};
+
+// hdr_diags/AutomaticGainControl.h:22-47.  The reference's constructor takes its owning Radio and reaches the
+// processor through it (AutomaticGainControl.cc:170-186); here the processor is handed over directly, and the
+// IF gain the AGC moves is the processor's (Radio::get/setReceiveIfGainInDb).  The AGC itself runs on the GPU,
+// once per accepted block, inside iqd_accept_iq.
+#define AGC_TYPE_LOWPASS (0)
+#define AGC_TYPE_HARRIS (1)
+
+class AutomaticGainControl
+{
+  public:
+  AutomaticGainControl(IqDataProcessor *processorPtr, int32_t operatingPointInDbFs);
+  ~AutomaticGainControl(void);
+
+  void setOperatingPoint(int32_t operatingPointInDbFs);
+  bool setAgcFilterCoefficient(float coefficient);
+  bool setType(uint32_t type);
+  bool setDeadband(uint32_t deadbandInDb);
+  bool setBlankingLimit(uint32_t blankingLimit);
+  bool enable(void);
+  bool disable(void);
+  bool isEnabled(void);
+  uint32_t getSignalMagnitude(void);
+  uint32_t getReceiveIfGainInDb(void);        // Radio::getReceiveIfGainInDb, Radio.cc:1223-1229
+  void displayInternalInformation(void);
+
+  private:
+  IqDataProcessor *processorPtr;
 };

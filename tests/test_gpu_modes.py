@@ -155,6 +155,28 @@ def test_file_tool_and_cpp_class(golden, tmp_path):
     assert np.array_equal(np.frombuffer(out, dtype=np.int16), golden["white"]["pcm_fm"])
 
 
+def test_file_tool_with_agc(oracle):
+    """The AutomaticGainControl mirror class around the same tool: PCM and the final IF gain equal the oracle's."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "rtlsdrdiags_amd", "bin", "iqdemod_file")
+    amps = [3, 3, 50, 50, 50, 110, 110, 4, 4, 4, 70, 70]
+    u8 = synth.stepped_amplitude(amps, block_samples=16384, seed=5)
+    for agc_type in (0, 1):
+        o = oracle.chain()
+        o.set_mode("fm")
+        o.set_squelch(-50)
+        o.agc_set_type(agc_type)
+        o.agc_enable(True)
+        ref, _, allowed = o.accept_stream(u8)
+        r = subprocess.run([tool, "2", "-50", str(agc_type)], input=u8.tobytes(), stdout=subprocess.PIPE,
+                           stderr=subprocess.PIPE, check=True)
+        assert np.array_equal(np.frombuffer(r.stdout, dtype=np.int16), ref)
+        assert ("IF gain: %d dB" % o.rx_gain_db()) in r.stderr.decode()
+        assert 0 < allowed.sum() < len(allowed)
+
+
 @pytest.mark.parametrize("mode", ["am", "lsb"])
 def test_many_channels_dc_blocker_batches(capi, oracle, mode):
     """200 channels (not a multiple of 64) over three calls: the batched DC-removal kernel and its
