@@ -374,7 +374,7 @@ IQD_DEV void dc_block_run(const int32_t *x, int n, float gain, float a1, DcCarry
         const float tn = xf - xp;        // exact: both are small integers
         const float r = a1 * yp;
         const float y = tn - r;
-        pcm[i] = (int16_t)cast_i16(gain * y);
+        if (pcm) pcm[i] = (int16_t)cast_i16(gain * y);
         xp = xf;
         yp = y;
     }
@@ -446,7 +446,7 @@ IQD_DEV void dc_real(const Consts &c, DcLds &lds, int nseg, int lane, float gain
         const float tn = xf - xp;
         const float r = a1 * y;
         y = tn - r;
-        pcm[lane * SEG + i] = (int16_t)cast_i16(gain * y);
+        if (pcm) pcm[lane * SEG + i] = (int16_t)cast_i16(gain * y);
         xp = xf;
     }
     lds.e[lane] = y;
@@ -477,7 +477,7 @@ IQD_DEV void dc_block_wave(Exec &ex, const Consts &c, DcLds &lds, const int32_t 
             ex.wave0([&](int lane) { dc_guess(c, lds, nfull, lane); });
             ex.wave0([&](int lane) { dc_warm(c, lds, nfull, lane); });
             do {
-                ex.wave0([&](int lane) { dc_real(c, lds, nfull, lane, gain, pcm + base); });
+                ex.wave0([&](int lane) { dc_real(c, lds, nfull, lane, gain, pcm ? pcm + base : nullptr); });
             } while (!ex.wave0_all([&](int lane) { return dc_check(lds, nfull, lane); }));
             ex.wave0([&](int lane) {
                 if (lane == 0) {
@@ -491,7 +491,7 @@ IQD_DEV void dc_block_wave(Exec &ex, const Consts &c, DcLds &lds, const int32_t 
             ex.wave0([&](int lane) {
                 if (lane != 0) return;
                 DcCarry t2{lds.x_carry, lds.y_carry};
-                dc_block_run(x + base + nfull * SEG, rest, gain, c.dc_a1, t2, pcm + base + nfull * SEG);
+                dc_block_run(x + base + nfull * SEG, rest, gain, c.dc_a1, t2, pcm ? pcm + base + nfull * SEG : nullptr);
                 lds.x_carry = t2.x_prev;
                 lds.y_carry = t2.y_prev;
             });
@@ -499,6 +499,47 @@ IQD_DEV void dc_block_wave(Exec &ex, const Consts &c, DcLds &lds, const int32_t 
     }
     st.x_prev = lds.x_carry;
     st.y_prev = lds.y_carry;
+}
+
+// ---- long streams, many waves per channel -------------------------------------------------------------
+// A channel's 8 kS/s stream is cut into tiles of DC_TILE samples, one wave each.  Tile 0 starts from the exact
+// carried state; every other tile first runs the DC_WARM samples in front of it from the zero state - two
+// trajectories of this contraction (pole 0.95) become bit-identical after a few hundred steps - and then its
+// own samples.  It records the state it started from and the state it ended in; dc_tiles_ok() accepts the
+// channel only if every tile's start state equals its predecessor's end state bit for bit, which by induction
+// from tile 0 makes every tile the serial result.  Otherwise (e.g. a decaying tail that has not reached zero)
+// the one-wave pass above redoes the channel from the carried state.
+constexpr int DC_TILE = DC_SUPER;     // 8192
+constexpr int DC_WARM = 2048;
+struct DcRecord { float y_start, y_end, x_end; uint32_t pad; };
+
+template <class Exec>
+IQD_DEV void dc_tile(Exec &ex, const Consts &c, DcLds &lds, const int32_t *x, int n, int tile, float gain,
+                     const DcCarry &carried, int16_t *pcm, DcRecord &rec)
+{
+    const int start = tile * DC_TILE;
+    const int len = n - start < DC_TILE ? n - start : DC_TILE;
+    DcCarry st = carried;
+    if (tile > 0) {
+        st.x_prev = (float)x[start - DC_WARM - 1];   // exact; DC_WARM < DC_TILE, so the index is >= 0
+        st.y_prev = 0.f;
+        dc_block_wave(ex, c, lds, x + start - DC_WARM, DC_WARM, gain, st, nullptr);
+    }
+    rec.y_start = st.y_prev;
+    dc_block_wave(ex, c, lds, x + start, len, gain, st, pcm + start);
+    rec.y_end = st.y_prev;
+    rec.x_end = st.x_prev;
+    rec.pad = 0;
+}
+
+// true if the tiles of one channel chain up exactly; then `out` is the state after the last one
+IQD_DEV bool dc_tiles_ok(const DcRecord *rec, int ntiles, DcCarry &out)
+{
+    for (int t = 1; t < ntiles; t++)
+        if (f2u(rec[t].y_start) != f2u(rec[t - 1].y_end)) return false;
+    out.x_prev = rec[ntiles - 1].x_end;
+    out.y_prev = rec[ntiles - 1].y_end;
+    return true;
 }
 
 }  // namespace iqd

@@ -21,6 +21,7 @@
 #include "iqd_host.h"
 #include "iqd_kernels.h"
 #include "iqd_wbfm.h"
+#include "iqd_chains.h"
 
 using namespace iqd;
 
@@ -84,7 +85,7 @@ struct iqd_engine {
     uint32_t *h_counters = nullptr;  // pinned
 
     // per-call scratch
-    DevBuf lists[FAM_COUNT + 1], mag_sums, blk_lists, vlen, records, base8k, gain_trace;
+    DevBuf lists[FAM_COUNT + 1], mag_sums, blk_lists, vlen, records, base8k, gain_trace, dc_records;
     DevBuf st_iq, st_pcm, st_count, st_mag, st_allowed;  // staging for host-pointer accepts
     // sliced host-pointer accepts: two staging sets, so that slice k+1 crosses PCIe while slice k runs
     DevBuf sl_iq[2], sl_pcm[2], sl_count[2], sl_mag[2], sl_allowed[2];
@@ -241,7 +242,7 @@ void iqd_destroy(iqd_t *e)
         if (p) (void)hipFree(p);
     if (e->h_counters) (void)hipHostFree(e->h_counters);
     for (auto &b : e->lists) b.release();
-    DevBuf *bufs[] = {&e->mag_sums, &e->blk_lists, &e->vlen, &e->records, &e->base8k, &e->gain_trace,
+    DevBuf *bufs[] = {&e->mag_sums, &e->blk_lists, &e->vlen, &e->records, &e->base8k, &e->gain_trace, &e->dc_records,
                       &e->st_iq, &e->st_pcm, &e->st_count, &e->st_mag, &e->st_allowed};
     for (DevBuf *b : bufs) b->release();
     for (int b = 0; b < 2; b++) {
@@ -713,6 +714,9 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         } else {
             HIP_TRY(e, e->base8k.ensure((size_t)n_ch * base.pcm_stride * sizeof(int32_t)));
             a.base8k = e->base8k.as<int32_t>();
+            a.dc_tiles = (uint32_t)((base.pcm_stride + DC_TILE - 1) / DC_TILE);
+            HIP_TRY(e, e->dc_records.ensure((size_t)n_list * a.dc_tiles * sizeof(DcRecord) + n_list * sizeof(uint32_t)));
+            a.dc_records = e->dc_records.p;
             HIP_TRY(e, launch_am(a, f, gated, fused_mag, n_list * a.tiles_per_ch, s));
         }
         if (e->profiling && !timed) { HIP_TRY(e, hipEventRecord(e->ev1, s)); timed = true; }
@@ -740,6 +744,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         HIP_TRY(e, hipMemcpyAsync(e->h_counters, e->d_counters, CNT_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
         HIP_TRY(e, hipStreamSynchronize(s));
     }
+    if (have_wbfm || timed) e->stats.state_repairs += e->h_counters[CNT_DC_REDO];   // AM/SSB rows redone serially
     if (have_wbfm) {
         e->stats.state_checks += e->h_counters[CNT_TILE_CHECKS];
         if (e->h_counters[CNT_TILE_MISMATCH]) {

@@ -11,7 +11,7 @@ namespace iqd {
 struct WbfmStart;
 struct WbfmRecord;
 
-enum Counter { CNT_TILE_MISMATCH = 0, CNT_TILE_CHECKS = 1, CNT_SEG_REPAIRS = 2, CNT_COUNT = 8 };
+enum Counter { CNT_TILE_MISMATCH = 0, CNT_TILE_CHECKS = 1, CNT_SEG_REPAIRS = 2, CNT_DC_REDO = 3, CNT_COUNT = 8 };
 constexpr uint32_t MAX_MISMATCH_LIST = 1024;
 
 // One chain launch = the channels of one demodulator family inside one accept call.
@@ -44,6 +44,8 @@ struct ChainLaunch {
     int32_t *base8k;              // AM/SSB detector input at 8 kS/s, n_ch_call * pcm_stride ints
     size_t base_stride_ch, base_stride_t;   // its layout: channel-major or time-major
     uint32_t n_ch_call;           // channels in this accept call
+    void *dc_records;             // long AM/SSB rows: [n_list][dc_tiles] DcRecord, then [n_list] redo flags
+    uint32_t dc_tiles;            // tiles per channel of the many-wave DC pass (0: not used)
     unsigned long long *stamps;   // diagnostic builds (IQD_STAMPS): [16] phase cycle sums
 };
 

@@ -264,6 +264,59 @@ __global__ __launch_bounds__(64) void dc_wave_kernel(const ChainLaunch a, int fa
     if (threadIdx.x == 0) a.dc_carry[2 * (size_t)ech + (family == FAM_SSB ? 1 : 0)] = st;
 }
 
+// Long rows: many waves per channel (dc_tile), the chain-up check, and the one-wave pass again for the
+// channels that did not chain up (never seen on live signals; a noiseless decaying tail provokes it).
+__global__ __launch_bounds__(64) void dc_tiled_kernel(const ChainLaunch a, int family)
+{
+    __shared__ DcLds lds;
+    const uint32_t li = blockIdx.y, tile = blockIdx.x;
+    const uint32_t ch = a.ch_list[li], ech = a.first_ch + ch;
+    const uint32_t n = (a.vlen_gated ? a.vlen_gated[ch] : a.vlen) / 32;
+    if ((size_t)tile * DC_TILE >= n) return;
+    const ChanParams &p = a.params[ech];
+    const DcCarry carried = a.dc_carry[2 * (size_t)ech + (family == FAM_SSB ? 1 : 0)];
+    DeviceExec ex{(int)threadIdx.x};
+    DcRecord rec;
+    dc_tile(ex, g_consts, lds, a.base8k + (size_t)ch * a.base_stride_ch, (int)n, (int)tile, p.gain[family], carried,
+            a.pcm + (size_t)ch * a.pcm_stride, rec);
+    if (threadIdx.x == 0) ((DcRecord *)a.dc_records)[(size_t)li * a.dc_tiles + tile] = rec;
+}
+
+__global__ void dc_chainup_kernel(const ChainLaunch a, int family)
+{
+    const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
+    if (li >= a.n_list) return;
+    const uint32_t ch = a.ch_list[li], ech = a.first_ch + ch;
+    const uint32_t n = (a.vlen_gated ? a.vlen_gated[ch] : a.vlen) / 32;
+    uint32_t *redo = (uint32_t *)((DcRecord *)a.dc_records + (size_t)a.n_list * a.dc_tiles);
+    redo[li] = 0;
+    if (n == 0) return;
+    const int ntiles = (int)((n + DC_TILE - 1) / DC_TILE);
+    DcCarry out;
+    if (dc_tiles_ok((const DcRecord *)a.dc_records + (size_t)li * a.dc_tiles, ntiles, out)) {
+        a.dc_carry[2 * (size_t)ech + (family == FAM_SSB ? 1 : 0)] = out;
+    } else {
+        redo[li] = 1;
+        atomicAdd(&a.counters[CNT_DC_REDO], 1u);
+    }
+}
+
+__global__ __launch_bounds__(64) void dc_redo_kernel(const ChainLaunch a, int family)
+{
+    __shared__ DcLds lds;
+    const uint32_t li = blockIdx.x;
+    const uint32_t *redo = (const uint32_t *)((const DcRecord *)a.dc_records + (size_t)a.n_list * a.dc_tiles);
+    if (!redo[li]) return;
+    const uint32_t ch = a.ch_list[li], ech = a.first_ch + ch;
+    const uint32_t vlen = a.vlen_gated ? a.vlen_gated[ch] : a.vlen;
+    const ChanParams &p = a.params[ech];
+    DcCarry st = a.dc_carry[2 * (size_t)ech + (family == FAM_SSB ? 1 : 0)];
+    DeviceExec ex{(int)threadIdx.x};
+    dc_block_wave(ex, g_consts, lds, a.base8k + (size_t)ch * a.base_stride_ch, (int)(vlen / 32), p.gain[family], st,
+                  a.pcm + (size_t)ch * a.pcm_stride);
+    if (threadIdx.x == 0) a.dc_carry[2 * (size_t)ech + (family == FAM_SSB ? 1 : 0)] = st;
+}
+
 // Hand-off check between consecutive tiles of a channel: a cold tile's own state at its
 // restart point must equal, bit for bit, what the tile before it recorded there.
 __global__ void wbfm_verify_kernel(const ChainLaunch a)
@@ -537,8 +590,15 @@ hipError_t launch_am(const ChainLaunch &a_in, int family, bool gated, bool mag, 
     else if (mag) hipLaunchKernelGGL((am_chain_kernel<false, true>), grid, block, 0, s, a, family);
     else hipLaunchKernelGGL((am_chain_kernel<false, false>), grid, block, 0, s, a, family);
     // short streams: one lane per channel; long streams: one wave per channel, segmented
-    if (batch) hipLaunchKernelGGL(dc_kernel, dim3((a.n_list + 63) / 64), dim3(64), 0, s, a, family);
-    else hipLaunchKernelGGL(dc_wave_kernel, dim3(a.n_list), dim3(64), 0, s, a, family);
+    if (batch) {
+        hipLaunchKernelGGL(dc_kernel, dim3((a.n_list + 63) / 64), dim3(64), 0, s, a, family);
+    } else if (a.dc_tiles >= 2 && a.dc_records) {   // rows longer than one tile: many waves per channel
+        hipLaunchKernelGGL(dc_tiled_kernel, dim3(a.dc_tiles, a.n_list), dim3(64), 0, s, a, family);
+        hipLaunchKernelGGL(dc_chainup_kernel, dim3((a.n_list + 63) / 64), dim3(64), 0, s, a, family);
+        hipLaunchKernelGGL(dc_redo_kernel, dim3(a.n_list), dim3(64), 0, s, a, family);
+    } else {
+        hipLaunchKernelGGL(dc_wave_kernel, dim3(a.n_list), dim3(64), 0, s, a, family);
+    }
     return hipGetLastError();
 }
 

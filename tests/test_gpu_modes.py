@@ -195,3 +195,71 @@ def test_many_channels_dc_blocker_batches(capi, oracle, mode):
         o = oracle.chain()
         o.set_mode(mode)
         assert np.array_equal(got[c], o.accept_stream(u8[c])[0]), c
+
+
+@pytest.mark.parametrize("mode", ["am", "usb"])
+def test_long_row_dc_removal_many_waves(capi, oracle, mode):
+    """One channel, 2^22 samples in two unequal calls: the 8 kS/s DC-removal recurrence is cut into tiles that
+    warm up from zero and must chain up bit for bit (dc_tiled_kernel / dc_chainup_kernel)."""
+    n = 1 << 22
+    u8 = np.tile(synth.am_tone(1 << 20, seed=71, tone=440.0, depth=0.6), 4) if mode == "am" else \
+        np.tile(synth.ssb_tone(1 << 20, seed=72), 4)
+    cut = 2 * (3 << 19)           # bytes: 1.5 * 2^20 samples
+    eng = capi.Engine(1)
+    eng.set_mode(mode)
+    pa, ca, _, _ = eng.accept(u8[:cut])
+    pb, cb, _, _ = eng.accept(u8[cut:])
+    o = oracle.chain()
+    o.set_mode(mode)
+    ref, _, _ = o.accept_stream(u8)
+    assert ca[0] + cb[0] == len(ref) == n // 32
+    assert np.array_equal(np.concatenate([pa[0, :ca[0]], pb[0, :cb[0]]]), ref)
+
+
+def test_long_row_dc_removal_falls_back_on_a_decaying_tail(capi, oracle):
+    """A noiseless carrier after a modulated stretch: the detector input is constant, the true state decays through
+    the denormals for ~2200 samples while a zero-state warm-up sits at exactly 0 - the tiles do not chain up and
+    the channel is redone by the one-wave pass.  Also pins denormal arithmetic on the device."""
+    n8k_tiles, t0 = 4, 2 * 8192 - 2100                       # 8 kS/s index where the modulation stops
+    n = 32 * 8192 * n8k_tiles
+    u8 = synth.am_tone(n, seed=73, tone=700.0, depth=0.8, sigma=2.0).reshape(-1, 2).copy()
+    carrier = np.array([[60, 0], [0, -60], [-60, 0], [0, 60]], np.int16)       # A * exp(-j pi n / 2)
+    k0 = 32 * t0
+    u8[k0:] = (128 + np.tile(carrier, ((n - k0) // 4, 1))).astype(np.uint8)
+    u8 = u8.reshape(-1)
+    eng = capi.Engine(1)
+    eng.set_mode("am")
+    eng.set_profiling(True)       # makes the call read the device counters back
+    pcm, cnt, _, _ = eng.accept(u8)
+    assert eng.stats()["state_repairs"] == 1          # the row was redone by the one-wave pass
+    o = oracle.chain()
+    o.set_mode("am")
+    ref, _, _ = o.accept_stream(u8)
+    assert np.array_equal(pcm[0, :cnt[0]], ref)
+    # a second call continues from the exact carried state (the redo pass wrote it)
+    more = synth.am_tone(1 << 19, seed=74)
+    p2, c2, _, _ = eng.accept(more)
+    r2, _, _ = o.accept_stream(more)
+    assert np.array_equal(p2[0, :c2[0]], r2)
+
+
+def test_long_rows_gated_dc_removal(capi, oracle):
+    """Three long rows with the squelch closing on some blocks: per-channel open lengths differ."""
+    nblk = 160
+    rng = np.random.default_rng(8)
+    eng = capi.Engine(3)
+    eng.set_squelch(-42)
+    rows = []
+    for c, mode in enumerate(["am", "lsb", "usb"]):
+        amps = [int(a) for a in np.where(rng.random(nblk) < 0.6, 80, 2)]
+        rows.append(synth.stepped_amplitude(amps, block_samples=16384, seed=90 + c))
+        eng.set_mode(mode, first=c, n=1)
+    iq = np.stack(rows)
+    pcm, cnt, mag, allowed = eng.accept(iq)
+    for c, mode in enumerate(["am", "lsb", "usb"]):
+        o = oracle.chain()
+        o.set_mode(mode)
+        o.set_squelch(-42)
+        ref, rmag, rallowed = o.accept_stream(iq[c])
+        assert np.array_equal(allowed[c], rallowed) and np.array_equal(mag[c], rmag)
+        assert cnt[c] == len(ref) and cnt[c] > 8192 and np.array_equal(pcm[c, :cnt[c]], ref), c
