@@ -785,40 +785,6 @@ IQD_DEV void wbfm_tile(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLds &ld
 // z/g/e and the carries; stages 2 and 3 touch y1, y2 and the loudness flags; phase 1 lives in registers.
 struct P1Pair { P1Out a, b; };
 
-template <bool GATED>
-IQD_DEV void p1_compute(const WbfmTile &t, const Consts &c, int cstart, int clen, int ga_raw, int gb_raw,
-                        bool wave_has_b, bool want_mag, P1Pair &r)
-{
-    const int ngroups = clen >> 4;
-    const int ga = ga_raw < ngroups ? ga_raw : ngroups - 1;   // lanes past the end redo the last group
-    const int gb = gb_raw < ngroups ? gb_raw : ngroups - 1;
-    r.a.valid = ga_raw < ngroups;
-    r.b.valid = wave_has_b && gb_raw < ngroups;
-    r.a.p = 16 * ga;
-    r.b.p = 16 * gb;
-    r.a.mag = r.b.mag = 0;
-    const P1Raw ra = p1_load<GATED>(t, t.v0 + cstart + 16 * ga);
-    uint32_t off[17];
-    float tha[17];
-    if (wave_has_b) {
-        const P1Raw rb = p1_load<GATED>(t, t.v0 + cstart + 16 * gb);
-        float thb[17];
-        p1_front(t, c, ra, off);
-        p1_gather(t, off, tha);
-        if (want_mag) r.a.mag = p1_magnitude(ra);
-        p1_front(t, c, rb, off);
-        p1_gather(t, off, thb);
-        if (want_mag) r.b.mag = p1_magnitude(rb);
-        p1_make(t, c, tha, r.a);
-        p1_make(t, c, thb, r.b);
-    } else {
-        p1_front(t, c, ra, off);
-        p1_gather(t, off, tha);
-        if (want_mag) r.a.mag = p1_magnitude(ra);
-        p1_make(t, c, tha, r.a);
-    }
-}
-
 // ---- phase 1 with neighbour sharing ------------------------------------------------------------
 // Consecutive lanes hold consecutive groups, so a lane's 16-sample lead-in is its left neighbour's
 // own rotated data and its theta[-1] the neighbour's theta[15]: both arrive by one DPP wave shift
@@ -886,7 +852,8 @@ IQD_DEV uint32_t p1s_magnitude(const P1Own &r)
     return magnitude16(own);
 }
 
-// Two passes (slots sa, sb) of one wave, interleaved like p1_compute.  lane = tid & 63.
+// Two passes (slots sa, sb) of one wave, interleaved: the second pass's FIR arithmetic runs while the first
+// pass's table gathers are in flight.  lane = tid & 63.
 template <class Exec>
 IQD_DEV void p1s_compute(Exec &ex, int tid, const WbfmTile &t, const Consts &c, const P1Own &ra, const P1Own &rb,
                          int ngroups, int sa, int sb, bool wave_has_b, bool want_mag, P1Pair &r)
@@ -916,23 +883,6 @@ IQD_DEV void p1s_compute(Exec &ex, int tid, const WbfmTile &t, const Consts &c, 
         tha[0] = u2f(ex.template shr1<8>(tid, f2u(tha[16])));
         p1_make(t, c, tha, r.a);
     }
-}
-
-// One group whose raw bytes were fetched earlier (wave 0 issues the loads before its IIR phase).
-IQD_DEV void p1_compute_one(const WbfmTile &t, const Consts &c, const P1Raw &ra, int ngroups, int g_raw,
-                            bool want_mag, P1Pair &r)
-{
-    const int g = g_raw < ngroups ? g_raw : ngroups - 1;
-    r.a.valid = g_raw < ngroups;
-    r.b.valid = 0;
-    r.a.p = 16 * g;
-    r.a.mag = 0;
-    uint32_t off[17];
-    float th[17];
-    p1_front(t, c, ra, off);
-    p1_gather(t, off, th);
-    if (want_mag) r.a.mag = p1_magnitude(ra);
-    p1_make(t, c, th, r.a);
 }
 
 constexpr int PIPE_OTHERS = WB_THREADS - 64;   // lanes of waves 1-3
