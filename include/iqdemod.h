@@ -119,10 +119,26 @@ typedef struct iqd_agc_state {
 } iqd_agc_state;
 int iqd_agc_get_state(iqd_t *e, uint32_t ch, iqd_agc_state *out);
 
+/* Replaces FrequencyScanner (hdr_diags/FrequencyScanner.h:33-75, src_diags/FrequencyScanner.cc), one per channel,
+ * idle at 162.55 MHz like the reference's constructor (:96-131).  A scanning channel advances its frequency by the
+ * increment on every block its squelch rejects - the reference's signalStateCallback -> run(), :47-62, :378-404 -
+ * and wraps from the end to the start frequency; every such step is one Radio::setReceiveFrequency command, which
+ * the host forwards to its tuner (nothing retunes recorded bytes).  iqd_scanner_set_parameters mirrors
+ * setScanParameters (:190-218, refused while scanning), iqd_scanner_start(…, 1/0) mirrors start()/stop()
+ * (:240-310; the first start after new parameters jumps to the END frequency); both return IQD_EALREADY where the
+ * reference returns false for every channel of the range. */
+int iqd_scanner_set_parameters(iqd_t *e, uint32_t first_ch, uint32_t n_ch, uint64_t start_hz, uint64_t end_hz,
+                               uint64_t increment_hz);
+int iqd_scanner_start(iqd_t *e, uint32_t first_ch, uint32_t n_ch, int start);
+/* The frequency the channel's radio was last told to tune to, the number of tuning commands so far, isScanning(). */
+int iqd_scanner_get(iqd_t *e, uint32_t ch, uint64_t *current_hz, uint64_t *tune_count, int *scanning);
+
 /* Optional record of the IF gain each block's squelch compared with, for the channels and blocks of the last
  * accept call: [n_ch][n_blocks], host memory. */
 int iqd_set_gain_trace(iqd_t *e, int enabled);
 int iqd_get_gain_trace(iqd_t *e, uint32_t first_ch, uint32_t n_ch, uint32_t *gain_db, size_t n_blocks);
+/* With the same switch: the frequency each channel was tuned to after each block, [n_ch][n_blocks]. */
+int iqd_get_frequency_trace(iqd_t *e, uint32_t first_ch, uint32_t n_ch, uint64_t *hz, size_t n_blocks);
 
 /* Front-end rotation selector: +1 = upconvertByFsOver4 (what acceptIqData applies,
  * IqDataProcessor.cc:749, the default), -1 = downconvertByFsOver4 (:496-540), 0 = none. */
@@ -168,6 +184,13 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch,
                          void *magnitude_dev, void *signal_present_dev);
 
 int iqd_synchronize(iqd_t *e);
+
+/* The front end alone, IqDataProcessor.cc:735-749: s = u - 128, then the channel's rotation; [n_ch][bytes_per_ch]
+ * signed bytes out.  This is what the reference leaves in the caller's buffer (it works in place) and what its
+ * IQ dump tap streams (:756-760, UdpClient::sendData); iqd_accept_* itself never modifies its input. */
+int iqd_front_end(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const uint8_t *iq, size_t bytes_per_ch, int8_t *out);
+int iqd_front_end_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void *iq_dev, size_t bytes_per_ch,
+                         void *out_dev);
 
 /* Diagnostics (the reference's displayInternalInformation() text dumps, e.g.
  * IqDataProcessor.cc:860-926, become queryable values). */

@@ -89,6 +89,12 @@ def _sig(fn, restype, argtypes):
     fn.restype, fn.argtypes = restype, argtypes
 
 
+class _Scanner(C.Structure):
+    _fields_ = [("start_hz", C.c_uint64), ("end_hz", C.c_uint64), ("increment_hz", C.c_uint64),
+                ("current_hz", C.c_uint64), ("new_configuration", C.c_int), ("scanning", C.c_int),
+                ("tuned_hz", C.c_uint64), ("tune_count", C.c_uint32)]
+
+
 class Oracle:
     """libiqd_oracle.so"""
 
@@ -113,6 +119,10 @@ class Oracle:
         _sig(L.iqo_agc_enable, C.c_int, [vp, C.c_int])
         _sig(L.iqo_agc_feed, None, [vp, C.c_uint32])
         _sig(L.iqo_get_rx_gain_db, C.c_uint32, [vp])
+        _sig(L.iqo_scanner_of, C.POINTER(_Scanner), [vp])
+        _sig(L.iqo_scanner_set_parameters, C.c_int, [vp, C.c_uint64, C.c_uint64, C.c_uint64])
+        _sig(L.iqo_scanner_start, C.c_int, [vp])
+        _sig(L.iqo_scanner_stop, C.c_int, [vp])
         _sig(L.iqo_accept_stream, C.c_long, [vp, vp, sz, sz, vp, sz, vp, vp])
         _sig(L.iqo_demod_accept, C.c_long, [vp, C.c_int, vp, sz, vp, sz])
         _sig(L.iqo_quantize_taps, None, [vp, C.c_int, vp])
@@ -145,6 +155,15 @@ class Oracle:
         c.agc_enable = lambda on=True: bool(L.iqo_agc_enable(c._h, 1 if on else 0))
         c.agc_feed = lambda m: L.iqo_agc_feed(c._h, int(m))
         c.rx_gain_db = lambda: int(L.iqo_get_rx_gain_db(c._h))
+        # FrequencyScanner
+        c.scanner_set_parameters = lambda a, b, inc: bool(L.iqo_scanner_set_parameters(c._h, int(a), int(b), int(inc)))
+        c.scanner_start = lambda: bool(L.iqo_scanner_start(c._h))
+        c.scanner_stop = lambda: bool(L.iqo_scanner_stop(c._h))
+
+        def tuned():
+            s = L.iqo_scanner_of(c._h).contents
+            return int(s.tuned_hz), int(s.tune_count)
+        c.scanner_tuned = tuned
         return c
 
     # ---- primitives ----
@@ -260,11 +279,15 @@ class Reference:
         _sig(L.ref_agc_set, C.c_int, [vp, C.c_int, C.c_float])
         _sig(L.ref_agc_run, None, [vp, C.c_uint32])
         _sig(L.ref_agc_if_gain, C.c_uint32, [vp])
+        _sig(L.ref_scanner_attach, None, [vp])
+        _sig(L.ref_scanner_cmd, C.c_int, [vp, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64])
+        _sig(L.ref_scanner_frequency, C.c_uint64, [vp, C.POINTER(C.c_uint32)])
 
-    def chain(self, agc=False, operating_point=-12):
+    def chain(self, agc=False, operating_point=-12, scanner=False):
         """agc=True attaches the reference's AutomaticGainControl the way Radio.cc:184 does; the chain then has
         its own IF gain (the harness' Radio double) instead of the process-global one, and per-block magnitudes
-        read 0xffffffff (the AGC owns the single magnitude-callback slot)."""
+        read 0xffffffff (the AGC owns the single magnitude-callback slot).  scanner=True attaches the reference's
+        FrequencyScanner (it owns the signal-state slot: `allowed` then reads 0xff)."""
         L = self.lib
         c = _Chain(L, "ref_")
         c.set_rx_gain_db = lambda g: L.ref_set_rx_gain_db(int(g))  # a process global
@@ -279,6 +302,17 @@ class Reference:
             c.agc_enable = lambda on=True: bool(L.ref_agc_set(c._h, 5, C.c_float(1.0 if on else 0.0)))
             c.agc_feed = lambda m: L.ref_agc_run(c._h, int(m))
             c.rx_gain_db = lambda: int(L.ref_agc_if_gain(c._h))
+        if scanner:
+            L.ref_scanner_attach(c._h)
+            c.scanner_set_parameters = lambda a, b, inc: bool(L.ref_scanner_cmd(c._h, 0, int(a), int(b), int(inc)))
+            c.scanner_start = lambda: bool(L.ref_scanner_cmd(c._h, 1, 0, 0, 0))
+            c.scanner_stop = lambda: bool(L.ref_scanner_cmd(c._h, 2, 0, 0, 0))
+
+            def tuned():
+                n = C.c_uint32()
+                f = L.ref_scanner_frequency(c._h, C.byref(n))
+                return int(f), int(n.value)
+            c.scanner_tuned = tuned
         return c
 
     def decimate_q15(self, taps, factor, x):

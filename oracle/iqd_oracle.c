@@ -395,6 +395,7 @@ struct iqo_chain {
     uint32_t rx_gain_db;
     int tracking; /* SignalTracker state: 0 NoSignal, 1 Tracking */
     iqo_agc agc;
+    iqo_scanner scanner;
     wbfm_t wbfm;
     fm_t fm;
     am_t am;
@@ -740,6 +741,70 @@ int iqo_agc_enable(iqo_chain *c, int on) /* enable :516-548 (the radio is receiv
     return 1;
 }
 
+/* ------------------------------------------------------------------------ */
+/* FrequencyScanner (src_diags/FrequencyScanner.cc)                           */
+/* ------------------------------------------------------------------------ */
+static void scanner_init(iqo_scanner *s) /* constructor :96-131 */
+{
+    s->start_hz = 162550000;
+    s->end_hz = 162550000;
+    s->increment_hz = 0;
+    s->current_hz = s->start_hz;
+    s->new_configuration = 0;
+    s->scanning = 0;
+    s->tuned_hz = 0;
+    s->tune_count = 0;
+}
+
+iqo_scanner *iqo_scanner_of(iqo_chain *c) { return &c->scanner; }
+
+int iqo_scanner_set_parameters(iqo_chain *c, uint64_t start_hz, uint64_t end_hz, uint64_t increment_hz) /* :190-218 */
+{
+    iqo_scanner *s = &c->scanner;
+    if (s->scanning) return 0;
+    s->start_hz = start_hz;
+    s->end_hz = end_hz;
+    s->increment_hz = increment_hz;
+    s->new_configuration = 1;
+    return 1;
+}
+
+static void scanner_tune(iqo_scanner *s) /* Radio::setReceiveFrequency(currentFrequencyInHertz) */
+{
+    s->tuned_hz = s->current_hz;
+    s->tune_count++;
+}
+
+int iqo_scanner_start(iqo_chain *c) /* :240-270 */
+{
+    iqo_scanner *s = &c->scanner;
+    if (s->scanning) return 0;
+    if (s->new_configuration) {
+        s->current_hz = s->end_hz;
+        scanner_tune(s);
+        s->new_configuration = 0;
+    }
+    s->scanning = 1;
+    return 1;
+}
+
+int iqo_scanner_stop(iqo_chain *c) /* :292-310 */
+{
+    if (!c->scanner.scanning) return 0;
+    c->scanner.scanning = 0;
+    return 1;
+}
+
+/* signalStateCallback :47-62 -> run :378-404 */
+void iqo_scanner_feed(iqo_chain *c, int signal_present)
+{
+    iqo_scanner *s = &c->scanner;
+    if (!s->scanning || signal_present) return;
+    s->current_hz = s->current_hz + s->increment_hz;
+    if (s->current_hz > s->end_hz) s->current_hz = s->start_hz;
+    scanner_tune(s);
+}
+
 iqo_chain *iqo_create(void)
 {
     iqo_chain *c = (iqo_chain *)calloc(1, sizeof(*c));
@@ -751,6 +816,7 @@ iqo_chain *iqo_create(void)
     c->rx_gain_db = 24;       /* Radio.cc:325-328 */
     c->tracking = 0;
     agc_init(&c->agc);
+    scanner_init(&c->scanner);
     wbfm_init(&c->wbfm);
     fm_init(&c->fm);
     am_init(&c->am);
@@ -824,6 +890,7 @@ long iqo_accept(iqo_chain *c, const uint8_t *iq, size_t bytes, int16_t *pcm, siz
     c->tracking = present;
     if (magnitude) *magnitude = mag;
     if (allowed_out) *allowed_out = (uint8_t)allowed;
+    iqo_scanner_feed(c, allowed); /* signalCallbackPtr(signalAllowed), :771-775 -> FrequencyScanner.cc:47-62 */
     /* signalMagnitudeCallback (:781-790 -> AutomaticGainControl.cc:47-64): after the squelch, before the
      * demodulator; a gain change is seen by the next block's squelch */
     if (c->agc.enabled) c->rx_gain_db = iqo_agc_run(&c->agc, mag, c->rx_gain_db);

@@ -61,6 +61,19 @@ int iqo_agc_set_blanking_limit(iqo_chain *c, uint32_t limit);
 void iqo_agc_set_operating_point(iqo_chain *c, int32_t dbfs);
 int iqo_agc_set_filter_coefficient(iqo_chain *c, float coefficient);
 int iqo_agc_enable(iqo_chain *c, int on);
+/* FrequencyScanner (src_diags/FrequencyScanner.cc): one per chain, idle, 162.55 MHz.  tuned_hz / tune_count record
+ * the Radio::setReceiveFrequency commands it issues. */
+typedef struct iqo_scanner {
+    uint64_t start_hz, end_hz, increment_hz, current_hz;
+    int new_configuration, scanning;
+    uint64_t tuned_hz;
+    uint32_t tune_count;
+} iqo_scanner;
+iqo_scanner *iqo_scanner_of(iqo_chain *c);
+int iqo_scanner_set_parameters(iqo_chain *c, uint64_t start_hz, uint64_t end_hz, uint64_t increment_hz);
+int iqo_scanner_start(iqo_chain *c);
+int iqo_scanner_stop(iqo_chain *c);
+void iqo_scanner_feed(iqo_chain *c, int signal_present);   /* one signal-state callback */
 /* One AutomaticGainControl::run(magnitude) with the radio's IF gain `gain`; returns the gain afterwards. */
 uint32_t iqo_agc_run(iqo_agc *a, uint32_t magnitude, uint32_t gain);
 

@@ -15,12 +15,12 @@
 // is a harness), not stand-ins for a missing library: Radio.cc / diagUi.cc need
 // librtlsdr + libusb and are outside the hot path.
 //
-// For the AGC row src_diags/AutomaticGainControl.cc is compiled
-// unmodified as well.  It talks to its owner through four accessors of class
-// Radio (hdr_diags/Radio.h: getIqProcessor, isReceiving, getReceiveIfGainInDb,
-// setReceiveIfGainInDb).  Radio.cc itself cannot be built here (it is the
+// For the AGC and scanner rows src_diags/AutomaticGainControl.cc
+// and src_diags/FrequencyScanner.cc are compiled unmodified as well.  They talk to
+// their owner through five accessors of class Radio (hdr_diags/Radio.h: getIqProcessor,
+// isReceiving, getReceiveIfGainInDb, setReceiveIfGainInDb, setReceiveFrequency).  Radio.cc itself cannot be built here (it is the
 // librtlsdr device driver front end), so the harness plays the owner: it
-// defines those four accessors as a recording test double that does what
+// defines those five accessors as a recording test double that does what
 // Radio.cc does when no device is open (Radio.cc:851-861, :1223-1229,
 // :1301-1305, :1472-1476: store the gain, mirror it into
 // radio_adjustableReceiveGainInDb, hand back the processor).  No librtlsdr or
@@ -49,6 +49,7 @@
 #define private public
 #include "Radio.h"
 #undef private
+#include "FrequencyScanner.h"
 
 uint32_t radio_adjustableReceiveGainInDb = 24;  // default: Radio.cc:325-328
 
@@ -70,6 +71,13 @@ bool Radio::setReceiveIfGainInDb(uint8_t stage, uint32_t gain)
   receiveIfGainInDb = gain;                        // Radio.cc:854
   radio_adjustableReceiveGainInDb = receiveIfGainInDb;   // Radio.cc:857
   receiveBlockCount++;                             // harness only: counts the adjustments
+  return true;
+}
+
+bool Radio::setReceiveFrequency(uint64_t frequency)
+{
+  receiveFrequency = frequency;                    // Radio.cc: the no-device branch stores the value
+  receiveTimeStamp++;                              // harness only: counts the tuning commands
   return true;
 }
 
@@ -106,8 +114,9 @@ struct RefChain
   SsbDemodulator *ssb;
   int lastAllowed;
   uint32_t lastMagnitude;
-  Radio *radio;                 // test double, only with an AGC attached
+  Radio *radio;                 // test double, only with an AGC / scanner attached
   AutomaticGainControl *agc;
+  FrequencyScanner *scanner;
 };
 
 void signalStateCb(bool present, void *ctx)
@@ -145,6 +154,7 @@ void *ref_create(void)
   c->lastMagnitude = 0;
   c->radio = 0;
   c->agc = 0;
+  c->scanner = 0;
   return c;
 }
 
@@ -152,6 +162,7 @@ void ref_destroy(void *h)
 {
   RefChain *c = (RefChain *)h;
   if (c->agc) delete c->agc;
+  if (c->scanner) delete c->scanner;
   if (c->radio) free(c->radio);
   delete c->proc;
   delete c->am;
@@ -215,6 +226,7 @@ long ref_accept(void *h, const uint8_t *iq, size_t byteCount,
   c->proc->acceptIqData(0, scratch, byteCount);
   g_sink = 0;
   if (c->agc) c->lastMagnitude = 0xffffffffu;   // the AGC owns the magnitude callback slot
+  if (c->scanner) c->lastAllowed = 0xff;        // the scanner owns the signal-state callback slot
   if (magnitude) *magnitude = c->lastMagnitude;
   if (allowed) *allowed = (uint8_t)c->lastAllowed;
   return (long)sink.count;
@@ -223,16 +235,56 @@ long ref_accept(void *h, const uint8_t *iq, size_t byteCount,
 // ---- AGC (src_diags/AutomaticGainControl.cc, unmodified) ---------------------
 // Attaches an AutomaticGainControl to the chain the way Radio.cc:184 does
 // (it registers itself for the magnitude callback, AutomaticGainControl.cc:170-186).
-void ref_agc_attach(void *h, int32_t operatingPointInDbFs)
+static void attachRadio(RefChain *c)
 {
-  RefChain *c = (RefChain *)h;
-  if (c->agc) return;
+  if (c->radio) return;
   // raw storage: the real constructor lives in Radio.cc; only the fields the accessors above touch are used
   c->radio = (Radio *)calloc(1, sizeof(Radio));
   c->radio->receiveDataProcessorPtr = c->proc;
   c->radio->receiveEnabled = true;
-  c->radio->receiveIfGainInDb = 24;                // Radio.cc:325-328 default
+  c->radio->receiveIfGainInDb = radio_adjustableReceiveGainInDb = 24;   // Radio.cc:325-328 default
+}
+
+void ref_agc_attach(void *h, int32_t operatingPointInDbFs)
+{
+  RefChain *c = (RefChain *)h;
+  if (c->agc) return;
+  attachRadio(c);
   c->agc = new AutomaticGainControl(c->radio, operatingPointInDbFs);
+}
+
+// ---- FrequencyScanner (src_diags/FrequencyScanner.cc, unmodified) --------------
+// Attaches a scanner the way the application does; it takes over the signal-state callback slot
+// (FrequencyScanner.cc: constructor), so `allowed` is recorded through a chained wrapper below.
+void ref_scanner_attach(void *h)
+{
+  RefChain *c = (RefChain *)h;
+  if (c->scanner) return;
+  attachRadio(c);
+  c->scanner = new FrequencyScanner(c->radio);
+}
+
+// what: 0 setScanParameters(a, b, inc)  1 start  2 stop.  Returns the reference's success flag.
+int ref_scanner_cmd(void *h, int what, uint64_t a, uint64_t b, uint64_t inc)
+{
+  RefChain *c = (RefChain *)h;
+  if (!c->scanner) return 0;
+  switch (what)
+  {
+    case 0: return c->scanner->setScanParameters(a, b, inc) ? 1 : 0;
+    case 1: return c->scanner->start() ? 1 : 0;
+    case 2: return c->scanner->stop() ? 1 : 0;
+  }
+  return 0;
+}
+
+// The frequency the radio was last told to tune to, and how many tuning commands it has received.
+uint64_t ref_scanner_frequency(void *h, uint32_t *tuneCount)
+{
+  RefChain *c = (RefChain *)h;
+  if (!c->radio) return 0;
+  if (tuneCount) *tuneCount = c->radio->receiveTimeStamp;
+  return c->radio->receiveFrequency;
 }
 
 // what: 0 setType, 1 setDeadband, 2 setBlankingLimit, 3 setAgcFilterCoefficient,

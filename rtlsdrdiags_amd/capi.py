@@ -51,7 +51,8 @@ EXPORTS = [
     "iqd_dev_download", "iqd_dev_tile", "iqd_stream", "iqd_debug_stamps", "iqd_host_alloc", "iqd_host_free",
     "iqd_get_rx_gain_db", "iqd_agc_set_type", "iqd_agc_set_deadband", "iqd_agc_set_blanking_limit",
     "iqd_agc_set_operating_point", "iqd_agc_set_filter_coefficient", "iqd_agc_enable", "iqd_agc_get_state",
-    "iqd_set_gain_trace", "iqd_get_gain_trace",
+    "iqd_set_gain_trace", "iqd_get_gain_trace", "iqd_scanner_set_parameters", "iqd_scanner_start",
+    "iqd_scanner_get", "iqd_get_frequency_trace", "iqd_front_end", "iqd_front_end_device",
 ]
 
 _LIB = None
@@ -84,6 +85,8 @@ def _lib():
     L.iqd_accept_iq.argtypes = [vp, u32, u32, vp, sz, vp, vp, vp, vp]
     L.iqd_accept_iq_device.argtypes = [vp, u32, u32, vp, sz, vp, vp, vp, vp]
     L.iqd_synchronize.argtypes = [vp]
+    L.iqd_front_end.argtypes = [vp, u32, u32, vp, sz, vp]
+    L.iqd_front_end_device.argtypes = [vp, u32, u32, vp, sz, vp]
     L.iqd_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.iqd_set_profiling.argtypes = [vp, C.c_int]
     L.iqd_get_channel_mode.argtypes = [vp, u32, C.POINTER(C.c_int)]
@@ -105,6 +108,11 @@ def _lib():
     L.iqd_agc_get_state.argtypes = [vp, u32, C.POINTER(AgcState)]
     L.iqd_set_gain_trace.argtypes = [vp, C.c_int]
     L.iqd_get_gain_trace.argtypes = [vp, u32, u32, vp, sz]
+    u64 = C.c_uint64
+    L.iqd_scanner_set_parameters.argtypes = [vp, u32, u32, u64, u64, u64]
+    L.iqd_scanner_start.argtypes = [vp, u32, u32, C.c_int]
+    L.iqd_scanner_get.argtypes = [vp, u32, C.POINTER(u64), C.POINTER(u64), C.POINTER(C.c_int)]
+    L.iqd_get_frequency_trace.argtypes = [vp, u32, u32, vp, sz]
     L.iqd_stream.argtypes = [vp]
     L.iqd_stream.restype = vp
     _LIB = L
@@ -218,6 +226,35 @@ class Engine:
         self._check(self._L.iqd_get_gain_trace(self._h, f, n, _np_ptr(out), n_blocks))
         return out
 
+    # ---- FrequencyScanner -------------------------------------------------------------------
+    def scanner_set_parameters(self, start_hz, end_hz, increment_hz, first=0, n=None):
+        f, n = self._range(first, n)
+        rc = self._L.iqd_scanner_set_parameters(self._h, f, n, int(start_hz), int(end_hz), int(increment_hz))
+        if rc == -6:
+            return False
+        self._check(rc)
+        return True
+
+    def scanner_start(self, start=True, first=0, n=None):
+        f, n = self._range(first, n)
+        rc = self._L.iqd_scanner_start(self._h, f, n, 1 if start else 0)
+        if rc == -6:
+            return False
+        self._check(rc)
+        return True
+
+    def scanner_tuned(self, ch=0):
+        """(frequency the radio was last told to tune to, number of tuning commands)"""
+        hz, n, sc = C.c_uint64(), C.c_uint64(), C.c_int()
+        self._check(self._L.iqd_scanner_get(self._h, ch, C.byref(hz), C.byref(n), C.byref(sc)))
+        return hz.value, n.value
+
+    def frequency_trace(self, n_blocks, first=0, n=None):
+        f, n = self._range(first, n)
+        out = np.zeros((n, n_blocks), np.uint64)
+        self._check(self._L.iqd_get_frequency_trace(self._h, f, n, _np_ptr(out), n_blocks))
+        return out
+
     # ---- data path ------------------------------------------------------------------------
     def accept(self, iq_u8, first=0, n=None):
         """iq_u8: [n_ch, bytes_per_ch] uint8 host array.  Returns (pcm rows, counts, magnitude, allowed)."""
@@ -232,6 +269,14 @@ class Engine:
         self._check(self._L.iqd_accept_iq(self._h, f, n, _np_ptr(iq_u8), bpc, _np_ptr(pcm), _np_ptr(cnt),
                                           _np_ptr(mag), _np_ptr(allowed)))
         return pcm, cnt, mag, allowed
+
+    def front_end(self, iq_u8, first=0, n=None):
+        """u8 -> s8 -> rotation only: the bytes the reference leaves in its buffer / dumps over UDP."""
+        f, n = self._range(first, n)
+        iq_u8 = np.ascontiguousarray(iq_u8, dtype=np.uint8).reshape(n, -1)
+        out = np.zeros(iq_u8.shape, np.int8)
+        self._check(self._L.iqd_front_end(self._h, f, n, _np_ptr(iq_u8), iq_u8.shape[1], _np_ptr(out)))
+        return out
 
     def accept_device(self, iq_dev, bytes_per_ch, pcm_dev, count_dev=0, mag_dev=0, allowed_dev=0, first=0, n=None):
         f, n = self._range(first, n)

@@ -44,7 +44,8 @@ IqDataProcessor::IqDataProcessor(char *hostIpAddress, int hostPort)
       amDemodulatorPtr(0), fmDemodulatorPtr(0), wbFmDemodulatorPtr(0), ssbDemodulatorPtr(0),
       signalNotificationEnabled(false), signalCallbackContextPtr(0), signalCallbackPtr(0),
       signalMagnitudeNotificationEnabled(false), signalMagnitudeCallbackContextPtr(0),
-      signalMagnitudeCallbackPtr(0), lastStatus(IQD_OK), receiveBlockCount(0)
+      signalMagnitudeCallbackPtr(0), iqDumpEnabled(false), iqDumpContextPtr(0), iqDumpCallbackPtr(0),
+      lastStatus(IQD_OK), receiveBlockCount(0)
 {
   (void)hostIpAddress;
   (void)hostPort;
@@ -130,6 +131,9 @@ void IqDataProcessor::acceptIqData(unsigned long timeStamp, unsigned char *buffe
   }
   uint32_t pcmCount = 0, magnitude = 0;
   uint8_t allowed = 0;
+  if (iqDumpEnabled && iqDumpCallbackPtr != 0 &&   // IqDataProcessor.cc:756-760
+      iqd_front_end(engine, 0, 1, bufferPtr, byteCount, dumpData) == IQD_OK)
+    iqDumpCallbackPtr(dumpData, (uint32_t)byteCount, iqDumpContextPtr);
   lastStatus = iqd_accept_iq(engine, 0, 1, bufferPtr, byteCount, pcmData, &pcmCount, &magnitude, &allowed);
   if (lastStatus != IQD_OK) return;
   receiveBlockCount++;
@@ -243,4 +247,56 @@ void AutomaticGainControl::displayInternalInformation(void)
   fprintf(stderr, "Signal Magnitude          : %u\n", st.signal_magnitude);
   fprintf(stderr, "RSSI (Before Amp)         : %d dBFs\n", st.normalized_level_dbfs);
   fprintf(stderr, "/------------------------\n");
+}
+
+// ---- IQ dump tap ------------------------------------------------------------------------------------
+void IqDataProcessor::enableIqDump(void) { iqDumpEnabled = true; }
+void IqDataProcessor::disableIqDump(void) { iqDumpEnabled = false; }
+bool IqDataProcessor::isIqDumpEnabled(void) { return iqDumpEnabled; }
+void IqDataProcessor::registerIqDumpCallback(void (*cb)(int8_t *, uint32_t, void *), void *contextPtr)
+{
+  iqDumpContextPtr = contextPtr;
+  iqDumpCallbackPtr = cb;
+}
+
+// ---- FrequencyScanner -------------------------------------------------------------------------------
+FrequencyScanner::FrequencyScanner(IqDataProcessor *processorPtr) { this->processorPtr = processorPtr; }
+FrequencyScanner::~FrequencyScanner(void) { stop(); }
+
+bool FrequencyScanner::setScanParameters(uint64_t startFrequencyInHertz, uint64_t endFrequencyInHertz,
+                                         uint64_t frequencyIncrementInHertz)
+{
+  return processorPtr->engine != 0 &&
+         iqd_scanner_set_parameters(processorPtr->engine, 0, 1, startFrequencyInHertz, endFrequencyInHertz,
+                                    frequencyIncrementInHertz) == IQD_OK;
+}
+
+bool FrequencyScanner::start(void)
+{
+  return processorPtr->engine != 0 && iqd_scanner_start(processorPtr->engine, 0, 1, 1) == IQD_OK;
+}
+
+bool FrequencyScanner::stop(void)
+{
+  return processorPtr->engine != 0 && iqd_scanner_start(processorPtr->engine, 0, 1, 0) == IQD_OK;
+}
+
+bool FrequencyScanner::isScanning(void)
+{
+  int scanning = 0;
+  return processorPtr->engine != 0 && iqd_scanner_get(processorPtr->engine, 0, 0, 0, &scanning) == IQD_OK && scanning != 0;
+}
+
+uint64_t FrequencyScanner::getCurrentFrequencyInHertz(void)
+{
+  uint64_t hz = 0;
+  if (processorPtr->engine != 0) iqd_scanner_get(processorPtr->engine, 0, &hz, 0, 0);
+  return hz;
+}
+
+uint64_t FrequencyScanner::getTuneCount(void)
+{
+  uint64_t n = 0;
+  if (processorPtr->engine != 0) iqd_scanner_get(processorPtr->engine, 0, 0, &n, 0);
+  return n;
 }

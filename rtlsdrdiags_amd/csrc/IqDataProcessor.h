@@ -92,6 +92,14 @@ class IqDataProcessor
   void registerSignalMagnitudeCallback(void (*callbackPtr)(uint32_t signalMagnitude, void *contextPtr),
                                        void *contextPtr);
 
+  // IQ dump tap (IqDataProcessor.h:54-56, IqDataProcessor.cc:756-760): the reference streams the rotated signed
+  // bytes of every block to a UDP peer; here they go to a sink callback (no networking in this library).
+  void enableIqDump(void);
+  void disableIqDump(void);
+  bool isIqDumpEnabled(void);
+  void registerIqDumpCallback(void (*callbackPtr)(int8_t *bufferPtr, uint32_t byteCount, void *contextPtr),
+                              void *contextPtr);
+
   // radio_adjustableReceiveGainInDb is a global in the reference (Radio.cc:19); here it is a
   // property of the processor.
   void setReceiveGainInDb(uint32_t gainInDb);
@@ -102,6 +110,7 @@ class IqDataProcessor
 
   private:
   friend class AutomaticGainControl;
+  friend class FrequencyScanner;
   void attach(DemodulatorHandle *h);
 
   iqd_t *engine;
@@ -118,7 +127,11 @@ class IqDataProcessor
   bool signalMagnitudeNotificationEnabled;
   void *signalMagnitudeCallbackContextPtr;
   void (*signalMagnitudeCallbackPtr)(uint32_t signalMagnitude, void *contextPtr);
+  bool iqDumpEnabled;
+  void *iqDumpContextPtr;
+  void (*iqDumpCallbackPtr)(int8_t *bufferPtr, uint32_t byteCount, void *contextPtr);
   int16_t pcmData[512];      // one block's PCM (32768 / 64)
+  int8_t dumpData[32768];
   int lastStatus;
   unsigned long receiveBlockCount;
 };
@@ -147,6 +160,27 @@ class AutomaticGainControl
   uint32_t getSignalMagnitude(void);
   uint32_t getReceiveIfGainInDb(void);        // Radio::getReceiveIfGainInDb, Radio.cc:1223-1229
   void displayInternalInformation(void);
+
+  private:
+  IqDataProcessor *processorPtr;
+};
+
+// hdr_diags/FrequencyScanner.h:18-75.  The reference's constructor takes the Radio; here the processor.  The
+// scanner runs on the GPU inside iqd_accept_iq (one step per block the squelch rejects); the frequency it wants
+// the tuner on is read back with getCurrentFrequencyInHertz() - what Radio::setReceiveFrequency was told last.
+class FrequencyScanner
+{
+  public:
+  FrequencyScanner(IqDataProcessor *processorPtr);
+  ~FrequencyScanner(void);
+
+  bool setScanParameters(uint64_t startFrequencyInHertz, uint64_t endFrequencyInHertz,
+                         uint64_t frequencyIncrementInHertz);
+  bool start(void);
+  bool stop(void);
+  bool isScanning(void);
+  uint64_t getCurrentFrequencyInHertz(void);
+  uint64_t getTuneCount(void);
 
   private:
   IqDataProcessor *processorPtr;

@@ -71,6 +71,15 @@ struct AgcState {
     uint32_t signal_magnitude;
     uint32_t pad;
 };
+// FrequencyScanner (hdr_diags/FrequencyScanner.h:33-75), one per channel: configuration from the host,
+// the current frequency on the device (it moves on every block the squelch rejects).
+struct ScanConfig {
+    unsigned long long start_hz, end_hz, increment_hz;
+    unsigned long long set_current;   // one-shot value for `current` (start() after new parameters)
+    uint32_t scanning;
+    uint32_t set_current_flag;        // one-shot: also counts as one tuning command
+};
+struct ScanState { unsigned long long current_hz; unsigned long long tune_count; };
 constexpr uint32_t AGC_MAX_GAIN = 46;   // MAX_ADJUSTIBLE_GAIN, AutomaticGainControl.cc:23
 
 struct VerifyRec { float y_in, y_out, u_out; uint32_t flags; };

@@ -68,6 +68,8 @@ struct iqd_engine {
     std::vector<AgcConfig> h_agc;           // per channel; the one-shot fields are cleared once applied
     std::vector<uint8_t> agc_touched;       // the device may have moved this channel's IF gain
     bool agc_dirty = true;
+    std::vector<ScanConfig> h_scan;         // per channel; one-shot fields cleared once applied
+    std::vector<uint8_t> scan_new_cfg;      // FrequencyScanner::newConfigurationAvailable
     bool trace_on = false;
     uint32_t trace_first = 0, trace_n = 0, trace_blocks = 0;   // what gain_trace holds
 
@@ -79,13 +81,15 @@ struct iqd_engine {
     uint32_t *d_tracker = nullptr;
     AgcConfig *d_agc_cfg = nullptr;
     AgcState *d_agc = nullptr;
+    ScanConfig *d_scan_cfg = nullptr;
+    ScanState *d_scan = nullptr;
     float *d_atan = nullptr, *d_fmlut = nullptr;
     uint32_t *d_counters = nullptr, *d_mismatch = nullptr;
     unsigned long long *d_stamps = nullptr;
     uint32_t *h_counters = nullptr;  // pinned
 
     // per-call scratch
-    DevBuf lists[FAM_COUNT + 1], mag_sums, blk_lists, vlen, records, base8k, gain_trace, dc_records;
+    DevBuf lists[FAM_COUNT + 1], mag_sums, blk_lists, vlen, records, base8k, gain_trace, freq_trace, dc_records;
     DevBuf st_iq, st_pcm, st_count, st_mag, st_allowed;  // staging for host-pointer accepts
     // sliced host-pointer accepts: two staging sets, so that slice k+1 crosses PCIe while slice k runs
     DevBuf sl_iq[2], sl_pcm[2], sl_count[2], sl_mag[2], sl_allowed[2];
@@ -187,6 +191,13 @@ int iqd_create(const iqd_config *cfg, iqd_t **out)
     AgcState st0{};
     st0.rx_gain = 24; st0.if_gain = 24; st0.filtered = 24.f; st0.normalized = -24; st0.signal_magnitude = 64;
     std::vector<AgcState> agc_states(e->n_ch, st0);
+    // FrequencyScanner constructor defaults (FrequencyScanner.cc:96-131)
+    ScanConfig sc0{};
+    sc0.start_hz = sc0.end_hz = 162550000ull;
+    e->h_scan.assign(e->n_ch, sc0);
+    e->scan_new_cfg.assign(e->n_ch, 0);
+    ScanState ss0{162550000ull, 0ull};
+    std::vector<ScanState> scan_states(e->n_ch, ss0);
 
     std::vector<float> atan_lut, fm_lut;
     build_atan2_lut(atan_lut);
@@ -201,6 +212,8 @@ int iqd_create(const iqd_config *cfg, iqd_t **out)
     ok = ok && hipMalloc((void **)&e->d_tracker, n * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc((void **)&e->d_agc_cfg, n * sizeof(AgcConfig)) == hipSuccess;
     ok = ok && hipMalloc((void **)&e->d_agc, n * sizeof(AgcState)) == hipSuccess;
+    ok = ok && hipMalloc((void **)&e->d_scan_cfg, n * sizeof(ScanConfig)) == hipSuccess;
+    ok = ok && hipMalloc((void **)&e->d_scan, n * sizeof(ScanState)) == hipSuccess;
     ok = ok && hipMalloc((void **)&e->d_atan, atan_lut.size() * sizeof(float)) == hipSuccess;
     ok = ok && hipMalloc((void **)&e->d_fmlut, fm_lut.size() * sizeof(float)) == hipSuccess;
     ok = ok && hipMalloc((void **)&e->d_counters, CNT_COUNT * sizeof(uint32_t)) == hipSuccess;
@@ -215,6 +228,8 @@ int iqd_create(const iqd_config *cfg, iqd_t **out)
         ok = ok && hipMemsetAsync(e->d_dc, 0, n * 2 * sizeof(DcCarry), e->stream) == hipSuccess;
         ok = ok && hipMemsetAsync(e->d_tracker, 0, n * sizeof(uint32_t), e->stream) == hipSuccess;
         ok = ok && hipMemcpyAsync(e->d_agc, agc_states.data(), n * sizeof(AgcState), hipMemcpyHostToDevice,
+                                  e->stream) == hipSuccess;
+        ok = ok && hipMemcpyAsync(e->d_scan, scan_states.data(), n * sizeof(ScanState), hipMemcpyHostToDevice,
                                   e->stream) == hipSuccess;
         ok = ok && hipMemcpyAsync(e->d_atan, atan_lut.data(), atan_lut.size() * sizeof(float),
                                   hipMemcpyHostToDevice, e->stream) == hipSuccess;
@@ -236,13 +251,13 @@ void iqd_destroy(iqd_t *e)
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    void *ptrs[] = {e->d_params, e->d_tails, e->d_wcarry, e->d_dc, e->d_tracker, e->d_agc_cfg, e->d_agc,
+    void *ptrs[] = {e->d_params, e->d_tails, e->d_wcarry, e->d_dc, e->d_tracker, e->d_agc_cfg, e->d_agc, e->d_scan_cfg, e->d_scan,
                     e->d_atan, e->d_fmlut, e->d_counters, e->d_mismatch, e->d_stamps};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (e->h_counters) (void)hipHostFree(e->h_counters);
     for (auto &b : e->lists) b.release();
-    DevBuf *bufs[] = {&e->mag_sums, &e->blk_lists, &e->vlen, &e->records, &e->base8k, &e->gain_trace, &e->dc_records,
+    DevBuf *bufs[] = {&e->mag_sums, &e->blk_lists, &e->vlen, &e->records, &e->base8k, &e->gain_trace, &e->freq_trace, &e->dc_records,
                       &e->st_iq, &e->st_pcm, &e->st_count, &e->st_mag, &e->st_allowed};
     for (DevBuf *b : bufs) b->release();
     for (int b = 0; b < 2; b++) {
@@ -376,9 +391,11 @@ static int agc_sync(iqd_t *e)
     if (!e->agc_dirty) return IQD_OK;
     hipStream_t s = e->stream;
     HIP_TRY(e, hipMemcpyAsync(e->d_agc_cfg, e->h_agc.data(), e->n_ch * sizeof(AgcConfig), hipMemcpyHostToDevice, s));
-    HIP_TRY(e, launch_agc_apply(e->d_agc_cfg, e->d_agc, e->n_ch, s));
+    HIP_TRY(e, hipMemcpyAsync(e->d_scan_cfg, e->h_scan.data(), e->n_ch * sizeof(ScanConfig), hipMemcpyHostToDevice, s));
+    HIP_TRY(e, launch_agc_apply(e->d_agc_cfg, e->d_agc, e->d_scan_cfg, e->d_scan, e->n_ch, s));
     HIP_TRY(e, hipStreamSynchronize(s));
     for (auto &a : e->h_agc) { a.reset_blanking = 0; a.set_gain = 0xffffffffu; }
+    for (auto &c : e->h_scan) c.set_current_flag = 0;
     e->agc_dirty = false;
     return IQD_OK;
 }
@@ -412,6 +429,81 @@ int iqd_get_rx_gain_db(iqd_t *e, uint32_t ch, uint32_t *gain_db)
     int rc = iqd_agc_get_state(e, ch, &st);
     if (rc == IQD_OK) *gain_db = st.rx_gain_db;
     return rc;
+}
+
+// ---- FrequencyScanner: the reference's methods one to one -------------------------------------------
+int iqd_scanner_set_parameters(iqd_t *e, uint32_t first_ch, uint32_t n_ch, uint64_t start_hz, uint64_t end_hz,
+                               uint64_t increment_hz)
+{
+    if (!range_ok(e, first_ch, n_ch)) return IQD_EINVAL;
+    std::lock_guard<std::mutex> lk(e->mu);
+    uint32_t changed = 0;
+    for (uint32_t c = first_ch; c < first_ch + n_ch; c++) {
+        ScanConfig &sc = e->h_scan[c];
+        if (sc.scanning) continue;           // setScanParameters() returns false while scanning
+        sc.start_hz = start_hz; sc.end_hz = end_hz; sc.increment_hz = increment_hz;
+        e->scan_new_cfg[c] = 1;
+        changed++;
+    }
+    if (!changed) return IQD_EALREADY;
+    e->agc_dirty = true;
+    return IQD_OK;
+}
+
+int iqd_scanner_start(iqd_t *e, uint32_t first_ch, uint32_t n_ch, int start)
+{
+    if (!range_ok(e, first_ch, n_ch)) return IQD_EINVAL;
+    std::lock_guard<std::mutex> lk(e->mu);
+    uint32_t changed = 0;
+    for (uint32_t c = first_ch; c < first_ch + n_ch; c++) {
+        ScanConfig &sc = e->h_scan[c];
+        if (start && !sc.scanning) {
+            if (e->scan_new_cfg[c]) {        // start(): jump to the end frequency and tune there
+                sc.set_current = sc.end_hz;
+                sc.set_current_flag = 1;
+                e->scan_new_cfg[c] = 0;
+            }
+            sc.scanning = 1;
+            changed++;
+        } else if (!start && sc.scanning) {
+            sc.scanning = 0;
+            changed++;
+        }
+    }
+    if (!changed) return IQD_EALREADY;       // start()/stop() return false
+    e->agc_dirty = true;
+    return IQD_OK;
+}
+
+int iqd_scanner_get(iqd_t *e, uint32_t ch, uint64_t *current_hz, uint64_t *tune_count, int *scanning)
+{
+    if (!e || ch >= e->n_ch) return IQD_EINVAL;
+    (void)hipSetDevice(e->device);
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        int rc = agc_sync(e);
+        if (rc != IQD_OK) return rc;
+        if (scanning) *scanning = (int)e->h_scan[ch].scanning;
+    }
+    ScanState ss;
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    HIP_TRY(e, hipMemcpy(&ss, e->d_scan + ch, sizeof(ss), hipMemcpyDeviceToHost));
+    if (current_hz) *current_hz = ss.current_hz;
+    if (tune_count) *tune_count = ss.tune_count;
+    return IQD_OK;
+}
+
+int iqd_get_frequency_trace(iqd_t *e, uint32_t first_ch, uint32_t n_ch, uint64_t *out, size_t n_blocks)
+{
+    if (!e || !out) return IQD_EINVAL;
+    if (!e->trace_n || first_ch < e->trace_first || n_ch == 0 || first_ch + n_ch > e->trace_first + e->trace_n ||
+        n_blocks != e->trace_blocks)
+        return e->fail(IQD_EINVAL, "no frequency trace for that range (tracing on? same channels and block count as the last accept?)");
+    (void)hipSetDevice(e->device);
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    HIP_TRY(e, hipMemcpy(out, e->freq_trace.as<unsigned long long>() + (size_t)(first_ch - e->trace_first) * n_blocks,
+                         (size_t)n_ch * n_blocks * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    return IQD_OK;
 }
 
 int iqd_set_gain_trace(iqd_t *e, int enabled)
@@ -547,6 +639,42 @@ int iqd_dev_download(iqd_t *e, void *dst, const void *src, size_t bytes)
     return IQD_OK;
 }
 
+// The front end alone: what the reference leaves in the caller's buffer / sends from its IQ dump tap.
+int iqd_front_end_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void *iq_dev, size_t bytes_per_ch,
+                         void *out_dev)
+{
+    if (!range_ok(e, first_ch, n_ch) || !iq_dev || !out_dev) return e ? e->fail(IQD_EINVAL, "bad channel range or NULL buffer") : IQD_EINVAL;
+    if (bytes_per_ch == 0 || bytes_per_ch % e->block_bytes != 0)
+        return e->fail(IQD_EINVAL, "bytes_per_ch (%zu) must be a positive multiple of block_bytes (%u)", bytes_per_ch, e->block_bytes);
+    if ((((uintptr_t)iq_dev) | ((uintptr_t)out_dev)) & 7) return e->fail(IQD_EINVAL, "buffers must be 8-byte aligned");
+    (void)hipSetDevice(e->device);
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        if (e->params_dirty) {
+            HIP_TRY(e, hipMemcpyAsync(e->d_params, e->h_params.data(), e->n_ch * sizeof(ChanParams), hipMemcpyHostToDevice, e->stream));
+            HIP_TRY(e, hipStreamSynchronize(e->stream));
+            e->params_dirty = false;
+        }
+    }
+    HIP_TRY(e, launch_front_end((const uint8_t *)iq_dev, (int8_t *)out_dev, e->d_params, first_ch, n_ch, bytes_per_ch, e->stream));
+    return IQD_OK;
+}
+
+int iqd_front_end(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const uint8_t *iq, size_t bytes_per_ch, int8_t *out)
+{
+    if (!range_ok(e, first_ch, n_ch) || !iq || !out) return e ? e->fail(IQD_EINVAL, "bad channel range or NULL buffer") : IQD_EINVAL;
+    (void)hipSetDevice(e->device);
+    const size_t bytes = (size_t)n_ch * bytes_per_ch;
+    HIP_TRY(e, e->st_iq.ensure(bytes));
+    HIP_TRY(e, e->st_pcm.ensure(bytes));
+    HIP_TRY(e, hipMemcpyAsync(e->st_iq.p, iq, bytes, hipMemcpyHostToDevice, e->stream));
+    int rc = iqd_front_end_device(e, first_ch, n_ch, e->st_iq.p, bytes_per_ch, e->st_pcm.p);
+    if (rc != IQD_OK) return rc;
+    HIP_TRY(e, hipMemcpyAsync(out, e->st_pcm.p, bytes, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return IQD_OK;
+}
+
 int iqd_host_alloc(iqd_t *e, size_t bytes, void **out)
 {
     if (!e || !out || bytes == 0) return IQD_EINVAL;
@@ -650,9 +778,13 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
     q.agc_cfg = e->d_agc_cfg;
     q.agc = e->d_agc;
     q.any_agc = any_agc ? 1u : 0u;
+    q.scan_cfg = e->d_scan_cfg;
+    q.scan = e->d_scan;
     if (e->trace_on) {
         HIP_TRY(e, e->gain_trace.ensure((size_t)n_ch * n_blocks * sizeof(uint32_t)));
         q.gain_trace = e->gain_trace.as<uint32_t>();
+        HIP_TRY(e, e->freq_trace.ensure((size_t)n_ch * n_blocks * sizeof(unsigned long long)));
+        q.freq_trace = e->freq_trace.as<unsigned long long>();
         e->trace_first = first_ch; e->trace_n = n_ch; e->trace_blocks = n_blocks;
     }
 

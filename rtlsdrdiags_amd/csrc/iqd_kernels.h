@@ -63,6 +63,9 @@ struct SquelchLaunch {
     AgcState *agc;                // [engine ch]: the IF gain the squelch uses, and the AGC behind it
     uint32_t any_agc;             // some channel of the call has its AGC enabled
     uint32_t *gain_trace;         // out, optional [n_ch][n_blocks]: the IF gain each block's squelch saw
+    const ScanConfig *scan_cfg;   // [engine ch]
+    ScanState *scan;              // [engine ch]
+    unsigned long long *freq_trace;   // out, optional [n_ch][n_blocks]: the tuned frequency after each block
 };
 
 hipError_t upload_consts(const Consts &c, hipStream_t s);
@@ -72,7 +75,10 @@ hipError_t launch_am(const ChainLaunch &a, int family, bool gated, bool mag, uin
 hipError_t launch_reset(uint8_t *tails, WbfmCarry *wc, DcCarry *dc, uint32_t first_ch, uint32_t n_ch,
                         uint32_t family_mask, hipStream_t s);
 hipError_t launch_wbfm_verify(const ChainLaunch &a, hipStream_t s);
-hipError_t launch_agc_apply(const AgcConfig *cfg, AgcState *st, uint32_t n_ch, hipStream_t s);
+hipError_t launch_front_end(const uint8_t *iq, int8_t *out, const ChanParams *params, uint32_t first_ch, uint32_t n_ch,
+                            size_t bytes_per_ch, hipStream_t s);
+hipError_t launch_agc_apply(const AgcConfig *cfg, AgcState *st, const ScanConfig *scfg, ScanState *sst, uint32_t n_ch,
+                            hipStream_t s);
 hipError_t launch_tail_update(const ChainLaunch &a, int family, bool guarded, hipStream_t s);
 hipError_t launch_magnitude(const uint8_t *iq, size_t ch_stride_bytes, const uint32_t *ch_list, uint32_t n_list,
                             uint32_t block_samples, uint32_t n_blocks, uint32_t *mag_sums, hipStream_t s);

@@ -415,6 +415,7 @@ __global__ void squelch_block_kernel(const SquelchLaunch q, int always_open)
     const ChanParams &p = q.params[ech];
     if (q.magnitude) q.magnitude[idx] = q.mag_sums[idx] / q.block_samples;
     if (q.gain_trace) q.gain_trace[idx] = q.agc[ech].rx_gain;   // channels with a running AGC overwrite theirs
+    if (q.freq_trace) q.freq_trace[idx] = q.scan[ech].current_hz;   // scanning, gated channels overwrite theirs
     if (always_open) {
         if (q.allowed) q.allowed[idx] = 1;
         if (b == q.n_blocks - 1) q.tracker[ech] = 1u;
@@ -483,6 +484,8 @@ __global__ void squelch_track_kernel(const SquelchLaunch q, int always_open)
     uint32_t gain = st.rx_gain;
     uint32_t tracking = q.tracker[ech];
     uint32_t open = 0;
+    const ScanConfig sc = q.scan_cfg[ech];
+    ScanState ss = q.scan[ech];
     for (uint32_t b = 0; b < q.n_blocks; b++) {
         const size_t idx = (size_t)ch * q.n_blocks + b;
         const uint32_t avg = q.mag_sums[idx] / q.block_samples;
@@ -497,7 +500,12 @@ __global__ void squelch_track_kernel(const SquelchLaunch q, int always_open)
             if (allowed) {
                 q.blk_lists[(size_t)ch * q.n_blocks + open] = b;
                 open++;
+            } else if (sc.scanning) {   // signalStateCallback -> FrequencyScanner::run, FrequencyScanner.cc:378-404
+                ss.current_hz = ss.current_hz + sc.increment_hz;
+                if (ss.current_hz > sc.end_hz) ss.current_hz = sc.start_hz;
+                ss.tune_count++;
             }
+            if (q.freq_trace) q.freq_trace[idx] = ss.current_hz;
         }
         if (q.gain_trace) q.gain_trace[idx] = gain;
         if (cfg.enabled) gain = agc_run(cfg, st, avg, gain);
@@ -506,6 +514,7 @@ __global__ void squelch_track_kernel(const SquelchLaunch q, int always_open)
     q.agc[ech] = st;
     if (!always_open) {
         q.tracker[ech] = tracking;
+        q.scan[ech] = ss;
         const uint32_t vlen = (p.mode == 0) ? 0u : open * q.block_samples;
         q.vlen_out[ch] = vlen;
         if (q.pcm_count) q.pcm_count[ch] = vlen / 32u;
@@ -513,14 +522,19 @@ __global__ void squelch_track_kernel(const SquelchLaunch q, int always_open)
 }
 
 // The operator's one-shot commands, applied before the next block: a manual IF gain
-// (Radio::setReceiveIfGainInDb) and resetBlankingSystem() (AutomaticGainControl.cc:625-634).
-__global__ void agc_apply_kernel(const AgcConfig *cfg, AgcState *st, uint32_t n_ch)
+// (Radio::setReceiveIfGainInDb), resetBlankingSystem() (AutomaticGainControl.cc:625-634), the scanner's jump to
+// its end frequency when it starts with new parameters.
+__global__ void agc_apply_kernel(const AgcConfig *cfg, AgcState *st, const ScanConfig *scfg, ScanState *sst, uint32_t n_ch)
 {
     const uint32_t ch = blockIdx.x * blockDim.x + threadIdx.x;
     if (ch >= n_ch) return;
     const AgcConfig c = cfg[ch];
     if (c.set_gain != 0xffffffffu) st[ch].rx_gain = c.set_gain;
     if (c.reset_blanking) { st[ch].blank_ctr = 0; st[ch].adjusted = 0; }
+    if (scfg[ch].set_current_flag) {   // FrequencyScanner::start() after new parameters, FrequencyScanner.cc:250-257
+        sst[ch].current_hz = scfg[ch].set_current;
+        sst[ch].tune_count++;
+    }
 }
 
 // resetDemodulator() for a channel range: histories become zero signal; the WBFM
@@ -545,6 +559,38 @@ __global__ void reset_kernel(uint8_t *tails, WbfmCarry *wc, DcCarry *dc, uint32_
         if (family_mask & (1u << FAM_AM)) dc[2 * (size_t)(first_ch + i)] = DcCarry{0.f, 0.f};
         if (family_mask & (1u << FAM_SSB)) dc[2 * (size_t)(first_ch + i) + 1] = DcCarry{0.f, 0.f};
     }
+}
+
+// The front end alone (IqDataProcessor.cc:735-749): u8 -> s8, then the channel's rotation, interleaved bytes
+// out - what the reference leaves in the caller's buffer and streams from its IQ dump tap (:756-760).
+// One thread per 4 samples (8 bytes); the rotation phase restarts with every block, and blocks are multiples
+// of 4 samples, so it is the sample index modulo 4.
+__global__ void front_end_kernel(const uint8_t *iq, int8_t *out, const ChanParams *params, uint32_t first_ch,
+                                 uint32_t n_ch, size_t bytes_per_ch)
+{
+    const size_t groups_per_ch = bytes_per_ch / 8;
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= groups_per_ch * n_ch) return;
+    const uint32_t ch = (uint32_t)(idx / groups_per_ch);
+    const int rotation = params[first_ch + ch].rotation;
+    const u32x2 raw = ((const u32x2 *)iq)[idx];
+    const uint32_t a = raw.x ^ 0x80808080u, b = raw.y ^ 0x80808080u;   // I0 Q0 I1 Q1 | I2 Q2 I3 Q3
+    u32x2 r;
+    if (rotation == 0) {
+        r = u32x2{a, b};
+    } else {
+        // sample 1: (-Q, I) up / (Q, -I) down; sample 2: (-I, -Q); sample 3: (Q, -I) up / (-Q, I) down
+        const uint32_t a_sw = perm(a, a, 0x02030100u);   // I0 Q0 Q1 I1
+        const uint32_t b_sw = perm(b, b, 0x02030100u);   // I2 Q2 Q3 I3
+        if (rotation > 0) {
+            r.x = neg_bytes(a_sw, 0x00ff0000u);          // I0 Q0 -Q1 I1
+            r.y = neg_bytes(b_sw, 0xff00ffffu);          // -I2 -Q2 Q3 -I3
+        } else {
+            r.x = neg_bytes(a_sw, 0xff000000u);          // I0 Q0 Q1 -I1
+            r.y = neg_bytes(b_sw, 0x00ffffffu);          // -I2 -Q2 -Q3 I3
+        }
+    }
+    ((u32x2 *)out)[idx] = r;
 }
 
 // Repeats the first `period` bytes of a buffer over the rest (bench input staging).
@@ -632,9 +678,10 @@ hipError_t launch_squelch(const SquelchLaunch &q, bool always_open, hipStream_t 
     return hipGetLastError();
 }
 
-hipError_t launch_agc_apply(const AgcConfig *cfg, AgcState *st, uint32_t n_ch, hipStream_t s)
+hipError_t launch_agc_apply(const AgcConfig *cfg, AgcState *st, const ScanConfig *scfg, ScanState *sst, uint32_t n_ch,
+                            hipStream_t s)
 {
-    hipLaunchKernelGGL(agc_apply_kernel, dim3((n_ch + 255) / 256), dim3(256), 0, s, cfg, st, n_ch);
+    hipLaunchKernelGGL(agc_apply_kernel, dim3((n_ch + 255) / 256), dim3(256), 0, s, cfg, st, scfg, sst, n_ch);
     return hipGetLastError();
 }
 
@@ -644,6 +691,15 @@ hipError_t launch_reset(uint8_t *tails, WbfmCarry *wc, DcCarry *dc, uint32_t fir
     uint32_t blocks = (n_ch + 255) / 256;
     if (blocks < 64) blocks = 64;
     hipLaunchKernelGGL(reset_kernel, dim3(blocks), dim3(256), 0, s, tails, wc, dc, first_ch, n_ch, family_mask);
+    return hipGetLastError();
+}
+
+hipError_t launch_front_end(const uint8_t *iq, int8_t *out, const ChanParams *params, uint32_t first_ch, uint32_t n_ch,
+                            size_t bytes_per_ch, hipStream_t s)
+{
+    const size_t n = bytes_per_ch / 8 * n_ch;
+    hipLaunchKernelGGL(front_end_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, iq, out, params, first_ch,
+                       n_ch, bytes_per_ch);
     return hipGetLastError();
 }
 

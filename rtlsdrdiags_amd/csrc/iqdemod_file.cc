@@ -5,9 +5,12 @@
 //     iqdemod_file <mode 0-5> [threshold dBFS [agc type 0|1]] < capture_u8.iq | aplay -f S16_LE -r 8000
 //
 // With an AGC type the channel's AutomaticGainControl runs (Radio.cc:184: operating point -12 dBFS) and the
-// IF gain it settles on is reported on stderr.
+// IF gain it settles on is reported on stderr.  Further options, anywhere after the mode:
+//     scan=<start>:<end>:<increment>   run the channel's FrequencyScanner (Hz); its last tuning command is reported
+//     dump=<file>                      IQ dump tap: the rotated signed bytes of every block go to <file>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include "IqDataProcessor.h"
 
@@ -16,12 +19,27 @@ static void processPcmData(int16_t *bufferPtr, uint32_t bufferLength)
   fwrite(bufferPtr, sizeof(int16_t), bufferLength, stdout);
 }
 
+static void dumpIqData(int8_t *bufferPtr, uint32_t byteCount, void *contextPtr)
+{
+  fwrite(bufferPtr, 1, byteCount, (FILE *)contextPtr);
+}
+
 int main(int argc, char **argv)
 {
   if (argc < 2) {
     fprintf(stderr, "usage: %s <mode: 0 none 1 am 2 fm 3 wbfm 4 lsb 5 usb> [squelch threshold dBFS [agc type: 0 lowpass 1 harris]]\n", argv[0]);
     return 2;
   }
+  const char *scanSpec = 0, *dumpPath = 0;
+  int npos = 0;
+  char *pos[8];
+  for (int i = 1; i < argc && npos < 8; i++) {
+    if (strncmp(argv[i], "scan=", 5) == 0) scanSpec = argv[i] + 5;
+    else if (strncmp(argv[i], "dump=", 5) == 0) dumpPath = argv[i] + 5;
+    else pos[npos++] = argv[i];
+  }
+  argc = npos + 1;
+  for (int i = 0; i < npos; i++) argv[i + 1] = pos[i];
   static char host[] = "127.0.0.1";
   IqDataProcessor processor(host, 8001);
   if (!processor.isOperational()) {
@@ -48,11 +66,31 @@ int main(int argc, char **argv)
     agc.enable();
   }
 
+  FrequencyScanner scanner(&processor);
+  if (scanSpec != 0) {
+    unsigned long long a = 0, b = 0, inc = 0;
+    if (sscanf(scanSpec, "%llu:%llu:%llu", &a, &b, &inc) != 3 || !scanner.setScanParameters(a, b, inc) || !scanner.start()) {
+      fprintf(stderr, "iqdemod_file: bad scan specification %s\n", scanSpec);
+      return 2;
+    }
+  }
+  FILE *dumpFile = 0;
+  if (dumpPath != 0) {
+    dumpFile = fopen(dumpPath, "wb");
+    if (dumpFile == 0) { perror(dumpPath); return 2; }
+    processor.registerIqDumpCallback(dumpIqData, dumpFile);
+    processor.enableIqDump();
+  }
+
   static unsigned char block[32768];
   unsigned long timeStamp = 0;
   while (fread(block, 1, sizeof(block), stdin) == sizeof(block))
     processor.acceptIqData(timeStamp++, block, sizeof(block));
   fflush(stdout);
   if (argc > 3) fprintf(stderr, "IF gain: %u dB\n", agc.getReceiveIfGainInDb());
+  if (scanSpec != 0)
+    fprintf(stderr, "scanner: %llu Hz after %llu tuning commands\n",
+            (unsigned long long)scanner.getCurrentFrequencyInHertz(), (unsigned long long)scanner.getTuneCount());
+  if (dumpFile != 0) fclose(dumpFile);
   return 0;
 }

@@ -98,3 +98,37 @@ STREAM_CASES = [   # (name, amplitudes per block, config)
     ("harris_wbfm_open", [20, 20, 20, 80, 80, 80, 80, 80, 80, 6, 6, 6, 6, 6, 6, 6, 6, 127, 127, 127, 127, 30, 30, 30],
      dict(mode="wbfm", type=1, alpha=0.5, deadband=0, blanking=0, operating_point=-20, gain=10)),
 ]
+
+
+# ---- FrequencyScanner scenario ------------------------------------------------------------------------
+SCAN_AMPS = [2, 2, 60, 60, 2, 2, 2, 90, 2, 2, 2, 2, 70, 2, 2, 2, 2, 2, 2, 2, 2, 50, 2, 2]
+SCAN_PARAMS = (100000000, 100300000, 100000)     # start, end, increment in Hz; wraps twice over SCAN_AMPS
+
+
+def scan_scenario(chain, iq_u8, block_bytes, feed):
+    """Commands around a stream: parameters, start (twice), the stream, parameters while scanning (rejected),
+    stop (twice), one more block while idle, new parameters, start.  `feed(chain, iq)` pushes bytes through the
+    chain and returns (pcm, tuned frequency after each block, tune count after each block).
+    Returns (flags, pcm, frequency per block, count per block, final (frequency, count))."""
+    chain.set_mode("fm")
+    chain.set_squelch(-40)
+    flags = [chain.scanner_set_parameters(*SCAN_PARAMS), chain.scanner_start(), chain.scanner_start()]
+    pcm, freq, count = feed(chain, iq_u8)
+    flags += [chain.scanner_set_parameters(1, 2, 3), chain.scanner_stop(), chain.scanner_stop()]
+    p2, f2, c2 = feed(chain, iq_u8[:2 * block_bytes])
+    flags += [chain.scanner_set_parameters(5, 50, 7), chain.scanner_start()]
+    return (np.array(flags, np.uint8), np.concatenate([pcm, p2]), np.concatenate([freq, f2]).astype(np.uint64),
+            np.concatenate([count, c2]).astype(np.uint32), np.array(chain.scanner_tuned(), np.uint64))
+
+
+def feed_blockwise(block_bytes):
+    def feed(chain, iq_u8):
+        pcm, freq, count = [], [], []
+        for off in range(0, len(iq_u8), block_bytes):
+            p, _, _ = chain.accept_stream(iq_u8[off:off + block_bytes], block_bytes)
+            pcm.append(p)
+            f, n = chain.scanner_tuned()
+            freq.append(f)
+            count.append(n)
+        return np.concatenate(pcm), np.array(freq, np.uint64), np.array(count, np.uint32)
+    return feed

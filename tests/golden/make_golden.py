@@ -153,6 +153,11 @@ def main():
         A.configure(c, cfg)
         pcm, allowed, gains = A.stream(c, u8, 4096)
         agc.update({name + "_iq": u8, name + "_pcm": pcm, name + "_allowed": allowed, name + "_gains": gains})
+    # FrequencyScanner (src_diags/FrequencyScanner.cc compiled unmodified): the tuning commands it issues
+    u8 = synth.stepped_amplitude(A.SCAN_AMPS, block_samples=2048, seed=23)
+    flags, pcm, freq, count, final = A.scan_scenario(R.chain(scanner=True), u8, 4096, A.feed_blockwise(4096))
+    agc.update({"scan_iq": u8, "scan_flags": flags, "scan_pcm": pcm, "scan_freq": freq, "scan_count": count,
+                "scan_final": final})
     np.savez_compressed(os.path.join(OUT, "agc.npz"), **agc)
 
     total = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT) if f.endswith(".npz"))

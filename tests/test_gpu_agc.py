@@ -189,3 +189,46 @@ def test_thousands_of_channels_each_with_its_own_agc(capi, oracle):
         assert cnt[c] == len(ref) and np.array_equal(pcm[c, :cnt[c]], ref), c
         assert eng.rx_gain_db(c) == o.rx_gain_db(), c
     assert 0 < allowed.sum() < allowed.size
+
+
+class ScanChain:
+    """Engine channel 0 with the chain interface agc_script.scan_scenario drives."""
+
+    def __init__(self, eng, one_call):
+        self.e, self.one_call = eng, one_call
+        self.set_mode, self.set_squelch = eng.set_mode, eng.set_squelch
+        self.scanner_set_parameters = eng.scanner_set_parameters
+        self.scanner_start = lambda: eng.scanner_start(True)
+        self.scanner_stop = lambda: eng.scanner_start(False)
+        self.scanner_tuned = lambda: eng.scanner_tuned(0)
+
+    def feed(self, _chain, iq):
+        bb = 4096
+        nblk = len(iq) // bb
+        if not self.one_call:
+            pcm, freq, count = [], [], []
+            for b in range(nblk):
+                p, c, _, _ = self.e.accept(iq[b * bb:(b + 1) * bb])
+                pcm.append(p[0, :c[0]])
+                f, n = self.e.scanner_tuned(0)
+                freq.append(f)
+                count.append(n)
+            return np.concatenate(pcm), np.array(freq, np.uint64), np.array(count, np.uint32)
+        before = self.e.scanner_tuned(0)
+        p, c, _, _ = self.e.accept(iq)
+        freq = self.e.frequency_trace(nblk)[0]
+        steps = np.cumsum(np.concatenate([[before[0]], freq])[1:] != np.concatenate([[before[0]], freq])[:-1])
+        assert before[1] + steps[-1] == self.e.scanner_tuned(0)[1]
+        return p[0, :c[0]], freq, (before[1] + steps).astype(np.uint32)
+
+
+@pytest.mark.parametrize("one_call", [False, True])
+def test_frequency_scanner_matches_the_reference(capi, golden, one_call):
+    g = golden["agc"]
+    eng = capi.Engine(1, block_bytes=4096)
+    eng.set_gain_trace(True)
+    ch = ScanChain(eng, one_call)
+    flags, pcm, freq, count, final = A.scan_scenario(ch, g["scan_iq"], 4096, ch.feed)
+    assert np.array_equal(flags, g["scan_flags"])
+    assert np.array_equal(freq, g["scan_freq"]) and np.array_equal(count, g["scan_count"])
+    assert np.array_equal(pcm, g["scan_pcm"]) and np.array_equal(final, g["scan_final"])

@@ -263,3 +263,43 @@ def test_long_rows_gated_dc_removal(capi, oracle):
         ref, rmag, rallowed = o.accept_stream(iq[c])
         assert np.array_equal(allowed[c], rallowed) and np.array_equal(mag[c], rmag)
         assert cnt[c] == len(ref) and cnt[c] > 8192 and np.array_equal(pcm[c, :cnt[c]], ref), c
+
+
+def test_file_tool_scanner_and_iq_dump(oracle, tmp_path):
+    """FrequencyScanner mirror class and the IQ dump tap through the tool: the rotated signed bytes equal the
+    oracle's front end, the last tuning command and the command count equal the oracle's scanner."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "rtlsdrdiags_amd", "bin", "iqdemod_file")
+    amps = [3, 3, 50, 50, 3, 3, 3, 110, 4, 4, 4, 70]
+    u8 = synth.stepped_amplitude(amps, block_samples=16384, seed=6)
+    o = oracle.chain()
+    o.set_mode("usb")
+    o.set_squelch(-45)
+    o.scanner_set_parameters(433000000, 433075000, 25000)
+    o.scanner_start()
+    ref, _, allowed = o.accept_stream(u8)
+    dump = tmp_path / "dump.s8"
+    r = subprocess.run([tool, "5", "-45", "scan=433000000:433075000:25000", "dump=%s" % dump], input=u8.tobytes(),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True)
+    assert np.array_equal(np.frombuffer(r.stdout, dtype=np.int16), ref)
+    assert ("scanner: %d Hz after %d tuning commands" % o.scanner_tuned()) in r.stderr.decode()
+    assert o.scanner_tuned()[1] == 1 + int((allowed == 0).sum()) > 4
+    want = np.concatenate([oracle.rotate((u8[k:k + 32768] ^ 0x80).view(np.int8), +1) for k in range(0, len(u8), 32768)])
+    assert np.array_equal(np.fromfile(dump, dtype=np.int8), want)
+
+
+@pytest.mark.parametrize("rotation", [1, 0, -1])
+def test_front_end_only(capi, oracle, golden, rotation):
+    """iqd_front_end: u8 -> s8 -> rotation, interleaved; includes the -128 negation cases (rails, white)."""
+    for name in ("rails", "white", "fm_tone"):
+        u8 = golden[name]["iq"][:65536]
+        eng = capi.Engine(2)
+        eng.set_rotation(rotation, first=1, n=1)
+        out = eng.front_end(np.stack([u8, u8]))
+        s8 = (u8 ^ 0x80).view(np.int8)
+        assert np.array_equal(out[0], np.concatenate([oracle.rotate(s8[k:k + 32768], +1) for k in (0, 32768)]))
+        assert np.array_equal(out[1], np.concatenate([oracle.rotate(s8[k:k + 32768], rotation) for k in (0, 32768)]))
+    if rotation == 1:
+        assert np.array_equal(oracle.rotate(golden["primitives"]["rot_in"], +1), golden["primitives"]["rot_up"])

@@ -174,3 +174,14 @@ def test_agc_inside_the_block_flow(oracle, golden, case):
     assert np.array_equal(allowed, g[case + "_allowed"])
     assert np.array_equal(pcm, g[case + "_pcm"])
     assert len(set(gains.tolist())) > 4
+
+
+def test_frequency_scanner_commands_and_tuning(oracle, golden):
+    """FrequencyScanner: advances on every block the squelch rejects, wraps from end to start, ignores
+    parameter changes while scanning."""
+    g = golden["agc"]
+    flags, pcm, freq, count, final = A.scan_scenario(oracle.chain(), g["scan_iq"], 4096, A.feed_blockwise(4096))
+    assert np.array_equal(flags, g["scan_flags"]) and flags.tolist() == [1, 1, 0, 0, 1, 0, 1, 1]
+    assert np.array_equal(freq, g["scan_freq"]) and np.array_equal(count, g["scan_count"])
+    assert np.array_equal(pcm, g["scan_pcm"]) and np.array_equal(final, g["scan_final"])
+    assert count[-3] > 12 and len(set(freq.tolist())) == 4      # the scan wrapped around
