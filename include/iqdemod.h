@@ -174,9 +174,9 @@ int iqd_accept_iq(iqd_t *e, uint32_t first_ch, uint32_t n_ch,
                   uint32_t *magnitude, uint8_t *signal_present);
 
 /* Device-pointer form: every pointer is HIP device memory (same layouts); the work is
- * enqueued on the engine's stream.  Calls that involve WBFM channels wait for the kernels
- * (they read the hand-off verification counter and, if ever needed, repair); calls without
- * WBFM channels return as soon as the work is queued.  Use iqd_synchronize() before reading
+ * enqueued on the engine's stream and the call returns as soon as it is queued (the WBFM
+ * hand-off verification and, if ever needed, its repair run on the device).  Keep the
+ * buffers alive and use iqd_synchronize() - or synchronise iqd_stream() - before reading
  * results. */
 int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch,
                          const void *iq_dev, size_t bytes_per_ch,
@@ -199,7 +199,7 @@ typedef struct iqd_stats {
     uint64_t samples;            /* IQ samples accepted, all channels */
     uint64_t kernel_launches;    /* chain-kernel launches */
     uint64_t state_checks;       /* tile hand-offs verified bit-exact (WBFM de-emphasis) */
-    uint64_t state_repairs;      /* tiles re-run with an exact carried state */
+    uint64_t state_repairs;      /* tiles (WBFM) / rows (AM, SSB DC removal) re-run from the exact carried state */
     double chain_kernel_ms;      /* HIP-event time of the chain kernels while profiling is on */
     uint64_t chain_kernel_count; /* launches covered by chain_kernel_ms */
 } iqd_stats;

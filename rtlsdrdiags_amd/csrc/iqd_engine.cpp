@@ -84,12 +84,12 @@ struct iqd_engine {
     ScanConfig *d_scan_cfg = nullptr;
     ScanState *d_scan = nullptr;
     float *d_atan = nullptr, *d_fmlut = nullptr;
-    uint32_t *d_counters = nullptr, *d_mismatch = nullptr;
+    uint32_t *d_counters = nullptr;      // cumulative, read by iqd_get_stats
     unsigned long long *d_stamps = nullptr;
     uint32_t *h_counters = nullptr;  // pinned
 
     // per-call scratch
-    DevBuf lists[FAM_COUNT + 1], mag_sums, blk_lists, vlen, records, base8k, gain_trace, freq_trace, dc_records;
+    DevBuf lists[FAM_COUNT + 1], mag_sums, blk_lists, vlen, records, base8k, gain_trace, freq_trace, dc_records, repair_flags;
     DevBuf st_iq, st_pcm, st_count, st_mag, st_allowed;  // staging for host-pointer accepts
     // sliced host-pointer accepts: two staging sets, so that slice k+1 crosses PCIe while slice k runs
     DevBuf sl_iq[2], sl_pcm[2], sl_count[2], sl_mag[2], sl_allowed[2];
@@ -99,7 +99,8 @@ struct iqd_engine {
     size_t h_slice_counts_cap = 0;
 
     bool profiling = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // profiling: one event pair per timed launch, read back lazily so that accepts stay asynchronous
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_free_pairs, ev_pending;
     iqd_stats stats{};
     std::string last_error;
 
@@ -217,11 +218,10 @@ int iqd_create(const iqd_config *cfg, iqd_t **out)
     ok = ok && hipMalloc((void **)&e->d_atan, atan_lut.size() * sizeof(float)) == hipSuccess;
     ok = ok && hipMalloc((void **)&e->d_fmlut, fm_lut.size() * sizeof(float)) == hipSuccess;
     ok = ok && hipMalloc((void **)&e->d_counters, CNT_COUNT * sizeof(uint32_t)) == hipSuccess;
-    ok = ok && hipMalloc((void **)&e->d_mismatch, MAX_MISMATCH_LIST * 2 * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMemset(e->d_counters, 0, CNT_COUNT * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc((void **)&e->d_stamps, 16 * sizeof(unsigned long long)) == hipSuccess;
     ok = ok && hipMemset(e->d_stamps, 0, 16 * sizeof(unsigned long long)) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&e->h_counters, CNT_COUNT * sizeof(uint32_t)) == hipSuccess;
-    ok = ok && hipEventCreate(&e->ev0) == hipSuccess && hipEventCreate(&e->ev1) == hipSuccess;
     if (ok) {
         ok = hipMemsetAsync(e->d_tails, 0x80, n * FAM_COUNT * TAIL_BYTES, e->stream) == hipSuccess;
         ok = ok && hipMemsetAsync(e->d_wcarry, 0, n * sizeof(WbfmCarry), e->stream) == hipSuccess;
@@ -252,12 +252,12 @@ void iqd_destroy(iqd_t *e)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     void *ptrs[] = {e->d_params, e->d_tails, e->d_wcarry, e->d_dc, e->d_tracker, e->d_agc_cfg, e->d_agc, e->d_scan_cfg, e->d_scan,
-                    e->d_atan, e->d_fmlut, e->d_counters, e->d_mismatch, e->d_stamps};
+                    e->d_atan, e->d_fmlut, e->d_counters, e->d_stamps};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (e->h_counters) (void)hipHostFree(e->h_counters);
     for (auto &b : e->lists) b.release();
-    DevBuf *bufs[] = {&e->mag_sums, &e->blk_lists, &e->vlen, &e->records, &e->base8k, &e->gain_trace, &e->freq_trace, &e->dc_records,
+    DevBuf *bufs[] = {&e->mag_sums, &e->blk_lists, &e->vlen, &e->records, &e->base8k, &e->gain_trace, &e->freq_trace, &e->dc_records, &e->repair_flags,
                       &e->st_iq, &e->st_pcm, &e->st_count, &e->st_mag, &e->st_allowed};
     for (DevBuf *b : bufs) b->release();
     for (int b = 0; b < 2; b++) {
@@ -268,8 +268,8 @@ void iqd_destroy(iqd_t *e)
     }
     if (e->h_slice_counts) (void)hipHostFree(e->h_slice_counts);
     if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
-    if (e->ev0) (void)hipEventDestroy(e->ev0);
-    if (e->ev1) (void)hipEventDestroy(e->ev1);
+    for (auto *v : {&e->ev_free_pairs, &e->ev_pending})
+        for (auto &pr : *v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -580,6 +580,20 @@ int iqd_set_profiling(iqd_t *e, int enabled)
 int iqd_get_stats(iqd_t *e, iqd_stats *out)
 {
     if (!e || !out) return IQD_EINVAL;
+    // the verification / repair counters live on the device (accepts do not wait for them): wait and read
+    (void)hipSetDevice(e->device);
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    HIP_TRY(e, hipMemcpy(e->h_counters, e->d_counters, CNT_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (auto &pr : e->ev_pending) {   // the stream is idle: every recorded pair has completed
+        float ms = 0.f;
+        HIP_TRY(e, hipEventElapsedTime(&ms, pr.first, pr.second));
+        e->stats.chain_kernel_ms += ms;
+        e->stats.chain_kernel_count++;
+        e->ev_free_pairs.push_back(pr);
+    }
+    e->ev_pending.clear();
+    e->stats.state_checks = e->h_counters[CNT_TILE_CHECKS];
+    e->stats.state_repairs = (uint64_t)e->h_counters[CNT_TILE_REPAIRS] + e->h_counters[CNT_DC_REDO];
     *out = e->stats;
     return IQD_OK;
 }
@@ -720,8 +734,6 @@ static void rebuild_lists(iqd_t *e, uint32_t first_ch, uint32_t n_ch)
     e->lists_dirty = false;
 }
 
-static int run_wbfm_repairs(iqd_t *e, ChainLaunch a, bool gated, uint32_t n_bad);
-
 int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void *iq_dev, size_t bytes_per_ch,
                          void *pcm_dev, void *pcm_count_dev, void *magnitude_dev, void *signal_present_dev)
 {
@@ -764,7 +776,6 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
     const bool want_mag = gated || any_agc || !(e->flags & IQD_F_NO_MAGNITUDE) || magnitude_dev;
 
     HIP_TRY(e, e->mag_sums.ensure((size_t)n_ch * n_blocks * sizeof(uint32_t)));
-    HIP_TRY(e, hipMemsetAsync(e->d_counters, 0, CNT_COUNT * sizeof(uint32_t), s));
     if (want_mag) HIP_TRY(e, hipMemsetAsync(e->mag_sums.p, 0, (size_t)n_ch * n_blocks * sizeof(uint32_t), s));
 
     SquelchLaunch q{};
@@ -819,14 +830,12 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
     base.pcm_stride = bytes_per_ch / 64;
     base.mag_sums = e->mag_sums.as<uint32_t>();
     base.counters = e->d_counters;
-    base.mismatch_list = e->d_mismatch;
     base.stamps = e->d_stamps;
     base.n_ch_call = n_ch;
 
     const bool fused_mag = want_mag && !gated;
     bool timed = false;
-    ChainLaunch wb{};
-    bool have_wbfm = false;
+    std::pair<hipEvent_t, hipEvent_t> evp{nullptr, nullptr};
     for (int f = 0; f < FAM_COUNT; f++) {
         const uint32_t n_list = (uint32_t)e->h_lists[f].size();
         if (!n_list) continue;
@@ -836,10 +845,25 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         const TilePlan plan = plan_tiles(vlen, n_list);
         a.tile_len = plan.tile_len;
         a.tiles_per_ch = plan.tiles_per_ch;
-        if (e->profiling && !timed) HIP_TRY(e, hipEventRecord(e->ev0, s));
+        if (e->profiling && !timed) {
+            if (e->ev_free_pairs.empty()) {
+                hipEvent_t a0, a1;
+                HIP_TRY(e, hipEventCreate(&a0));
+                HIP_TRY(e, hipEventCreate(&a1));
+                e->ev_free_pairs.emplace_back(a0, a1);
+            }
+            evp = e->ev_free_pairs.back();
+            e->ev_free_pairs.pop_back();
+            HIP_TRY(e, hipEventRecord(evp.first, s));
+        }
         if (f == FAM_WBFM) {
             HIP_TRY(e, e->records.ensure((size_t)n_list * a.tiles_per_ch * sizeof(WbfmRecord)));
             a.records = e->records.as<WbfmRecord>();
+            if (e->repair_flags.cap < n_list * sizeof(uint32_t)) {   // zero between calls: the repair kernel clears what it used
+                HIP_TRY(e, e->repair_flags.ensure(n_list * sizeof(uint32_t)));
+                HIP_TRY(e, hipMemsetAsync(e->repair_flags.p, 0, e->repair_flags.cap, s));
+            }
+            a.repair_flags = e->repair_flags.as<uint32_t>();
             HIP_TRY(e, launch_wbfm(a, gated, fused_mag, n_list * a.tiles_per_ch, s));
         } else if (f == FAM_FM) {
             HIP_TRY(e, launch_fm(a, gated, fused_mag, n_list * a.tiles_per_ch, s));
@@ -851,14 +875,17 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
             a.dc_records = e->dc_records.p;
             HIP_TRY(e, launch_am(a, f, gated, fused_mag, n_list * a.tiles_per_ch, s));
         }
-        if (e->profiling && !timed) { HIP_TRY(e, hipEventRecord(e->ev1, s)); timed = true; }
+        if (e->profiling && !timed) {
+            HIP_TRY(e, hipEventRecord(evp.second, s));
+            e->ev_pending.push_back(evp);
+            timed = true;
+        }
         e->stats.kernel_launches++;
         if (f == FAM_WBFM) {
+            // hand-off verification, repair of what it flags (normally an immediate exit), then state commit + tail
             HIP_TRY(e, launch_wbfm_verify(a, s));
-            // state commit + tail, skipped on the device if the verification flagged anything
-            HIP_TRY(e, launch_tail_update(a, FAM_WBFM, true, s));
-            wb = a;
-            have_wbfm = true;
+            HIP_TRY(e, launch_wbfm_repair(a, gated, s));
+            HIP_TRY(e, launch_tail_update(a, FAM_WBFM, false, s));
         } else {
             HIP_TRY(e, launch_tail_update(a, f, false, s));
         }
@@ -870,81 +897,8 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
                                     e->mag_sums.as<uint32_t>(), s));
     if (!gated && (want_mag || pcm_count_dev || signal_present_dev || e->trace_on)) HIP_TRY(e, launch_squelch(q, true, s));
 
-    // exact-state verification of the WBFM hand-offs (a mismatch has never been observed;
-    // the repair path re-runs the affected tiles from the neighbour's exact state)
-    if (have_wbfm || timed) {
-        HIP_TRY(e, hipMemcpyAsync(e->h_counters, e->d_counters, CNT_COUNT * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-        HIP_TRY(e, hipStreamSynchronize(s));
-    }
-    if (have_wbfm || timed) e->stats.state_repairs += e->h_counters[CNT_DC_REDO];   // AM/SSB rows redone serially
-    if (have_wbfm) {
-        e->stats.state_checks += e->h_counters[CNT_TILE_CHECKS];
-        if (e->h_counters[CNT_TILE_MISMATCH]) {
-            int rc = run_wbfm_repairs(e, wb, gated, e->h_counters[CNT_TILE_MISMATCH]);
-            if (rc != IQD_OK) return rc;
-            HIP_TRY(e, launch_tail_update(wb, FAM_WBFM, false, s));   // the guarded launch did nothing
-        }
-    }
-    if (timed) {
-        float ms = 0.f;
-        HIP_TRY(e, hipEventElapsedTime(&ms, e->ev0, e->ev1));
-        e->stats.chain_kernel_ms += ms;
-        e->stats.chain_kernel_count++;
-    }
     e->stats.accepts++;
     e->stats.samples += (uint64_t)vlen * n_ch;
-    return IQD_OK;
-}
-
-// Re-runs mismatching tiles, in stream order, from the exact state recorded by the tile before.
-static int run_wbfm_repairs(iqd_t *e, ChainLaunch a, bool gated, uint32_t n_bad)
-{
-    hipStream_t s = e->stream;
-    const size_t nrec = (size_t)a.n_list * a.tiles_per_ch;
-    std::vector<WbfmRecord> recs(nrec);
-    HIP_TRY(e, hipMemcpy(recs.data(), a.records, nrec * sizeof(WbfmRecord), hipMemcpyDeviceToHost));
-    DevBuf forced, sel;
-    HIP_TRY(e, forced.ensure(nrec * sizeof(WbfmStart)));
-    HIP_TRY(e, sel.ensure(2 * sizeof(uint32_t)));
-    std::vector<WbfmStart> starts(nrec);
-    std::vector<uint32_t> h_list(a.n_list), h_vlen;
-    HIP_TRY(e, hipMemcpy(h_list.data(), a.ch_list, a.n_list * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    if (a.vlen_gated) {
-        h_vlen.resize(e->list_n);
-        HIP_TRY(e, hipMemcpy(h_vlen.data(), a.vlen_gated, e->list_n * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    }
-    (void)n_bad;
-    for (uint32_t li = 0; li < a.n_list; li++) {
-        const uint32_t vlen = a.vlen_gated ? h_vlen[h_list[li]] : a.vlen;
-        const uint32_t ntiles = (vlen + a.tile_len - 1) / a.tile_len;
-        for (uint32_t tile = 1; tile < ntiles; tile++) {
-            WbfmRecord &cur = recs[(size_t)li * a.tiles_per_ch + tile];
-            const WbfmRecord &prev = recs[(size_t)li * a.tiles_per_ch + tile - 1];
-            if (f2u(cur.y_in) == f2u(prev.y_out)) continue;
-            WbfmStart st;
-            st.y = prev.y_out; st.u = prev.u_out; st.back = prev.back_out; st.cold = 0;
-            starts[(size_t)li * a.tiles_per_ch + tile] = st;
-            const uint32_t pair[2] = {li, tile};
-            HIP_TRY(e, hipMemcpy(forced.p, starts.data(), nrec * sizeof(WbfmStart), hipMemcpyHostToDevice));
-            HIP_TRY(e, hipMemcpy(sel.p, pair, sizeof(pair), hipMemcpyHostToDevice));
-            ChainLaunch r = a;
-            r.forced = forced.as<WbfmStart>();
-            r.tile_sel = sel.as<uint32_t>();
-            r.mag_sums = a.mag_sums;
-            HIP_TRY(e, launch_wbfm(r, gated, false, 1, s));
-            HIP_TRY(e, hipStreamSynchronize(s));
-            HIP_TRY(e, hipMemcpy(&cur, a.records + (size_t)li * a.tiles_per_ch + tile, sizeof(WbfmRecord),
-                                 hipMemcpyDeviceToHost));
-            e->stats.state_repairs++;
-            if (f2u(cur.y_in) != f2u(prev.y_out)) {
-                forced.release();
-                sel.release();
-                return e->fail(IQD_ESTATE, "WBFM tile %u of list entry %u could not be repaired", tile, li);
-            }
-        }
-    }
-    forced.release();
-    sel.release();
     return IQD_OK;
 }
 

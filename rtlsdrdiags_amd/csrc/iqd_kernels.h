@@ -11,7 +11,7 @@ namespace iqd {
 struct WbfmStart;
 struct WbfmRecord;
 
-enum Counter { CNT_TILE_MISMATCH = 0, CNT_TILE_CHECKS = 1, CNT_SEG_REPAIRS = 2, CNT_DC_REDO = 3, CNT_COUNT = 8 };
+enum Counter { CNT_TILE_MISMATCH = 0, CNT_TILE_CHECKS = 1, CNT_SEG_REPAIRS = 2, CNT_DC_REDO = 3, CNT_TILE_REPAIRS = 4, CNT_COUNT = 8 };
 constexpr uint32_t MAX_MISMATCH_LIST = 1024;
 
 // One chain launch = the channels of one demodulator family inside one accept call.
@@ -37,10 +37,8 @@ struct ChainLaunch {
     size_t pcm_stride;
     uint32_t *mag_sums;           // [n_ch][n_blocks]
     WbfmRecord *records;          // [n_list][tiles_per_ch]
-    const WbfmStart *forced;      // optional explicit start states, same indexing
-    const uint32_t *tile_sel;     // optional (list index, tile) pairs for a repair launch
+    uint32_t *repair_flags;       // [n_list]: set by the verification, cleared by the repair (zero between calls)
     uint32_t *counters;           // [CNT_COUNT]
-    uint32_t *mismatch_list;      // [MAX_MISMATCH_LIST][2]
     int32_t *base8k;              // AM/SSB detector input at 8 kS/s, n_ch_call * pcm_stride ints
     size_t base_stride_ch, base_stride_t;   // its layout: channel-major or time-major
     uint32_t n_ch_call;           // channels in this accept call
@@ -75,6 +73,7 @@ hipError_t launch_am(const ChainLaunch &a, int family, bool gated, bool mag, uin
 hipError_t launch_reset(uint8_t *tails, WbfmCarry *wc, DcCarry *dc, uint32_t first_ch, uint32_t n_ch,
                         uint32_t family_mask, hipStream_t s);
 hipError_t launch_wbfm_verify(const ChainLaunch &a, hipStream_t s);
+hipError_t launch_wbfm_repair(const ChainLaunch &a, bool gated, hipStream_t s);
 hipError_t launch_front_end(const uint8_t *iq, int8_t *out, const ChanParams *params, uint32_t first_ch, uint32_t n_ch,
                             size_t bytes_per_ch, hipStream_t s);
 hipError_t launch_agc_apply(const AgcConfig *cfg, AgcState *st, const ScanConfig *scfg, ScanState *sst, uint32_t n_ch,

@@ -94,4 +94,4 @@ def test_wbfm_handoff_repair_on_periodic_input(capi, oracle):
     pcm, cnt, _, _ = eng.accept(pattern)
     assert np.array_equal(pcm[0, :cnt[0]], ref)
     st = eng.stats()
-    assert st["state_repairs"] + st["state_checks"] >= 1
+    assert st["state_repairs"] >= 1 and st["state_checks"] >= 1      # repaired on the device, then chained up
