@@ -64,6 +64,7 @@ struct iqd_engine {
     bool lists_dirty = true;
     uint32_t list_first = 0, list_n = 0;
     std::vector<uint32_t> h_lists[FAM_COUNT + 1];  // per family; [FAM_COUNT] = mode None
+    uint32_t n_cus = 256;
     bool any_gated = false, any_agc = false;
     std::vector<AgcConfig> h_agc;           // per channel; the one-shot fields are cleared once applied
     std::vector<uint8_t> agc_touched;       // the device may have moved this channel's IF gain
@@ -176,6 +177,10 @@ int iqd_create(const iqd_config *cfg, iqd_t **out)
     iqd_t *e = new (std::nothrow) iqd_engine;
     if (!e) return IQD_ENOMEM;
     e->device = dev;
+    {
+        hipDeviceProp_t prop;
+        e->n_cus = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
+    }
     e->n_ch = cfg->n_channels;
     e->block_bytes = bb;
     e->block_samples = bb / 2;
@@ -842,7 +847,9 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         ChainLaunch a = base;
         a.ch_list = e->lists[f].as<uint32_t>();
         a.n_list = n_list;
-        const TilePlan plan = plan_tiles(vlen, n_list);
+        // workgroups a CU holds at once: WBFM 3 (LDS), the others 4 (registers)
+        const TilePlan plan = f == FAM_WBFM ? plan_tiles(vlen, n_list, WBFM_CHUNK, COLD_HALO, 3 * e->n_cus)
+                                            : plan_tiles(vlen, n_list, CH_CHUNK, FIR_HALO, 4 * e->n_cus);
         a.tile_len = plan.tile_len;
         a.tiles_per_ch = plan.tiles_per_ch;
         if (e->profiling && !timed) {

@@ -1,4 +1,5 @@
 #include "iqd_host.h"
+#include <stdlib.h>
 
 #include <math.h>
 #include <string.h>
@@ -151,23 +152,35 @@ bool squelch_always_open(const ChanParams &p, const Consts &c)
     return true;
 }
 
-TilePlan plan_tiles(uint32_t vlen, uint32_t n_channels)
+TilePlan plan_tiles(uint32_t vlen, uint32_t n_channels, uint32_t chunk, uint32_t halo, uint32_t resident_wgs)
 {
-    // One workgroup per tile.  Tiles are as long as possible (the lead-in of COLD_HALO samples
-    // is redone per tile) while the launch still has a few thousand workgroups to fill 256 CUs.
-    const uint32_t max_tile = 8 * WBFM_CHUNK;   // 61440 samples
-    const uint32_t min_tile = WBFM_CHUNK;
-    const uint32_t want_wgs = 3072;
+    // One workgroup per tile, a tile = k whole chunks.  The launch runs in "rounds" of resident_wgs workgroups;
+    // each round costs the tile plus its lead-in, and a partly filled last round costs as much as a full one.
+    // Pick the k with the least total; ties go to the longer tile (less lead-in work overall).
     TilePlan p;
-    if (vlen == 0 || n_channels == 0) { p.tile_len = min_tile; p.tiles_per_ch = 1; return p; }
-    uint32_t tiles = (vlen + max_tile - 1) / max_tile;
-    const uint32_t want = (want_wgs + n_channels - 1) / n_channels;
-    const uint32_t most = vlen / min_tile ? vlen / min_tile : 1;
-    if (tiles < want) tiles = want < most ? want : most;
-    uint32_t len = (vlen + tiles - 1) / tiles;
-    len = (len + SEG - 1) / SEG * SEG;
-    p.tile_len = len;
-    p.tiles_per_ch = (vlen + len - 1) / len;
+    p.tile_len = chunk;
+    p.tiles_per_ch = 1;
+    if (vlen == 0 || n_channels == 0) return p;
+    if (resident_wgs == 0) resident_wgs = 768;
+    const uint32_t overhead = chunk / 4;   // set-up, pipeline fill and drain of a tile, in samples
+    uint64_t best = ~0ull;
+    for (uint32_t k = 1; k <= 24; k++) {
+        const uint64_t len = (uint64_t)k * chunk;
+        const uint64_t per_ch = (vlen + len - 1) / len;
+        const uint64_t rounds = (per_ch * n_channels + resident_wgs - 1) / resident_wgs;
+        const uint64_t longest = len < vlen ? len : vlen;
+        const uint64_t cost = rounds * (longest + halo + overhead);
+        if (cost <= best) {
+            best = cost;
+            p.tile_len = (uint32_t)len;
+            p.tiles_per_ch = (uint32_t)per_ch;
+        }
+        if (len >= vlen) break;
+    }
+    if (const char *ov = getenv("IQD_PLAN_CHUNKS")) {   // experiments: force k chunks per tile
+        const uint32_t k = (uint32_t)atoi(ov);
+        if (k) { p.tile_len = k * chunk; p.tiles_per_ch = (vlen + p.tile_len - 1) / p.tile_len; }
+    }
     return p;
 }
 
