@@ -212,6 +212,26 @@ const char *iqd_last_error(iqd_t *e);
 const char *iqd_strerror(int status);
 uint32_t iqd_abi_version(void);
 
+/* The reference's stand-alone resampler classes (not used by any demodulator), block-wise and for
+ * n_channels independent streams at once.  A resampler replaces, per channel, one object of
+ *   IQD_RESAMPLE_DECIMATE_F32     Decimator(filterLength, coefficients, decimationFactor), Filters/Decimator.cc:
+ *                                 one output per `factor` inputs, when the last of them arrives (:283-321);
+ *   IQD_RESAMPLE_INTERPOLATE_F32  Interpolator(...), Filters/Interpolator.cc: `factor` outputs per input (:340-364);
+ *   IQD_RESAMPLE_INTERPOLATE_I16  Interpolator_int16(...), Filters/Int16/Interpolator_int16.cc: the same in Q15
+ *                                 with the per-MAC clamp (:203-246); int16 in and out,
+ * and a call with n_in samples per channel replaces n_in decimate()/interpolate() calls; the filter state (and the
+ * decimator's commutator phase) carries over to the next call.  Layouts: in [n_channels][n_in], out
+ * [n_channels][iqd_resampler_out_count(r, n_in)].  iqd_resampler_reset = resetFilterState(). */
+enum iqd_resample_kind { IQD_RESAMPLE_DECIMATE_F32 = 0, IQD_RESAMPLE_INTERPOLATE_F32 = 1, IQD_RESAMPLE_INTERPOLATE_I16 = 2 };
+typedef struct iqd_resampler iqd_resampler_t;
+int iqd_resampler_create(iqd_t *e, int kind, const float *taps, uint32_t n_taps, uint32_t factor, uint32_t n_channels,
+                         iqd_resampler_t **out);
+void iqd_resampler_destroy(iqd_resampler_t *r);
+int iqd_resampler_reset(iqd_resampler_t *r);
+size_t iqd_resampler_out_count(const iqd_resampler_t *r, size_t n_in);
+int iqd_resampler_run(iqd_resampler_t *r, const void *in, size_t n_in, void *out);                 /* host pointers */
+int iqd_resampler_run_device(iqd_resampler_t *r, const void *in_dev, size_t n_in, void *out_dev);  /* queued on the engine's stream */
+
 /* Small device-memory helpers so that non-HIP hosts (ctypes, cgo, JNI) can stage
  * device-resident buffers for iqd_accept_iq_device without linking the HIP runtime. */
 int iqd_dev_alloc(iqd_t *e, size_t bytes, void **out);

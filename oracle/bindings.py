@@ -131,6 +131,9 @@ class Oracle:
         _sig(L.iqo_fir_f32, None, [vp, C.c_int, vp, sz, vp])
         _sig(L.iqo_iir_f32, None, [vp, C.c_int, vp, C.c_int, vp, sz, vp])
         _sig(L.iqo_rotate, None, [vp, sz, C.c_int])
+        _sig(L.iqo_decimate_f32, C.c_long, [vp, C.c_int, C.c_int, vp, sz, vp])
+        _sig(L.iqo_interpolate_f32, None, [vp, C.c_int, C.c_int, vp, sz, vp])
+        _sig(L.iqo_interpolate_q15, None, [vp, C.c_int, C.c_int, vp, sz, vp])
         _sig(L.iqo_atan2_lut, None, [vp])
         _sig(L.iqo_fm_theta_lut, None, [vp, C.c_int])
         _sig(L.iqo_db_table, None, [vp])
@@ -197,6 +200,24 @@ class Oracle:
         x = np.ascontiguousarray(x, dtype=np.float32)
         out = np.zeros(len(x), dtype=np.float32)
         self.lib.iqo_iir_f32(_ptr(b), len(b), _ptr(a), len(a), _ptr(x), len(x), _ptr(out))
+        return out
+
+    def decimate_f32(self, taps, factor, x):
+        taps, x = np.ascontiguousarray(taps, np.float32), np.ascontiguousarray(x, np.float32)
+        out = np.zeros(len(x) // factor + 1, np.float32)
+        n = self.lib.iqo_decimate_f32(_ptr(taps), len(taps), factor, _ptr(x), len(x), _ptr(out))
+        return out[:n].copy()
+
+    def interpolate_f32(self, taps, factor, x):
+        taps, x = np.ascontiguousarray(taps, np.float32), np.ascontiguousarray(x, np.float32)
+        out = np.zeros(len(x) * factor, np.float32)
+        self.lib.iqo_interpolate_f32(_ptr(taps), len(taps), factor, _ptr(x), len(x), _ptr(out))
+        return out
+
+    def interpolate_q15(self, taps, factor, x):
+        taps, x = np.ascontiguousarray(taps, np.float32), np.ascontiguousarray(x, np.int16)
+        out = np.zeros(len(x) * factor, np.int16)
+        self.lib.iqo_interpolate_q15(_ptr(taps), len(taps), factor, _ptr(x), len(x), _ptr(out))
         return out
 
     def rotate(self, s8, rotation):
@@ -271,6 +292,9 @@ class Reference:
         _sig(L.ref_fir_int16, None, [vp, C.c_int, vp, sz, vp])
         _sig(L.ref_fir_f32, None, [vp, C.c_int, vp, sz, vp])
         _sig(L.ref_iir_f32, None, [vp, C.c_int, vp, C.c_int, vp, sz, vp])
+        _sig(L.ref_decimator_f32, C.c_long, [vp, C.c_int, C.c_int, vp, sz, vp])
+        _sig(L.ref_interpolator_f32, None, [vp, C.c_int, C.c_int, vp, sz, vp])
+        _sig(L.ref_interpolator_int16, None, [vp, C.c_int, C.c_int, vp, sz, vp])
         _sig(L.ref_squelch_create, vp, [C.c_int32])
         _sig(L.ref_squelch_destroy, None, [vp])
         _sig(L.ref_squelch_run, C.c_int, [vp, C.c_uint32, vp, C.c_uint32, vp])
@@ -321,6 +345,24 @@ class Reference:
         out = np.zeros(len(x) // factor + 1, dtype=np.int16)
         n = self.lib.ref_decimator_int16(_ptr(taps), len(taps), factor, _ptr(x), len(x), _ptr(out))
         return out[:n].copy()
+
+    def decimate_f32(self, taps, factor, x):
+        taps, x = np.ascontiguousarray(taps, np.float32), np.ascontiguousarray(x, np.float32)
+        out = np.zeros(len(x) // factor + 1, np.float32)
+        n = self.lib.ref_decimator_f32(_ptr(taps), len(taps), factor, _ptr(x), len(x), _ptr(out))
+        return out[:n].copy()
+
+    def interpolate_f32(self, taps, factor, x):
+        taps, x = np.ascontiguousarray(taps, np.float32), np.ascontiguousarray(x, np.float32)
+        out = np.zeros(len(x) * factor, np.float32)
+        self.lib.ref_interpolator_f32(_ptr(taps), len(taps), factor, _ptr(x), len(x), _ptr(out))
+        return out
+
+    def interpolate_q15(self, taps, factor, x):
+        taps, x = np.ascontiguousarray(taps, np.float32), np.ascontiguousarray(x, np.int16)
+        out = np.zeros(len(x) * factor, np.int16)
+        self.lib.ref_interpolator_int16(_ptr(taps), len(taps), factor, _ptr(x), len(x), _ptr(out))
+        return out
 
     def fir_q15(self, taps, x):
         taps = np.ascontiguousarray(taps, dtype=np.float32)

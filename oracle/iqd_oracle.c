@@ -615,6 +615,70 @@ static size_t ssb_run(iqo_chain *c, ssb_t *s, const int8_t *iq, size_t n, int16_
 /* Chain = IqDataProcessor                                                    */
 /* ------------------------------------------------------------------------ */
 /* ------------------------------------------------------------------------ */
+/* Float / int16 resamplers (Filters/Decimator.cc, Interpolator.cc,           */
+/* Int16/Interpolator_int16.cc): streams from the zero state                 */
+/* ------------------------------------------------------------------------ */
+/* Decimator::decimate :283-321 -> filterData :176-214: y = 0; y = y + h[k]*x[n-k], k ascending, binary32;
+ * one output per `factor` inputs, taken when the last of them arrives. */
+long iqo_decimate_f32(const float *h, int length, int factor, const float *in, size_t n, float *out)
+{
+    size_t m = 0, i;
+    for (i = (size_t)factor - 1; i < n; i += (size_t)factor) {
+        float y = 0;
+        int k;
+        for (k = 0; k < length; k++) {
+            const float x = (size_t)k <= i ? in[i - (size_t)k] : 0.0f;
+            y = y + (h[k] * x);
+        }
+        out[m++] = y;
+    }
+    return (long)m;
+}
+
+/* Interpolator::interpolate :340-364 with createPolyphaseCoefficients :263-300: sub-filter i holds
+ * h[i], h[i+L], ...; q = length / L taps each (integer division); L outputs per input. */
+void iqo_interpolate_f32(const float *h, int length, int factor, const float *in, size_t n, float *out)
+{
+    const int q = length / factor;
+    size_t i;
+    for (i = 0; i < n; i++) {
+        int p, k;
+        for (p = 0; p < factor; p++) {
+            float y = 0;
+            for (k = 0; k < q; k++) {
+                const float x = (size_t)k <= i ? in[i - (size_t)k] : 0.0f;
+                y = y + (h[p + k * factor] * x);
+            }
+            out[i * (size_t)factor + (size_t)p] = y;
+        }
+    }
+}
+
+/* Interpolator_int16: taps quantised like every Q15 filter (createPolyphaseCoefficients :270-296), then the
+ * Q15 accumulator with its per-MAC clamp (filterData :203-246). */
+void iqo_interpolate_q15(const float *h, int length, int factor, const int16_t *in, size_t n, int16_t *out)
+{
+    const int q = length / factor;
+    int16_t hq[1024];
+    size_t i;
+    if (length > 1024) return;
+    iqo_quantize_taps(h, length, hq);
+    for (i = 0; i < n; i++) {
+        int p, k;
+        for (p = 0; p < factor; p++) {
+            int32_t acc = 1 << 14;
+            for (k = 0; k < q; k++) {
+                const int32_t x = (size_t)k <= i ? in[i - (size_t)k] : 0;
+                acc = acc + ((int32_t)hq[p + k * factor] * x);
+                if (acc > 0x3fffffff) acc = 0x3fffffff;
+                if (acc < -0x40000000) acc = -0x40000000;
+            }
+            out[i * (size_t)factor + (size_t)p] = (int16_t)(acc >> 15);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------ */
 /* AutomaticGainControl (src_diags/AutomaticGainControl.cc)                   */
 /* ------------------------------------------------------------------------ */
 #define AGC_MAX_GAIN 46 /* MAX_ADJUSTIBLE_GAIN, AutomaticGainControl.cc:23 */

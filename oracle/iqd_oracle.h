@@ -101,6 +101,10 @@ void iqo_fir_q15(const float *h, int length, const int16_t *in, size_t n, int16_
 void iqo_fir_f32(const float *h, int length, const float *in, size_t n, float *out);
 void iqo_iir_f32(const float *b, int nb, const float *a, int na,
                  const float *in, size_t n, float *out);
+/* Float Decimator / Interpolator and Interpolator_int16 (Filters/), whole streams from the zero state */
+long iqo_decimate_f32(const float *h, int length, int factor, const float *in, size_t n, float *out);
+void iqo_interpolate_f32(const float *h, int length, int factor, const float *in, size_t n, float *out);
+void iqo_interpolate_q15(const float *h, int length, int factor, const int16_t *in, size_t n, int16_t *out);
 void iqo_rotate(int8_t *buf, size_t bytes, int rotation);
 void iqo_atan2_lut(float *lut /* [256][256], lut[y][x] */);
 void iqo_fm_theta_lut(float *lut, int half_range /* lut[(q+R)*(2R+1)+(i+R)] */);

@@ -35,6 +35,9 @@
 #include "FirFilter_int16.h"
 #include "FirFilter.h"
 #include "IirFilter.h"
+#include "Decimator.h"
+#include "Interpolator.h"
+#include "Interpolator_int16.h"
 #include "Squelch.h"
 #include "DbfsCalculator.h"
 #include "AutomaticGainControl.h"
@@ -410,6 +413,33 @@ void ref_iir_f32(const float *num, int numLength, const float *den, int denLengt
 {
   IirFilter f(numLength, (float *)num, denLength, (float *)den);
   for (size_t i = 0; i < n; i++) out[i] = f.filterData(in[i]);
+}
+
+// Float Decimator (Filters/Decimator.cc): returns the output count.
+long ref_decimator_f32(const float *taps, int length, int factor, const float *in, size_t n, float *out)
+{
+  Decimator d(length, (float *)taps, factor);
+  size_t m = 0;
+  for (size_t i = 0; i < n; i++)
+  {
+    float y;
+    if (d.decimate(in[i], &y)) out[m++] = y;
+  }
+  return (long)m;
+}
+
+// Float Interpolator (Filters/Interpolator.cc): n * factor outputs.
+void ref_interpolator_f32(const float *taps, int length, int factor, const float *in, size_t n, float *out)
+{
+  Interpolator p(length, (float *)taps, factor);
+  for (size_t i = 0; i < n; i++) p.interpolate(in[i], out + i * (size_t)factor);
+}
+
+// Interpolator_int16 (Filters/Int16/Interpolator_int16.cc).
+void ref_interpolator_int16(const float *taps, int length, int factor, const int16_t *in, size_t n, int16_t *out)
+{
+  Interpolator_int16 p(length, (float *)taps, factor);
+  for (size_t i = 0; i < n; i++) p.interpolate(in[i], out + i * (size_t)factor);
 }
 
 // Squelch (Squelch.cc / SignalDetector.cc / SignalTracker.cc) on signed data.

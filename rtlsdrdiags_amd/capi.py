@@ -53,6 +53,8 @@ EXPORTS = [
     "iqd_agc_set_operating_point", "iqd_agc_set_filter_coefficient", "iqd_agc_enable", "iqd_agc_get_state",
     "iqd_set_gain_trace", "iqd_get_gain_trace", "iqd_scanner_set_parameters", "iqd_scanner_start",
     "iqd_scanner_get", "iqd_get_frequency_trace", "iqd_front_end", "iqd_front_end_device",
+    "iqd_resampler_create", "iqd_resampler_destroy", "iqd_resampler_reset", "iqd_resampler_out_count",
+    "iqd_resampler_run", "iqd_resampler_run_device",
 ]
 
 _LIB = None
@@ -86,6 +88,14 @@ def _lib():
     L.iqd_accept_iq_device.argtypes = [vp, u32, u32, vp, sz, vp, vp, vp, vp]
     L.iqd_synchronize.argtypes = [vp]
     L.iqd_front_end.argtypes = [vp, u32, u32, vp, sz, vp]
+    L.iqd_resampler_create.argtypes = [vp, C.c_int, vp, u32, u32, u32, C.POINTER(vp)]
+    L.iqd_resampler_destroy.argtypes = [vp]
+    L.iqd_resampler_destroy.restype = None
+    L.iqd_resampler_reset.argtypes = [vp]
+    L.iqd_resampler_out_count.argtypes = [vp, sz]
+    L.iqd_resampler_out_count.restype = sz
+    L.iqd_resampler_run.argtypes = [vp, vp, sz, vp]
+    L.iqd_resampler_run_device.argtypes = [vp, vp, sz, vp]
     L.iqd_front_end_device.argtypes = [vp, u32, u32, vp, sz, vp]
     L.iqd_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.iqd_set_profiling.argtypes = [vp, C.c_int]
@@ -354,3 +364,33 @@ class Engine:
 
     def dev_tile(self, dst, period, total):
         self._check(self._L.iqd_dev_tile(self._h, C.c_void_p(dst), period, total))
+
+
+class Resampler:
+    """Block-wise Decimator / Interpolator / Interpolator_int16 for n_channels streams (include/iqdemod.h)."""
+    KINDS = {"decimate_f32": 0, "interpolate_f32": 1, "interpolate_i16": 2}
+
+    def __init__(self, engine, kind, taps, factor, n_channels=1):
+        self._e, self._L = engine, engine._L
+        self.kind, self.n_ch = self.KINDS[kind], n_channels
+        taps = np.ascontiguousarray(taps, np.float32)
+        h = C.c_void_p()
+        engine._check(self._L.iqd_resampler_create(engine._h, self.kind, _np_ptr(taps), len(taps), int(factor),
+                                                   n_channels, C.byref(h)))
+        self._h = h
+        self.dtype = np.int16 if self.kind == 2 else np.float32
+
+    def run(self, x):
+        x = np.ascontiguousarray(x, self.dtype).reshape(self.n_ch, -1)
+        out = np.zeros((self.n_ch, self._L.iqd_resampler_out_count(self._h, x.shape[1])), self.dtype)
+        self._e._check(self._L.iqd_resampler_run(self._h, _np_ptr(x), x.shape[1], _np_ptr(out)))
+        return out
+
+    def reset(self):
+        self._e._check(self._L.iqd_resampler_reset(self._h))
+
+    def close(self):
+        if self._h:
+            self._L.iqd_resampler_destroy(self._h)
+            self._h = None
+

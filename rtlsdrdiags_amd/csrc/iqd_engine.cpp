@@ -694,6 +694,119 @@ int iqd_front_end(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const uint8_t *iq,
     return IQD_OK;
 }
 
+// ---- resamplers (Filters/Decimator.cc, Interpolator.cc, Int16/Interpolator_int16.cc) ---------------------
+}  // extern "C"
+
+struct iqd_resampler {
+    iqd_t *e = nullptr;
+    int kind = 0;
+    uint32_t n_ch = 0, factor = 1, n_taps = 0 /* per output */, hist_len = 0, elem = 4;
+    uint64_t count = 0;          // samples accepted so far (the decimator's commutator phase)
+    DevBuf taps, hist[2], st_in, st_out;
+    int cur = 0;
+};
+
+extern "C" {
+
+int iqd_resampler_create(iqd_t *e, int kind, const float *taps, uint32_t n_taps, uint32_t factor, uint32_t n_channels,
+                         iqd_resampler_t **out)
+{
+    if (!e || !taps || !out || kind < IQD_RESAMPLE_DECIMATE_F32 || kind > IQD_RESAMPLE_INTERPOLATE_I16 || n_taps == 0 ||
+        factor == 0 || n_channels == 0)
+        return e ? e->fail(IQD_EINVAL, "bad resampler parameters") : IQD_EINVAL;
+    (void)hipSetDevice(e->device);
+    iqd_resampler *r = new (std::nothrow) iqd_resampler;
+    if (!r) return IQD_ENOMEM;
+    r->e = e; r->kind = kind; r->n_ch = n_channels; r->factor = factor;
+    r->elem = kind == IQD_RESAMPLE_INTERPOLATE_I16 ? 2 : 4;
+    std::vector<float> tf;
+    std::vector<int16_t> tq;
+    if (kind == IQD_RESAMPLE_DECIMATE_F32) {
+        r->n_taps = n_taps;
+        tf.assign(taps, taps + n_taps);
+    } else {   // polyphase order: sub-filter p holds h[p], h[p+L], ... (createPolyphaseCoefficients)
+        const uint32_t q = n_taps / factor;
+        if (q == 0) { delete r; return e->fail(IQD_EINVAL, "an interpolator needs at least `factor` taps"); }
+        r->n_taps = q;
+        std::vector<int16_t> hq(n_taps);
+        if (kind == IQD_RESAMPLE_INTERPOLATE_I16) quantize_q15(taps, (int)n_taps, hq.data());
+        for (uint32_t p = 0; p < factor; p++)
+            for (uint32_t k = 0; k < q; k++) {
+                if (kind == IQD_RESAMPLE_INTERPOLATE_I16) tq.push_back(hq[p + k * factor]);
+                else tf.push_back(taps[p + k * factor]);
+            }
+    }
+    r->hist_len = r->n_taps;   // one more than strictly needed; keeps the indexing plain
+    const void *src = tq.empty() ? (const void *)tf.data() : (const void *)tq.data();
+    const size_t tbytes = tq.empty() ? tf.size() * sizeof(float) : tq.size() * sizeof(int16_t);
+    bool ok = r->taps.ensure(tbytes) == hipSuccess;
+    for (int b = 0; b < 2 && ok; b++) ok = r->hist[b].ensure((size_t)r->n_ch * r->hist_len * r->elem) == hipSuccess;
+    ok = ok && hipMemcpy(r->taps.p, src, tbytes, hipMemcpyHostToDevice) == hipSuccess;
+    ok = ok && hipMemset(r->hist[0].p, 0, (size_t)r->n_ch * r->hist_len * r->elem) == hipSuccess;
+    if (!ok) { iqd_resampler_destroy(r); return e->fail(IQD_ENOMEM, "resampler allocation failed"); }
+    *out = r;
+    return IQD_OK;
+}
+
+void iqd_resampler_destroy(iqd_resampler_t *r)
+{
+    if (!r) return;
+    (void)hipSetDevice(r->e->device);
+    (void)hipStreamSynchronize(r->e->stream);
+    r->taps.release(); r->hist[0].release(); r->hist[1].release(); r->st_in.release(); r->st_out.release();
+    delete r;
+}
+
+int iqd_resampler_reset(iqd_resampler_t *r)   // resetFilterState()
+{
+    if (!r) return IQD_EINVAL;
+    (void)hipSetDevice(r->e->device);
+    HIP_TRY(r->e, hipMemsetAsync(r->hist[r->cur].p, 0, (size_t)r->n_ch * r->hist_len * r->elem, r->e->stream));
+    r->count = 0;
+    return IQD_OK;
+}
+
+size_t iqd_resampler_out_count(const iqd_resampler_t *r, size_t n_in)
+{
+    if (!r) return 0;
+    if (r->kind != IQD_RESAMPLE_DECIMATE_F32) return n_in * r->factor;
+    return (size_t)((r->count % r->factor + n_in) / r->factor);
+}
+
+int iqd_resampler_run_device(iqd_resampler_t *r, const void *in_dev, size_t n_in, void *out_dev)
+{
+    if (!r || !in_dev || !out_dev) return IQD_EINVAL;
+    iqd_t *e = r->e;
+    if (n_in == 0) return IQD_OK;
+    if (n_in > 0x7fffffffu / r->factor) return e->fail(IQD_EINVAL, "too many samples in one call");
+    (void)hipSetDevice(e->device);
+    const uint32_t n_out = (uint32_t)iqd_resampler_out_count(r, n_in);
+    const uint32_t phase = (uint32_t)(r->count % r->factor);
+    const uint32_t first = r->factor - 1 - phase;   // decimator: input index that completes the first group
+    HIP_TRY(e, launch_resample(r->kind, in_dev, out_dev, r->hist[r->cur].p, r->hist[r->cur ^ 1].p, r->taps.p, r->n_ch,
+                               (uint32_t)n_in, n_out, r->hist_len, r->n_taps, r->factor, first, e->stream));
+    r->cur ^= 1;
+    r->count += n_in;
+    return IQD_OK;
+}
+
+int iqd_resampler_run(iqd_resampler_t *r, const void *in, size_t n_in, void *out)
+{
+    if (!r || !in || !out) return IQD_EINVAL;
+    iqd_t *e = r->e;
+    (void)hipSetDevice(e->device);
+    const size_t n_out = iqd_resampler_out_count(r, n_in);
+    const size_t ib = (size_t)r->n_ch * n_in * r->elem, ob = (size_t)r->n_ch * n_out * r->elem;
+    HIP_TRY(e, r->st_in.ensure(ib ? ib : 16));
+    HIP_TRY(e, r->st_out.ensure(ob ? ob : 16));
+    HIP_TRY(e, hipMemcpyAsync(r->st_in.p, in, ib, hipMemcpyHostToDevice, e->stream));
+    int rc = iqd_resampler_run_device(r, r->st_in.p, n_in, r->st_out.p);
+    if (rc != IQD_OK) return rc;
+    if (ob) HIP_TRY(e, hipMemcpyAsync(out, r->st_out.p, ob, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    return IQD_OK;
+}
+
 int iqd_host_alloc(iqd_t *e, size_t bytes, void **out)
 {
     if (!e || !out || bytes == 0) return IQD_EINVAL;

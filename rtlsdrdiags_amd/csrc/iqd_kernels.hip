@@ -611,6 +611,100 @@ __global__ void front_end_kernel(const uint8_t *iq, int8_t *out, const ChanParam
     ((u32x2 *)out)[idx] = r;
 }
 
+// ---- float / int16 resamplers (Filters/Decimator.cc, Interpolator.cc, Int16/Interpolator_int16.cc) ----------
+// FIR only: every output is its own sequential sum over the samples behind it, so one thread per output and
+// channel; the samples come from [history | this call's input].  `hist` holds the last `hist_len` samples of
+// the stream before this call (zeros at the stream start).  Accumulation order and rounding are the reference's.
+struct ResampleLaunch {
+    const void *in;        // [n_ch][n_in]
+    void *out;             // [n_ch][n_out]
+    const void *hist;      // [n_ch][hist_len]
+    void *hist_next;       // [n_ch][hist_len]: the history after this call
+    const void *taps;      // float taps, or int16 Q15 taps for the int16 interpolator (polyphase order for both interpolators)
+    uint32_t n_ch, n_in, n_out, hist_len, n_taps, factor, first;   // first: input index of the first decimator output
+};
+
+template <class T>
+__device__ __forceinline__ T resample_sample(const ResampleLaunch &a, uint32_t ch, int64_t idx)   // idx < 0: history
+{
+    if (idx >= 0) return ((const T *)a.in)[(size_t)ch * a.n_in + idx];
+    const int64_t h = (int64_t)a.hist_len + idx;
+    return h >= 0 ? ((const T *)a.hist)[(size_t)ch * a.hist_len + h] : (T)0;
+}
+
+// Decimator::decimate -> filterData (Decimator.cc:176-214, :283-321): y = 0; y = y + h[k] * x[n-k]
+__global__ void decimate_f32_kernel(const ResampleLaunch a)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)a.n_ch * a.n_out) return;
+    const uint32_t ch = (uint32_t)(t / a.n_out), j = (uint32_t)(t - (size_t)ch * a.n_out);
+    const int64_t n = (int64_t)a.first + (int64_t)j * a.factor;
+    const float *h = (const float *)a.taps;
+    float y = 0;
+    for (uint32_t k = 0; k < a.n_taps; k++) y = y + (h[k] * resample_sample<float>(a, ch, n - k));
+    ((float *)a.out)[t] = y;
+}
+
+// Interpolator::interpolate -> filterData(sub-filter) (Interpolator.cc:166-196, :340-364); taps in polyphase order
+__global__ void interpolate_f32_kernel(const ResampleLaunch a)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)a.n_ch * a.n_out) return;
+    const uint32_t ch = (uint32_t)(t / a.n_out), j = (uint32_t)(t - (size_t)ch * a.n_out);
+    const uint32_t n = j / a.factor, p = j - n * a.factor;
+    const float *h = (const float *)a.taps + (size_t)p * a.n_taps;   // n_taps = taps per sub-filter
+    float y = 0;
+    for (uint32_t k = 0; k < a.n_taps; k++) y = y + (h[k] * resample_sample<float>(a, ch, (int64_t)n - k));
+    ((float *)a.out)[t] = y;
+}
+
+// Interpolator_int16::filterData (Interpolator_int16.cc:203-246): Q15, rounding term, clamp after every MAC
+__global__ void interpolate_i16_kernel(const ResampleLaunch a)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)a.n_ch * a.n_out) return;
+    const uint32_t ch = (uint32_t)(t / a.n_out), j = (uint32_t)(t - (size_t)ch * a.n_out);
+    const uint32_t n = j / a.factor, p = j - n * a.factor;
+    const int16_t *h = (const int16_t *)a.taps + (size_t)p * a.n_taps;
+    int32_t acc = 1 << 14;
+    for (uint32_t k = 0; k < a.n_taps; k++) {
+        acc = acc + ((int32_t)h[k] * (int32_t)resample_sample<int16_t>(a, ch, (int64_t)n - k));
+        acc = clamp_q30(acc);
+    }
+    ((int16_t *)a.out)[t] = (int16_t)(acc >> 15);
+}
+
+// The history after the call: the last hist_len samples of [history | input].
+template <class T>
+__global__ void resample_history_kernel(const ResampleLaunch a)
+{
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)a.n_ch * a.hist_len) return;
+    const uint32_t ch = (uint32_t)(t / a.hist_len), k = (uint32_t)(t - (size_t)ch * a.hist_len);
+    ((T *)a.hist_next)[t] = resample_sample<T>(a, ch, (int64_t)a.n_in - (int64_t)a.hist_len + k);
+}
+
+hipError_t launch_resample(int kind, const void *in, void *out, const void *hist, void *hist_next, const void *taps,
+                           uint32_t n_ch, uint32_t n_in, uint32_t n_out, uint32_t hist_len, uint32_t n_taps,
+                           uint32_t factor, uint32_t first, hipStream_t s)
+{
+    ResampleLaunch a{in, out, hist, hist_next, taps, n_ch, n_in, n_out, hist_len, n_taps, factor, first};
+    const size_t n = (size_t)n_ch * n_out;
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (n) {
+        if (kind == 0) hipLaunchKernelGGL(decimate_f32_kernel, grid, block, 0, s, a);
+        else if (kind == 1) hipLaunchKernelGGL(interpolate_f32_kernel, grid, block, 0, s, a);
+        else hipLaunchKernelGGL(interpolate_i16_kernel, grid, block, 0, s, a);
+    }
+    const size_t nh = (size_t)n_ch * hist_len;
+    if (nh) {
+        const dim3 gh((unsigned)((nh + 255) / 256));
+        if (kind == 2) hipLaunchKernelGGL(resample_history_kernel<int16_t>, gh, block, 0, s, a);
+        else hipLaunchKernelGGL(resample_history_kernel<float>, gh, block, 0, s, a);
+    }
+    return hipGetLastError();
+}
+
 // Repeats the first `period` bytes of a buffer over the rest (bench input staging).
 __global__ void tile_fill_kernel(uint8_t *dst, size_t period, size_t total)
 {

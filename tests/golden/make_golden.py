@@ -129,6 +129,21 @@ def main():
     prim["rot_down"] = R.rotate(s8, -1)
     np.savez_compressed(os.path.join(OUT, "primitives.npz"), **prim)
 
+    # stand-alone resamplers: float Decimator / Interpolator, Interpolator_int16 (Filters/)
+    rs = {}
+    rng = np.random.default_rng(17)
+    rs["x"] = rng.normal(0, 2000, 3000).astype(np.float32)
+    rs["x16"] = rng.integers(-32768, 32768, 3000).astype(np.int16)
+    rs["xsat"] = np.where(rng.random(3000) < 0.5, -32768, 32767).astype(np.int16)
+    for name, n_taps, factor in [("a", 33, 4), ("b", 7, 3), ("c", 64, 8), ("d", 5, 1)]:
+        h = (rng.normal(0, 0.25, n_taps)).astype(np.float32)
+        rs["h_" + name], rs["f_" + name] = h, factor
+        rs["dec_" + name] = R.decimate_f32(h, factor, rs["x"])
+        rs["int_" + name] = R.interpolate_f32(h, factor, rs["x"])
+        rs["i16_" + name] = R.interpolate_q15(h, factor, rs["x16"])
+        rs["i16sat_" + name] = R.interpolate_q15(np.clip(4 * h, -1, 0.99997).astype(np.float32), factor, rs["xsat"])
+    np.savez_compressed(os.path.join(OUT, "resample.npz"), **rs)
+
     # AutomaticGainControl (src_diags/AutomaticGainControl.cc compiled unmodified; see oracle/ref_shim.cc):
     # operator commands + magnitudes straight into the AGC, and the AGC inside the acceptIqData flow
     sys.path.insert(0, os.path.dirname(OUT))

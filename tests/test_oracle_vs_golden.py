@@ -185,3 +185,15 @@ def test_frequency_scanner_commands_and_tuning(oracle, golden):
     assert np.array_equal(freq, g["scan_freq"]) and np.array_equal(count, g["scan_count"])
     assert np.array_equal(pcm, g["scan_pcm"]) and np.array_equal(final, g["scan_final"])
     assert count[-3] > 12 and len(set(freq.tolist())) == 4      # the scan wrapped around
+
+
+@pytest.mark.parametrize("name", ["a", "b", "c", "d"])
+def test_standalone_resamplers(oracle, golden, name):
+    """Float Decimator / Interpolator and Interpolator_int16: bit-identical floats, int16 clamps."""
+    g = golden["resample"]
+    h, f = g["h_" + name], int(g["f_" + name])
+    assert np.array_equal(oracle.decimate_f32(h, f, g["x"]).view(np.uint32), g["dec_" + name].view(np.uint32))
+    assert np.array_equal(oracle.interpolate_f32(h, f, g["x"]).view(np.uint32), g["int_" + name].view(np.uint32))
+    assert np.array_equal(oracle.interpolate_q15(h, f, g["x16"]), g["i16_" + name])
+    hs = np.clip(4 * h, -1, 0.99997).astype(np.float32)
+    assert np.array_equal(oracle.interpolate_q15(hs, f, g["xsat"]), g["i16sat_" + name])
