@@ -11,7 +11,7 @@ namespace iqd {
 struct WbfmStart;
 struct WbfmRecord;
 
-enum Counter { CNT_TILE_MISMATCH = 0, CNT_TILE_CHECKS = 1, CNT_SEG_REPAIRS = 2, CNT_DC_REDO = 3, CNT_TILE_REPAIRS = 4, CNT_TILE_SOFT = 5, CNT_COUNT = 8 };
+enum Counter { CNT_TILE_MISMATCH = 0, CNT_TILE_CHECKS = 1, CNT_SEG_REPAIRS = 2, CNT_DC_REDO = 3, CNT_TILE_REPAIRS = 4, CNT_COUNT = 8 };
 constexpr uint32_t MAX_MISMATCH_LIST = 1024;
 
 // One chain launch = the channels of one demodulator family inside one accept call.

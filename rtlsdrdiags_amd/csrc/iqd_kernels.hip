@@ -162,27 +162,7 @@ __global__ __launch_bounds__(WB_THREADS, IQD_WBFM_MIN_WAVES) void wbfm_repair_ke
     WbfmRecord *r = a.records + (size_t)li * a.tiles_per_ch;
     for (uint32_t tile = 1; tile < ntiles; tile++) {
         const WbfmRecord prev = r[tile - 1];
-        WbfmRecord cur = r[tile];
-        if (f2u(cur.y_in) == f2u(prev.y_out)) continue;
-        // Both states far below anything the input can produce (digital silence, a noiseless carrier: the true
-        // state creeps down to a denormal and sticks, a cold tile sits at 0): the next nonzero input absorbs
-        // either of them completely, and until then every (int16)y is 0 - the tile's PCM is already exact, only
-        // the recorded states need the zero-input decay of the true state.  No re-run.
-        const float k = a.params[a.first_ch + ch].wbfm_k;
-        if (k >= 1.0f && fabsf(prev.y_out) < 0x1p-100f && fabsf(cur.y_in) < 0x1p-100f) {
-            if (threadIdx.x == 0) {
-                const uint32_t tlen = vlen - tile * a.tile_len < a.tile_len ? vlen - tile * a.tile_len : a.tile_len;
-                cur.y_in = prev.y_out;
-                const bool merged_mid = (cur.pad[0] & 1u) != 0;
-                if (!merged_mid) cur.y_out = iir_decay(g_consts, prev.y_out, (int)tlen);          // restart point to restart point
-                if (!merged_mid && !(cur.pad[0] & 2u)) cur.y_end = iir_decay(g_consts, cur.y_out, cur.back_out);
-                r[tile] = cur;
-                atomicAdd(&a.counters[CNT_TILE_SOFT], 1u);
-            }
-            __threadfence();
-            __syncthreads();
-            continue;
-        }
+        if (f2u(r[tile].y_in) == f2u(prev.y_out)) continue;
         WbfmStart start;
         start.y = prev.y_out; start.u = prev.u_out; start.back = prev.back_out; start.cold = 0;
         wbfm_run_tile<GATED, false>(a, lds, li, tile, ch, vlen, start);

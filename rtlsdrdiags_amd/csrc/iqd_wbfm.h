@@ -50,7 +50,6 @@ struct WbfmLds {
     uint32_t mag[WBFM_CHUNK / SEG + 2];    // squelch magnitude partial sums per block slot
     uint32_t repair_count;
     uint32_t sync_ctr;                     // arrivals at the waves-1-3 rendezvous (monotonic)
-    uint32_t nz_flags;                     // bit 0: some nonzero IIR input in [own restart point, record point), bit 1: behind it
     float part[WBFM_CHUNK / 16];           // per 16-sample group: sum c^(15-k) u[k], input of the IIR state guess
     uint32_t y2_peak, y2_peak_hist;        // max |y2| of this chunk (if loud) / reaching into the next
 };
@@ -366,15 +365,6 @@ IQD_DEV void wbfm_flush_mag(const WbfmTile &t, WbfmLds &lds, const ChunkBlocks &
     }
 }
 
-IQD_DEV void lds_or(uint32_t *slot, uint32_t v)
-{
-#if IQD_ON_DEVICE
-    atomicOr(slot, v);
-#else
-    *slot |= v;
-#endif
-}
-
 // ---- de-emphasis IIR -----------------------------------------------------------------------
 IQD_DEV float t_last(const WbfmLds &lds, int seg) { return u2f(lds.t4[t_slot(seg, 31)].w); }
 
@@ -407,15 +397,6 @@ IQD_DEV void iir_guess(const Consts &c, WbfmLds &lds, int nseg, int lane, const 
         y = tn_ - r_;              \
         up = (U);                  \
     }
-// the same, also collecting the bits of the recurrence's input (is any of it nonzero?)
-#define IQD_IIR_STEP_NZ(U)         \
-    {                              \
-        const float tn_ = (U) + up; \
-        const float r_ = a1 * y;   \
-        nz |= f2u(tn_);            \
-        y = tn_ - r_;              \
-        up = (U);                  \
-    }
 
 // lane j >= 1: run segment j-1 from the guessed state to get the state entering segment j.
 IQD_DEV void iir_warm(const Consts &c, WbfmLds &lds, int nseg, int lane)
@@ -441,11 +422,9 @@ IQD_DEV void iir_warm(const Consts &c, WbfmLds &lds, int nseg, int lane)
 // lane j: the real pass over segment j from g[j]; writes (int16)y and e[j].
 // bounded: the host proved |y| < 2^31 for this launch (|K| pi * 1.01 < 2^31), so the cast needs
 // no "integer indefinite" handling.
-// Returns the OR of the bits of every recurrence input u[n] + u[n-1] of the segment (sign bit included).
-IQD_DEV uint32_t iir_real(const Consts &c, WbfmLds &lds, int nseg, int lane, bool bounded)
+IQD_DEV void iir_real(const Consts &c, WbfmLds &lds, int nseg, int lane, bool bounded)
 {
-    if (lane >= nseg) return 0;
-    uint32_t nz = 0;
+    if (lane >= nseg) return;
     u32x4 *dst = (u32x4 *)&lds.w[lane * WSTRIDE];
     float up = iir_u_before(lds, lane), y = lds.g[lane];
     const float a1 = c.deemph_a1;
@@ -454,61 +433,35 @@ IQD_DEV uint32_t iir_real(const Consts &c, WbfmLds &lds, int nseg, int lane, boo
         for (int gi = 0; gi < 32; gi += 2) {
             const u32x4 a4 = lds.t4[t_slot(lane, gi)], b4 = lds.t4[t_slot(lane, gi + 1)];
             uint32_t w[8];
-            IQD_IIR_STEP_NZ(u2f(a4.x)) w[0] = cast_i16_bounded(y);
-            IQD_IIR_STEP_NZ(u2f(a4.y)) w[1] = cast_i16_bounded(y);
-            IQD_IIR_STEP_NZ(u2f(a4.z)) w[2] = cast_i16_bounded(y);
-            IQD_IIR_STEP_NZ(u2f(a4.w)) w[3] = cast_i16_bounded(y);
-            IQD_IIR_STEP_NZ(u2f(b4.x)) w[4] = cast_i16_bounded(y);
-            IQD_IIR_STEP_NZ(u2f(b4.y)) w[5] = cast_i16_bounded(y);
-            IQD_IIR_STEP_NZ(u2f(b4.z)) w[6] = cast_i16_bounded(y);
-            IQD_IIR_STEP_NZ(u2f(b4.w)) w[7] = cast_i16_bounded(y);
+            IQD_IIR_STEP(u2f(a4.x)) w[0] = cast_i16_bounded(y);
+            IQD_IIR_STEP(u2f(a4.y)) w[1] = cast_i16_bounded(y);
+            IQD_IIR_STEP(u2f(a4.z)) w[2] = cast_i16_bounded(y);
+            IQD_IIR_STEP(u2f(a4.w)) w[3] = cast_i16_bounded(y);
+            IQD_IIR_STEP(u2f(b4.x)) w[4] = cast_i16_bounded(y);
+            IQD_IIR_STEP(u2f(b4.y)) w[5] = cast_i16_bounded(y);
+            IQD_IIR_STEP(u2f(b4.z)) w[6] = cast_i16_bounded(y);
+            IQD_IIR_STEP(u2f(b4.w)) w[7] = cast_i16_bounded(y);
             dst[gi >> 1] = u32x4{pack_lo16(w[0], w[1]), pack_lo16(w[2], w[3]),
                                  pack_lo16(w[4], w[5]), pack_lo16(w[6], w[7])};
         }
         lds.e[lane] = y;
-        return nz;
+        return;
     }
 #pragma unroll 2
     for (int gi = 0; gi < 32; gi += 2) {
         const u32x4 a4 = lds.t4[t_slot(lane, gi)], b4 = lds.t4[t_slot(lane, gi + 1)];
         uint32_t w[8];
-        IQD_IIR_STEP_NZ(u2f(a4.x)) w[0] = (uint32_t)cast_i16(y) & 0xffffu;
-        IQD_IIR_STEP_NZ(u2f(a4.y)) w[1] = (uint32_t)cast_i16(y) << 16;
-        IQD_IIR_STEP_NZ(u2f(a4.z)) w[2] = (uint32_t)cast_i16(y) & 0xffffu;
-        IQD_IIR_STEP_NZ(u2f(a4.w)) w[3] = (uint32_t)cast_i16(y) << 16;
-        IQD_IIR_STEP_NZ(u2f(b4.x)) w[4] = (uint32_t)cast_i16(y) & 0xffffu;
-        IQD_IIR_STEP_NZ(u2f(b4.y)) w[5] = (uint32_t)cast_i16(y) << 16;
-        IQD_IIR_STEP_NZ(u2f(b4.z)) w[6] = (uint32_t)cast_i16(y) & 0xffffu;
-        IQD_IIR_STEP_NZ(u2f(b4.w)) w[7] = (uint32_t)cast_i16(y) << 16;
+        IQD_IIR_STEP(u2f(a4.x)) w[0] = (uint32_t)cast_i16(y) & 0xffffu;
+        IQD_IIR_STEP(u2f(a4.y)) w[1] = (uint32_t)cast_i16(y) << 16;
+        IQD_IIR_STEP(u2f(a4.z)) w[2] = (uint32_t)cast_i16(y) & 0xffffu;
+        IQD_IIR_STEP(u2f(a4.w)) w[3] = (uint32_t)cast_i16(y) << 16;
+        IQD_IIR_STEP(u2f(b4.x)) w[4] = (uint32_t)cast_i16(y) & 0xffffu;
+        IQD_IIR_STEP(u2f(b4.y)) w[5] = (uint32_t)cast_i16(y) << 16;
+        IQD_IIR_STEP(u2f(b4.z)) w[6] = (uint32_t)cast_i16(y) & 0xffffu;
+        IQD_IIR_STEP(u2f(b4.w)) w[7] = (uint32_t)cast_i16(y) << 16;
         dst[gi >> 1] = u32x4{w[0] | w[1], w[2] | w[3], w[4] | w[5], w[6] | w[7]};
     }
     lds.e[lane] = y;
-    return nz;
-}
-
-// After the IIR passes of a chunk: fold each segment's "nonzero input" bits into the tile's two interval flags.
-// `own` is the tile's own restart point (-FORCED_BACK for a cold tile, the start of processing otherwise).
-IQD_DEV void iir_note_nonzero(WbfmLds &lds, int nseg, int lane, uint32_t bits, int cstart, int own, int rec_pos)
-{
-    if (lane >= nseg || (bits & 0x7fffffffu) == 0) return;
-    const int pos = cstart + SEG * lane;
-    if (pos >= rec_pos) lds_or(&lds.nz_flags, 2u);
-    else if (pos >= own) lds_or(&lds.nz_flags, 1u);
-}
-
-// The de-emphasis recurrence fed with zeros (u[n] + u[n-1] = +0): n steps from y, stopping early at a fixed point
-// (a tiny state sticks at a denormal: rounding keeps 0.949 * k at k for |k| <= 9 units of 2^-149).
-IQD_DEV float iir_decay(const Consts &c, float y, int n)
-{
-    const float a1 = c.deemph_a1;
-    for (int i = 0; i < n; i++) {
-        const float tn = 0.f;
-        const float r = a1 * y;
-        const float next = tn - r;
-        if (f2u(next) == f2u(y)) break;
-        y = next;
-    }
-    return y;
 }
 
 // lane j >= 1: true when the state it started from is its neighbour's exact end state.
@@ -739,7 +692,6 @@ IQD_DEV void wbfm_tile(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLds &ld
             lds.y_carry = start.cold ? 0.f : start.y;
             lds.u_carry = start.cold ? 0.f : start.u;
             lds.repair_count = 0;
-            lds.nz_flags = 0;
             lds.y2_peak = 0;
             lds.y2_peak_hist = 0;
         }
@@ -748,7 +700,6 @@ IQD_DEV void wbfm_tile(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLds &ld
     // tile (plus its exact lead-in) is long enough, else the tile's own restart point.
     int rec_pos = t.tlen - FORCED_BACK;
     if (rec_pos < -halo) rec_pos = -halo;
-    typename Exec::template Local<uint32_t> seg_nz;   // per segment: bits of the IIR input seen by the last real pass
     WbfmRecord rec;
     rec.y_in = start.y;
     rec.y_out = start.y;
@@ -775,10 +726,9 @@ IQD_DEV void wbfm_tile(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLds &ld
             ex.stamp(2);
             int rounds = 0;
             do {
-                ex.wave0([&](int lane) { seg_nz.at(lane) = iir_real(c, lds, nseg, lane, t.bounded != 0); });
+                ex.wave0([&](int lane) { iir_real(c, lds, nseg, lane, t.bounded != 0); });
                 rounds++;
             } while (!ex.wave0_all([&](int lane) { return iir_check(lds, nseg, lane); }));
-            ex.wave0([&](int lane) { iir_note_nonzero(lds, nseg, lane, seg_nz.at(lane), cstart, start.cold ? -FORCED_BACK : -halo, rec_pos); });
             ex.stamp(3);
             if (rec_pos > cstart && rec_pos < cstart + clen) {
                 const int seg = (rec_pos - cstart) / SEG - 1;
@@ -814,8 +764,7 @@ IQD_DEV void wbfm_tile(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLds &ld
     if (ex.in_wave0() && rec_out) {
         rec.y_end = lds.y_carry;
         rec.u_end = lds.u_carry;
-        rec.pad[0] = lds.nz_flags;   // see iir_note_nonzero
-        rec.pad[1] = 0;
+        rec.pad[0] = rec.pad[1] = 0;
         ex.wave0([&](int lane) { if (lane == 0) *rec_out = rec; });
     }
 }
@@ -955,7 +904,6 @@ IQD_DEV void wbfm_tile_pipe(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLd
             lds.y_carry = start.cold ? 0.f : start.y;
             lds.u_carry = start.cold ? 0.f : start.u;
             lds.repair_count = 0;
-            lds.nz_flags = 0;
             lds.sync_ctr = 0;
             lds.y2_peak = 0;
             lds.y2_peak_hist = 0;
@@ -963,7 +911,6 @@ IQD_DEV void wbfm_tile_pipe(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLd
     });
     int rec_pos = t.tlen - FORCED_BACK;
     if (rec_pos < -halo) rec_pos = -halo;
-    typename Exec::template Local<uint32_t> seg_nz;   // per segment: bits of the IIR input seen by the last real pass
     WbfmRecord rec;
     rec.y_in = start.y;
     rec.y_out = start.y;
@@ -1003,10 +950,9 @@ IQD_DEV void wbfm_tile_pipe(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLd
                 ex.wave0([&](int lane) { iir_warm(c, lds, nseg, lane); });
                 int rounds = 0;
                 do {
-                    ex.wave0([&](int lane) { seg_nz.at(lane) = iir_real(c, lds, nseg, lane, t.bounded != 0); });
+                    ex.wave0([&](int lane) { iir_real(c, lds, nseg, lane, t.bounded != 0); });
                     rounds++;
                 } while (!ex.wave0_all([&](int lane) { return iir_check(lds, nseg, lane); }));
-                ex.wave0([&](int lane) { iir_note_nonzero(lds, nseg, lane, seg_nz.at(lane), cstart, start.cold ? -FORCED_BACK : -halo, rec_pos); });
                 if (rec_pos > cstart && rec_pos < cstart + clen) {
                     const int seg = (rec_pos - cstart) / SEG - 1;
                     rec.y_out = lds.e[seg];
@@ -1049,16 +995,7 @@ IQD_DEV void wbfm_tile_pipe(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLd
                 const bool wave_has_b = P1S_PER_WAVE * (w + 3) < ng;
                 const P1Own ra = p1s_load<GATED>(t, next_cstart, ng, p1s_group(w, lane));
                 const P1Own rb = wave_has_b ? p1s_load<GATED>(t, next_cstart, ng, p1s_group(w + 3, lane)) : ra;
-#ifdef IQD_P1_SEQ   // (experiment) one pass after the other: fewer registers, less overlap
-                p1s_compute(ex, tid, t, c, ra, ra, ng, w, w, false, next_mag, regs.at(tid));
-                if (wave_has_b) {
-                    P1Pair second;
-                    p1s_compute(ex, tid, t, c, rb, rb, ng, w + 3, w + 3, false, next_mag, second);
-                    regs.at(tid).b = second.a;
-                }
-#else
                 p1s_compute(ex, tid, t, c, ra, rb, ng, w, w + 3, wave_has_b, next_mag, regs.at(tid));
-#endif
             });
         ex.stamp(2);
         ex.sync();
@@ -1105,8 +1042,7 @@ IQD_DEV void wbfm_tile_pipe(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLd
     if (ex.in_wave0() && rec_out) {
         rec.y_end = lds.y_carry;
         rec.u_end = lds.u_carry;
-        rec.pad[0] = lds.nz_flags;   // see iir_note_nonzero
-        rec.pad[1] = 0;
+        rec.pad[0] = rec.pad[1] = 0;
         ex.wave0([&](int lane) { if (lane == 0) *rec_out = rec; });
     }
 }
