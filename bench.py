@@ -90,7 +90,7 @@ def main():
     ap.add_argument("--log2-samples", type=int, default=28, help="IQ samples per channel per step (default 2^28)")
     ap.add_argument("--channels", type=int, default=1, help="channels per GPU")
     ap.add_argument("--mode", default="wbfm")
-    ap.add_argument("--signal", default="fm_tone", choices=["fm_tone", "white"],
+    ap.add_argument("--signal", default="fm_tone", choices=["fm_tone", "white", "carrier", "quiet", "small", "large"],
                     help="synthetic input: the FM test tone of SURVEY 8(d) (default) or uniform random bytes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive iqd_accept_iq measurement")
@@ -121,7 +121,18 @@ def main():
     period = min(n, 1 << 24)
     dev = torch.device("cuda", local_rank)
     # the same seeded signal on every rank, phase-continuous over the period
-    period_u8 = synth.fm_tone(period, seed=1234) if args.signal == "fm_tone" else synth.white_u8(period, seed=1234)
+    if args.signal == "fm_tone":
+        period_u8 = synth.fm_tone(period, seed=1234)
+    elif args.signal == "white":
+        period_u8 = synth.white_u8(period, seed=1234)
+    elif args.signal == "carrier":      # unmodulated, noiseless: every sample hits the same table cell
+        period_u8 = synth.fm_tone(period, seed=1234, deviation=0.0, sigma=0.0)
+    elif args.signal == "small":        # weak signal: the table accesses stay within a few cache lines
+        period_u8 = synth.fm_tone(period, seed=1234, amplitude=6.0, sigma=1.0)
+    elif args.signal == "large":        # strong signal: a wide ring through the table
+        period_u8 = synth.fm_tone(period, seed=1234, amplitude=120.0)
+    else:                               # speech-like: 3 kHz deviation
+        period_u8 = synth.fm_tone(period, seed=1234, deviation=3000.0)
     iq = torch.from_numpy(period_u8).to(dev).repeat(n // period)
     if n_ch > 1:
         iq = iq.unsqueeze(0).repeat(n_ch, 1).contiguous()
@@ -170,7 +181,7 @@ def main():
             "value": round(value, 1), "unit": "MSamples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int8/int16 Q15 + f32", "data": "synthetic" if args.signal == "fm_tone" else "synthetic (uniform random bytes)",
+            "dtype": "int8/int16 Q15 + f32", "data": "synthetic" if args.signal == "fm_tone" else "synthetic (%s)" % args.signal,
             "config": {"workload": "%s, %d channel(s) per GPU, 2^%d IQ samples per channel per step, "
                                    "uint8 I/Q resident in HBM (BASELINE configs[1])"
                                    % (args.mode.upper(), n_ch, args.log2_samples),

@@ -162,7 +162,7 @@ __global__ __launch_bounds__(WB_THREADS, IQD_WBFM_MIN_WAVES) void wbfm_repair_ke
     WbfmRecord *r = a.records + (size_t)li * a.tiles_per_ch;
     for (uint32_t tile = 1; tile < ntiles; tile++) {
         const WbfmRecord prev = r[tile - 1];
-        if (f2u(r[tile].y_in) == f2u(prev.y_out)) continue;
+        if (iir_states_agree(r[tile].y_in, prev.y_out, a.params[a.first_ch + ch].wbfm_k >= 1.0f)) continue;
         WbfmStart start;
         start.y = prev.y_out; start.u = prev.u_out; start.back = prev.back_out; start.cold = 0;
         wbfm_run_tile<GATED, false>(a, lds, li, tile, ch, vlen, start);
@@ -351,7 +351,7 @@ __global__ void wbfm_verify_kernel(const ChainLaunch a)
     if (tile >= ntiles) return;
     const WbfmRecord *r = a.records + (size_t)li * a.tiles_per_ch;
     if (tile > 0) {
-        if (f2u(r[tile].y_in) != f2u(r[tile - 1].y_out)) {
+        if (!iir_states_agree(r[tile].y_in, r[tile - 1].y_out, a.params[a.first_ch + ch].wbfm_k >= 1.0f)) {
             atomicAdd(&a.counters[CNT_TILE_MISMATCH], 1u);
             a.repair_flags[li] = 1;
         } else {
