@@ -452,11 +452,14 @@ IQD_DEV void dc_real(const Consts &c, DcLds &lds, int nseg, int lane, float gain
     lds.e[lane] = y;
 }
 
-IQD_DEV bool dc_check(DcLds &lds, int nseg, int lane)
+// (As for the de-emphasis, two states below 2^-100 count as agreeing when |gain| <= 1e6: the next nonzero input
+// of this recurrence is an integer difference, which absorbs them, and gain * y stays far below one PCM step.
+// A constant detector output - an unmodulated carrier - leaves the true state stuck at a denormal.)
+IQD_DEV bool dc_check(DcLds &lds, int nseg, int lane, bool tiny_ok = false)
 {
     if (lane == 0 || lane >= nseg) return true;
     const float want = lds.e[lane - 1];
-    if (f2u(want) == f2u(lds.g[lane])) return true;
+    if (iir_states_agree(want, lds.g[lane], tiny_ok)) return true;
     lds.g[lane] = want;
     return false;
 }
@@ -478,7 +481,7 @@ IQD_DEV void dc_block_wave(Exec &ex, const Consts &c, DcLds &lds, const int32_t 
             ex.wave0([&](int lane) { dc_warm(c, lds, nfull, lane); });
             do {
                 ex.wave0([&](int lane) { dc_real(c, lds, nfull, lane, gain, pcm ? pcm + base : nullptr); });
-            } while (!ex.wave0_all([&](int lane) { return dc_check(lds, nfull, lane); }));
+            } while (!ex.wave0_all([&](int lane) { return dc_check(lds, nfull, lane, __builtin_fabsf(gain) <= 1e6f); }));
             ex.wave0([&](int lane) {
                 if (lane == 0) {
                     lds.y_carry = lds.e[nfull - 1];
@@ -533,10 +536,10 @@ IQD_DEV void dc_tile(Exec &ex, const Consts &c, DcLds &lds, const int32_t *x, in
 }
 
 // true if the tiles of one channel chain up exactly; then `out` is the state after the last one
-IQD_DEV bool dc_tiles_ok(const DcRecord *rec, int ntiles, DcCarry &out)
+IQD_DEV bool dc_tiles_ok(const DcRecord *rec, int ntiles, DcCarry &out, bool tiny_ok)
 {
     for (int t = 1; t < ntiles; t++)
-        if (f2u(rec[t].y_start) != f2u(rec[t - 1].y_end)) return false;
+        if (!iir_states_agree(rec[t].y_start, rec[t - 1].y_end, tiny_ok)) return false;
     out.x_prev = rec[ntiles - 1].x_end;
     out.y_prev = rec[ntiles - 1].y_end;
     return true;

@@ -314,7 +314,8 @@ __global__ void dc_chainup_kernel(const ChainLaunch a, int family)
     if (n == 0) return;
     const int ntiles = (int)((n + DC_TILE - 1) / DC_TILE);
     DcCarry out;
-    if (dc_tiles_ok((const DcRecord *)a.dc_records + (size_t)li * a.dc_tiles, ntiles, out)) {
+    if (dc_tiles_ok((const DcRecord *)a.dc_records + (size_t)li * a.dc_tiles, ntiles, out,
+                    fabsf(a.params[ech].gain[family]) <= 1e6f)) {
         a.dc_carry[2 * (size_t)ech + (family == FAM_SSB ? 1 : 0)] = out;
     } else {
         redo[li] = 1;
