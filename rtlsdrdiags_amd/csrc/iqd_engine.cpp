@@ -1005,9 +1005,9 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
             // hand-off verification, repair of what it flags (normally an immediate exit), then state commit + tail
             HIP_TRY(e, launch_wbfm_verify(a, s));
             HIP_TRY(e, launch_wbfm_repair(a, gated, s));
-            HIP_TRY(e, launch_tail_update(a, FAM_WBFM, false, s));
+            HIP_TRY(e, launch_tail_update(a, FAM_WBFM, s));
         } else {
-            HIP_TRY(e, launch_tail_update(a, f, false, s));
+            HIP_TRY(e, launch_tail_update(a, f, s));
         }
     }
     // channels in mode None still report their magnitudes

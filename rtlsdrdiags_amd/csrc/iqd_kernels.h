@@ -82,7 +82,7 @@ hipError_t launch_front_end(const uint8_t *iq, int8_t *out, const ChanParams *pa
                             size_t bytes_per_ch, hipStream_t s);
 hipError_t launch_agc_apply(const AgcConfig *cfg, AgcState *st, const ScanConfig *scfg, ScanState *sst, uint32_t n_ch,
                             hipStream_t s);
-hipError_t launch_tail_update(const ChainLaunch &a, int family, bool guarded, hipStream_t s);
+hipError_t launch_tail_update(const ChainLaunch &a, int family, hipStream_t s);
 hipError_t launch_magnitude(const uint8_t *iq, size_t ch_stride_bytes, const uint32_t *ch_list, uint32_t n_list,
                             uint32_t block_samples, uint32_t n_blocks, uint32_t *mag_sums, hipStream_t s);
 hipError_t launch_squelch(const SquelchLaunch &q, bool always_open, hipStream_t s);

@@ -104,14 +104,7 @@ __device__ __forceinline__ void wbfm_run_tile(const ChainLaunch &a, WbfmLds &lds
     t.lut = a.atan_lut;
     t.pcm_row = a.pcm + (size_t)ch * a.pcm_stride;
     t.mag_row = MAG ? a.mag_sums + (size_t)ch * a.n_blocks : nullptr;
-#ifndef IQD_ROT_MODE
-#define IQD_ROT_MODE 0
-#endif
-    // (diagnostic) which hardware wave plays "wave 0" can be rotated from workgroup to workgroup
-    uint32_t rot = 0;
-    if (IQD_ROT_MODE == 1) rot = blockIdx.x;
-    if (IQD_ROT_MODE == 2) rot = blockIdx.x >> 3;
-    DeviceExec ex{(int)((threadIdx.x + 64u * (rot & 3u)) & (WB_THREADS - 1))};
+    DeviceExec ex{(int)threadIdx.x};
 #ifdef IQD_WBFM_SERIAL_PHASES   // the first driver: IIR phase not overlapped (kept for A/B measurements)
     wbfm_tile<GATED, MAG>(ex, t, g_consts, lds, start, &a.records[(size_t)li * a.tiles_per_ch + tile]);
 #else
@@ -362,11 +355,9 @@ __global__ void wbfm_verify_kernel(const ChainLaunch a)
 }
 
 // New tail = last TAIL samples of [old tail | this call's open blocks] for one family.  For WBFM the
-// same launch commits the restart state of each channel's last tile; with `guarded` it does nothing
-// when the hand-off verification has flagged a mismatch (the host then repairs and launches it again).
-__global__ __launch_bounds__(256) void tail_update_kernel(const ChainLaunch a, int family, int guarded)
+// same launch commits the restart state of each channel's last tile (after verification and repair).
+__global__ __launch_bounds__(256) void tail_update_kernel(const ChainLaunch a, int family)
 {
-    (void)guarded;
     const uint32_t li = blockIdx.x;
     const uint32_t ch = a.ch_list[li];
     const uint32_t ech = a.first_ch + ch;
@@ -775,9 +766,9 @@ hipError_t launch_wbfm_repair(const ChainLaunch &a, bool gated, hipStream_t s)
     return hipGetLastError();
 }
 
-hipError_t launch_tail_update(const ChainLaunch &a, int family, bool guarded, hipStream_t s)
+hipError_t launch_tail_update(const ChainLaunch &a, int family, hipStream_t s)
 {
-    hipLaunchKernelGGL(tail_update_kernel, dim3(a.n_list), dim3(256), 0, s, a, family, guarded ? 1 : 0);
+    hipLaunchKernelGGL(tail_update_kernel, dim3(a.n_list), dim3(256), 0, s, a, family);
     return hipGetLastError();
 }
 
