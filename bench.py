@@ -142,7 +142,11 @@ def main():
     torch.cuda.synchronize()
 
     eng = capi.Engine(n_channels=n_ch, device=local_rank)
-    eng.set_mode(args.mode)
+    if args.mode == "mixed":     # BASELINE configs[3]: ch % 5 -> {AM, FM, WBFM, LSB, USB}
+        for c in range(n_ch):
+            eng.set_mode(["am", "fm", "wbfm", "lsb", "usb"][c % 5], first=c, n=1)
+    else:
+        eng.set_mode(args.mode)
 
     def step():
         eng.accept_device(iq.data_ptr(), 2 * n, pcm.data_ptr(), cnt.data_ptr(), mag.data_ptr())
@@ -190,7 +194,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": measured_traffic(args.mode, n_ch, args.log2_samples),
-                         "kernel": "%s_chain_kernel" % ("am" if args.mode in ("am", "lsb", "usb") else args.mode), "kernel_ms": round(kern_ms, 4),
+                         "kernel": "%s_chain_kernel" % ("am" if args.mode in ("am", "lsb", "usb") else ("first family's" if args.mode == "mixed" else args.mode)), "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_SAMPLE * n * n_ch},
             "state_checks": k1["state_checks"] - k0["state_checks"],
             "state_repairs": k1["state_repairs"] - k0["state_repairs"],

@@ -90,11 +90,14 @@ struct iqd_engine {
     uint32_t *h_counters = nullptr;  // pinned
 
     // per-call scratch
-    DevBuf lists[FAM_COUNT + 1], mag_sums, blk_lists, vlen, records, base8k, gain_trace, freq_trace, dc_records, repair_flags;
+    DevBuf lists[FAM_COUNT + 1], mag_sums, blk_lists, vlen, records, base8k, gain_trace, freq_trace, dc_records, dc_records2, repair_flags;
     DevBuf st_iq, st_pcm, st_count, st_mag, st_allowed;  // staging for host-pointer accepts
     // sliced host-pointer accepts: two staging sets, so that slice k+1 crosses PCIe while slice k runs
     DevBuf sl_iq[2], sl_pcm[2], sl_count[2], sl_mag[2], sl_allowed[2];
     hipStream_t copy_stream = nullptr;
+    // mixed-mode calls: one stream per demodulator family, so that their kernels share the GPU
+    hipStream_t fam_stream[FAM_COUNT] = {};
+    hipEvent_t fam_fork = nullptr, fam_join[FAM_COUNT] = {};
     hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
     uint32_t *h_slice_counts = nullptr;  // pinned, [2][n_ch of a slice]
     size_t h_slice_counts_cap = 0;
@@ -262,7 +265,7 @@ void iqd_destroy(iqd_t *e)
         if (p) (void)hipFree(p);
     if (e->h_counters) (void)hipHostFree(e->h_counters);
     for (auto &b : e->lists) b.release();
-    DevBuf *bufs[] = {&e->mag_sums, &e->blk_lists, &e->vlen, &e->records, &e->base8k, &e->gain_trace, &e->freq_trace, &e->dc_records, &e->repair_flags,
+    DevBuf *bufs[] = {&e->mag_sums, &e->blk_lists, &e->vlen, &e->records, &e->base8k, &e->gain_trace, &e->freq_trace, &e->dc_records, &e->dc_records2, &e->repair_flags,
                       &e->st_iq, &e->st_pcm, &e->st_count, &e->st_mag, &e->st_allowed};
     for (DevBuf *b : bufs) b->release();
     for (int b = 0; b < 2; b++) {
@@ -273,6 +276,11 @@ void iqd_destroy(iqd_t *e)
     }
     if (e->h_slice_counts) (void)hipHostFree(e->h_slice_counts);
     if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
+    for (int f = 0; f < FAM_COUNT; f++) {
+        if (e->fam_stream[f]) (void)hipStreamDestroy(e->fam_stream[f]);
+        if (e->fam_join[f]) (void)hipEventDestroy(e->fam_join[f]);
+    }
+    if (e->fam_fork) (void)hipEventDestroy(e->fam_fork);
     for (auto *v : {&e->ev_free_pairs, &e->ev_pending})
         for (auto &pr : *v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     if (e->stream) (void)hipStreamDestroy(e->stream);
@@ -954,9 +962,30 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
     const bool fused_mag = want_mag && !gated;
     bool timed = false;
     std::pair<hipEvent_t, hipEvent_t> evp{nullptr, nullptr};
+    // More than one demodulator family in the call: each gets its own stream between a fork and a join event, so
+    // that the (often small) per-family launches run side by side instead of each draining the GPU in turn.
+    int n_fams = 0;
+    for (int f = 0; f < FAM_COUNT; f++) n_fams += e->h_lists[f].empty() ? 0 : 1;
+    const bool forked = n_fams > 1;
+    hipStream_t const s_main = s;
+    if (forked) {
+        if (!e->fam_fork) {
+            HIP_TRY(e, hipEventCreateWithFlags(&e->fam_fork, hipEventDisableTiming));
+            for (int f = 0; f < FAM_COUNT; f++) {
+                HIP_TRY(e, hipStreamCreateWithFlags(&e->fam_stream[f], hipStreamNonBlocking));
+                HIP_TRY(e, hipEventCreateWithFlags(&e->fam_join[f], hipEventDisableTiming));
+            }
+        }
+        HIP_TRY(e, e->base8k.ensure((size_t)n_ch * base.pcm_stride * sizeof(int32_t)));   // before the fork: shared by AM and SSB
+        HIP_TRY(e, hipEventRecord(e->fam_fork, s_main));
+    }
     for (int f = 0; f < FAM_COUNT; f++) {
         const uint32_t n_list = (uint32_t)e->h_lists[f].size();
         if (!n_list) continue;
+        if (forked) {
+            s = e->fam_stream[f];
+            HIP_TRY(e, hipStreamWaitEvent(s, e->fam_fork, 0));
+        }
         ChainLaunch a = base;
         a.ch_list = e->lists[f].as<uint32_t>();
         a.n_list = n_list;
@@ -991,8 +1020,9 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
             HIP_TRY(e, e->base8k.ensure((size_t)n_ch * base.pcm_stride * sizeof(int32_t)));
             a.base8k = e->base8k.as<int32_t>();
             a.dc_tiles = (uint32_t)((base.pcm_stride + DC_TILE - 1) / DC_TILE);
-            HIP_TRY(e, e->dc_records.ensure((size_t)n_list * a.dc_tiles * sizeof(DcRecord) + n_list * sizeof(uint32_t)));
-            a.dc_records = e->dc_records.p;
+            DevBuf &dcr = f == FAM_SSB ? e->dc_records2 : e->dc_records;   // AM and SSB may run side by side
+            HIP_TRY(e, dcr.ensure((size_t)n_list * a.dc_tiles * sizeof(DcRecord) + n_list * sizeof(uint32_t)));
+            a.dc_records = dcr.p;
             HIP_TRY(e, launch_am(a, f, gated, fused_mag, n_list * a.tiles_per_ch, s));
         }
         if (e->profiling && !timed) {
@@ -1009,7 +1039,12 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         } else {
             HIP_TRY(e, launch_tail_update(a, f, s));
         }
+        if (forked) {
+            HIP_TRY(e, hipEventRecord(e->fam_join[f], s));
+            HIP_TRY(e, hipStreamWaitEvent(s_main, e->fam_join[f], 0));
+        }
     }
+    s = s_main;
     // channels in mode None still report their magnitudes
     if (fused_mag && !e->h_lists[FAM_COUNT].empty())
         HIP_TRY(e, launch_magnitude((const uint8_t *)iq_dev, bytes_per_ch, e->lists[FAM_COUNT].as<uint32_t>(),
