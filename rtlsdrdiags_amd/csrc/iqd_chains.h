@@ -18,7 +18,10 @@ namespace iqd {
 
 typedef WbfmTile Tile;
 
-constexpr int CH_CHUNK = 8192;       // samples per chunk of the FM / AM / SSB tile kernels
+#ifndef IQD_CH_CHUNK
+#define IQD_CH_CHUNK 8192
+#endif
+constexpr int CH_CHUNK = IQD_CH_CHUNK;       // samples per chunk of the FM / AM / SSB tile kernels
 constexpr int FIR_HALO = 1280;       // raw history a tile rebuilds its FIR states from
                                      // (FM needs 684, AM 260, SSB 1220 samples)
 
