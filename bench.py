@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--mode", default="wbfm")
     ap.add_argument("--signal", default="fm_tone", choices=["fm_tone", "white", "carrier", "quiet", "small", "large"],
                     help="synthetic input: the FM test tone of SURVEY 8(d) (default) or uniform random bytes")
+    ap.add_argument("--squelch", type=int, default=None, help="squelch threshold in dBFS (default: the reference's -200, never closes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive iqd_accept_iq measurement")
     ap.add_argument("--gather", action="store_true", help="also gather the PCM to rank 0 over RCCL each step")
@@ -147,6 +148,9 @@ def main():
             eng.set_mode(["am", "fm", "wbfm", "lsb", "usb"][c % 5], first=c, n=1)
     else:
         eng.set_mode(args.mode)
+
+    if args.squelch is not None:
+        eng.set_squelch(args.squelch)
 
     def step():
         eng.accept_device(iq.data_ptr(), 2 * n, pcm.data_ptr(), cnt.data_ptr(), mag.data_ptr())
