@@ -548,4 +548,58 @@ IQD_DEV bool dc_tiles_ok(const DcRecord *rec, int ntiles, DcCarry &out, bool tin
     return true;
 }
 
+// ---- per-block control loops carried by the squelch pass (host + device, like the chains) -----------------
+// AutomaticGainControl::run (AutomaticGainControl.cc:663-741) with runLowpass (:743-889) / runHarris
+// (:935-1062): one block magnitude in, the receiver's IF gain out.  binary32 arithmetic in the reference's order.
+IQD_DEV uint32_t agc_run(const Consts &c, const AgcConfig &cfg, AgcState &st, uint32_t magnitude, uint32_t gain)
+{
+    if (st.if_gain != gain) st.if_gain = gain;   // follow the operator's manual changes
+    bool allowed = false;
+    if (st.adjusted) {   // blank the measurements that follow an adjustment
+        if (st.blank_ctr < cfg.blanking_limit) {
+            st.blank_ctr++;
+        } else {
+            st.blank_ctr = 0;
+            st.adjusted = 0;
+            allowed = true;
+        }
+    } else {
+        allowed = true;
+    }
+    if (!allowed) return gain;
+    st.signal_magnitude = magnitude;
+    const uint32_t m = magnitude > 127u ? 127u : magnitude;   // DbfsCalculator.cc:122-125
+    const int32_t signal = c.db_table[m] - 42;
+    st.normalized = (int32_t)((uint32_t)signal - st.if_gain);
+    int32_t error = cfg.operating_point - signal;
+    if (st.if_gain == AGC_MAX_GAIN) {
+        if (error > 0) error = 0;
+    } else if (st.if_gain == 0) {
+        if (error < 0) error = 0;
+    }
+    if ((error < 0 ? -error : error) <= cfg.deadband) error = 0;
+    if (cfg.type == 0) {
+        const int32_t adjusted = (int32_t)(st.if_gain + (uint32_t)error);
+        st.filtered = (cfg.alpha * (float)adjusted) + ((1 - cfg.alpha) * st.filtered);
+    } else {
+        st.filtered = st.filtered + (cfg.alpha * (float)error);
+    }
+    if (st.filtered > (float)AGC_MAX_GAIN) st.filtered = (float)AGC_MAX_GAIN;
+    else if (st.filtered < 0) st.filtered = 0;
+    st.if_gain = (uint32_t)st.filtered;
+    if (error != 0) {
+        gain = st.if_gain;   // Radio::setReceiveIfGainInDb(0, ifGainInDb), Radio.cc:851-861
+        st.adjusted = 1;
+    }
+    return gain;
+}
+
+// FrequencyScanner::run on a rejected block (signalStateCallback -> run, FrequencyScanner.cc:47-62, :378-404)
+IQD_DEV void scanner_step(const ScanConfig &sc, ScanState &ss)
+{
+    ss.current_hz = ss.current_hz + sc.increment_hz;
+    if (ss.current_hz > sc.end_hz) ss.current_hz = sc.start_hz;
+    ss.tune_count++;
+}
+
 }  // namespace iqd

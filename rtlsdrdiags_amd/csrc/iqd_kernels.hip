@@ -433,51 +433,6 @@ __global__ void squelch_block_kernel(const SquelchLaunch q, int always_open)
     }
 }
 
-// AutomaticGainControl::run (AutomaticGainControl.cc:663-741) with runLowpass (:743-889) / runHarris
-// (:935-1062): one block magnitude in, the receiver's IF gain out.  binary32 arithmetic in the reference's order.
-__device__ __forceinline__ uint32_t agc_run(const AgcConfig &cfg, AgcState &st, uint32_t magnitude, uint32_t gain)
-{
-    if (st.if_gain != gain) st.if_gain = gain;   // follow the operator's manual changes
-    bool allowed = false;
-    if (st.adjusted) {   // blank the measurements that follow an adjustment
-        if (st.blank_ctr < cfg.blanking_limit) {
-            st.blank_ctr++;
-        } else {
-            st.blank_ctr = 0;
-            st.adjusted = 0;
-            allowed = true;
-        }
-    } else {
-        allowed = true;
-    }
-    if (!allowed) return gain;
-    st.signal_magnitude = magnitude;
-    const uint32_t m = magnitude > 127u ? 127u : magnitude;   // DbfsCalculator.cc:122-125
-    const int32_t signal = g_consts.db_table[m] - 42;
-    st.normalized = (int32_t)((uint32_t)signal - st.if_gain);
-    int32_t error = cfg.operating_point - signal;
-    if (st.if_gain == AGC_MAX_GAIN) {
-        if (error > 0) error = 0;
-    } else if (st.if_gain == 0) {
-        if (error < 0) error = 0;
-    }
-    if ((error < 0 ? -error : error) <= cfg.deadband) error = 0;
-    if (cfg.type == 0) {
-        const int32_t adjusted = (int32_t)(st.if_gain + (uint32_t)error);
-        st.filtered = (cfg.alpha * (float)adjusted) + ((1 - cfg.alpha) * st.filtered);
-    } else {
-        st.filtered = st.filtered + (cfg.alpha * (float)error);
-    }
-    if (st.filtered > (float)AGC_MAX_GAIN) st.filtered = (float)AGC_MAX_GAIN;
-    else if (st.filtered < 0) st.filtered = 0;
-    st.if_gain = (uint32_t)st.filtered;
-    if (error != 0) {
-        gain = st.if_gain;   // Radio::setReceiveIfGainInDb(0, ifGainInDb), Radio.cc:851-861
-        st.adjusted = 1;
-    }
-    return gain;
-}
-
 // Squelch, part 2, one thread per channel, blocks in order: the "signal present" comparison
 // (SignalDetector.cc:259-266) with the IF gain in force, the two-state tracker with its one-block tail
 // (SignalTracker.cc:104-145, Squelch.cc:240-269), the list of open blocks - and the magnitude callback into the
@@ -510,15 +465,13 @@ __global__ void squelch_track_kernel(const SquelchLaunch q, int always_open)
             if (allowed) {
                 q.blk_lists[(size_t)ch * q.n_blocks + open] = b;
                 open++;
-            } else if (sc.scanning) {   // signalStateCallback -> FrequencyScanner::run, FrequencyScanner.cc:378-404
-                ss.current_hz = ss.current_hz + sc.increment_hz;
-                if (ss.current_hz > sc.end_hz) ss.current_hz = sc.start_hz;
-                ss.tune_count++;
+            } else if (sc.scanning) {
+                scanner_step(sc, ss);
             }
             if (q.freq_trace) q.freq_trace[idx] = ss.current_hz;
         }
         if (q.gain_trace) q.gain_trace[idx] = gain;
-        if (cfg.enabled) gain = agc_run(cfg, st, avg, gain);
+        if (cfg.enabled) gain = agc_run(g_consts, cfg, st, avg, gain);
     }
     st.rx_gain = gain;
     q.agc[ech] = st;

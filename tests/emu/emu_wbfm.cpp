@@ -206,4 +206,26 @@ void emu_chain_accept(int family, int lsb, const uint8_t *iq, uint32_t n_samples
     memcpy(tail, nt.data(), TAIL_BYTES);
 }
 
+// The device's AGC step (iqd_chains.h: agc_run) on the host: n magnitudes through one channel's AGC.
+// cfg: {enabled, type, operating_point, deadband, alpha, blanking_limit}; state in/out: {rx_gain, if_gain,
+// filtered, blank_ctr, adjusted}; gains_out[i] = the IF gain after magnitude i.
+void emu_agc_run(uint32_t type, int32_t operating_point, int32_t deadband, float alpha, uint32_t blanking_limit,
+                 uint32_t *rx_gain, uint32_t *if_gain, float *filtered, uint32_t *blank_ctr, uint32_t *adjusted,
+                 const uint32_t *magnitudes, uint32_t n, uint32_t *gains_out)
+{
+    iqd::Consts c;
+    iqd::build_consts(c);
+    iqd::AgcConfig cfg{};
+    cfg.enabled = 1; cfg.type = type; cfg.operating_point = operating_point; cfg.deadband = deadband;
+    cfg.alpha = alpha; cfg.blanking_limit = blanking_limit;
+    iqd::AgcState st{};
+    st.rx_gain = *rx_gain; st.if_gain = *if_gain; st.filtered = *filtered; st.blank_ctr = *blank_ctr; st.adjusted = *adjusted;
+    uint32_t gain = st.rx_gain;
+    for (uint32_t i = 0; i < n; i++) {
+        gain = iqd::agc_run(c, cfg, st, magnitudes[i], gain);
+        gains_out[i] = gain;
+    }
+    *rx_gain = gain; *if_gain = st.if_gain; *filtered = st.filtered; *blank_ctr = st.blank_ctr; *adjusted = st.adjusted;
+}
+
 }  // extern "C"

@@ -96,3 +96,36 @@ def test_fm_loud_and_quiet_sections(emu, oracle):
     assert np.array_equal(pcm, ref)
     a = np.abs(ref.astype(np.int32))
     assert a.max() > 8000 and min(a[k:k + 40].max() for k in range(0, len(a) - 40, 20)) < 8000
+
+
+def test_device_agc_step_on_the_host():
+    """The AGC step the squelch kernel runs per block (iqd_chains.h: agc_run), compiled for the host, against the
+    oracle: runs of magnitudes between the commands of the random scripts (every parameter combination)."""
+    import ctypes as C
+    import agc_script as A
+    from oracle import bindings as B
+    L = emu_bind.lib()
+    u32p, f32p = C.POINTER(C.c_uint32), C.POINTER(C.c_float)
+    L.emu_agc_run.argtypes = [C.c_uint32, C.c_int32, C.c_int32, C.c_float, C.c_uint32, u32p, u32p, f32p, u32p, u32p,
+                              C.c_void_p, C.c_uint32, C.c_void_p]
+    O = B.Oracle()
+    rng = np.random.default_rng(9)
+    for trial in range(60):
+        typ, dead, blank = int(rng.integers(0, 2)), int(rng.integers(0, 11)), int(rng.integers(0, 11))
+        alpha, op = float(np.float32(rng.choice([0.001, 0.05, 0.3, 0.8, 0.998]))), int(rng.integers(-40, 1))
+        gain0 = int(rng.integers(0, 47))
+        mags = np.clip(rng.normal(40, 40, 300), 0, 191).astype(np.uint32)
+        o = O.chain()
+        o.agc_set_type(typ); o.agc_set_deadband(dead); o.agc_set_blanking_limit(blank)
+        o.agc_set_filter_coefficient(alpha); o.agc_set_operating_point(op); o.set_rx_gain_db(gain0)
+        o.agc_enable(True)
+        want = []
+        for m in mags:
+            o.agc_feed(int(m))
+            want.append(o.rx_gain_db())
+        rx, ifg, filt = C.c_uint32(gain0), C.c_uint32(24), C.c_float(24.0)
+        bc, adj = C.c_uint32(0), C.c_uint32(0)
+        got = np.zeros(len(mags), np.uint32)
+        L.emu_agc_run(typ, op, dead, alpha, blank, C.byref(rx), C.byref(ifg), C.byref(filt), C.byref(bc), C.byref(adj),
+                      mags.ctypes.data, len(mags), got.ctypes.data)
+        assert got.tolist() == want, trial
