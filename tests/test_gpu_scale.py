@@ -177,3 +177,34 @@ def test_config5_65536_ssb_channels_with_rotation_squelch_and_agc(capi, oracle):
         assert cnt[c] == len(ref) and np.array_equal(pcm[c, :cnt[c]], ref), c
         assert eng.rx_gain_db(c) == o.rx_gain_db(), c
     assert 0 < allowed.sum() < allowed.size
+
+
+def test_bench_workload_at_full_size_is_the_oracles_pcm(capi, oracle):
+    """BASELINE configs[1] exactly as bench.py runs it - WBFM, one channel, 2^28 samples resident in device memory,
+    two consecutive steps - with every one of the 2 x 8.4 M PCM samples compared with the oracle's (the oracle
+    needs ~25 s of one host core for the two steps), and the linearity-free property the domain offers at this size:
+    the second step continues the first (state carried), so it differs from it."""
+    n, period = 1 << 28, 1 << 24
+    u8 = synth.fm_tone(period, seed=1234)
+    eng = capi.Engine(1)
+    eng.set_mode("wbfm")
+    iq = eng.dev_alloc(2 * n)
+    pcm_dev = eng.dev_alloc(2 * (n // 32))
+    eng.dev_upload(iq, u8)
+    eng.dev_tile(iq, 2 * period, 2 * n)
+    o = oracle.chain()
+    o.set_mode("wbfm")
+    outs = []
+    for step in range(2):
+        eng.accept_device(iq, 2 * n, pcm_dev)
+        eng.synchronize()
+        got = eng.dev_download(pcm_dev, 2 * (n // 32), np.int16)
+        ref = np.concatenate([o.accept_stream(u8)[0] for _ in range(n // period)])
+        assert len(ref) == n // 32 and np.array_equal(got, ref), step
+        outs.append(got)
+    assert not np.array_equal(outs[0][:4096], outs[1][:4096])     # the start of step 2 carries step 1's state
+    assert np.array_equal(outs[0][period // 32:], outs[1][period // 32:])   # once the periodic input has settled
+    st = eng.stats()
+    assert st["state_checks"] > 1000 and st["state_repairs"] == 0
+    eng.dev_free(iq)
+    eng.dev_free(pcm_dev)
