@@ -16,7 +16,7 @@ class Carry(C.Structure):
 
 def lib():
     subprocess.run(["make", "-s", "-C", os.path.join(HERE, "emu")], check=True)
-    L = C.CDLL(SO)
+    L = C.CDLL(os.environ.get("IQD_EMU_LIB", SO))   # IQD_EMU_LIB: e.g. the sanitizer build (tests/emu/Makefile)
     L.emu_wbfm_accept.restype = C.c_int
     L.emu_wbfm_accept.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_float,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float]
