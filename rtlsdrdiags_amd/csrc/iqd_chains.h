@@ -187,21 +187,32 @@ IQD_DEV void fm_audio(const Consts &c, FmLds &lds, const Tile &t, int cstart, in
     }
 }
 
-IQD_DEV void fm_shift(FmLds &lds, int clen, int tid)
+// Histories for the next chunk.  Each buffer's tail moves to its front in the phase that follows its last reader
+// (that phase touches other buffers only), so no phase of its own is needed:
+//   rails after stage 1 (beside the discriminator), theta beside the post decimator, e and its loudness flags beside
+//   the audio decimator, y2 and its flags beside the next chunk's front end.
+IQD_DEV void fm_shift_rails(FmLds &lds, int clen, int tid)
 {
-    if (tid == 64) {   // conservative loudness flags for what stays in reach of the next chunk
+    shift_hist(lds.xi, 8, clen >> 2, tid, 0);
+    shift_hist(lds.xq, 8, clen >> 2, tid, 8);
+}
+IQD_DEV void fm_shift_theta(FmLds &lds, int clen, int tid) { shift_hist(lds.theta, 4, clen >> 2, tid, 16); }
+IQD_DEV void fm_shift_e(FmLds &lds, int clen, int tid)
+{
+    if (tid == 64) {   // conservative loudness flag for what stays in reach of the next chunk
         const uint32_t keep_e = (clen >> 2) >= 12 ? 0u : lds.e_peak_hist;
         lds.e_peak_hist = lds.e_peak > keep_e ? lds.e_peak : keep_e;
         lds.e_peak = 0;
+    }
+    shift_hist(lds.e, 6, clen >> 3, tid, 24);
+}
+IQD_DEV void fm_shift_y2(FmLds &lds, int clen, int tid)
+{
+    if (tid == 64) {
         const uint32_t keep_y = (clen >> 4) >= 40 ? 0u : lds.y2_peak_hist;
         lds.y2_peak_hist = lds.y2_peak > keep_y ? lds.y2_peak : keep_y;
         lds.y2_peak = 0;
     }
-    const int n4 = clen >> 2;                 // rail dwords and 64 kS/s samples in this chunk
-    shift_hist(lds.xi, 8, n4, tid, 0);
-    shift_hist(lds.xq, 8, n4, tid, 8);
-    shift_hist(lds.theta, 4, n4, tid, 16);
-    shift_hist(lds.e, 6, n4 >> 1, tid, 24);
     if ((clen >> 5) >= 20) shift_hist(lds.y2, 20, clen >> 5, tid, 32);
     else if (tid == 32) shift_hist_serial(lds.y2, 20, clen >> 5);
 }
@@ -217,18 +228,31 @@ IQD_DEV void fm_tile(Exec &ex, const Tile &t, const Consts &c, FmLds &lds, const
         if (tid < CH_CHUNK / SEG + 2) lds.mag[tid] = 0;
         if (tid == 0) lds.e_peak = lds.e_peak_hist = lds.y2_peak = lds.y2_peak_hist = 0;
     });
+    int prev_clen = 0;
     for (int cstart = -FIR_HALO; cstart < t.tlen;) {
         const int clen = cstart < 0 ? -cstart : (t.tlen - cstart < CH_CHUNK ? t.tlen - cstart : CH_CHUNK);
         const ChunkBlocks cb = chunk_blocks(t, cstart);
-        ex.all([&](int tid) { front_rotate<GATED, MAG>(t, lds, cb, cstart, clen, tid, 8); });
+        ex.all([&](int tid) {
+            if (prev_clen) fm_shift_y2(lds, prev_clen, tid);
+            front_rotate<GATED, MAG>(t, lds, cb, cstart, clen, tid, 8);
+        });
         ex.all([&](int tid) {
             if (MAG) flush_mag(t, lds, cb, cstart, clen, tid);
             fm_stage1(t, c, lds, clen, tid, fm_lut);
         });
-        ex.all([&](int tid) { fm_discriminate(t, lds, clen, tid); });
-        ex.all([&](int tid) { fm_post(c, lds, clen, tid); });
-        ex.all([&](int tid) { fm_audio(c, lds, t, cstart, clen, tid); });
-        ex.all([&](int tid) { fm_shift(lds, clen, tid); });
+        ex.all([&](int tid) {
+            fm_discriminate(t, lds, clen, tid);
+            fm_shift_rails(lds, clen, tid);
+        });
+        ex.all([&](int tid) {
+            fm_post(c, lds, clen, tid);
+            fm_shift_theta(lds, clen, tid);
+        });
+        ex.all([&](int tid) {
+            fm_audio(c, lds, t, cstart, clen, tid);
+            fm_shift_e(lds, clen, tid);
+        });
+        prev_clen = clen;
         cstart += clen;
     }
 }
@@ -321,15 +345,24 @@ IQD_DEV void am_detect(const Consts &c, AmLds &lds, const Tile &t, int cstart, i
     }
 }
 
-IQD_DEV void am_shift(AmLds &lds, int clen, int tid)
+// Histories for the next chunk, each moved in the phase that follows its buffer's last reader (see fm_shift_*).
+IQD_DEV void am_shift_rails(AmLds &lds, int clen, int tid)
 {
-    const int n4 = clen >> 2;
-    shift_hist(lds.xi, 4, n4, tid, 0);
-    shift_hist(lds.xq, 4, n4, tid, 4);
-    shift_hist(lds.s1i, 6, n4 >> 1, tid, 8);
-    shift_hist(lds.s1q, 6, n4 >> 1, tid, 16);
+    shift_hist(lds.xi, 4, clen >> 2, tid, 0);
+    shift_hist(lds.xq, 4, clen >> 2, tid, 4);
+}
+IQD_DEV void am_shift_s1(AmLds &lds, int clen, int tid)
+{
+    shift_hist(lds.s1i, 6, clen >> 3, tid, 8);
+    shift_hist(lds.s1q, 6, clen >> 3, tid, 16);
+}
+IQD_DEV void am_shift_s2(AmLds &lds, int clen, int tid)
+{
     shift_hist(lds.s2i, 8, clen >> 5, tid, 24);
     shift_hist(lds.s2q, 8, clen >> 5, tid, 32);
+}
+IQD_DEV void am_shift_s3(AmLds &lds, int clen, int tid)
+{
     if ((clen >> 6) >= 16) {
         shift_hist(lds.s3i, 16, clen >> 6, tid, 40);
         shift_hist(lds.s3q, 16, clen >> 6, tid, 56);
@@ -350,18 +383,31 @@ IQD_DEV void am_tile(Exec &ex, const Tile &t, const Consts &c, AmLds &lds, int s
         if (tid < 16) lds.s3i[tid] = 0, lds.s3q[tid] = 0;
         if (tid < CH_CHUNK / SEG + 2) lds.mag[tid] = 0;
     });
+    int prev_clen = 0;
     for (int cstart = -FIR_HALO; cstart < t.tlen;) {
         const int clen = cstart < 0 ? -cstart : (t.tlen - cstart < CH_CHUNK ? t.tlen - cstart : CH_CHUNK);
         const ChunkBlocks cb = chunk_blocks(t, cstart);
-        ex.all([&](int tid) { front_rotate<GATED, MAG>(t, lds, cb, cstart, clen, tid, 4); });
+        ex.all([&](int tid) {
+            if (prev_clen) am_shift_s3(lds, prev_clen, tid);
+            front_rotate<GATED, MAG>(t, lds, cb, cstart, clen, tid, 4);
+        });
         ex.all([&](int tid) {
             if (MAG) flush_mag(t, lds, cb, cstart, clen, tid);
             am_stage1(c, lds, clen, tid);
         });
-        ex.all([&](int tid) { am_stage2(c, lds, clen, tid); });
-        ex.all([&](int tid) { am_stage3(c, lds, clen, tid); });
-        ex.all([&](int tid) { am_detect(c, lds, t, cstart, clen, tid, ssb, lsb, base_row, base_stride_t); });
-        ex.all([&](int tid) { am_shift(lds, clen, tid); });
+        ex.all([&](int tid) {
+            am_stage2(c, lds, clen, tid);
+            am_shift_rails(lds, clen, tid);
+        });
+        ex.all([&](int tid) {
+            am_stage3(c, lds, clen, tid);
+            am_shift_s1(lds, clen, tid);
+        });
+        ex.all([&](int tid) {
+            am_detect(c, lds, t, cstart, clen, tid, ssb, lsb, base_row, base_stride_t);
+            am_shift_s2(lds, clen, tid);
+        });
+        prev_clen = clen;
         cstart += clen;
     }
 }
