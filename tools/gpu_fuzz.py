@@ -1,0 +1,141 @@
+"""Diagnostic: randomized engine-vs-oracle runs on an MI355X (modes, gains, rotation, squelch gating, AGC, scanner,
+block sizes, call boundaries, signal kinds).  `python tools/gpu_fuzz.py [seconds] [seed]`; exits non-zero on the first
+difference and prints the configuration that produced it."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np                                     # noqa: E402
+from oracle import bindings as B                       # noqa: E402
+from rtlsdrdiags_amd import capi, synth                # noqa: E402
+
+MODES = ["none", "am", "fm", "wbfm", "lsb", "usb"]
+DEMOD = {"am": 1, "fm": 2, "wbfm": 3, "lsb": 4, "usb": 4}
+
+
+def carrier(n, amp):
+    pat = np.array([[amp, 0], [0, -amp], [-amp, 0], [0, amp]], np.int16)
+    return (128 + np.tile(pat, (n // 4, 1))).astype(np.uint8).reshape(-1)
+
+
+def signal(rng, n, block_samples):
+    kind = rng.integers(0, 8)
+    if kind == 0:
+        return synth.white_u8(n, int(rng.integers(1 << 30)))
+    if kind == 1:
+        return synth.rails_u8(n, int(rng.integers(1 << 30)))
+    if kind == 2:
+        return carrier(n, int(rng.integers(0, 128)))
+    if kind == 3:
+        return np.full(2 * n, int(rng.integers(0, 256)), np.uint8)
+    if kind == 4:
+        nblk = n // block_samples
+        amps = [int(a) for a in rng.choice([0, 2, 30, 70, 120], nblk)]
+        return synth.stepped_amplitude(amps, block_samples=block_samples, seed=int(rng.integers(1 << 30)))
+    if kind == 5:   # bursts between noiseless stretches
+        a = carrier(n, 50).reshape(-1, 2)
+        k0, k1 = sorted(rng.integers(0, n, 2))
+        a[k0:k1] = synth.fm_tone(n, seed=int(rng.integers(1 << 30))).reshape(-1, 2)[k0:k1]
+        return a.reshape(-1)
+    if kind == 6:
+        return synth.am_tone(n, seed=int(rng.integers(1 << 30)), depth=float(rng.uniform(0, 1)),
+                             amplitude=float(rng.uniform(5, 100)))
+    return synth.fm_tone(n, seed=int(rng.integers(1 << 30)), deviation=float(rng.uniform(0, 9e4)),
+                         amplitude=float(rng.uniform(2, 127)), sigma=float(rng.choice([0.0, 1.0, 6.0])))
+
+
+def one_case(rng, O):
+    bb = int(rng.choice([256, 2048, 4096, 32768]))
+    n_ch = int(rng.integers(1, 6 if os.environ.get("FUZZ_BIG") else 24))
+    budget = (1 << 24) if os.environ.get("FUZZ_BIG") else (1 << 21)      # bytes of IQ per case, all channels
+    nblk = int(rng.integers(1, max(2, budget // (bb * n_ch))))
+    nblk = max(1, min(nblk, 4096))
+    n = nblk * bb // 2
+    cfg = []
+    eng = capi.Engine(n_ch, block_bytes=bb)
+    chains = []
+    iq = np.empty((n_ch, 2 * n), np.uint8)
+    for c in range(n_ch):
+        mode = MODES[int(rng.integers(0, 6))]
+        gain = None
+        if mode != "none" and rng.random() < 0.5:
+            gain = float(np.float32(10.0 ** rng.uniform(-2, 8)) * (1 if rng.random() < 0.9 else -1))
+        rot = int(rng.integers(-1, 2))
+        thr = int(rng.choice([-200, -200, -60, -45, -30]))
+        rxg = int(rng.integers(0, 47))
+        agc = rng.random() < 0.4
+        agc_type, agc_alpha = int(rng.integers(0, 2)), float(np.float32(rng.choice([0.05, 0.5, 0.8])))
+        scan = rng.random() < 0.3
+        cfg.append((mode, gain, rot, thr, rxg, agc, agc_type, agc_alpha, scan))
+        o = O.chain()
+        for tgt in (o,):
+            tgt.set_mode(mode)
+            if gain is not None:
+                tgt.set_gain(DEMOD[mode], gain)
+            tgt.set_rotation(rot)
+            tgt.set_squelch(thr)
+            tgt.set_rx_gain_db(rxg)
+            if agc:
+                tgt.agc_set_type(agc_type); tgt.agc_set_filter_coefficient(agc_alpha); tgt.agc_enable(True)
+            if scan:
+                tgt.scanner_set_parameters(1000, 9000, 1000); tgt.scanner_start()
+        eng.set_mode(mode, first=c, n=1)
+        if gain is not None:
+            eng.set_gain(DEMOD[mode], gain, first=c, n=1)
+        eng.set_rotation(rot, first=c, n=1)
+        eng.set_squelch(thr, first=c, n=1)
+        eng.set_rx_gain_db(rxg, first=c, n=1)
+        if agc:
+            eng.agc_set_type(agc_type, first=c, n=1); eng.agc_set_filter_coefficient(agc_alpha, first=c, n=1)
+            eng.agc_enable(True, first=c, n=1)
+        if scan:
+            eng.scanner_set_parameters(1000, 9000, 1000, first=c, n=1); eng.scanner_start(True, first=c, n=1)
+        chains.append(o)
+        iq[c] = signal(rng, n, bb // 2)
+    cuts = sorted(set([0, nblk] + [int(x) for x in rng.integers(0, nblk + 1, int(rng.integers(0, 3)))]))
+    got = [[] for _ in range(n_ch)]
+    got_allowed, got_mag = [], []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        pcm, cnt, mag, allowed = eng.accept(iq[:, a * bb:b * bb])
+        for c in range(n_ch):
+            got[c].append(pcm[c, :cnt[c]])
+        got_allowed.append(allowed)
+        got_mag.append(mag)
+    got_allowed, got_mag = np.concatenate(got_allowed, axis=1), np.concatenate(got_mag, axis=1)
+    for c in range(n_ch):
+        ref, rmag, rallowed = chains[c].accept_stream(iq[c], bb)
+        what = None
+        if not np.array_equal(got_allowed[c], rallowed):
+            what = "allowed"
+        elif not np.array_equal(got_mag[c], rmag):
+            what = "magnitude"
+        elif not np.array_equal(np.concatenate(got[c]), ref):
+            what = "pcm"
+        elif eng.rx_gain_db(c) != chains[c].rx_gain_db():
+            what = "gain"
+        elif cfg[c][8] and eng.scanner_tuned(c)[0] != chains[c].scanner_tuned()[0]:
+            what = "scanner"
+        if what:
+            print("MISMATCH in %s: channel %d of %d, block_bytes %d, %d blocks, cuts %s, cfg %s" %
+                  (what, c, n_ch, bb, nblk, cuts, cfg[c]))
+            return False
+    eng.close()
+    return True
+
+
+def main():
+    seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    O = B.Oracle()
+    t0, cases = time.time(), 0
+    while time.time() - t0 < seconds:
+        if not one_case(rng, O):
+            sys.exit(1)
+        cases += 1
+    print("gpu_fuzz: %d cases identical to the oracle in %.0f s (seed %d)" % (cases, time.time() - t0, seed))
+
+
+if __name__ == "__main__":
+    main()
