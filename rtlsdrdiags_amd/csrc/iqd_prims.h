@@ -141,8 +141,12 @@ IQD_DEV float wrap_delta(float d)
     const float PI_F = 3.14159274101257324f;       // smallest float > M_PI
     const float TWO_PI_HI = 6.28318548202514648f;  // (float)(2*M_PI)
     const float TWO_PI_LO = -1.74845553146951715e-7f;  // (float)(2*M_PI - TWO_PI_HI)
-    // k = sign(d) when |d| >= pi else 0;  d - k*HI is exact (Sterbenz), then one rounding
-    const float k = (__builtin_fabsf(d) >= PI_F) ? __builtin_copysignf(1.0f, d) : 0.0f;
+    // k = sign(d) when |d| >= PI_F else 0, for |d| <= 2*pi (differences of two table angles), as one multiply and
+    // one round-to-nearest-even: the product is monotone in d, equals 0.5 exactly at the float just below PI_F
+    // (ties go to the even 0) and 0.50000006 at PI_F, 1.0000001 at 2*pi (tests/test_host_logic.py checks the whole
+    // interval).  d - k*HI is exact (Sterbenz), then one rounding.
+    const float k = __builtin_rintf(d * 0.15915495157241821f);
+    (void)PI_F;
     d = __builtin_fmaf(-k, TWO_PI_HI, d);
     d = __builtin_fmaf(-k, TWO_PI_LO, d);
     return d;

@@ -30,6 +30,18 @@ def test_wrap_delta_float_only():
         mine = np.where(x >= pi_f, ((x - hi).astype(np.float32) - lo).astype(np.float32),
                         np.where(x <= -pi_f, ((x + hi).astype(np.float32) + lo).astype(np.float32), x))
         assert np.array_equal(mine.view(np.uint32), ref.view(np.uint32))
+        # the kernels pick the branch with k = rint(d * c) (one v_mul_f32 + one v_rndne_f32): it must be
+        # sign(d) exactly where |d| >= pi_f and 0 below, over this whole interval ...
+        c = f32(0.15915495157241821)
+        k = np.rint((x * c).astype(np.float32))
+        assert np.array_equal(k, np.where(np.abs(x) >= pi_f, f32(sign), f32(0.0)))
+    # ... and, the product being monotone in d, everywhere in [0, 2*pi]: zero up to the float below pi_f, one from pi_f on
+    c = f32(0.15915495157241821)
+    below = np.nextafter(pi_f, f32(0))
+    assert f32(below * c) == f32(0.5) and np.rint(f32(below * c)) == 0      # the tie goes to the even 0
+    assert np.rint(f32(pi_f * c)) == 1 and np.rint(f32(hi * c)) == 1 and f32(hi * c) < 1.5
+    lowbits = np.arange(0, np.array([pi_f]).view(np.uint32)[0], 4099, dtype=np.uint32).view(np.float32)
+    assert not np.rint((lowbits * c).astype(np.float32)).any()
 
 
 def test_library_exports_every_declared_symbol():
