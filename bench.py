@@ -202,6 +202,7 @@ def main():
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_SAMPLE * n * n_ch},
             "state_checks": k1["state_checks"] - k0["state_checks"],
             "state_repairs": k1["state_repairs"] - k0["state_repairs"],
+            "segment_repairs": k1["segment_repairs"] - k0["segment_repairs"],
         }
         if world == 1 and not args.no_host_path:
             out["host_path"] = host_path(eng, iq, n, n_ch)

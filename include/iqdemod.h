@@ -202,6 +202,8 @@ typedef struct iqd_stats {
     uint64_t state_repairs;      /* tiles (WBFM) / rows (AM, SSB DC removal) re-run from the exact carried state */
     double chain_kernel_ms;      /* HIP-event time of the chain kernels while profiling is on */
     uint64_t chain_kernel_count; /* launches covered by chain_kernel_ms */
+    uint64_t segment_repairs;    /* extra in-kernel passes of the segmented de-emphasis (a segment's warm-up had not
+                                    reached its neighbour's exact state yet) */
 } iqd_stats;
 
 int iqd_get_stats(iqd_t *e, iqd_stats *out);

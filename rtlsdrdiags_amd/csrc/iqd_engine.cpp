@@ -606,6 +606,7 @@ int iqd_get_stats(iqd_t *e, iqd_stats *out)
     }
     e->ev_pending.clear();
     e->stats.state_checks = e->h_counters[CNT_TILE_CHECKS];
+    e->stats.segment_repairs = e->h_counters[CNT_SEG_REPAIRS];
     e->stats.state_repairs = (uint64_t)e->h_counters[CNT_TILE_REPAIRS] + e->h_counters[CNT_DC_REDO];
     *out = e->stats;
     return IQD_OK;
