@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include "iqd_taps.h"
+#include "iqd_prims.h"
 
 namespace iqd {
 
@@ -104,7 +105,7 @@ void build_atan2_lut(std::vector<float> &lut)
     lut.resize(256 * 256);
     for (int x = 0; x < 256; x++)
         for (int y = 0; y < 256; y++)
-            lut[(size_t)y * 256 + x] = (float)atan2((double)y - 128, (double)x - 128);
+            lut[lut_index((uint32_t)(y * 256 + x))] = (float)atan2((double)y - 128, (double)x - 128);
 }
 
 void build_fm_lut(std::vector<float> &lut)

@@ -131,6 +131,22 @@ IQD_DEV uint32_t neg_bytes(uint32_t x, uint32_t mask)
     return ((t & 0x7f7f7f7fu) + (mask & 0x01010101u)) ^ (t & 0x80808080u);
 }
 
+// Where the atan2 table keeps the angle of (x, y), given off = (y << 8) | x.  The table is stored in
+// tiles of 4 rows x 8 columns (one 128-byte cache line each: index bits y7..y2 x7..x3 y1 y0 x2 x1 x0), so that the
+// ring of cells a constant-envelope signal visits covers 3-4 times fewer lines than with 1 x 32 row pieces
+// (measured: bench signal -1.6 %, full-scale signal -8 %, weak signal and uniform noise +2-3 %: four more
+// operations per sample against fewer L1 misses).
+IQD_DEV uint32_t lut_index(uint32_t off)
+{
+#ifndef IQD_LUT_ROWS   // (row-major table: the A/B alternative)
+    uint32_t t = (((off << 2) ^ off) & 0x03e0u) ^ off;      // bits 9..5 <- x7..x3       (v_lshlrev, v_bfi)
+    t = (((off >> 5) ^ t) & 0x0018u) ^ t;                   // bits 4..3 <- y1 y0         (v_lshrrev, v_bfi)
+    return t;
+#else
+    return off;
+#endif
+}
+
 // Branch-cut handling of the FM discriminators (WbFmDemodulator.cc:472-480,
 // FmDemodulator.cc:485-493).  The reference compares in double against M_PI and adds
 // -+2*M_PI in double before rounding to float; for |d| <= 2*pi that equals the two float

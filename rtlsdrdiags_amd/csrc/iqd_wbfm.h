@@ -222,7 +222,7 @@ IQD_DEV void p1_gather(const WbfmTile &t, const uint32_t (&off)[17], float (&th)
 #ifdef IQD_ABL_NOLUT   // diagnostic build: no table gather
         th[k] = u2f(0x3f000000u | (off[k] & 0xffu));
 #else
-        th[k] = t.lut[off[k]];
+        th[k] = t.lut[lut_index(off[k])];
 #endif
     }
 }
@@ -851,7 +851,7 @@ IQD_DEV void p1s_gather(const WbfmTile &t, const uint32_t (&off)[17], float (&th
 #ifdef IQD_ABL_NOLUT   // diagnostic build: no table gather
         th[k] = u2f(0x3f000000u | (off[k] & 0xffu));
 #else
-        th[k] = t.lut[off[k]];
+        th[k] = t.lut[lut_index(off[k])];
 #endif
     }
 }
