@@ -557,9 +557,9 @@ IQD_DEV void dc_block_wave(Exec &ex, const Consts &c, DcLds &lds, const int32_t 
 // A channel's 8 kS/s stream is cut into tiles of DC_TILE samples, one wave each.  Tile 0 starts from the exact
 // carried state; every other tile first runs the DC_WARM samples in front of it from the zero state - two
 // trajectories of this contraction (pole 0.95) become bit-identical after a few hundred steps - and then its
-// own samples.  It records the state it started from and the state it ended in; dc_tiles_ok() accepts the
-// channel only if every tile's start state equals its predecessor's end state bit for bit, which by induction
-// from tile 0 makes every tile the serial result.  Otherwise (e.g. a decaying tail that has not reached zero)
+// own samples.  It records the state it started from and the state it ended in; the channel is accepted
+// only if every tile's start state agrees with its predecessor's end state (dc_chainup_kernel), which by
+// induction from tile 0 makes every tile the serial result.  Otherwise (e.g. a decaying tail that has not reached zero)
 // the one-wave pass above redoes the channel from the carried state.
 constexpr int DC_TILE = DC_SUPER;     // 8192
 constexpr int DC_WARM = 2048;
@@ -582,16 +582,6 @@ IQD_DEV void dc_tile(Exec &ex, const Consts &c, DcLds &lds, const int32_t *x, in
     rec.y_end = st.y_prev;
     rec.x_end = st.x_prev;
     rec.pad = 0;
-}
-
-// true if the tiles of one channel chain up exactly; then `out` is the state after the last one
-IQD_DEV bool dc_tiles_ok(const DcRecord *rec, int ntiles, DcCarry &out, bool tiny_ok)
-{
-    for (int t = 1; t < ntiles; t++)
-        if (!iir_states_agree(rec[t].y_start, rec[t - 1].y_end, tiny_ok)) return false;
-    out.x_prev = rec[ntiles - 1].x_end;
-    out.y_prev = rec[ntiles - 1].y_end;
-    return true;
 }
 
 // ---- per-block control loops carried by the squelch pass (host + device, like the chains) -----------------

@@ -296,40 +296,49 @@ __global__ __launch_bounds__(64) void dc_tiled_kernel(const ChainLaunch a, int f
     if (threadIdx.x == 0) ((DcRecord *)a.dc_records)[(size_t)li * a.dc_tiles + tile] = rec;
 }
 
+// one thread per (channel, tile boundary): flags the channel when the boundary does not chain up
 __global__ void dc_chainup_kernel(const ChainLaunch a, int family)
 {
-    const uint32_t li = blockIdx.x * blockDim.x + threadIdx.x;
-    if (li >= a.n_list) return;
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t li = idx / a.dc_tiles, tile = idx - li * a.dc_tiles;
+    if (li >= a.n_list || tile == 0) return;
     const uint32_t ch = a.ch_list[li], ech = a.first_ch + ch;
     const uint32_t n = (a.vlen_gated ? a.vlen_gated[ch] : a.vlen) / 32;
-    uint32_t *redo = (uint32_t *)((DcRecord *)a.dc_records + (size_t)a.n_list * a.dc_tiles);
-    redo[li] = 0;
-    if (n == 0) return;
-    const int ntiles = (int)((n + DC_TILE - 1) / DC_TILE);
-    DcCarry out;
-    if (dc_tiles_ok((const DcRecord *)a.dc_records + (size_t)li * a.dc_tiles, ntiles, out,
-                    fabsf(a.params[ech].gain[family]) <= 1e6f)) {
-        a.dc_carry[2 * (size_t)ech + (family == FAM_SSB ? 1 : 0)] = out;
-    } else {
+    if ((size_t)tile * DC_TILE >= n) return;
+    const DcRecord *rec = (const DcRecord *)a.dc_records + (size_t)li * a.dc_tiles;
+    if (!iir_states_agree(rec[tile].y_start, rec[tile - 1].y_end, fabsf(a.params[ech].gain[family]) <= 1e6f)) {
+        uint32_t *redo = (uint32_t *)((DcRecord *)a.dc_records + (size_t)a.n_list * a.dc_tiles);
         redo[li] = 1;
-        atomicAdd(&a.counters[CNT_DC_REDO], 1u);
     }
 }
 
+// per channel: commit the last tile's state - or, if some boundary was flagged, redo the row with the one-wave pass
 __global__ __launch_bounds__(64) void dc_redo_kernel(const ChainLaunch a, int family)
 {
     __shared__ DcLds lds;
     const uint32_t li = blockIdx.x;
-    const uint32_t *redo = (const uint32_t *)((const DcRecord *)a.dc_records + (size_t)a.n_list * a.dc_tiles);
-    if (!redo[li]) return;
+    uint32_t *redo = (uint32_t *)((DcRecord *)a.dc_records + (size_t)a.n_list * a.dc_tiles);
     const uint32_t ch = a.ch_list[li], ech = a.first_ch + ch;
     const uint32_t vlen = a.vlen_gated ? a.vlen_gated[ch] : a.vlen;
+    const uint32_t n = vlen / 32;
+    DcCarry *carry = &a.dc_carry[2 * (size_t)ech + (family == FAM_SSB ? 1 : 0)];
+    if (!redo[li]) {
+        if (threadIdx.x == 0 && n) {
+            const DcRecord last = ((const DcRecord *)a.dc_records)[(size_t)li * a.dc_tiles + (n + DC_TILE - 1) / DC_TILE - 1];
+            *carry = DcCarry{last.x_end, last.y_end};
+        }
+        return;
+    }
     const ChanParams &p = a.params[ech];
-    DcCarry st = a.dc_carry[2 * (size_t)ech + (family == FAM_SSB ? 1 : 0)];
+    DcCarry st = *carry;
     DeviceExec ex{(int)threadIdx.x};
-    dc_block_wave(ex, g_consts, lds, a.base8k + (size_t)ch * a.base_stride_ch, (int)(vlen / 32), p.gain[family], st,
+    dc_block_wave(ex, g_consts, lds, a.base8k + (size_t)ch * a.base_stride_ch, (int)n, p.gain[family], st,
                   a.pcm + (size_t)ch * a.pcm_stride);
-    if (threadIdx.x == 0) a.dc_carry[2 * (size_t)ech + (family == FAM_SSB ? 1 : 0)] = st;
+    if (threadIdx.x == 0) {
+        *carry = st;
+        redo[li] = 0;   // zero between calls
+        atomicAdd(&a.counters[CNT_DC_REDO], 1u);
+    }
 }
 
 // Hand-off check between consecutive tiles of a channel: a cold tile's own state at its
@@ -699,7 +708,7 @@ hipError_t launch_am(const ChainLaunch &a_in, int family, bool gated, bool mag, 
         hipLaunchKernelGGL(dc_kernel, dim3((a.n_list + 63) / 64), dim3(64), 0, s, a, family);
     } else if (a.dc_tiles >= 2 && a.dc_records) {   // rows longer than one tile: many waves per channel
         hipLaunchKernelGGL(dc_tiled_kernel, dim3(a.dc_tiles, a.n_list), dim3(64), 0, s, a, family);
-        hipLaunchKernelGGL(dc_chainup_kernel, dim3((a.n_list + 63) / 64), dim3(64), 0, s, a, family);
+        hipLaunchKernelGGL(dc_chainup_kernel, dim3((a.n_list * a.dc_tiles + 255) / 256), dim3(256), 0, s, a, family);
         hipLaunchKernelGGL(dc_redo_kernel, dim3(a.n_list), dim3(64), 0, s, a, family);
     } else {
         hipLaunchKernelGGL(dc_wave_kernel, dim3(a.n_list), dim3(64), 0, s, a, family);
