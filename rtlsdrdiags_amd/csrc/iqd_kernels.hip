@@ -493,6 +493,85 @@ __global__ void squelch_track_kernel(const SquelchLaunch q, int always_open)
     }
 }
 
+// The same for rows of many blocks: one wave per channel, 64 blocks at a time.  The lanes fetch the 64 averages
+// together; with a fixed gain the decisions are independent (allowed = present | present of the block before) and
+// the open-block list is a ballot/popcount compaction; with a running AGC the wave steps through the 64 values in
+// order from registers (the recurrence stays serial, the memory latency is gone).
+__global__ __launch_bounds__(64) void squelch_track_wave_kernel(const SquelchLaunch q, int always_open)
+{
+    const uint32_t ch = blockIdx.x, lane = threadIdx.x;
+    const uint32_t ech = q.first_ch + ch;
+    const AgcConfig cfg = q.agc_cfg[ech];
+    if (always_open && !cfg.enabled) return;
+    const ChanParams &p = q.params[ech];
+    AgcState st = q.agc[ech];
+    uint32_t gain = st.rx_gain;
+    uint32_t tracking = q.tracker[ech];
+    uint32_t open = 0;
+    const ScanConfig sc = q.scan_cfg[ech];
+    ScanState ss = q.scan[ech];
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (uint32_t base = 0; base < q.n_blocks; base += 64) {
+        const uint32_t b = base + lane;
+        const bool valid = b < q.n_blocks;
+        const size_t idx = (size_t)ch * q.n_blocks + (valid ? b : q.n_blocks - 1);
+        const uint32_t avg = q.mag_sums[idx] / q.block_samples;
+        const uint32_t count = q.n_blocks - base < 64 ? q.n_blocks - base : 64;
+        uint32_t my_gain = gain, allowed = 0;
+        unsigned long long my_freq = ss.current_hz;
+        if (!cfg.enabled && !sc.scanning) {   // nothing moves from block to block but the tracker's one-block tail
+            if (!always_open) {
+                const uint32_t m = avg > 127u ? 127u : avg;
+                int32_t dbfs = g_consts.db_table[m] - 42;
+                dbfs = (int32_t)((uint32_t)dbfs - gain);
+                const uint32_t present = (valid && dbfs >= p.threshold) ? 1u : 0u;
+                uint32_t before = (uint32_t)__shfl_up((int)present, 1);
+                if (lane == 0) before = tracking;
+                allowed = present | before;
+                tracking = (uint32_t)__shfl((int)present, (int)count - 1);
+            }
+        } else {
+            for (uint32_t j = 0; j < count; j++) {   // wave-uniform state, block j's average from lane j
+                const uint32_t a = (uint32_t)__shfl((int)avg, (int)j);
+                uint32_t al = 1;
+                if (!always_open) {
+                    const uint32_t m = a > 127u ? 127u : a;
+                    int32_t dbfs = g_consts.db_table[m] - 42;
+                    dbfs = (int32_t)((uint32_t)dbfs - gain);
+                    const uint32_t present = dbfs >= p.threshold ? 1u : 0u;
+                    al = present | tracking;
+                    tracking = present;
+                    if (!al && sc.scanning) scanner_step(sc, ss);
+                }
+                if (lane == j) { allowed = al; my_gain = gain; my_freq = ss.current_hz; }
+                if (cfg.enabled) gain = agc_run(g_consts, cfg, st, a, gain);
+            }
+        }
+        if (valid) {
+            if (q.gain_trace) q.gain_trace[idx] = my_gain;
+            if (!always_open) {
+                if (q.allowed) q.allowed[idx] = (uint8_t)allowed;
+                if (q.freq_trace) q.freq_trace[idx] = my_freq;
+            }
+        }
+        if (!always_open) {
+            const unsigned long long ball = __ballot(valid && allowed);
+            if (valid && allowed) q.blk_lists[(size_t)ch * q.n_blocks + open + (uint32_t)__popcll(ball & below)] = b;
+            open += (uint32_t)__popcll(ball);
+        }
+    }
+    if (lane != 0) return;
+    st.rx_gain = gain;
+    q.agc[ech] = st;
+    if (!always_open) {
+        q.tracker[ech] = tracking;
+        q.scan[ech] = ss;
+        const uint32_t vlen = (p.mode == 0) ? 0u : open * q.block_samples;
+        q.vlen_out[ch] = vlen;
+        if (q.pcm_count) q.pcm_count[ch] = vlen / 32u;
+    }
+}
+
 // The operator's one-shot commands, applied before the next block: a manual IF gain
 // (Radio::setReceiveIfGainInDb), resetBlankingSystem() (AutomaticGainControl.cc:625-634), the scanner's jump to
 // its end frequency when it starts with new parameters.
@@ -748,8 +827,12 @@ hipError_t launch_squelch(const SquelchLaunch &q, bool always_open, hipStream_t 
 {
     const uint32_t n = q.n_ch * q.n_blocks;
     hipLaunchKernelGGL(squelch_block_kernel, dim3((n + 255) / 256), dim3(256), 0, s, q, always_open ? 1 : 0);
-    if (!always_open || q.any_agc)
-        hipLaunchKernelGGL(squelch_track_kernel, dim3((q.n_ch + 63) / 64), dim3(64), 0, s, q, always_open ? 1 : 0);
+    if (!always_open || q.any_agc) {
+        if (q.n_blocks >= 32)   // long rows: one wave per channel
+            hipLaunchKernelGGL(squelch_track_wave_kernel, dim3(q.n_ch), dim3(64), 0, s, q, always_open ? 1 : 0);
+        else
+            hipLaunchKernelGGL(squelch_track_kernel, dim3((q.n_ch + 63) / 64), dim3(64), 0, s, q, always_open ? 1 : 0);
+    }
     return hipGetLastError();
 }
 
