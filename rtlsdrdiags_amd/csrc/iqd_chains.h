@@ -587,47 +587,50 @@ IQD_DEV void dc_tile(Exec &ex, const Consts &c, DcLds &lds, const int32_t *x, in
 // ---- per-block control loops carried by the squelch pass (host + device, like the chains) -----------------
 // AutomaticGainControl::run (AutomaticGainControl.cc:663-741) with runLowpass (:743-889) / runHarris
 // (:935-1062): one block magnitude in, the receiver's IF gain out.  binary32 arithmetic in the reference's order.
+// convertMagnitudeToDbFs for the AGC and the squelch (DbfsCalculator.cc:111-147 with full scale 127)
+IQD_DEV int32_t magnitude_dbfs(const Consts &c, uint32_t magnitude)
+{
+    const uint32_t m = magnitude > 127u ? 127u : magnitude;   // :122-125
+    return c.db_table[m] - 42;
+}
+
+IQD_DEV uint32_t agc_run_dbfs(const AgcConfig &cfg, AgcState &st, uint32_t magnitude, int32_t signal, uint32_t gain);
+
 IQD_DEV uint32_t agc_run(const Consts &c, const AgcConfig &cfg, AgcState &st, uint32_t magnitude, uint32_t gain)
 {
-    if (st.if_gain != gain) st.if_gain = gain;   // follow the operator's manual changes
-    bool allowed = false;
-    if (st.adjusted) {   // blank the measurements that follow an adjustment
-        if (st.blank_ctr < cfg.blanking_limit) {
-            st.blank_ctr++;
-        } else {
-            st.blank_ctr = 0;
-            st.adjusted = 0;
-            allowed = true;
-        }
-    } else {
-        allowed = true;
-    }
-    if (!allowed) return gain;
-    st.signal_magnitude = magnitude;
-    const uint32_t m = magnitude > 127u ? 127u : magnitude;   // DbfsCalculator.cc:122-125
-    const int32_t signal = c.db_table[m] - 42;
-    st.normalized = (int32_t)((uint32_t)signal - st.if_gain);
+    return agc_run_dbfs(cfg, st, magnitude, magnitude_dbfs(c, magnitude), gain);
+}
+
+// the same with the magnitude's dBFS value already looked up (the wave kernel does that for 64 blocks at once).
+// Written with selects instead of branches: the long-row kernel runs it once per block on wave-uniform values, where
+// every branch costs more than the arithmetic it skips.
+IQD_DEV uint32_t agc_run_dbfs(const AgcConfig &cfg, AgcState &st, uint32_t magnitude, int32_t signal, uint32_t gain)
+{
+    st.if_gain = gain;   // run(): follow the operator's manual changes (:682-688)
+    // blank the measurements that follow an adjustment (:690-707)
+    const bool adjusted = st.adjusted != 0;
+    const bool blank = adjusted && st.blank_ctr < cfg.blanking_limit;
+    st.blank_ctr = blank ? st.blank_ctr + 1 : (adjusted ? 0u : st.blank_ctr);
+    const bool allowed = !blank;
+    // runLowpass / runHarris on the side, committed only if allowed
     int32_t error = cfg.operating_point - signal;
-    if (st.if_gain == AGC_MAX_GAIN) {
-        if (error > 0) error = 0;
-    } else if (st.if_gain == 0) {
-        if (error < 0) error = 0;
-    }
-    if ((error < 0 ? -error : error) <= cfg.deadband) error = 0;
-    if (cfg.type == 0) {
-        const int32_t adjusted = (int32_t)(st.if_gain + (uint32_t)error);
-        st.filtered = (cfg.alpha * (float)adjusted) + ((1 - cfg.alpha) * st.filtered);
-    } else {
-        st.filtered = st.filtered + (cfg.alpha * (float)error);
-    }
-    if (st.filtered > (float)AGC_MAX_GAIN) st.filtered = (float)AGC_MAX_GAIN;
-    else if (st.filtered < 0) st.filtered = 0;
-    st.if_gain = (uint32_t)st.filtered;
-    if (error != 0) {
-        gain = st.if_gain;   // Radio::setReceiveIfGainInDb(0, ifGainInDb), Radio.cc:851-861
-        st.adjusted = 1;
-    }
-    return gain;
+    const bool at_max = st.if_gain == AGC_MAX_GAIN, at_min = st.if_gain == 0;
+    error = (at_max && error > 0) ? 0 : error;
+    error = (!at_max && at_min && error < 0) ? 0 : error;
+    error = ((error < 0 ? -error : error) <= cfg.deadband) ? 0 : error;
+    const int32_t target = (int32_t)(st.if_gain + (uint32_t)error);
+    const float lowpass = (cfg.alpha * (float)target) + ((1 - cfg.alpha) * st.filtered);
+    const float harris = st.filtered + (cfg.alpha * (float)error);
+    float filtered = cfg.type == 0 ? lowpass : harris;
+    filtered = filtered > (float)AGC_MAX_GAIN ? (float)AGC_MAX_GAIN : (filtered < 0 ? 0.f : filtered);
+    const uint32_t if_gain = (uint32_t)filtered;
+    const bool changed = allowed && error != 0;
+    st.signal_magnitude = allowed ? magnitude : st.signal_magnitude;
+    st.normalized = allowed ? (int32_t)((uint32_t)signal - st.if_gain) : st.normalized;
+    st.filtered = allowed ? filtered : st.filtered;
+    st.if_gain = allowed ? if_gain : st.if_gain;
+    st.adjusted = changed ? 1u : (blank ? 1u : 0u);
+    return changed ? if_gain : gain;   // Radio::setReceiveIfGainInDb(0, ifGainInDb), Radio.cc:851-861
 }
 
 // FrequencyScanner::run on a rejected block (signalStateCallback -> run, FrequencyScanner.cc:47-62, :378-404)

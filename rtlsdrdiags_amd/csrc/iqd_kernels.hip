@@ -501,12 +501,21 @@ __global__ __launch_bounds__(64) void squelch_track_wave_kernel(const SquelchLau
 {
     const uint32_t ch = blockIdx.x, lane = threadIdx.x;
     const uint32_t ech = q.first_ch + ch;
-    const AgcConfig cfg = q.agc_cfg[ech];
+    // everything the block loop carries is the same in all lanes: say so (readfirstlane), and the integer part of the
+    // per-block state machine runs on the scalar unit
+    auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+    AgcConfig cfg = q.agc_cfg[ech];
+    cfg.enabled = uni(cfg.enabled); cfg.type = uni(cfg.type); cfg.operating_point = (int32_t)uni((uint32_t)cfg.operating_point);
+    cfg.deadband = (int32_t)uni((uint32_t)cfg.deadband); cfg.blanking_limit = uni(cfg.blanking_limit);
+    cfg.alpha = u2f(uni(f2u(cfg.alpha)));
     if (always_open && !cfg.enabled) return;
     const ChanParams &p = q.params[ech];
+    const int32_t threshold = (int32_t)uni((uint32_t)p.threshold);
     AgcState st = q.agc[ech];
-    uint32_t gain = st.rx_gain;
-    uint32_t tracking = q.tracker[ech];
+    st.if_gain = uni(st.if_gain); st.blank_ctr = uni(st.blank_ctr); st.adjusted = uni(st.adjusted);
+    st.filtered = u2f(uni(f2u(st.filtered)));
+    uint32_t gain = uni(st.rx_gain);
+    uint32_t tracking = uni(q.tracker[ech]);
     uint32_t open = 0;
     const ScanConfig sc = q.scan_cfg[ech];
     ScanState ss = q.scan[ech];
@@ -524,27 +533,27 @@ __global__ __launch_bounds__(64) void squelch_track_wave_kernel(const SquelchLau
                 const uint32_t m = avg > 127u ? 127u : avg;
                 int32_t dbfs = g_consts.db_table[m] - 42;
                 dbfs = (int32_t)((uint32_t)dbfs - gain);
-                const uint32_t present = (valid && dbfs >= p.threshold) ? 1u : 0u;
+                const uint32_t present = (valid && dbfs >= threshold) ? 1u : 0u;
                 uint32_t before = (uint32_t)__shfl_up((int)present, 1);
                 if (lane == 0) before = tracking;
                 allowed = present | before;
                 tracking = (uint32_t)__shfl((int)present, (int)count - 1);
             }
         } else {
-            for (uint32_t j = 0; j < count; j++) {   // wave-uniform state, block j's average from lane j
-                const uint32_t a = (uint32_t)__shfl((int)avg, (int)j);
+            const int32_t my_sig = magnitude_dbfs(g_consts, avg);   // the table look-ups of all 64 blocks at once
+            for (uint32_t j = 0; j < count; j++) {   // wave-uniform state, block j's values from lane j
+                const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)avg, (int)j);
+                const int32_t sig = __builtin_amdgcn_readlane(my_sig, (int)j);
                 uint32_t al = 1;
                 if (!always_open) {
-                    const uint32_t m = a > 127u ? 127u : a;
-                    int32_t dbfs = g_consts.db_table[m] - 42;
-                    dbfs = (int32_t)((uint32_t)dbfs - gain);
-                    const uint32_t present = dbfs >= p.threshold ? 1u : 0u;
+                    const int32_t dbfs = (int32_t)((uint32_t)sig - gain);
+                    const uint32_t present = dbfs >= threshold ? 1u : 0u;
                     al = present | tracking;
                     tracking = present;
                     if (!al && sc.scanning) scanner_step(sc, ss);
                 }
                 if (lane == j) { allowed = al; my_gain = gain; my_freq = ss.current_hz; }
-                if (cfg.enabled) gain = agc_run(g_consts, cfg, st, a, gain);
+                if (cfg.enabled) gain = agc_run_dbfs(cfg, st, a, sig, gain);
             }
         }
         if (valid) {
