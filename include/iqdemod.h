@@ -74,7 +74,10 @@ void iqd_destroy(iqd_t *e);
  * (Lsb/Usb also select the SsbDemodulator sideband, :244-256). */
 int iqd_set_mode(iqd_t *e, uint32_t first_ch, uint32_t n_ch, int mode);
 
-/* Replaces {Am,Fm,WbFm,Ssb}Demodulator::setDemodulatorGain (e.g. WbFmDemodulator.cc:341-348). */
+/* Replaces {Am,Fm,WbFm,Ssb}Demodulator::setDemodulatorGain (e.g. WbFmDemodulator.cc:341-348).  Takes effect with the
+ * first sample of the next accept; what the filters already hold keeps the old gain, as in the reference (the engine
+ * remembers one earlier gain per demodulator for that: changes of the same gain less than 2048 samples - 8 ms - apart
+ * are reproduced from the more recent one only). */
 int iqd_set_gain(iqd_t *e, uint32_t first_ch, uint32_t n_ch, int demod, float gain);
 
 /* Replaces IqDataProcessor::setSignalDetectThreshold, IqDataProcessor.cc:284-295. */
@@ -143,6 +146,9 @@ int iqd_get_frequency_trace(iqd_t *e, uint32_t first_ch, uint32_t n_ch, uint64_t
 /* Front-end rotation selector: +1 = upconvertByFsOver4 (what acceptIqData applies,
  * IqDataProcessor.cc:749, the default), -1 = downconvertByFsOver4 (:496-540), 0 = none. */
 int iqd_set_rotation(iqd_t *e, uint32_t first_ch, uint32_t n_ch, int rotation);
+/* (The reference has no such switch.  The engine keeps a channel's filter histories as raw samples, so a selector
+ * changed in mid-stream re-reads the last 8 ms of history with the new rotation; choose it before a stream starts,
+ * or call iqd_reset afterwards.) */
 
 /* Replaces {Am,Fm,WbFm,Ssb}Demodulator::resetDemodulator() for all four demodulators of the
  * channels (note WbFmDemodulator.cc:304-320 leaves the de-emphasis filter state alone). */

@@ -230,7 +230,9 @@ IQD_DEV void fm_tile(Exec &ex, const Tile &t, const Consts &c, FmLds &lds, const
     });
     int prev_clen = 0;
     for (int cstart = -FIR_HALO; cstart < t.tlen;) {
-        const int clen = cstart < 0 ? -cstart : (t.tlen - cstart < CH_CHUNK ? t.tlen - cstart : CH_CHUNK);
+        const int clen = wbfm_chunk_len(t, cstart, CH_CHUNK);   // the lead-in splits where the gain last changed
+        Tile tc = t;
+        tc.k = wbfm_chunk_gain(t, cstart);
         const ChunkBlocks cb = chunk_blocks(t, cstart);
         ex.all([&](int tid) {
             if (prev_clen) fm_shift_y2(lds, prev_clen, tid);
@@ -241,7 +243,7 @@ IQD_DEV void fm_tile(Exec &ex, const Tile &t, const Consts &c, FmLds &lds, const
             fm_stage1(t, c, lds, clen, tid, fm_lut);
         });
         ex.all([&](int tid) {
-            fm_discriminate(t, lds, clen, tid);
+            fm_discriminate(tc, lds, clen, tid);
             fm_shift_rails(lds, clen, tid);
         });
         ex.all([&](int tid) {

@@ -39,7 +39,15 @@ struct ChanParams {
     float gain[4];          // demodulatorGain per family
     float wbfm_k;           // (gain / 75000) * 32767, evaluated in binary32 on the host
     float fm_k;             // (gain / 15000) * 32767
-    uint32_t pad[3];
+    // A demodulator gain changes between two accept calls, i.e. at the start of a call's data.  The histories a tile
+    // rebuilds from the raw tail belong to the time before it: they are computed with the gain that was in force
+    // then (k_prev), `since` samples back from the stream end (GainEpoch, maintained on the device).
+    float wbfm_k_prev, fm_k_prev;   // (host -> device hand-over: the K the device last ran with)
+    uint32_t k_changed;     // one-shot: bit 0 WBFM, bit 1 FM - the gain differs from the last accept's
+};
+struct GainEpoch {          // per channel, on the device
+    uint32_t wbfm_since, fm_since;   // samples the family has consumed since its gain last changed (saturates at TAIL)
+    float wbfm_k_prev, fm_k_prev;    // the K in force before that change
 };
 
 // ---- per-channel carried state ------------------------------------------------------------

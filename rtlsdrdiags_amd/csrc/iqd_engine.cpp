@@ -83,6 +83,8 @@ struct iqd_engine {
     uint32_t *d_tracker = nullptr;
     AgcConfig *d_agc_cfg = nullptr;
     AgcState *d_agc = nullptr;
+    GainEpoch *d_epochs = nullptr;
+    std::vector<float> k_applied;           // [n_ch][2]: the WBFM / FM K the device last ran with
     ScanConfig *d_scan_cfg = nullptr;
     ScanState *d_scan = nullptr;
     float *d_atan = nullptr, *d_fmlut = nullptr;
@@ -201,6 +203,14 @@ int iqd_create(const iqd_config *cfg, iqd_t **out)
     AgcState st0{};
     st0.rx_gain = 24; st0.if_gain = 24; st0.filtered = 24.f; st0.normalized = -24; st0.signal_magnitude = 64;
     std::vector<AgcState> agc_states(e->n_ch, st0);
+    e->k_applied.resize(2 * (size_t)e->n_ch);
+    for (uint32_t c = 0; c < e->n_ch; c++) {
+        e->k_applied[2 * c] = e->h_params[c].wbfm_k;
+        e->k_applied[2 * c + 1] = e->h_params[c].fm_k;
+        e->h_params[c].wbfm_k_prev = e->h_params[c].wbfm_k;
+        e->h_params[c].fm_k_prev = e->h_params[c].fm_k;
+        e->h_params[c].k_changed = 0;
+    }
     // FrequencyScanner constructor defaults (FrequencyScanner.cc:96-131)
     ScanConfig sc0{};
     sc0.start_hz = sc0.end_hz = 162550000ull;
@@ -222,6 +232,7 @@ int iqd_create(const iqd_config *cfg, iqd_t **out)
     ok = ok && hipMalloc((void **)&e->d_tracker, n * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc((void **)&e->d_agc_cfg, n * sizeof(AgcConfig)) == hipSuccess;
     ok = ok && hipMalloc((void **)&e->d_agc, n * sizeof(AgcState)) == hipSuccess;
+    ok = ok && hipMalloc((void **)&e->d_epochs, n * sizeof(GainEpoch)) == hipSuccess;
     ok = ok && hipMalloc((void **)&e->d_scan_cfg, n * sizeof(ScanConfig)) == hipSuccess;
     ok = ok && hipMalloc((void **)&e->d_scan, n * sizeof(ScanState)) == hipSuccess;
     ok = ok && hipMalloc((void **)&e->d_atan, atan_lut.size() * sizeof(float)) == hipSuccess;
@@ -238,6 +249,7 @@ int iqd_create(const iqd_config *cfg, iqd_t **out)
         ok = ok && hipMemsetAsync(e->d_tracker, 0, n * sizeof(uint32_t), e->stream) == hipSuccess;
         ok = ok && hipMemcpyAsync(e->d_agc, agc_states.data(), n * sizeof(AgcState), hipMemcpyHostToDevice,
                                   e->stream) == hipSuccess;
+        ok = ok && hipMemsetAsync(e->d_epochs, 0x7f, n * sizeof(GainEpoch), e->stream) == hipSuccess;   // "long ago"
         ok = ok && hipMemcpyAsync(e->d_scan, scan_states.data(), n * sizeof(ScanState), hipMemcpyHostToDevice,
                                   e->stream) == hipSuccess;
         ok = ok && hipMemcpyAsync(e->d_atan, atan_lut.data(), atan_lut.size() * sizeof(float),
@@ -260,7 +272,7 @@ void iqd_destroy(iqd_t *e)
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    void *ptrs[] = {e->d_params, e->d_tails, e->d_wcarry, e->d_dc, e->d_tracker, e->d_agc_cfg, e->d_agc, e->d_scan_cfg, e->d_scan,
+    void *ptrs[] = {e->d_params, e->d_tails, e->d_wcarry, e->d_dc, e->d_tracker, e->d_agc_cfg, e->d_agc, e->d_epochs, e->d_scan_cfg, e->d_scan,
                     e->d_atan, e->d_fmlut, e->d_counters, e->d_stamps};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -399,6 +411,23 @@ int iqd_agc_enable(iqd_t *e, uint32_t first_ch, uint32_t n_ch, int enabled)
     return rc;
 }
 
+// Uploads the channel parameters if they changed.  A WBFM / FM gain that differs from what the device last ran with
+// hands the old K over for the histories (GainEpoch); agc_sync() then applies and clears the flags.  Call with e->mu held.
+static int upload_params(iqd_t *e)
+{
+    if (!e->params_dirty) return IQD_OK;
+    for (uint32_t c = 0; c < e->n_ch; c++) {
+        ChanParams &p = e->h_params[c];
+        if (f2u(p.wbfm_k) != f2u(e->k_applied[2 * c])) { p.wbfm_k_prev = e->k_applied[2 * c]; p.k_changed |= 1u; e->k_applied[2 * c] = p.wbfm_k; }
+        if (f2u(p.fm_k) != f2u(e->k_applied[2 * c + 1])) { p.fm_k_prev = e->k_applied[2 * c + 1]; p.k_changed |= 2u; e->k_applied[2 * c + 1] = p.fm_k; }
+        if (p.k_changed) e->agc_dirty = true;
+    }
+    HIP_TRY(e, hipMemcpyAsync(e->d_params, e->h_params.data(), e->n_ch * sizeof(ChanParams), hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(e, hipStreamSynchronize(e->stream));  // the mirror may change once the lock is dropped
+    e->params_dirty = false;
+    return IQD_OK;
+}
+
 // Uploads the AGC configuration and applies the pending one-shot commands.  Call with e->mu held.
 static int agc_sync(iqd_t *e)
 {
@@ -406,10 +435,11 @@ static int agc_sync(iqd_t *e)
     hipStream_t s = e->stream;
     HIP_TRY(e, hipMemcpyAsync(e->d_agc_cfg, e->h_agc.data(), e->n_ch * sizeof(AgcConfig), hipMemcpyHostToDevice, s));
     HIP_TRY(e, hipMemcpyAsync(e->d_scan_cfg, e->h_scan.data(), e->n_ch * sizeof(ScanConfig), hipMemcpyHostToDevice, s));
-    HIP_TRY(e, launch_agc_apply(e->d_agc_cfg, e->d_agc, e->d_scan_cfg, e->d_scan, e->n_ch, s));
+    HIP_TRY(e, launch_agc_apply(e->d_agc_cfg, e->d_agc, e->d_scan_cfg, e->d_scan, e->d_params, e->d_epochs, e->n_ch, s));
     HIP_TRY(e, hipStreamSynchronize(s));
     for (auto &a : e->h_agc) { a.reset_blanking = 0; a.set_gain = 0xffffffffu; }
     for (auto &c : e->h_scan) c.set_current_flag = 0;
+    for (auto &p : e->h_params) p.k_changed = 0;   // (the kernel cleared the device copies)
     e->agc_dirty = false;
     return IQD_OK;
 }
@@ -679,11 +709,8 @@ int iqd_front_end_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
     (void)hipSetDevice(e->device);
     {
         std::lock_guard<std::mutex> lk(e->mu);
-        if (e->params_dirty) {
-            HIP_TRY(e, hipMemcpyAsync(e->d_params, e->h_params.data(), e->n_ch * sizeof(ChanParams), hipMemcpyHostToDevice, e->stream));
-            HIP_TRY(e, hipStreamSynchronize(e->stream));
-            e->params_dirty = false;
-        }
+        int rc = upload_params(e);
+        if (rc != IQD_OK) return rc;
     }
     HIP_TRY(e, launch_front_end((const uint8_t *)iq_dev, (int8_t *)out_dev, e->d_params, first_ch, n_ch, bytes_per_ch, e->stream));
     return IQD_OK;
@@ -879,11 +906,9 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
     bool gated, any_agc;
     {
         std::lock_guard<std::mutex> lk(e->mu);
-        if (e->params_dirty) {
-            HIP_TRY(e, hipMemcpyAsync(e->d_params, e->h_params.data(), e->n_ch * sizeof(ChanParams),
-                                      hipMemcpyHostToDevice, s));
-            HIP_TRY(e, hipStreamSynchronize(s));  // the mirror may change once the lock is dropped
-            e->params_dirty = false;
+        {
+            int rc = upload_params(e);
+            if (rc != IQD_OK) return rc;
         }
         if (e->lists_dirty || e->list_first != first_ch || e->list_n != n_ch) {
             rebuild_lists(e, first_ch, n_ch);
@@ -952,6 +977,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
     base.params = e->d_params;
     base.wbfm_carry = e->d_wcarry;
     base.dc_carry = e->d_dc;
+    base.epochs = e->d_epochs;
     base.atan_lut = e->d_atan;
     base.fm_lut = e->d_fmlut;
     base.pcm = (int16_t *)pcm_dev;

@@ -31,6 +31,7 @@ struct ChainLaunch {
     const ChanParams *params;     // [engine ch]
     WbfmCarry *wbfm_carry;        // [engine ch]
     DcCarry *dc_carry;            // [engine ch][2] (AM, SSB)
+    GainEpoch *epochs;            // [engine ch]: samples since the WBFM / FM gain last changed
     const float *atan_lut;        // 256x256
     const float *fm_lut;          // 283x283
     int16_t *pcm;                 // [n_ch][pcm_stride]
@@ -80,8 +81,8 @@ hipError_t launch_resample(int kind, const void *in, void *out, const void *hist
 hipError_t launch_wbfm_repair(const ChainLaunch &a, bool gated, hipStream_t s);
 hipError_t launch_front_end(const uint8_t *iq, int8_t *out, const ChanParams *params, uint32_t first_ch, uint32_t n_ch,
                             size_t bytes_per_ch, hipStream_t s);
-hipError_t launch_agc_apply(const AgcConfig *cfg, AgcState *st, const ScanConfig *scfg, ScanState *sst, uint32_t n_ch,
-                            hipStream_t s);
+hipError_t launch_agc_apply(const AgcConfig *cfg, AgcState *st, const ScanConfig *scfg, ScanState *sst,
+                            ChanParams *params, GainEpoch *epochs, uint32_t n_ch, hipStream_t s);
 hipError_t launch_tail_update(const ChainLaunch &a, int family, hipStream_t s);
 hipError_t launch_magnitude(const uint8_t *iq, size_t ch_stride_bytes, const uint32_t *ch_list, uint32_t n_list,
                             uint32_t block_samples, uint32_t n_blocks, uint32_t *mag_sums, hipStream_t s);

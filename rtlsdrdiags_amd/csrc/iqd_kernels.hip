@@ -100,7 +100,14 @@ __device__ __forceinline__ void wbfm_run_tile(const ChainLaunch &a, WbfmLds &lds
     t.tlen = (int32_t)(((int64_t)vlen - v0) < (int64_t)a.tile_len ? ((int64_t)vlen - v0) : (int64_t)a.tile_len);
     rotation_selectors(p.rotation, t);
     t.k = p.wbfm_k;
-    t.bounded = (fabsf(p.wbfm_k) * 3.1730f < 2147483648.0f) ? 1u : 0u;
+    t.k_prev = p.wbfm_k;
+    t.k_switch = INT32_MIN;
+    if (tile == 0) {   // only a call's first tile reaches back before the call, where the previous gain applies
+        const uint32_t since = a.epochs[ech].wbfm_since;
+        if (since < (uint32_t)TAIL) { t.k_prev = a.epochs[ech].wbfm_k_prev; t.k_switch = -(int32_t)since; }
+    }
+    const float kmax = fmaxf(fabsf(t.k), fabsf(t.k_prev));
+    t.bounded = (kmax * 3.1730f < 2147483648.0f) ? 1u : 0u;
     t.lut = a.atan_lut;
     t.pcm_row = a.pcm + (size_t)ch * a.pcm_stride;
     t.mag_row = MAG ? a.mag_sums + (size_t)ch * a.n_blocks : nullptr;
@@ -185,7 +192,13 @@ __device__ __forceinline__ bool setup_tile(const ChainLaunch &a, bool gated, int
     t.tlen = (int32_t)(((int64_t)vlen - v0) < (int64_t)a.tile_len ? ((int64_t)vlen - v0) : (int64_t)a.tile_len);
     rotation_selectors(p.rotation, t);
     t.k = p.fm_k;
-    t.bounded = (fabsf(p.fm_k) * 6.35f < 2147483648.0f) ? 1u : 0u;   // |K * dtheta| <= |K| * 2 pi
+    t.k_prev = p.fm_k;
+    t.k_switch = INT32_MIN;
+    if (family == FAM_FM && t.v0 == 0) {
+        const uint32_t since = a.epochs[ech].fm_since;
+        if (since < (uint32_t)TAIL) { t.k_prev = a.epochs[ech].fm_k_prev; t.k_switch = -(int32_t)since; }
+    }
+    t.bounded = (fmaxf(fabsf(t.k), fabsf(t.k_prev)) * 6.35f < 2147483648.0f) ? 1u : 0u;   // |K * dtheta| <= |K| * 2 pi
     t.lut = nullptr;
     t.pcm_row = a.pcm + (size_t)ch * a.pcm_stride;
     t.mag_row = a.mag_sums + (size_t)ch * a.n_blocks;
@@ -380,6 +393,11 @@ __global__ __launch_bounds__(256) void tail_update_kernel(const ChainLaunch a, i
         cy.y_end = r.y_end; cy.u_end = r.u_end;
         cy.pad[0] = cy.pad[1] = cy.pad[2] = 0;
         a.wbfm_carry[ech] = cy;
+    }
+    if (threadIdx.x == 0 && (family == FAM_WBFM || family == FAM_FM)) {   // this call's samples now lie behind the gain change
+        uint32_t *since = family == FAM_WBFM ? &a.epochs[ech].wbfm_since : &a.epochs[ech].fm_since;
+        const uint64_t total = (uint64_t)*since + vlen;
+        *since = total < (uint64_t)TAIL ? (uint32_t)total : (uint32_t)TAIL;
     }
     uint8_t *tail = a.tails + ((size_t)ech * FAM_COUNT + family) * TAIL_BYTES;
     const uint8_t *iq_ch = a.iq + (size_t)ch * a.ch_stride_bytes;
@@ -584,10 +602,23 @@ __global__ __launch_bounds__(64) void squelch_track_wave_kernel(const SquelchLau
 // The operator's one-shot commands, applied before the next block: a manual IF gain
 // (Radio::setReceiveIfGainInDb), resetBlankingSystem() (AutomaticGainControl.cc:625-634), the scanner's jump to
 // its end frequency when it starts with new parameters.
-__global__ void agc_apply_kernel(const AgcConfig *cfg, AgcState *st, const ScanConfig *scfg, ScanState *sst, uint32_t n_ch)
+__global__ void agc_apply_kernel(const AgcConfig *cfg, AgcState *st, const ScanConfig *scfg, ScanState *sst,
+                                 ChanParams *params, GainEpoch *epochs, uint32_t n_ch)
 {
     const uint32_t ch = blockIdx.x * blockDim.x + threadIdx.x;
     if (ch >= n_ch) return;
+    // a demodulator gain changed since the last accept: the new one starts with the next sample; the one before it is
+    // remembered for the histories - unless no sample was consumed since the previous change, whose "before" still holds
+    const uint32_t changed = params[ch].k_changed;
+    if (changed & 1u) {
+        if (epochs[ch].wbfm_since != 0) epochs[ch].wbfm_k_prev = params[ch].wbfm_k_prev;
+        epochs[ch].wbfm_since = 0;
+    }
+    if (changed & 2u) {
+        if (epochs[ch].fm_since != 0) epochs[ch].fm_k_prev = params[ch].fm_k_prev;
+        epochs[ch].fm_since = 0;
+    }
+    if (changed) params[ch].k_changed = 0;
     const AgcConfig c = cfg[ch];
     if (c.set_gain != 0xffffffffu) st[ch].rx_gain = c.set_gain;
     if (c.reset_blanking) { st[ch].blank_ctr = 0; st[ch].adjusted = 0; }
@@ -845,10 +876,10 @@ hipError_t launch_squelch(const SquelchLaunch &q, bool always_open, hipStream_t 
     return hipGetLastError();
 }
 
-hipError_t launch_agc_apply(const AgcConfig *cfg, AgcState *st, const ScanConfig *scfg, ScanState *sst, uint32_t n_ch,
-                            hipStream_t s)
+hipError_t launch_agc_apply(const AgcConfig *cfg, AgcState *st, const ScanConfig *scfg, ScanState *sst,
+                            ChanParams *params, GainEpoch *epochs, uint32_t n_ch, hipStream_t s)
 {
-    hipLaunchKernelGGL(agc_apply_kernel, dim3((n_ch + 255) / 256), dim3(256), 0, s, cfg, st, scfg, sst, n_ch);
+    hipLaunchKernelGGL(agc_apply_kernel, dim3((n_ch + 255) / 256), dim3(256), 0, s, cfg, st, scfg, sst, params, epochs, n_ch);
     return hipGetLastError();
 }
 

@@ -69,6 +69,8 @@ struct WbfmTile {
     int32_t tlen;                // tile length
     uint32_t sel_i, sel_q, neg_i, neg_q;  // rotation as byte selectors / negate masks
     float k;                     // (gain / 75000) * 32767
+    float k_prev;                // the same before the last gain change ...
+    int32_t k_switch;            // ... which applies to samples before this position (<= 0; INT32_MIN: none in reach)
     uint32_t bounded;            // |k| * pi * 1.01 < 2^31: (int16) casts cannot hit the indefinite value
     const float *lut;            // atan2 table, lut[y * 256 + x]
     int16_t *pcm_row;            // PCM of virtual sample 0
@@ -689,6 +691,15 @@ struct WbfmRecord {  // what the tile reports for hand-off verification and the 
     uint32_t pad[2];
 };
 
+// Chunk boundaries of a tile: the lead-in [-halo, 0) is one chunk - or two, split where the demodulator gain last
+// changed (k_switch), so that every chunk has one gain.
+IQD_DEV int wbfm_chunk_len(const WbfmTile &t, int cs, int chunk)
+{
+    if (cs < 0) return (cs < t.k_switch && t.k_switch < 0 ? t.k_switch : 0) - cs;
+    return t.tlen - cs < chunk ? t.tlen - cs : chunk;
+}
+IQD_DEV float wbfm_chunk_gain(const WbfmTile &t, int cs) { return cs < t.k_switch ? t.k_prev : t.k; }
+
 template <bool GATED, bool MAG, class Exec>
 IQD_DEV void wbfm_tile(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLds &lds,
                        const WbfmStart &start, WbfmRecord *rec_out)
@@ -719,13 +730,15 @@ IQD_DEV void wbfm_tile(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLds &ld
 
     int prev_clen = 0;
     for (int cstart = -halo; cstart < t.tlen;) {
-        const int clen = cstart < 0 ? -cstart : (t.tlen - cstart < WBFM_CHUNK ? t.tlen - cstart : WBFM_CHUNK);
+        const int clen = wbfm_chunk_len(t, cstart, WBFM_CHUNK);
+        WbfmTile tc = t;
+        tc.k = wbfm_chunk_gain(t, cstart);
         const int nseg = clen / SEG;
         const ChunkBlocks cb = chunk_blocks(t, cstart);
         ex.stamp(7);
         ex.all([&](int tid) {
             if (prev_clen) wbfm_shift_b(lds, prev_clen, tid);
-            wbfm_phase1<GATED, MAG>(t, c, lds, cb, cstart, clen, tid);
+            wbfm_phase1<GATED, MAG>(tc, c, lds, cb, cstart, clen, tid);
         });
         ex.stamp(0);
         if (ex.in_wave0()) {
@@ -739,7 +752,7 @@ IQD_DEV void wbfm_tile(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLds &ld
             do {
                 ex.wave0([&](int lane) { iir_real(c, lds, nseg, lane, t.bounded != 0); });
                 rounds++;
-            } while (!ex.wave0_all([&](int lane) { return iir_check(lds, nseg, lane, t.k >= 1.0f); }));
+            } while (!ex.wave0_all([&](int lane) { return iir_check(lds, nseg, lane, t.k >= 1.0f && t.k_prev >= 1.0f); }));
             ex.stamp(3);
             if (rec_pos > cstart && rec_pos < cstart + clen) {
                 const int seg = (rec_pos - cstart) / SEG - 1;
@@ -930,7 +943,8 @@ IQD_DEV void wbfm_tile_pipe(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLd
 
     typename Exec::template Local<P1Pair> regs;
     typename Exec::template Local<P1Own> raw0;   // wave 0's prefetched group
-    auto chunk_len = [&](int cs) { return cs < 0 ? -cs : (t.tlen - cs < WBFM_CHUNK ? t.tlen - cs : WBFM_CHUNK); };
+    auto chunk_len = [&](int cs) { return wbfm_chunk_len(t, cs, WBFM_CHUNK); };
+    const bool tiny_ok = t.k >= 1.0f && t.k_prev >= 1.0f;
 #ifdef IQD_ABL_NOMAG
     const bool mag_on = false;
 #else
@@ -950,6 +964,8 @@ IQD_DEV void wbfm_tile_pipe(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLd
         const bool cur_mag = mag_on && has_cur && cstart >= 0;
         const bool next_mag = mag_on && has_next && next_cstart >= 0;
         const bool w0_share = W0_CAN_SHARE && has_next && (next_clen >> 4) > P1S_PER_WAVE * 6;   // slot 6: groups 378 ..
+        WbfmTile tn = t;   // phase 1 of the next chunk runs with that chunk's gain
+        tn.k = wbfm_chunk_gain(t, next_cstart);
         // ---- X ----
         ex.stamp(7);
         if (ex.in_wave0()) {
@@ -963,7 +979,7 @@ IQD_DEV void wbfm_tile_pipe(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLd
                 do {
                     ex.wave0([&](int lane) { iir_real(c, lds, nseg, lane, t.bounded != 0); });
                     rounds++;
-                } while (!ex.wave0_all([&](int lane) { return iir_check(lds, nseg, lane, t.k >= 1.0f); }));
+                } while (!ex.wave0_all([&](int lane) { return iir_check(lds, nseg, lane, tiny_ok); }));
                 if (rec_pos > cstart && rec_pos < cstart + clen) {
                     const int seg = (rec_pos - cstart) / SEG - 1;
                     rec.y_out = lds.e[seg];
@@ -981,7 +997,7 @@ IQD_DEV void wbfm_tile_pipe(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLd
             ex.stamp(1);
             if (w0_share)
                 ex.wave0([&](int lane) {
-                    p1s_compute(ex, lane, t, c, raw0.at(lane), raw0.at(lane), next_clen >> 4, 6, 6, false, next_mag, regs.at(lane));
+                    p1s_compute(ex, lane, tn, c, raw0.at(lane), raw0.at(lane), next_clen >> 4, 6, 6, false, next_mag, regs.at(lane));
                 });
         }
         if (cur_mag || st_clen)
@@ -1006,7 +1022,7 @@ IQD_DEV void wbfm_tile_pipe(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLd
                 const bool wave_has_b = P1S_PER_WAVE * (w + 3) < ng;
                 const P1Own ra = p1s_load<GATED>(t, next_cstart, ng, p1s_group(w, lane));
                 const P1Own rb = wave_has_b ? p1s_load<GATED>(t, next_cstart, ng, p1s_group(w + 3, lane)) : ra;
-                p1s_compute(ex, tid, t, c, ra, rb, ng, w, w + 3, wave_has_b, next_mag, regs.at(tid));
+                p1s_compute(ex, tid, tn, c, ra, rb, ng, w, w + 3, wave_has_b, next_mag, regs.at(tid));
             });
         ex.stamp(2);
         ex.sync();

@@ -323,3 +323,36 @@ def test_long_row_dc_removal_on_a_noiseless_carrier(capi, oracle, mode):
     ref, _, _ = o.accept_stream(u8)
     assert np.array_equal(pcm[0, :cnt[0]], ref)
     assert eng.stats()["state_repairs"] == 0
+
+
+@pytest.mark.parametrize("mode", ["fm", "wbfm", "am", "usb"])
+@pytest.mark.parametrize("block_bytes", [32768, 1024])
+def test_demodulator_gain_changes_between_calls(capi, oracle, mode, block_bytes):
+    """setDemodulatorGain between accept calls: the histories a tile rebuilds from the raw tail lie before the change
+    and must be computed with the gain that was in force then (FM / WBFM: the post-discriminator decimators and the
+    de-emphasis see K; AM / SSB apply the gain behind every filter).  Short blocks put the change point inside the
+    lead-in, long ones at its end."""
+    which = {"am": 1, "fm": 2, "wbfm": 3, "usb": 4}[mode]
+    base = {1: 300.0, 2: 10185.9, 3: 40743.7, 4: 300.0}[which]
+    u8 = synth.fm_tone(24 * 16384, seed=45)
+    calls = [(0, 4, 1.0), (4, 5, 0.25), (5, 9, 0.25), (9, 10, 3.0), (10, 18, 0.02), (18, 24, 1.0)]
+    if block_bytes == 1024:     # the same stream in many short calls; a change every 2560+ samples
+        u8 = u8[:2 * 40960]
+        calls = [(k, k + 5, g) for k, g in zip(range(0, 80, 5), [1.0, 0.3, 0.3, 2.0, 0.05, 1.0, 1.0, 4.0] * 2)]
+    eng = capi.Engine(2, block_bytes=block_bytes)       # channel 1 keeps its gain: must not be disturbed
+    eng.set_mode(mode)
+    o, o1 = oracle.chain(), oracle.chain()
+    o.set_mode(mode)
+    o1.set_mode(mode)
+    got, ref, ref1, got1 = [], [], [], []
+    for a, b, g in calls:
+        eng.set_gain(which, base * g, first=0, n=1)
+        o.set_gain(which, base * g)
+        part = u8[a * block_bytes:b * block_bytes]
+        pcm, cnt, _, _ = eng.accept(np.stack([part, part]))
+        got.append(pcm[0, :cnt[0]])
+        got1.append(pcm[1, :cnt[1]])
+        ref.append(o.accept_stream(part, block_bytes)[0])
+        ref1.append(o1.accept_stream(part, block_bytes)[0])
+    assert np.array_equal(np.concatenate(got), np.concatenate(ref))
+    assert np.array_equal(np.concatenate(got1), np.concatenate(ref1))

@@ -91,3 +91,20 @@ def test_agc_inside_random_streams(oracle, reference, seed):
     pr, ar, gr = A.stream(r, u8, 2048)
     po, ao, go = A.stream(o, u8, 2048)
     assert np.array_equal(gr, go) and np.array_equal(ar, ao) and np.array_equal(pr, po)
+
+
+@pytest.mark.parametrize("mode", ["fm", "wbfm", "am", "usb"])
+def test_gain_changes_between_blocks(oracle, reference, mode):
+    """setDemodulatorGain at run time: the demodulators' decimator histories keep what the old gain produced."""
+    u8 = synth.fm_tone(6 * 16384, seed=44)
+    which = {"am": 1, "fm": 2, "wbfm": 3, "usb": 4}[mode]
+    base = {1: 300.0, 2: 10185.9, 3: 40743.7, 4: 300.0}[which]
+    out = []
+    for c in (reference.chain(), oracle.chain()):
+        c.set_mode(mode)
+        parts = []
+        for k, g in enumerate([1.0, 0.25, 0.25, 3.0, 0.01, 1.0]):
+            c.set_gain(which, base * g)
+            parts.append(c.accept_stream(u8[k * 32768:(k + 1) * 32768])[0])
+        out.append(np.concatenate(parts))
+    assert np.array_equal(out[0], out[1])

@@ -93,18 +93,56 @@ def one_case(rng, O):
             eng.scanner_set_parameters(1000, 9000, 1000, first=c, n=1); eng.scanner_start(True, first=c, n=1)
         chains.append(o)
         iq[c] = signal(rng, n, bb // 2)
-    cuts = sorted(set([0, nblk] + [int(x) for x in rng.integers(0, nblk + 1, int(rng.integers(0, 3)))]))
+    cuts = sorted(set([0, nblk] + [int(x) for x in rng.integers(0, nblk + 1, int(rng.integers(0, 6)))]))
     got = [[] for _ in range(n_ch)]
     got_allowed, got_mag = [], []
+    ref_parts = [[[], [], []] for _ in range(n_ch)]
+    last_gain_change = [[-(1 << 30)] * 5 for _ in range(n_ch)]     # block index of the last change, per demodulator
     for a, b in zip(cuts[:-1], cuts[1:]):
+        if a and rng.random() < 0.6:     # between calls: the operator changes something on a few channels
+            for c in rng.integers(0, n_ch, int(rng.integers(1, 4))):
+                c = int(c)
+                what = int(rng.choice([0, 1, 2, 3, 5, 6]))     # 4 = rotation: a stream keeps its rotation (see iqdemod.h)
+                if os.environ.get("FUZZ_OPS"):
+                    what = int(rng.choice([int(x) for x in os.environ["FUZZ_OPS"].split(",")]))
+                if what == 0:
+                    m = MODES[int(rng.integers(0, 6))]
+                    chains[c].set_mode(m); eng.set_mode(m, first=c, n=1)
+                elif what == 1:
+                    chains[c].reset(); eng.reset(first=c, n=1)
+                elif what == 2:
+                    # (the engine keeps ONE earlier gain per demodulator for the histories a tile rebuilds: two changes
+                    # of the same gain less than 2048 samples apart are outside what it reproduces exactly)
+                    d, g = int(rng.integers(1, 5)), float(np.float32(10.0 ** rng.uniform(0, 6)))
+                    if (a - last_gain_change[c][d]) * (bb // 2) >= 2048:
+                        chains[c].set_gain(d, g); eng.set_gain(d, g, first=c, n=1)
+                        last_gain_change[c][d] = a
+                elif what == 3:
+                    t = int(rng.choice([-200, -70, -50, -35]))
+                    chains[c].set_squelch(t); eng.set_squelch(t, first=c, n=1)
+                elif what == 4:
+                    r = int(rng.integers(-1, 2))
+                    chains[c].set_rotation(r); eng.set_rotation(r, first=c, n=1)
+                elif what == 5:
+                    g = int(rng.integers(0, 47))
+                    chains[c].set_rx_gain_db(g); eng.set_rx_gain_db(g, first=c, n=1)
+                else:
+                    on = bool(rng.integers(0, 2))
+                    chains[c].agc_enable(on); eng.agc_enable(on, first=c, n=1)
+                    p = int(rng.integers(-30, 0))
+                    chains[c].agc_set_operating_point(p); eng.agc_set_operating_point(p, first=c, n=1)
         pcm, cnt, mag, allowed = eng.accept(iq[:, a * bb:b * bb])
         for c in range(n_ch):
             got[c].append(pcm[c, :cnt[c]])
+            r = chains[c].accept_stream(iq[c, a * bb:b * bb], bb)
+            for k in range(3):
+                ref_parts[c][k].append(r[k])
         got_allowed.append(allowed)
         got_mag.append(mag)
     got_allowed, got_mag = np.concatenate(got_allowed, axis=1), np.concatenate(got_mag, axis=1)
+    ref_out = [tuple(np.concatenate(ref_parts[c][k]) for k in range(3)) for c in range(n_ch)]
     for c in range(n_ch):
-        ref, rmag, rallowed = chains[c].accept_stream(iq[c], bb)
+        ref, rmag, rallowed = ref_out[c]
         what = None
         if not np.array_equal(got_allowed[c], rallowed):
             what = "allowed"
