@@ -106,6 +106,7 @@ class Oracle:
         _sig(L.iqo_create, vp, [])
         _sig(L.iqo_destroy, None, [vp])
         _sig(L.iqo_reset, None, [vp])
+        _sig(L.iqo_reset_demod, None, [vp, C.c_int])
         _sig(L.iqo_set_mode, None, [vp, C.c_int])
         _sig(L.iqo_set_gain, None, [vp, C.c_int, C.c_float])
         _sig(L.iqo_set_squelch, None, [vp, C.c_int32])
@@ -158,6 +159,7 @@ class Oracle:
         c.agc_enable = lambda on=True: bool(L.iqo_agc_enable(c._h, 1 if on else 0))
         c.agc_feed = lambda m: L.iqo_agc_feed(c._h, int(m))
         c.rx_gain_db = lambda: int(L.iqo_get_rx_gain_db(c._h))
+        c.reset_demod = lambda which: L.iqo_reset_demod(c._h, int(which))
         # FrequencyScanner
         c.scanner_set_parameters = lambda a, b, inc: bool(L.iqo_scanner_set_parameters(c._h, int(a), int(b), int(inc)))
         c.scanner_start = lambda: bool(L.iqo_scanner_start(c._h))

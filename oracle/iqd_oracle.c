@@ -898,6 +898,18 @@ void iqo_reset(iqo_chain *c)
     ssb_reset(&c->ssb);
 }
 
+/* one demodulator's resetDemodulator(): which = 1 AM, 2 FM, 3 WBFM, 4 SSB */
+void iqo_reset_demod(iqo_chain *c, int which)
+{
+    switch (which) {
+    case 1: am_reset(&c->am); break;
+    case 2: fm_reset(&c->fm); break;
+    case 3: wbfm_reset(&c->wbfm); break;
+    case 4: ssb_reset(&c->ssb); break;
+    default: break;
+    }
+}
+
 /* IqDataProcessor.cc:236-262 */
 void iqo_set_mode(iqo_chain *c, int mode)
 {

@@ -29,6 +29,7 @@ typedef struct iqo_chain iqo_chain;
 iqo_chain *iqo_create(void);
 void iqo_destroy(iqo_chain *c);
 void iqo_reset(iqo_chain *c);                       /* all four demodulators */
+void iqo_reset_demod(iqo_chain *c, int which);      /* one of them: 1 AM 2 FM 3 WBFM 4 SSB */
 void iqo_set_mode(iqo_chain *c, int mode);
 void iqo_set_gain(iqo_chain *c, int which, float gain); /* 1 AM 2 FM 3 WBFM 4 SSB */
 void iqo_set_squelch(iqo_chain *c, int32_t threshold);

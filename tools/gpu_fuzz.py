@@ -102,7 +102,7 @@ def one_case(rng, O):
         if a and rng.random() < 0.6:     # between calls: the operator changes something on a few channels
             for c in rng.integers(0, n_ch, int(rng.integers(1, 4))):
                 c = int(c)
-                what = int(rng.choice([0, 1, 2, 3, 5, 6]))     # 4 = rotation: a stream keeps its rotation (see iqdemod.h)
+                what = int(rng.choice([0, 1, 2, 3, 5, 6, 7, 8]))     # 4 = rotation: a stream keeps its rotation (see iqdemod.h)
                 if os.environ.get("FUZZ_OPS"):
                     what = int(rng.choice([int(x) for x in os.environ["FUZZ_OPS"].split(",")]))
                 if what == 0:
@@ -126,19 +126,38 @@ def one_case(rng, O):
                 elif what == 5:
                     g = int(rng.integers(0, 47))
                     chains[c].set_rx_gain_db(g); eng.set_rx_gain_db(g, first=c, n=1)
-                else:
+                elif what == 6:
                     on = bool(rng.integers(0, 2))
                     chains[c].agc_enable(on); eng.agc_enable(on, first=c, n=1)
                     p = int(rng.integers(-30, 0))
                     chains[c].agc_set_operating_point(p); eng.agc_set_operating_point(p, first=c, n=1)
-        pcm, cnt, mag, allowed = eng.accept(iq[:, a * bb:b * bb])
+                elif what == 7:
+                    d = int(rng.integers(1, 5))
+                    chains[c].reset_demod(d); eng.reset_demod(d, first=c, n=1)
+                else:
+                    t_, db_, bl_ = int(rng.integers(0, 2)), int(rng.integers(0, 11)), int(rng.integers(0, 11))
+                    al_ = float(np.float32(rng.choice([0.01, 0.3, 0.9])))
+                    for tgt, kw in ((chains[c], {}), (eng, dict(first=c, n=1))):
+                        tgt.agc_set_type(t_, **kw); tgt.agc_set_deadband(db_, **kw)
+                        tgt.agc_set_blanking_limit(bl_, **kw); tgt.agc_set_filter_coefficient(al_, **kw)
+        # the call covers all channels - or, sometimes, two calls cover two sub-ranges in a random order
+        ranges = [(0, n_ch)]
+        if n_ch > 1 and rng.random() < 0.4:
+            m = int(rng.integers(1, n_ch))
+            ranges = [(0, m), (m, n_ch)] if rng.random() < 0.5 else [(m, n_ch), (0, m)]
+        allowed_call = np.zeros((n_ch, b - a), np.uint8)
+        mag_call = np.zeros((n_ch, b - a), np.uint32)
+        for c0, c1 in ranges:
+            pcm, cnt, mag, allowed = eng.accept(iq[c0:c1, a * bb:b * bb], first=c0, n=c1 - c0)
+            allowed_call[c0:c1], mag_call[c0:c1] = allowed, mag
+            for c in range(c0, c1):
+                got[c].append(pcm[c - c0, :cnt[c - c0]])
         for c in range(n_ch):
-            got[c].append(pcm[c, :cnt[c]])
             r = chains[c].accept_stream(iq[c, a * bb:b * bb], bb)
             for k in range(3):
                 ref_parts[c][k].append(r[k])
-        got_allowed.append(allowed)
-        got_mag.append(mag)
+        got_allowed.append(allowed_call)
+        got_mag.append(mag_call)
     got_allowed, got_mag = np.concatenate(got_allowed, axis=1), np.concatenate(got_mag, axis=1)
     ref_out = [tuple(np.concatenate(ref_parts[c][k]) for k in range(3)) for c in range(n_ch)]
     for c in range(n_ch):
