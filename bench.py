@@ -92,6 +92,7 @@ def main():
     ap.add_argument("--mode", default="wbfm")
     ap.add_argument("--signal", default="fm_tone", choices=["fm_tone", "white", "carrier", "quiet", "small", "large"],
                     help="synthetic input: the FM test tone of SURVEY 8(d) (default) or uniform random bytes")
+    ap.add_argument("--no-magnitude", action="store_true", help="IQD_F_NO_MAGNITUDE: skip the per-block squelch magnitudes (nobody listens to them at the default threshold)")
     ap.add_argument("--squelch", type=int, default=None, help="squelch threshold in dBFS (default: the reference's -200, never closes)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive iqd_accept_iq measurement")
@@ -142,7 +143,7 @@ def main():
     mag = torch.zeros(n_ch * (2 * n // 32768), dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
 
-    eng = capi.Engine(n_channels=n_ch, device=local_rank)
+    eng = capi.Engine(n_channels=n_ch, device=local_rank, flags=1 if args.no_magnitude else 0)
     if args.mode == "mixed":     # BASELINE configs[3]: ch % 5 -> {AM, FM, WBFM, LSB, USB}
         for c in range(n_ch):
             eng.set_mode(["am", "fm", "wbfm", "lsb", "usb"][c % 5], first=c, n=1)
@@ -153,7 +154,10 @@ def main():
         eng.set_squelch(args.squelch)
 
     def step():
-        eng.accept_device(iq.data_ptr(), 2 * n, pcm.data_ptr(), cnt.data_ptr(), mag.data_ptr())
+        if args.no_magnitude:
+            eng.accept_device(iq.data_ptr(), 2 * n, pcm.data_ptr())
+        else:
+            eng.accept_device(iq.data_ptr(), 2 * n, pcm.data_ptr(), cnt.data_ptr(), mag.data_ptr())
         if args.gather and dist is not None:
             shard.gather_pcm(pcm.view(n_ch, -1), cnt, dst=0)
 

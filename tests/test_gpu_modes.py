@@ -356,3 +356,24 @@ def test_demodulator_gain_changes_between_calls(capi, oracle, mode, block_bytes)
         ref1.append(o1.accept_stream(part, block_bytes)[0])
     assert np.array_equal(np.concatenate(got), np.concatenate(ref))
     assert np.array_equal(np.concatenate(got1), np.concatenate(ref1))
+
+
+@pytest.mark.parametrize("mode", ["am", "fm", "wbfm", "usb"])
+def test_no_magnitude_flag_device_path(capi, oracle, mode):
+    """IQD_F_NO_MAGNITUDE with only the PCM pointer given: the chain kernels' variants without the squelch magnitude
+    (the reference computes it only to feed callbacks nobody registered) - PCM unchanged, through the device entry."""
+    n = 5 * 16384
+    u8 = synth.fm_tone(n, seed=91)
+    eng = capi.Engine(2, flags=1)
+    eng.set_mode(mode)
+    iq_dev, pcm_dev = eng.dev_alloc(2 * 2 * n), eng.dev_alloc(2 * 2 * (n // 32))
+    eng.dev_upload(iq_dev, np.stack([u8, u8[::-1].copy()]))
+    eng.accept_device(iq_dev, 2 * n, pcm_dev)
+    eng.synchronize()
+    got = eng.dev_download(pcm_dev, 2 * 2 * (n // 32), np.int16).reshape(2, -1)
+    for c, sig in enumerate([u8, u8[::-1].copy()]):
+        o = oracle.chain()
+        o.set_mode(mode)
+        assert np.array_equal(got[c], o.accept_stream(sig)[0]), c
+    eng.dev_free(iq_dev)
+    eng.dev_free(pcm_dev)
