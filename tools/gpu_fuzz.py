@@ -102,7 +102,7 @@ def one_case(rng, O):
         if a and rng.random() < 0.6:     # between calls: the operator changes something on a few channels
             for c in rng.integers(0, n_ch, int(rng.integers(1, 4))):
                 c = int(c)
-                what = int(rng.choice([0, 1, 2, 3, 5, 6, 7, 8]))     # 4 = rotation: a stream keeps its rotation (see iqdemod.h)
+                what = int(rng.choice([0, 1, 2, 3, 5, 6, 7, 8, 9]))     # 4 = rotation: a stream keeps its rotation (see iqdemod.h)
                 if os.environ.get("FUZZ_OPS"):
                     what = int(rng.choice([int(x) for x in os.environ["FUZZ_OPS"].split(",")]))
                 if what == 0:
@@ -134,6 +134,16 @@ def one_case(rng, O):
                 elif what == 7:
                     d = int(rng.integers(1, 5))
                     chains[c].reset_demod(d); eng.reset_demod(d, first=c, n=1)
+                elif what == 9:
+                    k = int(rng.integers(0, 3))
+                    if k == 0:
+                        a_, b_, i_ = int(rng.integers(1, 5000)), int(rng.integers(5000, 9000)), int(rng.integers(0, 3000))
+                        assert chains[c].scanner_set_parameters(a_, b_, i_) == eng.scanner_set_parameters(a_, b_, i_, first=c, n=1)
+                    elif k == 1:
+                        assert chains[c].scanner_start() == eng.scanner_start(True, first=c, n=1)
+                    else:
+                        assert chains[c].scanner_stop() == eng.scanner_start(False, first=c, n=1)
+                    cfg[c] = cfg[c][:8] + (True,)      # compare the tuned frequency at the end
                 else:
                     t_, db_, bl_ = int(rng.integers(0, 2)), int(rng.integers(0, 11)), int(rng.integers(0, 11))
                     al_ = float(np.float32(rng.choice([0.01, 0.3, 0.9])))
@@ -171,7 +181,7 @@ def one_case(rng, O):
             what = "pcm"
         elif eng.rx_gain_db(c) != chains[c].rx_gain_db():
             what = "gain"
-        elif cfg[c][8] and eng.scanner_tuned(c)[0] != chains[c].scanner_tuned()[0]:
+        elif cfg[c][8] and chains[c].scanner_tuned()[1] > 0 and eng.scanner_tuned(c) != chains[c].scanner_tuned():
             what = "scanner"
         if what:
             print("MISMATCH in %s: channel %d of %d, block_bytes %d, %d blocks, cuts %s, cfg %s" %
