@@ -148,16 +148,27 @@ IQD_DEV void fm_stage1(const Tile &t, const Consts &c, FmLds &lds, int clen, int
 // (int16) cast (:485-498, :540).
 IQD_DEV void fm_discriminate(const Tile &t, FmLds &lds, int clen, int tid)
 {
-    const int nout = clen >> 2;
+    // eight consecutive outputs per lane: theta[m-4 .. m+5] in three 16-byte reads, the int16 results in two 8-byte writes
+    const int ngroups = clen >> 5;   // clen is a multiple of 128
     uint32_t peak = 0;
-    for (int m = tid; m < nout; m += WB_THREADS) {
-        float d = u2f(lds.theta[4 + m - 2]) - u2f(lds.theta[4 + m - 4]);
-        d = wrap_delta(d);
-        const float v = t.k * d;
-        const int e = (int)(int16_t)(uint16_t)(t.bounded ? cast_i16_bounded(v) : (uint32_t)cast_i16(v));
-        put_i16(lds.e, 12 + m, e);
-        const uint32_t a = (uint32_t)(e < 0 ? -e : e);
-        peak = a > peak ? a : peak;
+    for (int g = tid; g < ngroups; g += WB_THREADS) {
+        const u32x4 *p = (const u32x4 *)&lds.theta[8 * g];   // theta of output m sits at index 4 + m
+        const u32x4 a = p[0], b = p[1], c4 = p[2];
+        const float th[10] = {u2f(a.x), u2f(a.y), u2f(a.z), u2f(a.w), u2f(b.x), u2f(b.y), u2f(b.z), u2f(b.w), u2f(c4.x), u2f(c4.y)};
+        uint32_t e[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {   // output m = 8g + k: theta[m-2] - theta[m-4] = th[k+2] - th[k]
+            float d = th[k + 2] - th[k];
+            d = wrap_delta(d);
+            const float v = t.k * d;
+            const int ev = (int)(int16_t)(uint16_t)(t.bounded ? cast_i16_bounded(v) : (uint32_t)cast_i16(v));
+            e[k] = (uint32_t)ev;
+            const uint32_t m = (uint32_t)(ev < 0 ? -ev : ev);
+            peak = m > peak ? m : peak;
+        }
+        u32x2 *dst = (u32x2 *)&lds.e[6 + 4 * g];   // int16 index 12 + 8g
+        dst[0] = u32x2{pack_lo16(e[0], e[1]), pack_lo16(e[2], e[3])};
+        dst[1] = u32x2{pack_lo16(e[4], e[5]), pack_lo16(e[6], e[7])};
     }
     if (peak > (uint32_t)POST12_SAFE) lds_max(&lds.e_peak, peak);
 }
