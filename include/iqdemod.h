@@ -146,9 +146,8 @@ int iqd_get_frequency_trace(iqd_t *e, uint32_t first_ch, uint32_t n_ch, uint64_t
 /* Front-end rotation selector: +1 = upconvertByFsOver4 (what acceptIqData applies,
  * IqDataProcessor.cc:749, the default), -1 = downconvertByFsOver4 (:496-540), 0 = none. */
 int iqd_set_rotation(iqd_t *e, uint32_t first_ch, uint32_t n_ch, int rotation);
-/* (The reference has no such switch.  The engine keeps a channel's filter histories as raw samples, so a selector
- * changed in mid-stream re-reads the last 8 ms of history with the new rotation; choose it before a stream starts,
- * or call iqd_reset afterwards.) */
+/* (The reference has no such switch.  A selector changed in mid-stream takes effect with the first sample of the next
+ * accept; what the filters already hold keeps the old rotation, as in-place rotation at acceptance time would.) */
 
 /* Replaces {Am,Fm,WbFm,Ssb}Demodulator::resetDemodulator() for all four demodulators of the
  * channels (note WbFmDemodulator.cc:304-320 leaves the de-emphasis filter state alone). */

@@ -43,7 +43,9 @@ struct ChanParams {
     // rebuilds from the raw tail belong to the time before it: they are computed with the gain that was in force
     // then (k_prev), `since` samples back from the stream end (GainEpoch, maintained on the device).
     float wbfm_k_prev, fm_k_prev;   // (host -> device hand-over: the K the device last ran with)
-    uint32_t k_changed;     // one-shot: bit 0 WBFM, bit 1 FM - the gain differs from the last accept's
+    uint32_t k_changed;     // one-shot: bit 0 WBFM, bit 1 FM - the gain differs from the last accept's; bit 2: the rotation does
+    int32_t rotation_prev;  // the rotation the device last ran with (for bit 2)
+    uint32_t pad;
 };
 struct GainEpoch {          // per channel, on the device
     uint32_t wbfm_since, fm_since;   // samples the family has consumed since its gain last changed (saturates at TAIL)

@@ -85,6 +85,8 @@ struct iqd_engine {
     AgcState *d_agc = nullptr;
     GainEpoch *d_epochs = nullptr;
     std::vector<float> k_applied;           // [n_ch][2]: the WBFM / FM K the device last ran with
+    std::vector<int32_t> rot_applied;       // [n_ch]: the rotation the device last ran with
+    bool rot_changed = false;               // some channel's tails need rewriting (retail_kernel)
     ScanConfig *d_scan_cfg = nullptr;
     ScanState *d_scan = nullptr;
     float *d_atan = nullptr, *d_fmlut = nullptr;
@@ -210,7 +212,10 @@ int iqd_create(const iqd_config *cfg, iqd_t **out)
         e->h_params[c].wbfm_k_prev = e->h_params[c].wbfm_k;
         e->h_params[c].fm_k_prev = e->h_params[c].fm_k;
         e->h_params[c].k_changed = 0;
+        e->h_params[c].rotation_prev = e->h_params[c].rotation;
     }
+    e->rot_applied.resize(e->n_ch);
+    for (uint32_t c = 0; c < e->n_ch; c++) e->rot_applied[c] = e->h_params[c].rotation;
     // FrequencyScanner constructor defaults (FrequencyScanner.cc:96-131)
     ScanConfig sc0{};
     sc0.start_hz = sc0.end_hz = 162550000ull;
@@ -420,6 +425,7 @@ static int upload_params(iqd_t *e)
         ChanParams &p = e->h_params[c];
         if (f2u(p.wbfm_k) != f2u(e->k_applied[2 * c])) { p.wbfm_k_prev = e->k_applied[2 * c]; p.k_changed |= 1u; e->k_applied[2 * c] = p.wbfm_k; }
         if (f2u(p.fm_k) != f2u(e->k_applied[2 * c + 1])) { p.fm_k_prev = e->k_applied[2 * c + 1]; p.k_changed |= 2u; e->k_applied[2 * c + 1] = p.fm_k; }
+        if (p.rotation != e->rot_applied[c]) { p.rotation_prev = e->rot_applied[c]; p.k_changed |= 4u; e->rot_applied[c] = p.rotation; e->rot_changed = true; }
         if (p.k_changed) e->agc_dirty = true;
     }
     HIP_TRY(e, hipMemcpyAsync(e->d_params, e->h_params.data(), e->n_ch * sizeof(ChanParams), hipMemcpyHostToDevice, e->stream));
@@ -435,6 +441,10 @@ static int agc_sync(iqd_t *e)
     hipStream_t s = e->stream;
     HIP_TRY(e, hipMemcpyAsync(e->d_agc_cfg, e->h_agc.data(), e->n_ch * sizeof(AgcConfig), hipMemcpyHostToDevice, s));
     HIP_TRY(e, hipMemcpyAsync(e->d_scan_cfg, e->h_scan.data(), e->n_ch * sizeof(ScanConfig), hipMemcpyHostToDevice, s));
+    if (e->rot_changed) {   // before the flags are cleared: rewrite the tails of the channels whose rotation changed
+        HIP_TRY(e, launch_retail(e->d_tails, e->d_params, e->n_ch, s));
+        e->rot_changed = false;
+    }
     HIP_TRY(e, launch_agc_apply(e->d_agc_cfg, e->d_agc, e->d_scan_cfg, e->d_scan, e->d_params, e->d_epochs, e->n_ch, s));
     HIP_TRY(e, hipStreamSynchronize(s));
     for (auto &a : e->h_agc) { a.reset_blanking = 0; a.set_gain = 0xffffffffu; }

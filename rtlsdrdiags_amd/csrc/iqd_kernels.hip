@@ -652,6 +652,18 @@ __global__ void reset_kernel(uint8_t *tails, WbfmCarry *wc, DcCarry *dc, uint32_
     }
 }
 
+// One group of 4 signed samples (I0 Q0 I1 Q1 | I2 Q2 I3 Q3) through upconvertByFsOver4 (rotation > 0,
+// IqDataProcessor.cc:567-611), downconvertByFsOver4 (< 0, :496-540) or neither.
+__device__ __forceinline__ u32x2 rotate_group(u32x2 g, int rotation)
+{
+    if (rotation == 0) return g;
+    // sample 1: (-Q, I) up / (Q, -I) down; sample 2: (-I, -Q); sample 3: (Q, -I) up / (-Q, I) down
+    const uint32_t a_sw = perm(g.x, g.x, 0x02030100u);   // I0 Q0 Q1 I1
+    const uint32_t b_sw = perm(g.y, g.y, 0x02030100u);   // I2 Q2 Q3 I3
+    if (rotation > 0) return u32x2{neg_bytes(a_sw, 0x00ff0000u), neg_bytes(b_sw, 0xff00ffffu)};   // I0 Q0 -Q1 I1 | -I2 -Q2 Q3 -I3
+    return u32x2{neg_bytes(a_sw, 0xff000000u), neg_bytes(b_sw, 0x00ffffffu)};                      // I0 Q0 Q1 -I1 | -I2 -Q2 -Q3 I3
+}
+
 // The front end alone (IqDataProcessor.cc:735-749): u8 -> s8, then the channel's rotation, interleaved bytes
 // out - what the reference leaves in the caller's buffer and streams from its IQ dump tap (:756-760).
 // One thread per 4 samples (8 bytes); the rotation phase restarts with every block, and blocks are multiples
@@ -665,23 +677,26 @@ __global__ void front_end_kernel(const uint8_t *iq, int8_t *out, const ChanParam
     const uint32_t ch = (uint32_t)(idx / groups_per_ch);
     const int rotation = params[first_ch + ch].rotation;
     const u32x2 raw = ((const u32x2 *)iq)[idx];
-    const uint32_t a = raw.x ^ 0x80808080u, b = raw.y ^ 0x80808080u;   // I0 Q0 I1 Q1 | I2 Q2 I3 Q3
-    u32x2 r;
-    if (rotation == 0) {
-        r = u32x2{a, b};
-    } else {
-        // sample 1: (-Q, I) up / (Q, -I) down; sample 2: (-I, -Q); sample 3: (Q, -I) up / (-Q, I) down
-        const uint32_t a_sw = perm(a, a, 0x02030100u);   // I0 Q0 Q1 I1
-        const uint32_t b_sw = perm(b, b, 0x02030100u);   // I2 Q2 Q3 I3
-        if (rotation > 0) {
-            r.x = neg_bytes(a_sw, 0x00ff0000u);          // I0 Q0 -Q1 I1
-            r.y = neg_bytes(b_sw, 0xff00ffffu);          // -I2 -Q2 Q3 -I3
-        } else {
-            r.x = neg_bytes(a_sw, 0xff000000u);          // I0 Q0 Q1 -I1
-            r.y = neg_bytes(b_sw, 0x00ffffffu);          // -I2 -Q2 -Q3 I3
-        }
+    ((u32x2 *)out)[idx] = rotate_group(u32x2{raw.x ^ 0x80808080u, raw.y ^ 0x80808080u}, rotation);
+}
+
+// A rotation selector changed between two calls.  The filter histories live on as raw tail bytes that every tile
+// re-rotates with the channel's (now new) selector, while the reference's histories hold what the OLD selector
+// produced.  Rotations are exactly invertible on int8 (negation is an involution, -128 its fixed point), so the
+// tails are rewritten once: tail' = rot(-new)(rot(old)(tail)); read back through the new selector they give the
+// old-rotated history bit for bit.  One workgroup per channel, all four families' tails.
+__global__ __launch_bounds__(256) void retail_kernel(uint8_t *tails, const ChanParams *params, uint32_t n_ch)
+{
+    const uint32_t ch = blockIdx.x;
+    if (ch >= n_ch || !(params[ch].k_changed & 4u)) return;
+    const int old_rot = params[ch].rotation_prev, new_rot = params[ch].rotation;
+    u32x2 *t = (u32x2 *)(tails + (size_t)ch * FAM_COUNT * TAIL_BYTES);
+    for (uint32_t i = threadIdx.x; i < FAM_COUNT * TAIL_BYTES / 8; i += blockDim.x) {   // groups of 4 samples, phase 0 first
+        const u32x2 raw = t[i];
+        u32x2 s = rotate_group(u32x2{raw.x ^ 0x80808080u, raw.y ^ 0x80808080u}, old_rot);
+        s = rotate_group(s, -new_rot);
+        t[i] = u32x2{s.x ^ 0x80808080u, s.y ^ 0x80808080u};
     }
-    ((u32x2 *)out)[idx] = r;
 }
 
 // ---- float / int16 resamplers (Filters/Decimator.cc, Interpolator.cc, Int16/Interpolator_int16.cc) ----------
@@ -898,6 +913,12 @@ hipError_t launch_front_end(const uint8_t *iq, int8_t *out, const ChanParams *pa
     const size_t n = bytes_per_ch / 8 * n_ch;
     hipLaunchKernelGGL(front_end_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, iq, out, params, first_ch,
                        n_ch, bytes_per_ch);
+    return hipGetLastError();
+}
+
+hipError_t launch_retail(uint8_t *tails, const ChanParams *params, uint32_t n_ch, hipStream_t s)
+{
+    hipLaunchKernelGGL(retail_kernel, dim3(n_ch), dim3(256), 0, s, tails, params, n_ch);
     return hipGetLastError();
 }
 

@@ -377,3 +377,24 @@ def test_no_magnitude_flag_device_path(capi, oracle, mode):
         assert np.array_equal(got[c], o.accept_stream(sig)[0]), c
     eng.dev_free(iq_dev)
     eng.dev_free(pcm_dev)
+
+
+@pytest.mark.parametrize("mode", ["am", "fm", "wbfm", "lsb"])
+def test_rotation_selector_changes_between_calls(capi, oracle, mode):
+    """The selector changed in mid-stream: the histories keep what the old rotation produced (the engine rewrites its
+    raw tails through the inverse of the new rotation once, so that every tile reads the old-rotated history back)."""
+    u8 = synth.fm_tone(10 * 16384, seed=46)
+    u8[:64] = 0                                   # some -128 samples: the negation's fixed point
+    eng = capi.Engine(1)
+    eng.set_mode(mode)
+    o = oracle.chain()
+    o.set_mode(mode)
+    got, ref = [], []
+    for k, rot in enumerate([1, -1, -1, 0, 1, 0, -1, 1, 1, 0]):
+        eng.set_rotation(rot)
+        o.set_rotation(rot)
+        part = u8[k * 32768:(k + 1) * 32768]
+        pcm, cnt, _, _ = eng.accept(part)
+        got.append(pcm[0, :cnt[0]])
+        ref.append(o.accept_stream(part)[0])
+    assert np.array_equal(np.concatenate(got), np.concatenate(ref))
