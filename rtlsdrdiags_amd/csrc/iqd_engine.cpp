@@ -20,6 +20,8 @@
 
 #include "iqd_host.h"
 #include "iqd_kernels.h"
+#include "iqd_stream.h"
+#include "iqd_taps.h"
 #include "iqd_wbfm.h"
 #include "iqd_chains.h"
 
@@ -90,6 +92,11 @@ struct iqd_engine {
     ScanConfig *d_scan_cfg = nullptr;
     ScanState *d_scan = nullptr;
     float *d_atan = nullptr, *d_fmlut = nullptr;
+    float *d_half_lut = nullptr;         // streaming WBFM kernel: |atan2| half table, tap matrices per rotation (-1, 0, +1)
+    uint32_t *d_amat[3] = {nullptr, nullptr, nullptr};
+    bool stream_ok = false;              // the half table's symmetry holds on this host's libm
+    std::vector<float> wbfm_kmax;        // [n_ch]: largest |K| a channel has run with since creation (casts stay bounded)
+    StreamArgs stream_args{};
     uint32_t *d_counters = nullptr;      // cumulative, read by iqd_get_stats
     unsigned long long *d_stamps = nullptr;
     uint32_t *h_counters = nullptr;  // pinned
@@ -227,6 +234,22 @@ int iqd_create(const iqd_config *cfg, iqd_t **out)
     std::vector<float> atan_lut, fm_lut;
     build_atan2_lut(atan_lut);
     build_fm_lut(fm_lut);
+    std::vector<float> half_lut((size_t)129 * ST_ROW_FLOATS);
+    e->stream_ok = build_half_lut(half_lut.data());
+    std::vector<uint32_t> amat[3];
+    {
+        int16_t pre[16];
+        quantize_q15(taps::WBFM_PRE, 16, pre);
+        for (int r = 0; r < 3; r++) {
+            amat[r].assign(8 * 64 * 4, 0u);
+            build_stream_amat(r - 1, pre, amat[r].data());
+        }
+    }
+    build_stream_taps(e->consts.wbfm_d1, e->consts.post12, e->consts.audio40, e->stream_args);
+    e->stream_args.b0 = e->consts.deemph_b0;
+    e->stream_args.a1 = e->consts.deemph_a1;
+    e->wbfm_kmax.resize(e->n_ch);
+    for (uint32_t c = 0; c < e->n_ch; c++) e->wbfm_kmax[c] = fabsf(e->h_params[c].wbfm_k);
 
     const size_t n = e->n_ch;
     bool ok = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) == hipSuccess;
@@ -242,6 +265,8 @@ int iqd_create(const iqd_config *cfg, iqd_t **out)
     ok = ok && hipMalloc((void **)&e->d_scan, n * sizeof(ScanState)) == hipSuccess;
     ok = ok && hipMalloc((void **)&e->d_atan, atan_lut.size() * sizeof(float)) == hipSuccess;
     ok = ok && hipMalloc((void **)&e->d_fmlut, fm_lut.size() * sizeof(float)) == hipSuccess;
+    ok = ok && hipMalloc((void **)&e->d_half_lut, half_lut.size() * sizeof(float)) == hipSuccess;
+    for (int r = 0; r < 3; r++) ok = ok && hipMalloc((void **)&e->d_amat[r], amat[r].size() * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc((void **)&e->d_counters, CNT_COUNT * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMemset(e->d_counters, 0, CNT_COUNT * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc((void **)&e->d_stamps, 16 * sizeof(unsigned long long)) == hipSuccess;
@@ -261,6 +286,11 @@ int iqd_create(const iqd_config *cfg, iqd_t **out)
                                   hipMemcpyHostToDevice, e->stream) == hipSuccess;
         ok = ok && hipMemcpyAsync(e->d_fmlut, fm_lut.data(), fm_lut.size() * sizeof(float),
                                   hipMemcpyHostToDevice, e->stream) == hipSuccess;
+        ok = ok && hipMemcpyAsync(e->d_half_lut, half_lut.data(), half_lut.size() * sizeof(float),
+                                  hipMemcpyHostToDevice, e->stream) == hipSuccess;
+        for (int r = 0; r < 3; r++)
+            ok = ok && hipMemcpyAsync(e->d_amat[r], amat[r].data(), amat[r].size() * sizeof(uint32_t),
+                                      hipMemcpyHostToDevice, e->stream) == hipSuccess;
         ok = ok && upload_consts(e->consts, e->stream) == hipSuccess;
         ok = ok && hipStreamSynchronize(e->stream) == hipSuccess;
     }
@@ -278,7 +308,7 @@ void iqd_destroy(iqd_t *e)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     void *ptrs[] = {e->d_params, e->d_tails, e->d_wcarry, e->d_dc, e->d_tracker, e->d_agc_cfg, e->d_agc, e->d_epochs, e->d_scan_cfg, e->d_scan,
-                    e->d_atan, e->d_fmlut, e->d_counters, e->d_stamps};
+                    e->d_atan, e->d_fmlut, e->d_counters, e->d_stamps, e->d_half_lut, e->d_amat[0], e->d_amat[1], e->d_amat[2]};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (e->h_counters) (void)hipHostFree(e->h_counters);
@@ -326,6 +356,8 @@ int iqd_set_gain(iqd_t *e, uint32_t first_ch, uint32_t n_ch, int demod, float ga
     for (uint32_t c = first_ch; c < first_ch + n_ch; c++) {
         e->h_params[c].gain[fam[demod]] = gain;
         derive_params(e->h_params[c]);
+        const float ak = fabsf(e->h_params[c].wbfm_k);
+        if (!(ak <= e->wbfm_kmax[c])) e->wbfm_kmax[c] = ak;   // (NaN included: never "bounded" again)
     }
     e->params_dirty = true;
     return IQD_OK;
@@ -1051,6 +1083,30 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
                                             : plan_tiles(vlen, n_list, CH_CHUNK, FIR_HALO, 4 * e->n_cus);
         a.tile_len = plan.tile_len;
         a.tiles_per_ch = plan.tiles_per_ch;
+        // WBFM: the streaming pipeline (iqd_stream.hip) when the launch can fill the chip with it and nothing it does
+        // not handle is in play: squelch-gated rows, channels with different rotation selectors, a K so large that
+        // (int16)y can hit the "integer indefinite" value.  Results are identical either way.
+        bool use_stream = false;
+        int stream_rot = 0;
+        if (f == FAM_WBFM && e->stream_ok && !gated && !(e->flags & IQD_F_WBFM_TILES) && vlen % 128 == 0) {
+            const auto &l = e->h_lists[FAM_WBFM];
+            stream_rot = e->h_params[first_ch + l[0]].rotation;
+            bool ok = true;
+            for (uint32_t c : l) {
+                const ChanParams &p = e->h_params[first_ch + c];
+                ok = ok && p.rotation == stream_rot && e->wbfm_kmax[first_ch + c] * 3.1730f < 2147483648.0f;
+            }
+            int want = 0;   // 0 auto, 1 stream, -1 tiles
+            if (e->flags & IQD_F_WBFM_STREAM) want = 1;
+            if (const char *env = getenv("IQD_WBFM_PATH")) want = env[0] == 's' ? 1 : env[0] == 't' ? -1 : want;
+            const uint64_t work = (uint64_t)vlen * n_list;
+            if (ok && want >= 0 && (want > 0 || work >= (uint64_t)e->n_cus * ST_SEGS * 2048)) {
+                const TilePlan sp = plan_stream(vlen, n_list, e->n_cus * ST_SEGS);
+                a.tile_len = sp.tile_len;
+                a.tiles_per_ch = sp.tiles_per_ch;
+                use_stream = true;
+            }
+        }
         if (e->profiling && !timed) {
             if (e->ev_free_pairs.empty()) {
                 hipEvent_t a0, a1;
@@ -1070,7 +1126,19 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
                 HIP_TRY(e, hipMemsetAsync(e->repair_flags.p, 0, e->repair_flags.cap, s));
             }
             a.repair_flags = e->repair_flags.as<uint32_t>();
-            HIP_TRY(e, launch_wbfm(a, gated, fused_mag, n_list * a.tiles_per_ch, s));
+            if (use_stream) {
+                StreamArgs sa = e->stream_args;
+                sa.amat = e->d_amat[stream_rot + 1];
+                sa.half_lut = e->d_half_lut;
+                sa.n_segments = n_list * a.tiles_per_ch;
+                const uint32_t wgs_needed = (sa.n_segments + ST_SEGS - 1) / ST_SEGS;
+                const uint32_t grid = wgs_needed < e->n_cus ? wgs_needed : e->n_cus;
+                sa.rounds = (wgs_needed + grid - 1) / grid;
+                HIP_TRY(e, launch_wbfm_stream(a, sa, stream_rot, fused_mag, grid, s));
+                e->stats.stream_launches++;
+            } else {
+                HIP_TRY(e, launch_wbfm(a, gated, fused_mag, n_list * a.tiles_per_ch, s));
+            }
         } else if (f == FAM_FM) {
             HIP_TRY(e, launch_fm(a, gated, fused_mag, n_list * a.tiles_per_ch, s));
         } else {

@@ -6,6 +6,7 @@
 
 #include "iqd_taps.h"
 #include "iqd_prims.h"
+#include "iqd_stream.h"
 
 namespace iqd {
 
@@ -182,6 +183,84 @@ TilePlan plan_tiles(uint32_t vlen, uint32_t n_channels, uint32_t chunk, uint32_t
         const uint32_t k = (uint32_t)atoi(ov);
         if (k) { p.tile_len = k * chunk; p.tiles_per_ch = (vlen + p.tile_len - 1) / p.tile_len; }
     }
+    return p;
+}
+
+// ---- streaming WBFM kernel (iqd_stream.hip) -----------------------------------------------------------------
+// Byte j of lane group g of an MFMA operand is raw byte 16 g + j of a 64-byte run of interleaved I/Q: sample
+// 8 g + j / 2, component j & 1.  Output row rho of the "N" window is sample 16 + rho of that run; in the "S"
+// window the run is [piece bytes 0..31 | previous piece's bytes 32..63] and row rho is sample rho of the piece.
+void build_stream_amat(int rotation, const int16_t *pre_q15, uint32_t *out)
+{
+    for (int type = 0; type < 2; type++)
+        for (int rail = 0; rail < 2; rail++)
+            for (int plane = 0; plane < 2; plane++) {
+                uint32_t *m = out + (size_t)(4 * type + 2 * rail + plane) * 64 * 4;
+                for (int lane = 0; lane < 64; lane++) {
+                    const int rho = lane & 15, g = lane >> 4;
+                    for (int j = 0; j < 16; j++) {
+                        int i_rel = 8 * g + (j >> 1);
+                        if (type == 1 && g >= 2) i_rel -= 32;
+                        const int outpos = type == 0 ? 16 + rho : rho;
+                        const int k = outpos - i_rel;                     // y[n] = sum h[k] x[n-k]
+                        const int phase = ((i_rel % 4) + 4) % 4, comp = j & 1;
+                        const bool feeds_i = rotation == 0 ? comp == 0 : comp == (phase & 1);
+                        int8_t v = 0;
+                        if (k >= 0 && k < 16 && feeds_i == (rail == 0)) {
+                            const int t2 = 2 * (int)pre_q15[k];           // doubled: the index byte lands on bits 16..23
+                            const int8_t lo = (int8_t)(t2 & 0xff);
+                            const int hi = (t2 - lo) / 256;               // |2 h| <= 31866 -> |hi| <= 125
+                            v = plane == 0 ? lo : (int8_t)hi;
+                        }
+                        m[lane * 4 + (j >> 2)] &= ~(0xffu << (8 * (j & 3)));
+                        m[lane * 4 + (j >> 2)] |= (uint32_t)(uint8_t)v << (8 * (j & 3));
+                    }
+                }
+            }
+}
+
+// |atan2(-r, x - 128)| for r = 0..128.  The kernel negates every angle (theta' = -theta, with -K), so that the
+// sign bit of theta' is simply bit 7 of the y index: y < 0 -> theta < 0 -> theta' = +|theta|; y >= 0 ->
+// theta' = -|theta| (y = 0: -0 or -pi).  Valid because the reference's table is odd in y bit for bit; checked here.
+bool build_half_lut(float *out)
+{
+    for (int r = 0; r <= 128; r++)
+        for (int x = 0; x < 256; x++) {
+            const float neg = (float)atan2((double)-r, (double)x - 128);
+            out[r * ST_ROW_FLOATS + x] = fabsf(neg);
+            if (r >= 1 && r <= 127) {
+                const float pos = (float)atan2((double)r, (double)x - 128);
+                if (f2u(pos) != (f2u(neg) ^ 0x80000000u)) return false;
+            }
+            if (r == 0 && (f2u(neg) & 0x80000000u)) return false;     // atan2(-0.0 ...) is not what (double)0 gives
+        }
+    for (int r = 0; r <= 128; r++)
+        for (int x = 256; x < ST_ROW_FLOATS; x++) out[r * ST_ROW_FLOATS + x] = 0.f;
+    return true;
+}
+
+void build_stream_taps(const int16_t *d1, const int16_t *post12, const int16_t *audio40, StreamArgs &sa)
+{
+    auto pair = [](int16_t lo, int16_t hi) { return (uint32_t)(uint16_t)lo | ((uint32_t)(uint16_t)hi << 16); };
+    // stage 1: window x[4m-4 .. 4m+3] ascending <-> taps h[7 .. 0]
+    for (int q = 0; q < 4; q++) sa.d1p[q] = pair(d1[7 - 2 * q], d1[6 - 2 * q]);
+    // stages 2 and 3: pair q counts back from the newest dword (older sample low: h[2q+1], newer high: h[2q])
+    for (int q = 0; q < 6; q++) sa.p12p[q] = pair(post12[2 * q + 1], post12[2 * q]);
+    for (int q = 0; q < 20; q++) sa.a40p[q] = pair(audio40[2 * q + 1], audio40[2 * q]);
+}
+
+// Segments of the streaming kernel: about `streams` of them in all, whole 128-sample units.
+TilePlan plan_stream(uint32_t vlen, uint32_t n_channels, uint32_t streams)
+{
+    TilePlan p;
+    uint32_t per_ch = n_channels ? (streams + n_channels - 1) / n_channels : 1;
+    if (per_ch == 0) per_ch = 1;
+    uint64_t len = ((uint64_t)vlen + per_ch - 1) / per_ch;
+    len = (len + 127) / 128 * 128;
+    if (len < 128) len = 128;
+    p.tile_len = (uint32_t)len;
+    p.tiles_per_ch = (uint32_t)(((uint64_t)vlen + len - 1) / len);
+    if (p.tiles_per_ch == 0) p.tiles_per_ch = 1;
     return p;
 }
 

@@ -30,6 +30,8 @@ bool squelch_always_open(const ChanParams &p, const Consts &c);
 struct TilePlan { uint32_t tile_len, tiles_per_ch; };
 TilePlan plan_tiles(uint32_t vlen, uint32_t n_channels, uint32_t chunk, uint32_t halo, uint32_t resident_wgs);
 
+TilePlan plan_stream(uint32_t vlen, uint32_t n_channels, uint32_t streams);
+
 uint32_t block_magic(uint32_t block_samples);
 
 }  // namespace iqd

@@ -74,6 +74,8 @@ hipError_t launch_am(const ChainLaunch &a, int family, bool gated, bool mag, uin
 hipError_t launch_reset(uint8_t *tails, WbfmCarry *wc, DcCarry *dc, uint32_t first_ch, uint32_t n_ch,
                         uint32_t family_mask, hipStream_t s);
 hipError_t launch_wbfm_verify(const ChainLaunch &a, hipStream_t s);
+struct StreamArgs;
+hipError_t launch_wbfm_stream(const ChainLaunch &a, const StreamArgs &sa, int rotation, bool mag, uint32_t grid, hipStream_t s);
 hipError_t launch_retail(uint8_t *tails, const ChanParams *params, uint32_t n_ch, hipStream_t s);
 // kind: 0 float decimator, 1 float interpolator, 2 int16 interpolator
 hipError_t launch_resample(int kind, const void *in, void *out, const void *hist, void *hist_next, const void *taps,

@@ -1,0 +1,60 @@
+// WBFM chain as a streaming pipeline (gfx950): launch descriptor and host helpers.
+//
+// One persistent workgroup of 15 waves per CU.  The exact atan2 half table (129 rows, the reference's
+// table is odd in y bit for bit: WbFmDemodulator.cc:159-170) lives in LDS for the lifetime of the
+// workgroup.  A *segment* is what the tile kernels call a tile: a run of consecutive samples of one
+// channel with its lead-in, cold-started and verified against its predecessor (wbfm_verify_kernel).
+// The 192 segments of a round advance in lock step, 16 samples (a *window*) at a time:
+//
+//   12 P waves, 16 segments each: raw bytes -> signed, rotation signs (SDWA byte negation keeps
+//       -(-128) = -128) -> both 16-tap Q15 rails as v_mfma_i32_16x16x64_i8 (taps split in a low and a
+//       high byte plane, rotation's rail selection folded into the tap matrices) -> table index ->
+//       ds_read_b32 gather -> delta theta, branch cut, K, b0 -> u[n] into an LDS ring slot
+//   3 IIR waves, 64 segments each (one per lane): u[n] from the ring -> de-emphasis recurrence,
+//       (int16), /4 /4 /2 Q15 decimators with their histories in registers -> PCM
+//
+// Reference: WbFmDemodulator.cc:383-562 behind IqDataProcessor.cc:735-749.
+#pragma once
+#include <stdint.h>
+
+#include "iqd_device.h"
+
+namespace iqd {
+
+constexpr int ST_WAVES = 15;
+constexpr int ST_THREADS = 64 * ST_WAVES;
+constexpr int ST_RINGS = 3;                 // = IIR waves
+constexpr int ST_P_PER_RING = 4;            // P waves feeding one ring (16 segments each)
+constexpr int ST_SEGS = 64 * ST_RINGS;      // segments per workgroup and round
+constexpr int ST_HALO = 1408;               // lead-in of a cold segment: 640 samples for the de-emphasis state to
+                                            // become exact, then FORCED_BACK = 768 of exact decimator history
+constexpr int ST_ROW_FLOATS = 260;          // half-table row stride (1040 B: bank = x + 4 r)
+constexpr int ST_TABLE_BYTES = 129 * ST_ROW_FLOATS * 4;
+constexpr int ST_SLOT_BYTES = 64 * 16 * 4;  // one window of one ring: 64 segments x 16 samples, f32
+constexpr int ST_RING_SLOTS = 2;
+constexpr int ST_SYNC_WORDS = 16;
+constexpr int ST_LDS_BYTES = ST_TABLE_BYTES + ST_RINGS * ST_RING_SLOTS * ST_SLOT_BYTES + ST_SYNC_WORDS * 4;
+static_assert(ST_LDS_BYTES <= 160 * 1024, "table + rings must fit the CU's LDS");
+static_assert(ST_HALO % 128 == 0 && ST_HALO + 32 <= TAIL, "the lead-in is whole 128-sample units inside the kept tail");
+
+struct StreamArgs {
+    const uint32_t *amat;     // [8][64][4]: tap matrices as MFMA A operands, see build_stream_amat()
+    const float *half_lut;    // [129][ST_ROW_FLOATS]: |atan2(-r, x - 128)|
+    uint32_t n_segments;      // n_list * tiles_per_ch
+    uint32_t rounds;          // rounds per workgroup
+    uint32_t d1p[4];          // decimator taps as v_dot2 pairs (see build_stream_taps)
+    uint32_t p12p[6];
+    uint32_t a40p[20];
+    float b0, a1;
+};
+
+// A operands of v_mfma_i32_16x16x64_i8 for the pre-demodulation FIR of one rotation selector.
+// Matrix index = 4 * window_type + 2 * rail + plane; window_type 0 = "N" (the 16 outputs of the second
+// half of a 32-sample piece, operand = the piece), 1 = "S" (first half: lanes 0-31 hold the piece's first
+// 32 bytes, lanes 32-63 the previous piece's last 32 bytes); rail 0 = I', 1 = Q'; plane 0 = low byte,
+// 1 = high byte of the DOUBLED Q15 tap (2 h = lo + 256 hi).
+void build_stream_amat(int rotation, const int16_t *pre_q15, uint32_t *out /* [8*64*4] */);
+bool build_half_lut(float *out /* [129*ST_ROW_FLOATS] */);   // false: libm's atan2 is not odd in y bit for bit
+void build_stream_taps(const int16_t *d1, const int16_t *post12, const int16_t *audio40, StreamArgs &sa);
+
+}  // namespace iqd

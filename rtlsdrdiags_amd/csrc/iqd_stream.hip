@@ -1,0 +1,457 @@
+// WBFM chain as a streaming pipeline: one persistent 15-wave workgroup per CU (see iqd_stream.h).
+// hipcc --offload-arch=gfx950 -ffp-contract=off.
+#include <hip/hip_runtime.h>
+
+#include "iqd_kernels.h"
+#include "iqd_stream.h"
+#include "iqd_wbfm.h"
+
+namespace iqd {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+
+// ---- small device helpers -----------------------------------------------------------------------
+// byte B of x replaced by its two's-complement negation, the other bytes kept (v_sub_u32_sdwa): int8
+// wrap, so -(-128) stays -128 like the reference's rotation (IqDataProcessor.cc:594-607)
+#define ST_NEG_BYTE(x, B)                                                                                     \
+    asm("v_sub_u32_sdwa %0, %1, %0 dst_sel:BYTE_" #B " dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_" #B \
+        : "+v"(x) : "v"(zero))
+
+// raw offset-binary bytes of 8 samples -> signed bytes with the rotation's SIGNS applied in place (which
+// byte feeds which rail is folded into the tap matrices).  +Fs/4: I' = {I0,-Q1,-I2,Q3}, Q' = {Q0,I1,-Q2,-I3};
+// -Fs/4: I' = {I0,Q1,-I2,-Q3}, Q' = {Q0,-I1,-Q2,I3} (IqDataProcessor.cc:567-611).
+template <int ROT>
+__device__ __forceinline__ uint4 st_front(uint4 raw, uint32_t zero)
+{
+    uint32_t d[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+    for (int h = 0; h < 4; h += 2) {
+        uint32_t d0 = d[h], d1 = d[h + 1];
+        if (ROT == 0) {
+            d0 ^= 0x80808080u;
+            d1 ^= 0x80808080u;
+        } else if (ROT > 0) {
+            d0 = (d0 ^ 0x7f808080u) + 0x01000000u;   // byte 3 (Q1): ~s + 1, the carry leaves the register
+            d1 ^= 0x80808080u;
+            ST_NEG_BYTE(d1, 0);
+            ST_NEG_BYTE(d1, 1);
+            ST_NEG_BYTE(d1, 2);
+        } else {
+            d0 ^= 0x80808080u;
+            ST_NEG_BYTE(d0, 2);
+            d1 = (d1 ^ 0x7f808080u) + 0x01000000u;   // byte 3 (Q3)
+            ST_NEG_BYTE(d1, 0);
+            ST_NEG_BYTE(d1, 1);
+        }
+        d[h] = d0;
+        d[h + 1] = d1;
+    }
+    return uint4{d[0], d[1], d[2], d[3]};
+}
+
+// sum over the 2 samples of a dword of signed bytes of max(|I|,|Q|) + min(|I|,|Q|)/2, added into two 16-bit
+// lanes of acc (SignalDetector.cc:227-247).  |x| of all four bytes at once: (x ^ m) + t with t the sign bits.
+__device__ __forceinline__ uint32_t st_mag_dword(uint32_t sx, uint32_t acc)
+{
+    const uint32_t t = (sx >> 7) & 0x01010101u;
+    const uint32_t m = (t << 8) - t;
+    const uint32_t ab = (sx ^ m) + t;                      // bytes |I0| |Q0| |I1| |Q1|, each <= 128
+    const us2 a = __builtin_bit_cast(us2, ab & 0x00ff00ffu);
+    const us2 b = __builtin_bit_cast(us2, (ab >> 8) & 0x00ff00ffu);
+    const us2 mx = __builtin_elementwise_max(a, b), mn = __builtin_elementwise_min(a, b);
+    return acc + __builtin_bit_cast(uint32_t, mx) + __builtin_bit_cast(uint32_t, (us2)(mn >> 1));
+}
+
+__device__ __forceinline__ uint32_t lds_load_relaxed(const uint32_t *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// byte offset of granule q (4 samples) of ring row j inside a slot: XOR swizzle, conflict-free for the
+// P waves' ds_write_b128 and the IIR lanes' ds_read_b128
+__device__ __forceinline__ uint32_t st_slot_off(uint32_t j, uint32_t q) { return j * 64u + ((q ^ ((j >> 2) & 3u)) << 4); }
+
+struct StSeg {           // what a lane knows about its segment
+    uint32_t valid, li, tile, ch, ech;
+    int32_t v0, tlen;
+};
+
+__device__ __forceinline__ StSeg st_segment(const ChainLaunch &a, uint32_t sid, uint32_t n_segments)
+{
+    StSeg s;
+    s.valid = sid < n_segments ? 1u : 0u;
+    const uint32_t id = s.valid ? sid : 0u;
+    s.li = id / a.tiles_per_ch;
+    s.tile = id - s.li * a.tiles_per_ch;
+    s.ch = a.ch_list[s.li];
+    s.ech = a.first_ch + s.ch;
+    const int64_t v0 = (int64_t)s.tile * a.tile_len;
+    if (v0 >= (int64_t)a.vlen) { s.valid = 0; s.v0 = 0; s.tlen = 0; return s; }
+    s.v0 = (int32_t)v0;
+    const int64_t rest = (int64_t)a.vlen - v0;
+    s.tlen = (int32_t)(rest < (int64_t)a.tile_len ? rest : (int64_t)a.tile_len);
+    if (!s.valid) s.tlen = 0;
+    return s;
+}
+
+// ---- P wave: 16 segments, raw bytes -> u[n] -------------------------------------------------------
+template <int ROT, bool MAG>
+__device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs &sa, uint8_t *lds, uint32_t *sync,
+                                          int pw, int lane)
+{
+    const int ring = pw / ST_P_PER_RING, cg = pw % ST_P_PER_RING;
+    const int g = lane >> 4, c = lane & 15;
+    const uint32_t row = (uint32_t)(16 * cg + c);                // ring row of this lane's segment
+    uint8_t *ring_base = lds + ST_TABLE_BYTES + ring * (ST_RING_SLOTS * ST_SLOT_BYTES);
+    const uint32_t *full = sync + ring * 2;
+    const uint32_t *consumed = sync + 8 + ring;
+    const uint32_t wr_off = st_slot_off(row, (uint32_t)g);
+    const int src_lane4 = ((lane - 16) & 63) << 2;               // whose theta[3] precedes this lane's theta[0]
+
+    v4i A[8];
+#pragma unroll
+    for (int m = 0; m < 8; m++) A[m] = ((const v4i *)sa.amat)[m * 64 + lane];
+    const v4i cbias = {WB_BIAS, WB_BIAS, WB_BIAS, WB_BIAS}, czero = {0, 0, 0, 0};
+    uint32_t zero = 0;
+    asm volatile("" : "+v"(zero));   // a VGPR holding 0 for the SDWA negations
+
+    const int n_pieces = (ST_HALO + (int)a.tile_len) >> 5;
+    uint32_t wg = 0;                                             // windows this ring has seen (all rounds)
+    for (uint32_t round = 0; round < sa.rounds; round++) {
+        const uint32_t sid = (round * gridDim.x + blockIdx.x) * ST_SEGS + ring * 64 + row;
+        const StSeg sg = st_segment(a, sid, sa.n_segments);
+        const ChanParams &p = a.params[sg.ech];
+        const uint8_t *iq_ch = a.iq + (size_t)sg.ch * a.ch_stride_bytes;
+        const uint8_t *tail = a.tails + ((size_t)sg.ech * FAM_COUNT + FAM_WBFM) * TAIL_BYTES + TAIL_BYTES;
+        const int32_t vmax = (int32_t)a.vlen - 8;
+        float kneg = -p.wbfm_k, kneg_prev = kneg;
+        int32_t k_switch = INT32_MIN;
+        {   // every segment whose lead-in reaches back before the last gain change runs that part with the old gain
+            const uint32_t since = a.epochs[sg.ech].wbfm_since;
+            if (since < (uint32_t)TAIL && (int64_t)sg.v0 - ST_HALO - 32 < -(int64_t)since) {
+                kneg_prev = -a.epochs[sg.ech].wbfm_k_prev;
+                k_switch = -(int32_t)since - sg.v0;
+            }
+        }
+        uint32_t *mag_row = MAG ? a.mag_sums + (size_t)sg.ch * a.n_blocks : nullptr;
+        // squelch magnitude bookkeeping: this lane's chunks are 32 samples apart
+        uint32_t macc = 0, mblk = 0, minblk = 0;
+        bool mstarted = false;
+
+        auto load_piece = [&](int pos) -> uint4 {
+            int32_t v = sg.v0 + pos + 8 * g;
+            v = v < vmax ? v : vmax;
+            const uint8_t *ptr = v < 0 ? tail + 2 * (int64_t)v : iq_ch + 2 * (int64_t)v;
+            return *(const uint4 *)ptr;
+        };
+
+        float last_prev = 0.f;                                   // theta'[3] of this lane's previous window
+        uint4 prev = st_front<ROT>(load_piece(-ST_HALO - 32), zero);
+        uint4 raw_next = load_piece(-ST_HALO);
+        for (int q = 0; q < n_pieces; q++) {
+            const int pos = -ST_HALO + 32 * q;
+            const uint4 cur = st_front<ROT>(raw_next, zero);
+            raw_next = load_piece(pos + 32);                     // in flight during this piece's arithmetic
+            if (MAG) {
+                const int cpos = pos + 8 * g;
+                if (cpos >= 0 && cpos < sg.tlen && sg.valid) {
+                    if (!mstarted) {
+                        const uint32_t v = (uint32_t)(sg.v0 + cpos);
+                        mblk = v / a.block_samples;
+                        minblk = v - mblk * a.block_samples;
+                        mstarted = true;
+                    }
+                    uint32_t m16 = st_mag_dword(cur.x, 0u);
+                    m16 = st_mag_dword(cur.y, m16);
+                    m16 = st_mag_dword(cur.z, m16);
+                    m16 = st_mag_dword(cur.w, m16);
+                    macc += (m16 & 0xffffu) + (m16 >> 16);
+                    minblk += 32;
+                    if (minblk >= a.block_samples) {             // the next chunk belongs to the next block
+                        atomicAdd(&mag_row[mblk], macc);
+                        macc = 0;
+                        mblk++;
+                        minblk -= a.block_samples;
+                    }
+                }
+            }
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                const int wpos = pos + 16 * half;
+                v4i B;
+                if (half == 0) {   // "S" window: lanes 0-31 this piece's first 32 bytes, lanes 32-63 the previous piece's last 32
+                    B = v4i{(int)(lane < 32 ? cur.x : prev.x), (int)(lane < 32 ? cur.y : prev.y),
+                            (int)(lane < 32 ? cur.z : prev.z), (int)(lane < 32 ? cur.w : prev.w)};
+                } else {
+                    B = v4i{(int)cur.x, (int)cur.y, (int)cur.z, (int)cur.w};
+                }
+                const int mb = half == 0 ? 4 : 0;
+                const v4i ilo = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[mb + 0], B, cbias, 0, 0, 0);
+                const v4i ihi = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[mb + 1], B, czero, 0, 0, 0);
+                const v4i qlo = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[mb + 2], B, cbias, 0, 0, 0);
+                const v4i qhi = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[mb + 3], B, czero, 0, 0, 0);
+                // twice the Q15 sums + WB_BIAS: byte 2 is (uint8)((int8)(acc >> 15) + 128), the table index
+                float th[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const uint32_t ti = (uint32_t)ilo[r] + ((uint32_t)ihi[r] << 8);
+                    const uint32_t tq = (uint32_t)qlo[r] + ((uint32_t)qhi[r] << 8);
+                    uint32_t rr;                                 // |y| = |byte 2 of tq - 128|
+                    asm("v_msad_u8 %0, %1, %2, 0" : "=v"(rr) : "v"(tq), "s"(0x00800000u));
+                    const uint32_t xb = bfe(ti, 16, 8);
+                    const uint32_t addr = rr * (uint32_t)(ST_ROW_FLOATS * 4) + (xb << 2);
+                    const uint32_t t = *(const uint32_t *)(lds + addr);
+                    // the table holds |theta|; theta' = -theta carries the sign bit of y >= 0 (index bit 7)
+                    th[r] = u2f(t | ((tq << 8) & 0x80000000u));
+                }
+                const float give = g == 3 ? last_prev : th[3];
+                const float before = u2f((uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)f2u(give)));
+                last_prev = th[3];
+                const float kk = wpos < k_switch ? kneg_prev : kneg;
+                float u[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const float d = wrap_delta(th[r] - (r == 0 ? before : th[r - 1]));   // = -(delta theta)
+                    const float v = kk * d;
+                    u[r] = sa.b0 * v;
+                }
+                // hand the 4 samples to the IIR wave: slot wg & 1, free once window wg - 2 has been consumed
+                if (wg >= 2)
+                    while ((int32_t)(lds_load_relaxed(consumed) - (wg - 1)) < 0) __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                *(u32x4 *)(ring_base + (wg & 1u) * ST_SLOT_BYTES + wr_off) = u32x4{f2u(u[0]), f2u(u[1]), f2u(u[2]), f2u(u[3])};
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) __hip_atomic_fetch_add((uint32_t *)&full[wg & 1u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                wg++;
+            }
+            prev = cur;
+        }
+        if (MAG && mstarted && macc) atomicAdd(&mag_row[mblk], macc);
+    }
+}
+
+// ---- IIR wave: 64 segments, u[n] -> PCM ------------------------------------------------------------
+struct StIir {
+    float y, up;
+    uint32_t wlast[2];     // the last 4 (int16)y
+    uint32_t y1h[4];       // the last 8 stage-1 outputs
+    uint32_t y2p[24];      // stage-2 outputs as pairs; variant V of a piece uses [V+1 .. V+20]
+    uint32_t y2lo;         // first stage-2 output of the current piece
+    int loud;              // pieces for which a |y2| > AUDIO40_SAFE stays in reach of the 40-tap window
+};
+
+// 16 samples of one segment: de-emphasis (IirFilter.cc:161-176 op by op), (int16), /4 with 8 taps, then one
+// /4 output with 12 taps.  Returns that stage-2 output.
+__device__ __forceinline__ int st_iir_window(const StreamArgs &sa, StIir &s, const float (&u)[16])
+{
+    uint32_t wv[16];
+    float y = s.y, up = s.up;
+    const float a1 = sa.a1;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        IQD_IIR_STEP(u[k])
+        wv[k] = cast_i16_bounded(y);
+    }
+    s.y = y;
+    s.up = up;
+    uint32_t wq[10];                                   // 20 samples: the last quad, then this window's four
+    wq[0] = s.wlast[0];
+    wq[1] = s.wlast[1];
+#pragma unroll
+    for (int k = 0; k < 8; k++) wq[2 + k] = pack_lo16(wv[2 * k], wv[2 * k + 1]);
+    s.wlast[0] = wq[8];
+    s.wlast[1] = wq[9];
+    uint32_t y1[4];
+#pragma unroll
+    for (int o = 0; o < 4; o++) {                      // window x[4m-4 .. 4m+3] <-> taps h[7 .. 0]
+        int acc = 1 << 14;
+        acc = dot2(wq[2 * o], sa.d1p[0], acc);
+        acc = dot2(wq[2 * o + 1], sa.d1p[1], acc);
+        acc = dot2(wq[2 * o + 2], sa.d1p[2], acc);
+        acc = dot2(wq[2 * o + 3], sa.d1p[3], acc);
+        y1[o] = (uint32_t)(acc >> 15);
+    }
+    // stage 2: output k from y1[4k-8 .. 4k+3], 12 taps, newest pair first
+    const uint32_t d[6] = {s.y1h[0], s.y1h[1], s.y1h[2], s.y1h[3], pack_lo16(y1[0], y1[1]), pack_lo16(y1[2], y1[3])};
+    int acc = 1 << 14;
+#pragma unroll
+    for (int q = 0; q < 6; q++) acc = dot2(d[5 - q], sa.p12p[q], acc);
+    s.y1h[0] = d[2];
+    s.y1h[1] = d[3];
+    s.y1h[2] = d[4];
+    s.y1h[3] = d[5];
+    return acc >> 15;
+}
+
+// /2, 40 taps over the pairs p[1..20] (p[20] newest): without clamps when no loud value is in reach, else in
+// the reference's order with the clamp after every MAC (Decimator_int16.cc:176-238)
+template <int V>
+__device__ __forceinline__ int st_audio(const StreamArgs &sa, const StIir &s, bool quiet)
+{
+    int acc = 1 << 14;
+    if (quiet) {
+#pragma unroll
+        for (int q = 0; q < 20; q++) acc = dot2(s.y2p[V + 20 - q], sa.a40p[q], acc);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 20; q++) {
+            acc = clamp_q30(dot2(s.y2p[V + 20 - q], sa.a40p[q] & 0xffff0000u, acc));   // newer sample of the pair: h[2q]
+            acc = clamp_q30(dot2(s.y2p[V + 20 - q], sa.a40p[q] & 0x0000ffffu, acc));   // older: h[2q+1]
+        }
+    }
+    return acc >> 15;
+}
+
+struct StIirSeg {
+    StSeg sg;
+    int32_t back;          // tile 0: the carried exact state sits `back` samples before the tile; else -1
+    float cy_y, cy_u;
+    int32_t rec_pos;
+    WbfmRecord rec;
+    int16_t *pcm_row;
+};
+
+__device__ __forceinline__ void st_iir_marks(StIirSeg &q, StIir &s, int pos)
+{
+    if (q.back >= 0) {                                 // warm segment: silence before the carried state applies
+        if (pos == -q.back) { s.y = q.cy_y; s.up = q.cy_u; }
+        else if (pos < -q.back) { s.y = 0.f; s.up = 0.f; }
+    } else if (pos == -FORCED_BACK) {
+        q.rec.y_in = s.y;
+    }
+    if (pos == q.rec_pos) { q.rec.y_out = s.y; q.rec.u_out = s.up; }
+    if (pos == q.sg.tlen) { q.rec.y_end = s.y; q.rec.u_end = s.up; }
+}
+
+template <int V>
+__device__ __forceinline__ void st_iir_piece(const StreamArgs &sa, uint8_t *ring_base, const uint32_t *full, uint32_t *consumed,
+                                             uint32_t &wg, StIirSeg &q, StIir &s, int pos, uint32_t rd_off0, uint32_t rd_swz, int lane)
+{
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        const int wpos = pos + 16 * half;
+        const uint32_t target = 4u * ((wg >> 1) + 1u);
+        while ((int32_t)(lds_load_relaxed(&full[wg & 1u]) - target) < 0) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const uint8_t *slot = ring_base + (wg & 1u) * ST_SLOT_BYTES + rd_off0;
+        float u[16];
+#pragma unroll
+        for (int gq = 0; gq < 4; gq++) {
+            const u32x4 v = *(const u32x4 *)(slot + (((uint32_t)gq ^ rd_swz) << 4));
+            u[4 * gq] = u2f(v.x); u[4 * gq + 1] = u2f(v.y); u[4 * gq + 2] = u2f(v.z); u[4 * gq + 3] = u2f(v.w);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the reads have returned
+        if (lane == 0) __hip_atomic_fetch_add(consumed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        wg++;
+        st_iir_marks(q, s, wpos);
+        const int y2 = st_iir_window(sa, s, u);
+        const uint32_t mag = (uint32_t)(y2 < 0 ? -y2 : y2);
+        if (mag > (uint32_t)AUDIO40_SAFE) s.loud = 21;
+        if (half == 0) s.y2lo = (uint32_t)y2;
+        else s.y2p[V + 20] = pack_lo16(s.y2lo, (uint32_t)y2);
+    }
+    const bool quiet = !__any(s.loud > 0);
+    const int pcm = quiet ? st_audio<V>(sa, s, true) : st_audio<V>(sa, s, false);
+    if (s.loud > 0) s.loud--;
+    if (q.sg.valid && pos >= 0 && pos < q.sg.tlen) q.pcm_row[(q.sg.v0 + pos) >> 5] = (int16_t)pcm;
+}
+
+__device__ __forceinline__ void st_iir_wave(const ChainLaunch &a, const StreamArgs &sa, uint8_t *lds, uint32_t *sync,
+                                            int ring, int lane)
+{
+    uint8_t *ring_base = lds + ST_TABLE_BYTES + ring * (ST_RING_SLOTS * ST_SLOT_BYTES);
+    const uint32_t *full = sync + ring * 2;
+    uint32_t *consumed = sync + 8 + ring;
+    const uint32_t rd_off0 = (uint32_t)lane * 64u, rd_swz = ((uint32_t)lane >> 2) & 3u;
+    const int n_pieces = (ST_HALO + (int)a.tile_len) >> 5;       // a multiple of 4
+    uint32_t wg = 0;
+    for (uint32_t round = 0; round < sa.rounds; round++) {
+        const uint32_t sid = (round * gridDim.x + blockIdx.x) * ST_SEGS + ring * 64 + lane;
+        StIirSeg q;
+        q.sg = st_segment(a, sid, sa.n_segments);
+        q.pcm_row = a.pcm + (size_t)q.sg.ch * a.pcm_stride;
+        q.back = -1;
+        q.cy_y = q.cy_u = 0.f;
+        int32_t halo = ST_HALO;
+        if (q.sg.tile == 0) {
+            const WbfmCarry cy = a.wbfm_carry[q.sg.ech];
+            q.back = cy.back;
+            q.cy_y = cy.y;
+            q.cy_u = cy.u;
+            halo = cy.back;
+        }
+        q.rec_pos = q.sg.tlen - FORCED_BACK;
+        if (q.rec_pos < -halo) q.rec_pos = -halo;
+        q.rec.y_in = q.cy_y;
+        q.rec.y_out = q.cy_y;
+        q.rec.u_out = q.cy_u;
+        q.rec.back_out = q.sg.tlen - q.rec_pos;
+        q.rec.y_end = 0.f;
+        q.rec.u_end = 0.f;
+        q.rec.pad[0] = q.rec.pad[1] = 0;
+        StIir s;
+        s.y = 0.f; s.up = 0.f;
+        s.wlast[0] = s.wlast[1] = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) s.y1h[k] = 0;
+#pragma unroll
+        for (int k = 0; k < 24; k++) s.y2p[k] = 0;
+        s.y2lo = 0;
+        s.loud = 0;
+        for (int pq = 0; pq < n_pieces; pq += 4) {
+            const int pos = -ST_HALO + 32 * pq;
+            st_iir_piece<0>(sa, ring_base, full, consumed, wg, q, s, pos, rd_off0, rd_swz, lane);
+            st_iir_piece<1>(sa, ring_base, full, consumed, wg, q, s, pos + 32, rd_off0, rd_swz, lane);
+            st_iir_piece<2>(sa, ring_base, full, consumed, wg, q, s, pos + 64, rd_off0, rd_swz, lane);
+            st_iir_piece<3>(sa, ring_base, full, consumed, wg, q, s, pos + 96, rd_off0, rd_swz, lane);
+#pragma unroll
+            for (int k = 0; k < 20; k++) s.y2p[k] = s.y2p[k + 4];
+        }
+        st_iir_marks(q, s, (int)a.tile_len);
+        if (q.sg.valid) a.records[(size_t)q.sg.li * a.tiles_per_ch + q.sg.tile] = q.rec;
+    }
+}
+
+template <int ROT, bool MAG>
+__global__ __launch_bounds__(ST_THREADS, 4) void wbfm_stream_kernel(const ChainLaunch a, const StreamArgs sa)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t st_lds[];
+    uint32_t *sync = (uint32_t *)(st_lds + ST_TABLE_BYTES + ST_RINGS * ST_RING_SLOTS * ST_SLOT_BYTES);
+    const int tid = (int)threadIdx.x;
+    for (int i = tid; i < ST_TABLE_BYTES / 16; i += ST_THREADS) ((uint4 *)st_lds)[i] = ((const uint4 *)sa.half_lut)[i];
+    if (tid < ST_SYNC_WORDS) sync[tid] = 0;
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    if (wave < ST_RINGS) st_iir_wave(a, sa, st_lds, sync, wave, lane);
+    else st_p_wave<ROT, MAG>(a, sa, st_lds, sync, wave - ST_RINGS, lane);
+}
+
+hipError_t launch_wbfm_stream(const ChainLaunch &a, const StreamArgs &sa, int rotation, bool mag, uint32_t grid, hipStream_t s)
+{
+    static bool attr_set = false;
+    if (!attr_set) {
+        const void *ks[] = {(const void *)wbfm_stream_kernel<0, false>, (const void *)wbfm_stream_kernel<0, true>,
+                            (const void *)wbfm_stream_kernel<1, false>, (const void *)wbfm_stream_kernel<1, true>,
+                            (const void *)wbfm_stream_kernel<-1, false>, (const void *)wbfm_stream_kernel<-1, true>};
+        for (const void *k : ks) {
+            hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS_BYTES);
+            if (e != hipSuccess) return e;
+        }
+        attr_set = true;
+    }
+    const dim3 g(grid), b(ST_THREADS);
+    if (rotation == 0) {
+        if (mag) hipLaunchKernelGGL((wbfm_stream_kernel<0, true>), g, b, ST_LDS_BYTES, s, a, sa);
+        else hipLaunchKernelGGL((wbfm_stream_kernel<0, false>), g, b, ST_LDS_BYTES, s, a, sa);
+    } else if (rotation > 0) {
+        if (mag) hipLaunchKernelGGL((wbfm_stream_kernel<1, true>), g, b, ST_LDS_BYTES, s, a, sa);
+        else hipLaunchKernelGGL((wbfm_stream_kernel<1, false>), g, b, ST_LDS_BYTES, s, a, sa);
+    } else {
+        if (mag) hipLaunchKernelGGL((wbfm_stream_kernel<-1, true>), g, b, ST_LDS_BYTES, s, a, sa);
+        else hipLaunchKernelGGL((wbfm_stream_kernel<-1, false>), g, b, ST_LDS_BYTES, s, a, sa);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace iqd
