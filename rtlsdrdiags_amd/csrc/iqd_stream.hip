@@ -55,7 +55,9 @@ __device__ __forceinline__ uint4 st_front(uint4 raw, uint32_t zero)
 __device__ __forceinline__ uint32_t st_mag_dword(uint32_t sx, uint32_t acc)
 {
     const uint32_t t = (sx >> 7) & 0x01010101u;
-    const uint32_t m = (t << 8) - t;
+    uint32_t t8 = t << 8;
+    asm("" : "+v"(t8));                                    // (else hipcc folds this into a quarter-rate v_mul_lo_u32 by 255)
+    const uint32_t m = t8 - t;
     const uint32_t ab = (sx ^ m) + t;                      // bytes |I0| |Q0| |I1| |Q1|, each <= 128
     const us2 a = __builtin_bit_cast(us2, ab & 0x00ff00ffu);
     const us2 b = __builtin_bit_cast(us2, (ab >> 8) & 0x00ff00ffu);
@@ -66,6 +68,14 @@ __device__ __forceinline__ uint32_t st_mag_dword(uint32_t sx, uint32_t acc)
 __device__ __forceinline__ uint32_t lds_load_relaxed(const uint32_t *p)
 {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// lane 0 adds 1 to an LDS word (exec is all ones wherever this is used); the plain HIP form costs a dozen
+// instructions of "which lane is first" bookkeeping per call
+__device__ __forceinline__ void lds_signal(const uint32_t *p)
+{
+    const uint32_t addr = (uint32_t)(uintptr_t)p, one = 1u;
+    asm volatile("s_mov_b64 exec, 1\n\tds_add_u32 %0, %1\n\ts_mov_b64 exec, -1" :: "v"(addr), "v"(one) : "memory");
 }
 
 // byte offset of granule q (4 samples) of ring row j inside a slot: XOR swizzle, conflict-free for the
@@ -136,14 +146,20 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
         }
         uint32_t *mag_row = MAG ? a.mag_sums + (size_t)sg.ch * a.n_blocks : nullptr;
         // squelch magnitude bookkeeping: this lane's chunks are 32 samples apart
-        uint32_t macc = 0, mblk = 0, minblk = 0;
-        bool mstarted = false;
+        const bool mcount = MAG && sg.valid;
+        const int32_t mlimit = sg.tlen - 8 * g;                  // chunks at pos < mlimit lie inside the segment
+        uint32_t macc = 0;
+        uint32_t mblk = (uint32_t)(sg.v0 + 8 * g) / a.block_samples;
+        uint32_t minblk = (uint32_t)(sg.v0 + 8 * g) - mblk * a.block_samples;
 
+        // this lane's 8 samples of the piece at `pos`: virtual sample v = v0 + 8 g + pos, from the kept tail while v < 0
+        const int32_t vlane = sg.v0 + 8 * g;
+        const uint8_t *base_iq = iq_ch + 2 * (int64_t)vlane, *base_tail = tail + 2 * (int64_t)vlane;
+        const int32_t pos_max = vmax - vlane;
         auto load_piece = [&](int pos) -> uint4 {
-            int32_t v = sg.v0 + pos + 8 * g;
-            v = v < vmax ? v : vmax;
-            const uint8_t *ptr = v < 0 ? tail + 2 * (int64_t)v : iq_ch + 2 * (int64_t)v;
-            return *(const uint4 *)ptr;
+            const int32_t pc = pos < pos_max ? pos : pos_max;
+            const uint8_t *base = pc < -vlane ? base_tail : base_iq;
+            return *(const uint4 *)(base + 2 * (int64_t)pc);
         };
 
         float last_prev = 0.f;                                   // theta'[3] of this lane's previous window
@@ -153,81 +169,96 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
             const int pos = -ST_HALO + 32 * q;
             const uint4 cur = st_front<ROT>(raw_next, zero);
             raw_next = load_piece(pos + 32);                     // in flight during this piece's arithmetic
-            if (MAG) {
-                const int cpos = pos + 8 * g;
-                if (cpos >= 0 && cpos < sg.tlen && sg.valid) {
-                    if (!mstarted) {
-                        const uint32_t v = (uint32_t)(sg.v0 + cpos);
-                        mblk = v / a.block_samples;
-                        minblk = v - mblk * a.block_samples;
-                        mstarted = true;
-                    }
-                    uint32_t m16 = st_mag_dword(cur.x, 0u);
-                    m16 = st_mag_dword(cur.y, m16);
-                    m16 = st_mag_dword(cur.z, m16);
-                    m16 = st_mag_dword(cur.w, m16);
-                    macc += (m16 & 0xffffu) + (m16 >> 16);
-                    minblk += 32;
-                    if (minblk >= a.block_samples) {             // the next chunk belongs to the next block
-                        atomicAdd(&mag_row[mblk], macc);
-                        macc = 0;
-                        mblk++;
-                        minblk -= a.block_samples;
-                    }
+            // both windows' MFMAs go out first: the second window's run under the first window's index arithmetic.
+            // "S" window (the piece's first 16 outputs): lanes 0-31 this piece's first 32 bytes, lanes 32-63 the
+            // previous piece's last 32; "N" window: the piece itself.
+            const v4i bs = v4i{(int)(lane < 32 ? cur.x : prev.x), (int)(lane < 32 ? cur.y : prev.y),
+                               (int)(lane < 32 ? cur.z : prev.z), (int)(lane < 32 ? cur.w : prev.w)};
+            const v4i bn = v4i{(int)cur.x, (int)cur.y, (int)cur.z, (int)cur.w};
+            v4i acc[2][4];
+            acc[0][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[4], bs, cbias, 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[5], bs, czero, 0, 0, 0);
+            acc[0][2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[6], bs, cbias, 0, 0, 0);
+            acc[0][3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[7], bs, czero, 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[0], bn, cbias, 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[1], bn, czero, 0, 0, 0);
+            acc[1][2] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[2], bn, cbias, 0, 0, 0);
+            acc[1][3] = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[3], bn, czero, 0, 0, 0);
+            // phase A, both windows: table addresses and the gathers.  Twice the Q15 sums + WB_BIAS: byte 2 is
+            // (uint8)((int8)(acc >> 15) + 128), the table index.
+            uint32_t traw[2][4], tqs[2][4];
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const uint32_t ti = (uint32_t)acc[half][0][r] + ((uint32_t)acc[half][1][r] << 8);
+                    const uint32_t tq = (uint32_t)acc[half][2][r] + ((uint32_t)acc[half][3][r] << 8);
+                    uint32_t rr;                                 // |y| = |byte 2 of tq - 128|
+                    asm("v_msad_u8 %0, %1, %2, 0" : "=v"(rr) : "v"(tq), "s"(0x00800000u));
+                    const uint32_t x4 = bfe(ti, 16, 8) << 2;
+                    uint32_t addr;                               // row |y|, column x of the half table
+                    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(addr) : "v"(rr), "s"((uint32_t)(ST_ROW_FLOATS * 4)), "v"(x4));
+                    traw[half][r] = *(const uint32_t *)(lds + addr);
+                    tqs[half][r] = tq;
                 }
             }
+            uint32_t seen = lds_load_relaxed(consumed);          // asked early, needed only before the ring stores
+            // phase B: squelch magnitudes of this lane's 8 samples, while the gathers are in flight
+            if (MAG && pos >= 0) {
+                uint32_t m16 = st_mag_dword(cur.x, 0u);
+                m16 = st_mag_dword(cur.y, m16);
+                m16 = st_mag_dword(cur.z, m16);
+                m16 = st_mag_dword(cur.w, m16);
+                const uint32_t m = (m16 & 0xffffu) + (m16 >> 16);
+                macc += mcount && pos < mlimit ? m : 0u;
+                minblk += 32;
+                if (minblk >= a.block_samples) {                 // the next chunk belongs to the next block
+                    if (macc) atomicAdd(&mag_row[mblk], macc);
+                    macc = 0;
+                    mblk++;
+                    minblk -= a.block_samples;
+                }
+            }
+            // phase C, both windows: sign, delta theta, branch cut, K, b0
+            float u[2][4];
 #pragma unroll
             for (int half = 0; half < 2; half++) {
                 const int wpos = pos + 16 * half;
-                v4i B;
-                if (half == 0) {   // "S" window: lanes 0-31 this piece's first 32 bytes, lanes 32-63 the previous piece's last 32
-                    B = v4i{(int)(lane < 32 ? cur.x : prev.x), (int)(lane < 32 ? cur.y : prev.y),
-                            (int)(lane < 32 ? cur.z : prev.z), (int)(lane < 32 ? cur.w : prev.w)};
-                } else {
-                    B = v4i{(int)cur.x, (int)cur.y, (int)cur.z, (int)cur.w};
-                }
-                const int mb = half == 0 ? 4 : 0;
-                const v4i ilo = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[mb + 0], B, cbias, 0, 0, 0);
-                const v4i ihi = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[mb + 1], B, czero, 0, 0, 0);
-                const v4i qlo = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[mb + 2], B, cbias, 0, 0, 0);
-                const v4i qhi = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[mb + 3], B, czero, 0, 0, 0);
-                // twice the Q15 sums + WB_BIAS: byte 2 is (uint8)((int8)(acc >> 15) + 128), the table index
                 float th[4];
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const uint32_t ti = (uint32_t)ilo[r] + ((uint32_t)ihi[r] << 8);
-                    const uint32_t tq = (uint32_t)qlo[r] + ((uint32_t)qhi[r] << 8);
-                    uint32_t rr;                                 // |y| = |byte 2 of tq - 128|
-                    asm("v_msad_u8 %0, %1, %2, 0" : "=v"(rr) : "v"(tq), "s"(0x00800000u));
-                    const uint32_t xb = bfe(ti, 16, 8);
-                    const uint32_t addr = rr * (uint32_t)(ST_ROW_FLOATS * 4) + (xb << 2);
-                    const uint32_t t = *(const uint32_t *)(lds + addr);
-                    // the table holds |theta|; theta' = -theta carries the sign bit of y >= 0 (index bit 7)
-                    th[r] = u2f(t | ((tq << 8) & 0x80000000u));
+                for (int r = 0; r < 4; r++) {   // the table holds |theta|; theta' = -theta carries the sign bit of y >= 0 (index bit 7)
+                    uint32_t bits;
+                    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(bits) : "s"(0x7fffffffu), "v"(traw[half][r]), "v"(tqs[half][r] << 8));
+                    th[r] = u2f(bits);
                 }
                 const float give = g == 3 ? last_prev : th[3];
                 const float before = u2f((uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)f2u(give)));
                 last_prev = th[3];
                 const float kk = wpos < k_switch ? kneg_prev : kneg;
-                float u[4];
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const float d = wrap_delta(th[r] - (r == 0 ? before : th[r - 1]));   // = -(delta theta)
                     const float v = kk * d;
-                    u[r] = sa.b0 * v;
+                    u[half][r] = sa.b0 * v;
                 }
-                // hand the 4 samples to the IIR wave: slot wg & 1, free once window wg - 2 has been consumed
-                if (wg >= 2)
-                    while ((int32_t)(lds_load_relaxed(consumed) - (wg - 1)) < 0) __builtin_amdgcn_s_sleep(1);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                *(u32x4 *)(ring_base + (wg & 1u) * ST_SLOT_BYTES + wr_off) = u32x4{f2u(u[0]), f2u(u[1]), f2u(u[2]), f2u(u[3])};
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                if (lane == 0) __hip_atomic_fetch_add((uint32_t *)&full[wg & 1u], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                wg++;
             }
+            // hand the 2 x 4 samples to the IIR wave: slots wg & 1 and (wg + 1) & 1, free once the previous piece's
+            // windows wg - 2 and wg - 1 have been consumed
+            if (wg >= 2)
+                while ((int32_t)(seen - wg) < 0) {
+                    __builtin_amdgcn_s_sleep(1);
+                    seen = lds_load_relaxed(consumed);
+                }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            *(u32x4 *)(ring_base + (wg & 1u) * ST_SLOT_BYTES + wr_off) = u32x4{f2u(u[0][0]), f2u(u[0][1]), f2u(u[0][2]), f2u(u[0][3])};
+            *(u32x4 *)(ring_base + ((wg + 1u) & 1u) * ST_SLOT_BYTES + wr_off) = u32x4{f2u(u[1][0]), f2u(u[1][1]), f2u(u[1][2]), f2u(u[1][3])};
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            lds_signal(&full[wg & 1u]);
+            lds_signal(&full[(wg + 1u) & 1u]);
+            wg += 2;
             prev = cur;
         }
-        if (MAG && mstarted && macc) atomicAdd(&mag_row[mblk], macc);
+        if (MAG && macc) atomicAdd(&mag_row[mblk], macc);
     }
 }
 
@@ -325,7 +356,7 @@ __device__ __forceinline__ void st_iir_marks(StIirSeg &q, StIir &s, int pos)
 }
 
 template <int V>
-__device__ __forceinline__ void st_iir_piece(const StreamArgs &sa, uint8_t *ring_base, const uint32_t *full, uint32_t *consumed,
+__device__ __forceinline__ int st_iir_piece(const StreamArgs &sa, uint8_t *ring_base, const uint32_t *full, uint32_t *consumed,
                                              uint32_t &wg, StIirSeg &q, StIir &s, int pos, uint32_t rd_off0, uint32_t rd_swz, int lane)
 {
 #pragma unroll
@@ -342,7 +373,7 @@ __device__ __forceinline__ void st_iir_piece(const StreamArgs &sa, uint8_t *ring
             u[4 * gq] = u2f(v.x); u[4 * gq + 1] = u2f(v.y); u[4 * gq + 2] = u2f(v.z); u[4 * gq + 3] = u2f(v.w);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the reads have returned
-        if (lane == 0) __hip_atomic_fetch_add(consumed, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        lds_signal(consumed);
         wg++;
         st_iir_marks(q, s, wpos);
         const int y2 = st_iir_window(sa, s, u);
@@ -354,7 +385,7 @@ __device__ __forceinline__ void st_iir_piece(const StreamArgs &sa, uint8_t *ring
     const bool quiet = !__any(s.loud > 0);
     const int pcm = quiet ? st_audio<V>(sa, s, true) : st_audio<V>(sa, s, false);
     if (s.loud > 0) s.loud--;
-    if (q.sg.valid && pos >= 0 && pos < q.sg.tlen) q.pcm_row[(q.sg.v0 + pos) >> 5] = (int16_t)pcm;
+    return pcm;
 }
 
 __device__ __forceinline__ void st_iir_wave(const ChainLaunch &a, const StreamArgs &sa, uint8_t *lds, uint32_t *sync,
@@ -401,10 +432,13 @@ __device__ __forceinline__ void st_iir_wave(const ChainLaunch &a, const StreamAr
         s.loud = 0;
         for (int pq = 0; pq < n_pieces; pq += 4) {
             const int pos = -ST_HALO + 32 * pq;
-            st_iir_piece<0>(sa, ring_base, full, consumed, wg, q, s, pos, rd_off0, rd_swz, lane);
-            st_iir_piece<1>(sa, ring_base, full, consumed, wg, q, s, pos + 32, rd_off0, rd_swz, lane);
-            st_iir_piece<2>(sa, ring_base, full, consumed, wg, q, s, pos + 64, rd_off0, rd_swz, lane);
-            st_iir_piece<3>(sa, ring_base, full, consumed, wg, q, s, pos + 96, rd_off0, rd_swz, lane);
+            const int p0 = st_iir_piece<0>(sa, ring_base, full, consumed, wg, q, s, pos, rd_off0, rd_swz, lane);
+            const int p1 = st_iir_piece<1>(sa, ring_base, full, consumed, wg, q, s, pos + 32, rd_off0, rd_swz, lane);
+            const int p2 = st_iir_piece<2>(sa, ring_base, full, consumed, wg, q, s, pos + 64, rd_off0, rd_swz, lane);
+            const int p3 = st_iir_piece<3>(sa, ring_base, full, consumed, wg, q, s, pos + 96, rd_off0, rd_swz, lane);
+            // 128 samples = 4 PCM samples = one 8-byte store (segments start and end on multiples of 128)
+            if (q.sg.valid && pos >= 0 && pos < q.sg.tlen)
+                *(u32x2 *)(q.pcm_row + ((q.sg.v0 + pos) >> 5)) = u32x2{pack_lo16((uint32_t)p0, (uint32_t)p1), pack_lo16((uint32_t)p2, (uint32_t)p3)};
 #pragma unroll
             for (int k = 0; k < 20; k++) s.y2p[k] = s.y2p[k + 4];
         }
