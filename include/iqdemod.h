@@ -201,6 +201,10 @@ int iqd_synchronize(iqd_t *e);
 int iqd_front_end(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const uint8_t *iq, size_t bytes_per_ch, int8_t *out);
 int iqd_front_end_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void *iq_dev, size_t bytes_per_ch,
                          void *out_dev);
+/* Replaces IqDataProcessor::upconvertByFsOver4 (direction +1, IqDataProcessor.cc:567-611) and
+ * downconvertByFsOver4 (direction -1, :487-531; hdr_diags/IqDataProcessor.h:32-33) as stand-alone calls: `buffer`
+ * holds SIGNED interleaved I/Q, is rotated in place (-(-128) stays -128), byte_count a multiple of 8. */
+int iqd_convert_fs_over_4(iqd_t *e, int direction, int8_t *buffer, size_t byte_count);
 
 /* Diagnostics (the reference's displayInternalInformation() text dumps, e.g.
  * IqDataProcessor.cc:860-926, become queryable values). */

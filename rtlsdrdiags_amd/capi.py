@@ -53,7 +53,7 @@ EXPORTS = [
     "iqd_get_rx_gain_db", "iqd_agc_set_type", "iqd_agc_set_deadband", "iqd_agc_set_blanking_limit",
     "iqd_agc_set_operating_point", "iqd_agc_set_filter_coefficient", "iqd_agc_enable", "iqd_agc_get_state",
     "iqd_set_gain_trace", "iqd_get_gain_trace", "iqd_scanner_set_parameters", "iqd_scanner_start",
-    "iqd_scanner_get", "iqd_get_frequency_trace", "iqd_front_end", "iqd_front_end_device",
+    "iqd_scanner_get", "iqd_get_frequency_trace", "iqd_front_end", "iqd_front_end_device", "iqd_convert_fs_over_4",
     "iqd_resampler_create", "iqd_resampler_destroy", "iqd_resampler_reset", "iqd_resampler_out_count",
     "iqd_resampler_run", "iqd_resampler_run_device",
 ]
@@ -98,6 +98,7 @@ def _lib():
     L.iqd_resampler_run.argtypes = [vp, vp, sz, vp]
     L.iqd_resampler_run_device.argtypes = [vp, vp, sz, vp]
     L.iqd_front_end_device.argtypes = [vp, u32, u32, vp, sz, vp]
+    L.iqd_convert_fs_over_4.argtypes = [vp, C.c_int, vp, sz]
     L.iqd_get_stats.argtypes = [vp, C.POINTER(Stats)]
     L.iqd_set_profiling.argtypes = [vp, C.c_int]
     L.iqd_get_channel_mode.argtypes = [vp, u32, C.POINTER(C.c_int)]
@@ -288,6 +289,12 @@ class Engine:
         out = np.zeros(iq_u8.shape, np.int8)
         self._check(self._L.iqd_front_end(self._h, f, n, _np_ptr(iq_u8), iq_u8.shape[1], _np_ptr(out)))
         return out
+
+    def convert_fs_over_4(self, direction, s8):
+        """IqDataProcessor::upconvertByFsOver4 (+1) / downconvertByFsOver4 (-1) on a copy of signed bytes."""
+        buf = np.array(s8, dtype=np.int8, copy=True)
+        self._check(self._L.iqd_convert_fs_over_4(self._h, int(direction), _np_ptr(buf), buf.size))
+        return buf
 
     def accept_device(self, iq_dev, bytes_per_ch, pcm_dev, count_dev=0, mag_dev=0, allowed_dev=0, first=0, n=None):
         f, n = self._range(first, n)

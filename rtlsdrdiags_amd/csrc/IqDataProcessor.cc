@@ -45,7 +45,7 @@ IqDataProcessor::IqDataProcessor(char *hostIpAddress, int hostPort)
       signalNotificationEnabled(false), signalCallbackContextPtr(0), signalCallbackPtr(0),
       signalMagnitudeNotificationEnabled(false), signalMagnitudeCallbackContextPtr(0),
       signalMagnitudeCallbackPtr(0), iqDumpEnabled(false), iqDumpContextPtr(0), iqDumpCallbackPtr(0),
-      lastStatus(IQD_OK), receiveBlockCount(0)
+      lastStatus(IQD_OK), receiveBlockCount(0), rejectedBlocks(0)
 {
   (void)hostIpAddress;
   (void)hostPort;
@@ -125,17 +125,26 @@ void IqDataProcessor::registerSignalMagnitudeCallback(void (*cb)(uint32_t, void 
 void IqDataProcessor::acceptIqData(unsigned long timeStamp, unsigned char *bufferPtr, unsigned long byteCount)
 {
   (void)timeStamp;
-  if (engine == 0 || byteCount != blockBytes) {
-    lastStatus = engine == 0 ? lastStatus : IQD_EINVAL;
+  if (engine == 0) {   // no HIP device: there is no CPU path, every block is reported
+    rejectedBlocks++;
     return;
   }
+  // Whatever the read returned is one block (short USB reads included; the squelch averages over this call).
+  // What the engine cannot take - an empty call, more than the 32768 bytes of SignalDetector.h:49, or a
+  // length that is not a whole number of 256-byte units - is refused by iqd_accept_iq and surfaced here.
   uint32_t pcmCount = 0, magnitude = 0;
   uint8_t allowed = 0;
-  if (iqDumpEnabled && iqDumpCallbackPtr != 0 &&   // IqDataProcessor.cc:756-760
+  if (iqDumpEnabled && iqDumpCallbackPtr != 0 && byteCount <= blockBytes && byteCount % 8 == 0 &&   // IqDataProcessor.cc:756-760
       iqd_front_end(engine, 0, 1, bufferPtr, byteCount, dumpData) == IQD_OK)
     iqDumpCallbackPtr(dumpData, (uint32_t)byteCount, iqDumpContextPtr);
-  lastStatus = iqd_accept_iq(engine, 0, 1, bufferPtr, byteCount, pcmData, &pcmCount, &magnitude, &allowed);
-  if (lastStatus != IQD_OK) return;
+  lastStatus = byteCount > blockBytes ? IQD_EINVAL
+                                      : iqd_accept_iq(engine, 0, 1, bufferPtr, byteCount, pcmData, &pcmCount, &magnitude, &allowed);
+  if (lastStatus != IQD_OK) {
+    rejectedBlocks++;
+    fprintf(stderr, "IqDataProcessor::acceptIqData: %lu bytes not processed: %s\n", byteCount,
+            byteCount > blockBytes ? "more than one 32768-byte block" : iqd_last_error(engine));
+    return;
+  }
   receiveBlockCount++;
   if (signalNotificationEnabled && signalCallbackPtr != 0)
     signalCallbackPtr(allowed != 0, signalCallbackContextPtr);
@@ -153,6 +162,16 @@ void IqDataProcessor::acceptIqData(unsigned long timeStamp, unsigned char *buffe
   if (h != 0 && h->pcmCallbackPtr != 0) h->pcmCallbackPtr(pcmData, pcmCount);
 }
 
+void IqDataProcessor::upconvertByFsOver4(int8_t *bufferPtr, uint32_t byteCount)
+{
+  if (engine != 0) lastStatus = iqd_convert_fs_over_4(engine, +1, bufferPtr, byteCount);
+}
+
+void IqDataProcessor::downconvertByFsOver4(int8_t *bufferPtr, uint32_t byteCount)
+{
+  if (engine != 0) lastStatus = iqd_convert_fs_over_4(engine, -1, bufferPtr, byteCount);
+}
+
 void IqDataProcessor::displayInternalInformation(void)
 {
   static const char *modes[] = {"None", "AM", "FM", "WBFM", "LSB", "USB"};
@@ -160,6 +179,7 @@ void IqDataProcessor::displayInternalInformation(void)
   fprintf(stderr, "Demodulator Mode         : %s\n", modes[(int)demodulatorMode]);
   fprintf(stderr, "Signal Detect Threshold  : %d dBFs\n", (int)signalDetectThreshold);
   fprintf(stderr, "Receive Block Count      : %lu\n", receiveBlockCount);
+  fprintf(stderr, "Rejected Block Count     : %lu\n", rejectedBlocks);
   fprintf(stderr, "Engine                   : %s\n", engine != 0 ? "MI355X (HIP)" : "unavailable");
 }
 

@@ -4,9 +4,11 @@
 // the arithmetic runs on the GPU through the C ABI (include/iqdemod.h).
 //
 // One IqDataProcessor owns one single-channel engine.  Differences from the reference, all on
-// the host side: acceptIqData() does not modify the caller's buffer, byteCount must be the
-// engine's block size (32768 by default, as Radio.cc:1895 always passes), the UDP IQ dump
-// (IqDataProcessor.cc:756-760) is not provided.
+// the host side: acceptIqData() does not modify the caller's buffer (the converted bytes are
+// available through the IQ dump tap); byteCount is whatever the read returned (Radio.cc:1895-1906
+// forwards short reads), as long as it is a whole number of 256-byte units up to 32768 - anything
+// else is counted, reported through lastError() and a line on stderr, never dropped silently; the
+// IQ dump (IqDataProcessor.cc:756-760) hands its bytes to a callback instead of a UDP socket.
 #pragma once
 #include <stdint.h>
 
@@ -81,6 +83,10 @@ class IqDataProcessor
   void setSsbDemodulator(SsbDemodulator *demodulatorPtr);
   void setSignalDetectThreshold(int32_t threshold);
 
+  // hdr_diags/IqDataProcessor.h:32-33: in place, signed bytes, byteCount a multiple of 8
+  void downconvertByFsOver4(int8_t *bufferPtr, uint32_t byteCount);
+  void upconvertByFsOver4(int8_t *bufferPtr, uint32_t byteCount);
+
   void acceptIqData(unsigned long timeStamp, unsigned char *bufferPtr, unsigned long byteCount);
 
   void enableSignalNotification(void);
@@ -107,6 +113,8 @@ class IqDataProcessor
   void displayInternalInformation(void);
   bool isOperational(void) const { return engine != 0; }   // false when no HIP device was found
   const char *lastError(void) const;
+  int lastStatusCode(void) const { return lastStatus; }     // IQD_OK or the failure of the most recent call
+  unsigned long rejectedBlockCount(void) const { return rejectedBlocks; }   // acceptIqData calls that could not be processed
 
   private:
   friend class AutomaticGainControl;
@@ -134,6 +142,7 @@ class IqDataProcessor
   int8_t dumpData[32768];
   int lastStatus;
   unsigned long receiveBlockCount;
+  unsigned long rejectedBlocks;
 };
 
 // hdr_diags/AutomaticGainControl.h:22-47.  The reference's constructor takes its owning Radio and reaches the

@@ -740,13 +740,27 @@ int iqd_dev_download(iqd_t *e, void *dst, const void *src, size_t bytes)
     return IQD_OK;
 }
 
+// A call is k whole blocks of block_bytes (k consecutive acceptIqData calls) - or ONE short block: the reference
+// forwards whatever rtlsdr_read_sync returned (Radio.cc:1895-1906; DataConsumer.cc:238-242 only counts short
+// reads) and acceptIqData averages the squelch over that call's samples (IqDataProcessor.cc:722-749).  Short
+// blocks come in whole 256-byte units (the chains' state is kept in 128-sample units; USB reads are multiples of
+// 512 bytes).  Returns the block size in force for the call, 0 if the length is not acceptable.
+static uint32_t call_block_bytes(const iqd_t *e, size_t bytes_per_ch)
+{
+    if (bytes_per_ch == 0) return 0;
+    if (bytes_per_ch % e->block_bytes == 0) return e->block_bytes;
+    if (bytes_per_ch < e->block_bytes && bytes_per_ch % 256 == 0) return (uint32_t)bytes_per_ch;
+    return 0;
+}
+#define IQD_LEN_MSG "bytes_per_ch (%zu) must be a positive multiple of block_bytes (%u), or one short block: a multiple of 256 below it"
+
 // The front end alone: what the reference leaves in the caller's buffer / sends from its IQ dump tap.
 int iqd_front_end_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void *iq_dev, size_t bytes_per_ch,
                          void *out_dev)
 {
     if (!range_ok(e, first_ch, n_ch) || !iq_dev || !out_dev) return e ? e->fail(IQD_EINVAL, "bad channel range or NULL buffer") : IQD_EINVAL;
-    if (bytes_per_ch == 0 || bytes_per_ch % e->block_bytes != 0)
-        return e->fail(IQD_EINVAL, "bytes_per_ch (%zu) must be a positive multiple of block_bytes (%u)", bytes_per_ch, e->block_bytes);
+    if (bytes_per_ch == 0 || bytes_per_ch % 8 != 0)   // the rotation pattern spans 4 samples (IqDataProcessor.cc:567-611)
+        return e->fail(IQD_EINVAL, "bytes_per_ch (%zu) must be a positive multiple of 8", bytes_per_ch);
     if ((((uintptr_t)iq_dev) | ((uintptr_t)out_dev)) & 7) return e->fail(IQD_EINVAL, "buffers must be 8-byte aligned");
     (void)hipSetDevice(e->device);
     {
@@ -912,6 +926,23 @@ int iqd_dev_tile(iqd_t *e, void *dst, size_t period, size_t total)
     return IQD_OK;
 }
 
+// IqDataProcessor::upconvertByFsOver4 / downconvertByFsOver4 (IqDataProcessor.cc:487-611) as the reference offers
+// them: in place, on signed bytes, a multiple of 8 of them.
+int iqd_convert_fs_over_4(iqd_t *e, int direction, int8_t *buffer, size_t byte_count)
+{
+    if (!e || !buffer) return e ? e->fail(IQD_EINVAL, "NULL buffer") : IQD_EINVAL;
+    if (direction != 1 && direction != -1) return e->fail(IQD_EINVAL, "direction must be +1 (up) or -1 (down)");
+    if (byte_count == 0 || byte_count % 8 != 0) return e->fail(IQD_EINVAL, "byte_count (%zu) must be a positive multiple of 8", byte_count);
+    (void)hipSetDevice(e->device);
+    hipStream_t s = e->stream;
+    HIP_TRY(e, e->st_iq.ensure(byte_count));
+    HIP_TRY(e, hipMemcpyAsync(e->st_iq.p, buffer, byte_count, hipMemcpyHostToDevice, s));
+    HIP_TRY(e, launch_rotate_signed((int8_t *)e->st_iq.p, byte_count, direction, s));
+    HIP_TRY(e, hipMemcpyAsync(buffer, e->st_iq.p, byte_count, hipMemcpyDeviceToHost, s));
+    HIP_TRY(e, hipStreamSynchronize(s));
+    return IQD_OK;
+}
+
 // ---- accept ------------------------------------------------------------------------------------
 
 static void rebuild_lists(iqd_t *e, uint32_t first_ch, uint32_t n_ch)
@@ -935,15 +966,15 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
                          void *pcm_dev, void *pcm_count_dev, void *magnitude_dev, void *signal_present_dev)
 {
     if (!range_ok(e, first_ch, n_ch) || !iq_dev || !pcm_dev) return e ? e->fail(IQD_EINVAL, "bad channel range or NULL buffer") : IQD_EINVAL;
-    if (bytes_per_ch == 0 || bytes_per_ch % e->block_bytes != 0)
-        return e->fail(IQD_EINVAL, "bytes_per_ch (%zu) must be a positive multiple of block_bytes (%u)",
-                       bytes_per_ch, e->block_bytes);
+    const uint32_t call_bb = call_block_bytes(e, bytes_per_ch);
+    if (!call_bb) return e->fail(IQD_EINVAL, IQD_LEN_MSG, bytes_per_ch, e->block_bytes);
+    const uint32_t call_bs = call_bb / 2;
     if (bytes_per_ch / 2 > 0x7fff0000ull) return e->fail(IQD_EINVAL, "bytes_per_ch too large");
     if (((uintptr_t)iq_dev & 15) != 0) return e->fail(IQD_EINVAL, "iq_dev must be 16-byte aligned");
     (void)hipSetDevice(e->device);
     hipStream_t s = e->stream;
 
-    const uint32_t n_blocks = (uint32_t)(bytes_per_ch / e->block_bytes);
+    const uint32_t n_blocks = (uint32_t)(bytes_per_ch / call_bb);
     const uint32_t vlen = (uint32_t)(bytes_per_ch / 2);
     bool gated, any_agc;
     {
@@ -974,7 +1005,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
     if (want_mag) HIP_TRY(e, hipMemsetAsync(e->mag_sums.p, 0, (size_t)n_ch * n_blocks * sizeof(uint32_t), s));
 
     SquelchLaunch q{};
-    q.n_ch = n_ch; q.first_ch = first_ch; q.n_blocks = n_blocks; q.block_samples = e->block_samples;
+    q.n_ch = n_ch; q.first_ch = first_ch; q.n_blocks = n_blocks; q.block_samples = call_bs;
     q.params = e->d_params;
     q.mag_sums = e->mag_sums.as<uint32_t>();
     q.tracker = e->d_tracker;
@@ -998,7 +1029,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         // pass 1: magnitudes of every block, then the squelch decisions and open-block lists
         HIP_TRY(e, e->blk_lists.ensure((size_t)n_ch * n_blocks * sizeof(uint32_t)));
         HIP_TRY(e, e->vlen.ensure((size_t)n_ch * sizeof(uint32_t)));
-        HIP_TRY(e, launch_magnitude((const uint8_t *)iq_dev, bytes_per_ch, nullptr, n_ch, e->block_samples,
+        HIP_TRY(e, launch_magnitude((const uint8_t *)iq_dev, bytes_per_ch, nullptr, n_ch, call_bs,
                                     n_blocks, e->mag_sums.as<uint32_t>(), s));
         q.blk_lists = e->blk_lists.as<uint32_t>();
         q.vlen_out = e->vlen.as<uint32_t>();
@@ -1013,8 +1044,8 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
     base.vlen_gated = gated ? e->vlen.as<uint32_t>() : nullptr;
     base.blk_lists = gated ? e->blk_lists.as<uint32_t>() : nullptr;
     base.n_blocks = n_blocks;
-    base.block_samples = e->block_samples;
-    base.block_magic = block_magic(e->block_samples);
+    base.block_samples = call_bs;
+    base.block_magic = block_magic(call_bs);
     base.tails = e->d_tails;
     base.params = e->d_params;
     base.wbfm_carry = e->d_wcarry;
@@ -1184,7 +1215,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
     // channels in mode None still report their magnitudes
     if (fused_mag && !e->h_lists[FAM_COUNT].empty())
         HIP_TRY(e, launch_magnitude((const uint8_t *)iq_dev, bytes_per_ch, e->lists[FAM_COUNT].as<uint32_t>(),
-                                    (uint32_t)e->h_lists[FAM_COUNT].size(), e->block_samples, n_blocks,
+                                    (uint32_t)e->h_lists[FAM_COUNT].size(), call_bs, n_blocks,
                                     e->mag_sums.as<uint32_t>(), s));
     if (!gated && (want_mag || pcm_count_dev || signal_present_dev || e->trace_on)) HIP_TRY(e, launch_squelch(q, true, s));
 
@@ -1316,14 +1347,13 @@ int iqd_accept_iq(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const uint8_t *iq,
                   int16_t *pcm, uint32_t *pcm_count, uint32_t *magnitude, uint8_t *signal_present)
 {
     if (!range_ok(e, first_ch, n_ch) || !iq || !pcm) return e ? e->fail(IQD_EINVAL, "bad channel range or NULL buffer") : IQD_EINVAL;
-    if (bytes_per_ch == 0 || bytes_per_ch % e->block_bytes != 0)
-        return e->fail(IQD_EINVAL, "bytes_per_ch (%zu) must be a positive multiple of block_bytes (%u)",
-                       bytes_per_ch, e->block_bytes);
+    const uint32_t call_bb = call_block_bytes(e, bytes_per_ch);
+    if (!call_bb) return e->fail(IQD_EINVAL, IQD_LEN_MSG, bytes_per_ch, e->block_bytes);
     (void)hipSetDevice(e->device);
     hipStream_t s = e->stream;
     const size_t in_bytes = (size_t)n_ch * bytes_per_ch;
     const size_t pcm_bytes = (size_t)n_ch * (bytes_per_ch / 64) * sizeof(int16_t);
-    const size_t nb = (size_t)n_ch * (bytes_per_ch / e->block_bytes);
+    const size_t nb = (size_t)n_ch * (bytes_per_ch / call_bb);
     if (in_bytes >= 2 * SLICE_BYTES)
         return accept_sliced(e, first_ch, n_ch, iq, bytes_per_ch, pcm, pcm_count, magnitude, signal_present);
     HIP_TRY(e, e->st_iq.ensure(in_bytes));

@@ -84,6 +84,7 @@ hipError_t launch_resample(int kind, const void *in, void *out, const void *hist
 hipError_t launch_wbfm_repair(const ChainLaunch &a, bool gated, hipStream_t s);
 hipError_t launch_front_end(const uint8_t *iq, int8_t *out, const ChanParams *params, uint32_t first_ch, uint32_t n_ch,
                             size_t bytes_per_ch, hipStream_t s);
+hipError_t launch_rotate_signed(int8_t *buf_dev, size_t bytes, int rotation, hipStream_t s);
 hipError_t launch_agc_apply(const AgcConfig *cfg, AgcState *st, const ScanConfig *scfg, ScanState *sst,
                             ChanParams *params, GainEpoch *epochs, uint32_t n_ch, hipStream_t s);
 hipError_t launch_tail_update(const ChainLaunch &a, int family, hipStream_t s);

@@ -668,16 +668,19 @@ __device__ __forceinline__ u32x2 rotate_group(u32x2 g, int rotation)
 // out - what the reference leaves in the caller's buffer and streams from its IQ dump tap (:756-760).
 // One thread per 4 samples (8 bytes); the rotation phase restarts with every block, and blocks are multiples
 // of 4 samples, so it is the sample index modulo 4.
+// params == nullptr: every row is rotated by `fixed_rotation` and holds SIGNED bytes already (the stand-alone
+// up/downconvertByFsOver4 of IqDataProcessor.cc:487-611, which work on the converted buffer).
 __global__ void front_end_kernel(const uint8_t *iq, int8_t *out, const ChanParams *params, uint32_t first_ch,
-                                 uint32_t n_ch, size_t bytes_per_ch)
+                                 uint32_t n_ch, size_t bytes_per_ch, int fixed_rotation)
 {
     const size_t groups_per_ch = bytes_per_ch / 8;
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= groups_per_ch * n_ch) return;
     const uint32_t ch = (uint32_t)(idx / groups_per_ch);
-    const int rotation = params[first_ch + ch].rotation;
+    const int rotation = params ? params[first_ch + ch].rotation : fixed_rotation;
+    const uint32_t to_signed = params ? 0x80808080u : 0u;
     const u32x2 raw = ((const u32x2 *)iq)[idx];
-    ((u32x2 *)out)[idx] = rotate_group(u32x2{raw.x ^ 0x80808080u, raw.y ^ 0x80808080u}, rotation);
+    ((u32x2 *)out)[idx] = rotate_group(u32x2{raw.x ^ to_signed, raw.y ^ to_signed}, rotation);
 }
 
 // A rotation selector changed between two calls.  The filter histories live on as raw tail bytes that every tile
@@ -912,7 +915,15 @@ hipError_t launch_front_end(const uint8_t *iq, int8_t *out, const ChanParams *pa
 {
     const size_t n = bytes_per_ch / 8 * n_ch;
     hipLaunchKernelGGL(front_end_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, iq, out, params, first_ch,
-                       n_ch, bytes_per_ch);
+                       n_ch, bytes_per_ch, 0);
+    return hipGetLastError();
+}
+
+hipError_t launch_rotate_signed(int8_t *buf, size_t bytes, int rotation, hipStream_t s)
+{
+    const size_t n = bytes / 8;
+    hipLaunchKernelGGL(front_end_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const uint8_t *)buf, buf,
+                       (const ChanParams *)nullptr, 0u, 1u, bytes, rotation);
     return hipGetLastError();
 }
 

@@ -8,6 +8,7 @@
 // IF gain it settles on is reported on stderr.  Further options, anywhere after the mode:
 //     scan=<start>:<end>:<increment>   run the channel's FrequencyScanner (Hz); its last tuning command is reported
 //     dump=<file>                      IQ dump tap: the rotated signed bytes of every block go to <file>
+//     blocks=<n1,n2,...>               read blocks of these sizes in turn (default 32768): short reads
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -30,12 +31,13 @@ int main(int argc, char **argv)
     fprintf(stderr, "usage: %s <mode: 0 none 1 am 2 fm 3 wbfm 4 lsb 5 usb> [squelch threshold dBFS [agc type: 0 lowpass 1 harris]]\n", argv[0]);
     return 2;
   }
-  const char *scanSpec = 0, *dumpPath = 0;
+  const char *scanSpec = 0, *dumpPath = 0, *blockSpec = 0;
   int npos = 0;
   char *pos[8];
   for (int i = 1; i < argc && npos < 8; i++) {
     if (strncmp(argv[i], "scan=", 5) == 0) scanSpec = argv[i] + 5;
     else if (strncmp(argv[i], "dump=", 5) == 0) dumpPath = argv[i] + 5;
+    else if (strncmp(argv[i], "blocks=", 7) == 0) blockSpec = argv[i] + 7;
     else pos[npos++] = argv[i];
   }
   argc = npos + 1;
@@ -82,15 +84,32 @@ int main(int argc, char **argv)
     processor.enableIqDump();
   }
 
+  // Blocks of 32768 bytes like Radio.cc:1895; a read that comes back short (a pipe, the end of the file) is handed
+  // on as it is, like Radio.cc:1895-1906 does - the processor takes whole 256-byte units and reports the rest.
+  // Extra option blocks=<a,b,c,...>: read these block sizes in turn instead (short-read experiments).
   static unsigned char block[32768];
   unsigned long timeStamp = 0;
-  while (fread(block, 1, sizeof(block), stdin) == sizeof(block))
-    processor.acceptIqData(timeStamp++, block, sizeof(block));
+  size_t sizes[64], nsizes = 0, next = 0;
+  if (blockSpec != 0)
+    for (const char *q = blockSpec; *q != 0 && nsizes < 64;) {
+      sizes[nsizes++] = (size_t)strtoul(q, (char **)&q, 10);
+      if (*q == ',') q++;
+    }
+  for (;;) {
+    size_t want = nsizes ? sizes[next++ % nsizes] : sizeof(block);
+    if (want == 0 || want > sizeof(block)) want = sizeof(block);
+    const size_t got = fread(block, 1, want, stdin);
+    if (got == 0) break;
+    processor.acceptIqData(timeStamp++, block, got);
+    if (got < want) break;
+  }
   fflush(stdout);
+  if (processor.rejectedBlockCount() != 0)
+    fprintf(stderr, "iqdemod_file: %lu block(s) could not be processed (%s)\n", processor.rejectedBlockCount(), processor.lastError());
   if (argc > 3) fprintf(stderr, "IF gain: %u dB\n", agc.getReceiveIfGainInDb());
   if (scanSpec != 0)
     fprintf(stderr, "scanner: %llu Hz after %llu tuning commands\n",
             (unsigned long long)scanner.getCurrentFrequencyInHertz(), (unsigned long long)scanner.getTuneCount());
   if (dumpFile != 0) fclose(dumpFile);
-  return 0;
+  return processor.rejectedBlockCount() != 0 ? 3 : 0;
 }

@@ -1,0 +1,118 @@
+"""GPU (MI355X): the drop-in boundary accepts what the reference accepts.
+
+IqDataProcessor::acceptIqData processes whatever one read returned (src_diags/Radio.cc:1895-1906 forwards short
+reads, src_diags/DataConsumer.cc:238-242 only counts them): one call = one squelch block of that length
+(src_diags/IqDataProcessor.cc:722-749).  hdr_diags/IqDataProcessor.h:32-33 also offers the two Fs/4 rotations
+as public members.  Everything here goes through the C ABI / the C++ mirror class and is compared with the
+oracle fed the SAME sequence of calls."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from rtlsdrdiags_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOOL = os.path.join(ROOT, "rtlsdrdiags_amd", "bin", "iqdemod_file")
+MODES = ["none", "am", "fm", "wbfm", "lsb", "usb"]
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from rtlsdrdiags_amd import capi as c
+    return c
+
+
+def oracle_calls(oracle, mode, u8, sizes, threshold=None):
+    """One oracle accept per call, each call one block of its own length."""
+    c = oracle.chain()
+    c.set_mode(mode)
+    if threshold is not None:
+        c.set_squelch(threshold)
+    pcm, mags, allowed = [], [], []
+    off = 0
+    k = 0
+    while off < len(u8):
+        n = min(sizes[k % len(sizes)], len(u8) - off)
+        p, m, a = c.accept_stream(u8[off:off + n], n)
+        pcm.append(p)
+        mags.append(int(m[0]))
+        allowed.append(int(a[0]))
+        off += n
+        k += 1
+    return np.concatenate(pcm), mags, allowed
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3, 4, 5])
+def test_short_reads_through_the_cpp_class(oracle, mode):
+    """32768 / 16384 / 4096 / 32768-byte calls through IqDataProcessor::acceptIqData (iqdemod_file blocks=...)."""
+    sizes = [32768, 16384, 4096, 32768]
+    u8 = synth.fm_tone(5 * (32768 + 16384 + 4096 + 32768) // 2 + 2048, seed=40 + mode, deviation=30e3)
+    ref, _, _ = oracle_calls(oracle, MODES[mode], u8, sizes)
+    r = subprocess.run([TOOL, str(mode), "blocks=" + ",".join(map(str, sizes))], input=u8.tobytes(),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    assert np.array_equal(np.frombuffer(r.stdout, dtype=np.int16), ref)
+
+
+def test_short_reads_with_a_closing_squelch(oracle):
+    """The squelch averages over each call's own samples: a short quiet read closes it like a full block would."""
+    sizes = [32768, 8192, 2048, 32768, 512]
+    amps = [60, 60, 2, 2, 60, 2, 60, 60]
+    u8 = synth.stepped_amplitude(amps, block_samples=16384, seed=8)
+    ref, _, allowed = oracle_calls(oracle, "fm", u8, sizes, threshold=-30)
+    assert 0 < sum(allowed) < len(allowed)
+    r = subprocess.run([TOOL, "2", "-30", "blocks=" + ",".join(map(str, sizes))], input=u8.tobytes(),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    assert np.array_equal(np.frombuffer(r.stdout, dtype=np.int16), ref)
+
+
+def test_short_block_through_the_c_abi(capi, oracle):
+    """iqd_accept_iq with fewer bytes than block_bytes = one short block: PCM, magnitude and squelch result."""
+    u8 = synth.fm_tone(3 * 16384, seed=12)
+    sizes = [32768, 12288, 32768, 20480]
+    for mode in ("wbfm", "am"):
+        ref, mags, allowed = oracle_calls(oracle, mode, u8, sizes)
+        eng = capi.Engine(1)
+        eng.set_mode(mode)
+        out, off = [], 0
+        for k, n in enumerate(sizes):
+            n = min(n, len(u8) - off)
+            pcm, cnt, mag, ok = eng.accept(u8[off:off + n])
+            out.append(pcm[0, :cnt[0]])
+            assert int(mag[0, 0]) == mags[k] and int(ok[0, 0]) == allowed[k], (mode, k)
+            off += n
+        assert np.array_equal(np.concatenate(out), ref), mode
+
+
+def test_unacceptable_lengths_are_reported_not_dropped(capi):
+    eng = capi.Engine(1)
+    eng.set_mode("fm")
+    with pytest.raises(capi.IqdError) as e:
+        eng.accept(np.zeros(1000, np.uint8))
+    assert "256" in str(e.value)
+    u8 = synth.fm_tone(16384 + 500, seed=1)          # a trailing 1000-byte read
+    r = subprocess.run([TOOL, "2"], input=u8.tobytes(), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 3
+    err = r.stderr.decode()
+    assert "1000 bytes not processed" in err and "1 block(s) could not be processed" in err
+    assert len(r.stdout) == 2 * 512                    # the full block before it was demodulated
+
+
+@pytest.mark.parametrize("direction", [1, -1])
+def test_public_fs_over_4_conversions(capi, oracle, direction):
+    """upconvertByFsOver4 / downconvertByFsOver4 as stand-alone calls on signed bytes, -128 included."""
+    rng = np.random.default_rng(3)
+    s8 = rng.integers(-128, 128, size=4096, dtype=np.int8)
+    s8[:16] = -128
+    eng = capi.Engine(1)
+    got = eng.convert_fs_over_4(direction, s8)
+    assert np.array_equal(got, oracle.rotate(s8, direction))
+    back = eng.convert_fs_over_4(-direction, got)
+    assert np.array_equal(back, s8)                   # exact inverse: negation is an involution with -128 fixed
+    with pytest.raises(capi.IqdError):
+        eng.convert_fs_over_4(direction, s8[:12])
