@@ -41,16 +41,20 @@ struct ChanParams {
     float fm_k;             // (gain / 15000) * 32767
     // A demodulator gain changes between two accept calls, i.e. at the start of a call's data.  The histories a tile
     // rebuilds from the raw tail belong to the time before it: they are computed with the gain that was in force
-    // then (k_prev), `since` samples back from the stream end (GainEpoch, maintained on the device).
+    // then (k_prev), `since` samples back from the stream end (GainEpoch: a list of such changes, maintained on the device).
     float wbfm_k_prev, fm_k_prev;   // (host -> device hand-over: the K the device last ran with)
     uint32_t k_changed;     // one-shot: bit 0 WBFM, bit 1 FM - the gain differs from the last accept's; bit 2: the rotation does
     int32_t rotation_prev;  // the rotation the device last ran with (for bit 2)
     uint32_t pad;
 };
-struct GainEpoch {          // per channel, on the device
-    uint32_t wbfm_since, fm_since;   // samples the family has consumed since its gain last changed (saturates at TAIL)
-    float wbfm_k_prev, fm_k_prev;    // the K in force before that change
+// Gain changes whose samples are still inside the kept tail, most recent first.  A gain can only change between
+// two accepts and an accept consumes at least 128 samples, so TAIL / 128 entries cover every possible history.
+constexpr int EPOCHS = TAIL / 128;
+struct GainEpochList {
+    uint32_t since[EPOCHS];    // samples the family has consumed since change i (saturates at TAIL = out of reach)
+    float k_before[EPOCHS];    // the K in force before change i
 };
+struct GainEpoch { GainEpochList wbfm, fm; };   // per channel, on the device
 
 // ---- per-channel carried state ------------------------------------------------------------
 struct WbfmCarry {          // exact de-emphasis state `back` samples before the stream end

@@ -455,9 +455,24 @@ static int upload_params(iqd_t *e)
     if (!e->params_dirty) return IQD_OK;
     for (uint32_t c = 0; c < e->n_ch; c++) {
         ChanParams &p = e->h_params[c];
-        if (f2u(p.wbfm_k) != f2u(e->k_applied[2 * c])) { p.wbfm_k_prev = e->k_applied[2 * c]; p.k_changed |= 1u; e->k_applied[2 * c] = p.wbfm_k; }
-        if (f2u(p.fm_k) != f2u(e->k_applied[2 * c + 1])) { p.fm_k_prev = e->k_applied[2 * c + 1]; p.k_changed |= 2u; e->k_applied[2 * c + 1] = p.fm_k; }
-        if (p.rotation != e->rot_applied[c]) { p.rotation_prev = e->rot_applied[c]; p.k_changed |= 4u; e->rot_applied[c] = p.rotation; e->rot_changed = true; }
+        // (a change still pending - uploaded by a front-end call, not yet applied by agc_sync - keeps ITS "before":
+        // the histories on the device were made with that one, whatever the value was set to in between)
+        if (f2u(p.wbfm_k) != f2u(e->k_applied[2 * c])) {
+            if (!(p.k_changed & 1u)) p.wbfm_k_prev = e->k_applied[2 * c];
+            p.k_changed |= 1u;
+            e->k_applied[2 * c] = p.wbfm_k;
+        }
+        if (f2u(p.fm_k) != f2u(e->k_applied[2 * c + 1])) {
+            if (!(p.k_changed & 2u)) p.fm_k_prev = e->k_applied[2 * c + 1];
+            p.k_changed |= 2u;
+            e->k_applied[2 * c + 1] = p.fm_k;
+        }
+        if (p.rotation != e->rot_applied[c]) {
+            if (!(p.k_changed & 4u)) p.rotation_prev = e->rot_applied[c];
+            p.k_changed |= 4u;
+            e->rot_applied[c] = p.rotation;
+            e->rot_changed = true;
+        }
         if (p.k_changed) e->agc_dirty = true;
     }
     HIP_TRY(e, hipMemcpyAsync(e->d_params, e->h_params.data(), e->n_ch * sizeof(ChanParams), hipMemcpyHostToDevice, e->stream));

@@ -100,13 +100,10 @@ __device__ __forceinline__ void wbfm_run_tile(const ChainLaunch &a, WbfmLds &lds
     t.tlen = (int32_t)(((int64_t)vlen - v0) < (int64_t)a.tile_len ? ((int64_t)vlen - v0) : (int64_t)a.tile_len);
     rotation_selectors(p.rotation, t);
     t.k = p.wbfm_k;
-    t.k_prev = p.wbfm_k;
-    t.k_switch = INT32_MIN;
-    if (tile == 0) {   // only a call's first tile reaches back before the call, where the previous gain applies
-        const uint32_t since = a.epochs[ech].wbfm_since;
-        if (since < (uint32_t)TAIL) { t.k_prev = a.epochs[ech].wbfm_k_prev; t.k_switch = -(int32_t)since; }
-    }
-    const float kmax = fmaxf(fabsf(t.k), fabsf(t.k_prev));
+    // only a call's first tile reaches back before the call, where earlier gains may apply
+    t.epochs = tile == 0 && a.epochs[ech].wbfm.since[0] < (uint32_t)TAIL ? &a.epochs[ech].wbfm : nullptr;
+    float kmax;
+    epoch_k_range(t.epochs, t.k, kmax, t.k_min);
     t.bounded = (kmax * 3.1730f < 2147483648.0f) ? 1u : 0u;
     t.lut = a.atan_lut;
     t.pcm_row = a.pcm + (size_t)ch * a.pcm_stride;
@@ -192,13 +189,10 @@ __device__ __forceinline__ bool setup_tile(const ChainLaunch &a, bool gated, int
     t.tlen = (int32_t)(((int64_t)vlen - v0) < (int64_t)a.tile_len ? ((int64_t)vlen - v0) : (int64_t)a.tile_len);
     rotation_selectors(p.rotation, t);
     t.k = p.fm_k;
-    t.k_prev = p.fm_k;
-    t.k_switch = INT32_MIN;
-    if (family == FAM_FM && t.v0 == 0) {
-        const uint32_t since = a.epochs[ech].fm_since;
-        if (since < (uint32_t)TAIL) { t.k_prev = a.epochs[ech].fm_k_prev; t.k_switch = -(int32_t)since; }
-    }
-    t.bounded = (fmaxf(fabsf(t.k), fabsf(t.k_prev)) * 6.35f < 2147483648.0f) ? 1u : 0u;   // |K * dtheta| <= |K| * 2 pi
+    t.epochs = family == FAM_FM && t.v0 == 0 && a.epochs[ech].fm.since[0] < (uint32_t)TAIL ? &a.epochs[ech].fm : nullptr;
+    float kmax;
+    epoch_k_range(t.epochs, t.k, kmax, t.k_min);
+    t.bounded = (kmax * 6.35f < 2147483648.0f) ? 1u : 0u;   // |K * dtheta| <= |K| * 2 pi
     t.lut = nullptr;
     t.pcm_row = a.pcm + (size_t)ch * a.pcm_stride;
     t.mag_row = a.mag_sums + (size_t)ch * a.n_blocks;
@@ -394,8 +388,8 @@ __global__ __launch_bounds__(256) void tail_update_kernel(const ChainLaunch a, i
         cy.pad[0] = cy.pad[1] = cy.pad[2] = 0;
         a.wbfm_carry[ech] = cy;
     }
-    if (threadIdx.x == 0 && (family == FAM_WBFM || family == FAM_FM)) {   // this call's samples now lie behind the gain change
-        uint32_t *since = family == FAM_WBFM ? &a.epochs[ech].wbfm_since : &a.epochs[ech].fm_since;
+    if (threadIdx.x < EPOCHS && (family == FAM_WBFM || family == FAM_FM)) {   // this call's samples now lie behind the gain changes
+        uint32_t *since = (family == FAM_WBFM ? a.epochs[ech].wbfm.since : a.epochs[ech].fm.since) + threadIdx.x;
         const uint64_t total = (uint64_t)*since + vlen;
         *since = total < (uint64_t)TAIL ? (uint32_t)total : (uint32_t)TAIL;
     }
@@ -610,14 +604,15 @@ __global__ void agc_apply_kernel(const AgcConfig *cfg, AgcState *st, const ScanC
     // a demodulator gain changed since the last accept: the new one starts with the next sample; the one before it is
     // remembered for the histories - unless no sample was consumed since the previous change, whose "before" still holds
     const uint32_t changed = params[ch].k_changed;
-    if (changed & 1u) {
-        if (epochs[ch].wbfm_since != 0) epochs[ch].wbfm_k_prev = params[ch].wbfm_k_prev;
-        epochs[ch].wbfm_since = 0;
-    }
-    if (changed & 2u) {
-        if (epochs[ch].fm_since != 0) epochs[ch].fm_k_prev = params[ch].fm_k_prev;
-        epochs[ch].fm_since = 0;
-    }
+    // (a change with no sample consumed since the one before it replaces nothing: that one's "before" still holds)
+    auto push = [](GainEpochList &l, float k_before) {
+        if (l.since[0] == 0) return;
+        for (int i = EPOCHS - 1; i > 0; i--) { l.since[i] = l.since[i - 1]; l.k_before[i] = l.k_before[i - 1]; }
+        l.since[0] = 0;
+        l.k_before[0] = k_before;
+    };
+    if (changed & 1u) push(epochs[ch].wbfm, params[ch].wbfm_k_prev);
+    if (changed & 2u) push(epochs[ch].fm, params[ch].fm_k_prev);
     if (changed) params[ch].k_changed = 0;
     const AgcConfig c = cfg[ch];
     if (c.set_gain != 0xffffffffu) st[ch].rx_gain = c.set_gain;

@@ -135,15 +135,11 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
         const uint8_t *iq_ch = a.iq + (size_t)sg.ch * a.ch_stride_bytes;
         const uint8_t *tail = a.tails + ((size_t)sg.ech * FAM_COUNT + FAM_WBFM) * TAIL_BYTES + TAIL_BYTES;
         const int32_t vmax = (int32_t)a.vlen - 8;
-        float kneg = -p.wbfm_k, kneg_prev = kneg;
-        int32_t k_switch = INT32_MIN;
-        {   // every segment whose lead-in reaches back before the last gain change runs that part with the old gain
-            const uint32_t since = a.epochs[sg.ech].wbfm_since;
-            if (since < (uint32_t)TAIL && (int64_t)sg.v0 - ST_HALO - 32 < -(int64_t)since) {
-                kneg_prev = -a.epochs[sg.ech].wbfm_k_prev;
-                k_switch = -(int32_t)since - sg.v0;
-            }
-        }
+        const float kneg = -p.wbfm_k;
+        // segments whose lead-in reaches back before the call's start may meet earlier gains (GainEpochList)
+        const GainEpochList *ep = &a.epochs[sg.ech].wbfm;
+        const bool ep_reach = ep->since[0] < (uint32_t)TAIL && (int64_t)sg.v0 - ST_HALO - 32 < -(int64_t)ep->since[0];
+        const bool ep_any = __any(ep_reach);
         uint32_t *mag_row = MAG ? a.mag_sums + (size_t)sg.ch * a.n_blocks : nullptr;
         // squelch magnitude bookkeeping: this lane's chunks are 32 samples apart
         const bool mcount = MAG && sg.valid;
@@ -234,7 +230,8 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
                 const float give = g == 3 ? last_prev : th[3];
                 const float before = u2f((uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)f2u(give)));
                 last_prev = th[3];
-                const float kk = wpos < k_switch ? kneg_prev : kneg;
+                float kk = kneg;
+                if (ep_any && ep_reach) kk = -epoch_gain(ep, p.wbfm_k, sg.v0 + wpos);   // (rare: right after a gain change)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const float d = wrap_delta(th[r] - (r == 0 ? before : th[r - 1]));   // = -(delta theta)

@@ -69,8 +69,9 @@ struct WbfmTile {
     int32_t tlen;                // tile length
     uint32_t sel_i, sel_q, neg_i, neg_q;  // rotation as byte selectors / negate masks
     float k;                     // (gain / 75000) * 32767
-    float k_prev;                // the same before the last gain change ...
-    int32_t k_switch;            // ... which applies to samples before this position (<= 0; INT32_MIN: none in reach)
+    const GainEpochList *epochs; // gain changes still inside the tail (tile 0 of a call only; else nullptr):
+                                 // samples before position -since[i] (call-relative) ran with k_before[i]
+    float k_min;                 // smallest K among k and the k_before in reach (the tiny-state rule wants all >= 1)
     uint32_t bounded;            // |k| * pi * 1.01 < 2^31: (int16) casts cannot hit the indefinite value
     const float *lut;            // atan2 table, lut[y * 256 + x]
     int16_t *pcm_row;            // PCM of virtual sample 0
@@ -692,13 +693,45 @@ struct WbfmRecord {  // what the tile reports for hand-off verification and the 
 };
 
 // Chunk boundaries of a tile: the lead-in [-halo, 0) is one chunk - or two, split where the demodulator gain last
-// changed (k_switch), so that every chunk has one gain.
+// changed (the channel's GainEpochList), so that every chunk has one gain.
+// The gain in force at call-relative position v < 0: the list is ordered, most recent change first.
+IQD_DEV float epoch_gain(const GainEpochList *ep, float k_now, int v)
+{
+    float k = k_now;
+    if (ep)
+        for (int i = 0; i < EPOCHS; i++) {
+            if (ep->since[i] >= (uint32_t)TAIL || v >= -(int)ep->since[i]) break;
+            k = ep->k_before[i];
+        }
+    return k;
+}
 IQD_DEV int wbfm_chunk_len(const WbfmTile &t, int cs, int chunk)
 {
-    if (cs < 0) return (cs < t.k_switch && t.k_switch < 0 ? t.k_switch : 0) - cs;
+    if (cs < 0) {   // the lead-in ends at the tile start or at the next gain change, whichever comes first
+        int next = 0;
+        if (t.epochs)
+            for (int i = 0; i < EPOCHS; i++) {
+                const int sw = -(int)t.epochs->since[i];
+                if (t.epochs->since[i] < (uint32_t)TAIL && sw > cs && sw < next) next = sw;
+            }
+        return next - cs;
+    }
     return t.tlen - cs < chunk ? t.tlen - cs : chunk;
 }
-IQD_DEV float wbfm_chunk_gain(const WbfmTile &t, int cs) { return cs < t.k_switch ? t.k_prev : t.k; }
+IQD_DEV float wbfm_chunk_gain(const WbfmTile &t, int cs) { return cs < 0 ? epoch_gain(t.epochs, t.k, cs) : t.k; }
+// largest |K| and smallest K a tile can meet: now, and every earlier gain still inside its lead-in
+IQD_DEV void epoch_k_range(const GainEpochList *ep, float k_now, float &kmax_abs, float &kmin)
+{
+    kmax_abs = __builtin_fabsf(k_now);
+    kmin = k_now;
+    if (ep)
+        for (int i = 0; i < EPOCHS; i++) {
+            if (ep->since[i] >= (uint32_t)TAIL) break;
+            const float k = ep->k_before[i], a = __builtin_fabsf(k);
+            kmax_abs = a > kmax_abs ? a : kmax_abs;
+            kmin = k < kmin ? k : kmin;
+        }
+}
 
 template <bool GATED, bool MAG, class Exec>
 IQD_DEV void wbfm_tile(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLds &lds,
@@ -752,7 +785,7 @@ IQD_DEV void wbfm_tile(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLds &ld
             do {
                 ex.wave0([&](int lane) { iir_real(c, lds, nseg, lane, t.bounded != 0); });
                 rounds++;
-            } while (!ex.wave0_all([&](int lane) { return iir_check(lds, nseg, lane, t.k >= 1.0f && t.k_prev >= 1.0f); }));
+            } while (!ex.wave0_all([&](int lane) { return iir_check(lds, nseg, lane, t.k_min >= 1.0f); }));
             ex.stamp(3);
             if (rec_pos > cstart && rec_pos < cstart + clen) {
                 const int seg = (rec_pos - cstart) / SEG - 1;
@@ -944,7 +977,7 @@ IQD_DEV void wbfm_tile_pipe(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLd
     typename Exec::template Local<P1Pair> regs;
     typename Exec::template Local<P1Own> raw0;   // wave 0's prefetched group
     auto chunk_len = [&](int cs) { return wbfm_chunk_len(t, cs, WBFM_CHUNK); };
-    const bool tiny_ok = t.k >= 1.0f && t.k_prev >= 1.0f;
+    const bool tiny_ok = t.k_min >= 1.0f;
 #ifdef IQD_ABL_NOMAG
     const bool mag_on = false;
 #else

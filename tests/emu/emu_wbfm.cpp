@@ -96,8 +96,8 @@ int emu_wbfm_accept(const uint8_t *iq, uint32_t n_samples, uint32_t tile_len, ui
             t.neg_q = rotation > 0 ? 0xffff0000u : 0x00ffff00u;
         }
         t.k = p.wbfm_k;
-        t.k_prev = p.wbfm_k;
-        t.k_switch = INT32_MIN;
+        t.epochs = nullptr;
+        t.k_min = p.wbfm_k;
         t.bounded = (fabsf(p.wbfm_k) * 3.1730f < 2147483648.0f) ? 1u : 0u;
         t.lut = lut.data();
         t.pcm_row = pcm;
@@ -175,8 +175,8 @@ void emu_chain_accept(int family, int lsb, const uint8_t *iq, uint32_t n_samples
             t.neg_q = rotation > 0 ? 0xffff0000u : 0x00ffff00u;
         }
         t.k = p.fm_k;
-        t.k_prev = p.fm_k;
-        t.k_switch = INT32_MIN;
+        t.epochs = nullptr;
+        t.k_min = p.fm_k;
         t.bounded = (fabsf(p.fm_k) * 6.35f < 2147483648.0f) ? 1u : 0u;
         t.lut = nullptr;
         t.pcm_row = pcm;

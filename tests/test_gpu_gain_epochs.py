@@ -1,0 +1,65 @@
+"""GPU (MI355X): setDemodulatorGain() at run time is a plain store that takes effect with the next sample
+(WbFmDemodulator/WbFmDemodulator.cc:341-348, 444-450; FmDemodulator/FmDemodulator.cc twin).  The engine rebuilds
+its post-discriminator histories from the raw tail, so it has to remember every gain whose samples are still in
+that tail: any sequence of changes, however close together, must give the reference's PCM."""
+import numpy as np
+import pytest
+
+from rtlsdrdiags_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from rtlsdrdiags_amd import capi as c
+    return c
+
+
+GAINS = [91000.0, 700.0, 40743.665, 3.0, 250000.0, 12000.0, 1.0e6, 55.5, 18000.0]
+
+
+@pytest.mark.parametrize("mode,demod", [("wbfm", 3), ("fm", 2)])
+@pytest.mark.parametrize("flags", [0x2, 0x4], ids=["tiles", "stream"])
+def test_gain_changes_on_consecutive_256_byte_calls(capi, oracle, mode, demod, flags):
+    """block_bytes 256: a change before every one of nine consecutive calls (128 samples apart), then longer runs."""
+    u8 = synth.fm_tone(40 * 128 + 3 * 16384, seed=17, deviation=50e3)
+    c = oracle.chain()
+    c.set_mode(mode)
+    eng = capi.Engine(1, block_bytes=256, flags=flags)
+    eng.set_mode(mode)
+    ref, out = [], []
+    off = 0
+    plan = [(256, g) for g in GAINS] + [(256, None)] * 3 + [(512, GAINS[2]), (256, GAINS[5]), (2048, None), (256, GAINS[0]),
+                                                           (4096, GAINS[1]), (256, None), (32768, GAINS[3]), (65536, None)]
+    for nbytes, gain in plan:
+        if gain is not None:
+            c.set_gain(demod, gain)
+            eng.set_gain(mode, gain)
+        piece = u8[off:off + nbytes]
+        off += nbytes
+        r, _, _ = c.accept_stream(piece, 256)
+        pcm, cnt, _, _ = eng.accept(piece)
+        ref.append(r)
+        out.append(pcm[0, :cnt[0]])
+    for k in range(len(plan)):
+        assert np.array_equal(out[k], ref[k]), (k, plan[k])
+
+
+def test_two_changes_between_two_accepts_and_a_front_end_call_in_between(capi, oracle):
+    """set_gain(B), front_end() (uploads the parameters), set_gain(C), accept: the histories were made with A."""
+    u8 = synth.fm_tone(4 * 16384, seed=23, deviation=60e3)
+    c = oracle.chain()
+    c.set_mode("wbfm")
+    eng = capi.Engine(1)
+    eng.set_mode("wbfm")
+    a0, _, _ = c.accept_stream(u8[:32768])
+    p0, n0, _, _ = eng.accept(u8[:32768])
+    c.set_gain(3, 5000.0)
+    eng.set_gain("wbfm", 5000.0)
+    eng.front_end(u8[:32768])
+    c.set_gain(3, 77777.0)
+    eng.set_gain("wbfm", 77777.0)
+    a1, _, _ = c.accept_stream(u8[32768:])
+    p1, n1, _, _ = eng.accept(u8[32768:])
+    assert np.array_equal(p0[0, :n0[0]], a0) and np.array_equal(p1[0, :n1[0]], a1)

@@ -97,7 +97,6 @@ def one_case(rng, O):
     got = [[] for _ in range(n_ch)]
     got_allowed, got_mag = [], []
     ref_parts = [[[], [], []] for _ in range(n_ch)]
-    last_gain_change = [[-(1 << 30)] * 5 for _ in range(n_ch)]     # block index of the last change, per demodulator
     for a, b in zip(cuts[:-1], cuts[1:]):
         if a and rng.random() < 0.6:     # between calls: the operator changes something on a few channels
             for c in rng.integers(0, n_ch, int(rng.integers(1, 4))):
@@ -111,12 +110,10 @@ def one_case(rng, O):
                 elif what == 1:
                     chains[c].reset(); eng.reset(first=c, n=1)
                 elif what == 2:
-                    # (the engine keeps ONE earlier gain per demodulator for the histories a tile rebuilds: two changes
-                    # of the same gain less than 2048 samples apart are outside what it reproduces exactly)
+                    # any sequence of gain changes, however close together (the engine keeps every change whose
+                    # samples are still inside the 2048-sample tail: GainEpochList)
                     d, g = int(rng.integers(1, 5)), float(np.float32(10.0 ** rng.uniform(0, 6)))
-                    if (a - last_gain_change[c][d]) * (bb // 2) >= 2048:
-                        chains[c].set_gain(d, g); eng.set_gain(d, g, first=c, n=1)
-                        last_gain_change[c][d] = a
+                    chains[c].set_gain(d, g); eng.set_gain(d, g, first=c, n=1)
                 elif what == 3:
                     t = int(rng.choice([-200, -70, -50, -35]))
                     chains[c].set_squelch(t); eng.set_squelch(t, first=c, n=1)
