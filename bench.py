@@ -1,15 +1,22 @@
 #!/usr/bin/env python3
-"""bench.py — IQ MSamples/s through the WBFM chain on N MI355X GPUs, with the HBM roofline fraction
-of the chain kernel and the CPU baseline timed beside it.
+"""bench.py — IQ MSamples/s through the demodulator chains on N MI355X GPUs, with the HBM roofline fraction
+of the dominant kernel and the CPU baseline timed beside it.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 1|2|3|4]
 
-Workload (BASELINE.json configs[1]): WBFM, 1 channel per GPU,
-2^28 synthetic IQ samples (512 MiB of uint8 I/Q) resident in HBM before the timed region.
-A "step" is one iqd_accept_iq_device() call over the whole batch: the fused chain kernel, the
-tile hand-off verification, the squelch bookkeeping and the state update.  With N > 1 every rank
-runs its own channel on its own GPU (independent channels are the shard; no data-path collective),
-so the job is weak-scaled and `value` is the sum over ranks divided by the slowest rank's time.
+Default workload (BASELINE.json configs[1]): WBFM, 1 channel per GPU, 2^28 synthetic IQ samples
+(512 MiB of uint8 I/Q) resident in HBM before the timed region.  `--config N` selects BASELINE.json configs[N]:
+
+    1  WBFM, 1 channel x 2^28 samples                                   (the metric's configuration)
+    2  FM, 4096 channels x 2^16 samples (256 ms of signal each)
+    3  mixed AM/FM/WBFM/LSB/USB, 4096 channels per GPU x 2^16 samples    (32768 channels over 8 GPUs)
+    4  LSB+USB, rotation selector varying per channel, Harris AGC running, 8192 channels per GPU x 2^16 samples
+                                                                         (65536 channels over 8 GPUs)
+
+A "step" is one iqd_accept_iq_device() call over the whole batch: the chain kernel(s), the hand-off verification, the
+squelch / AGC bookkeeping and the state update.  With N > 1 every rank runs its own channels on its own GPU
+(independent channels are the shard; no data-path collective), so the job is weak-scaled and `value` is the sum over
+ranks divided by the slowest rank's time.
 
 Prints ONE JSON line on rank 0.
 """
@@ -27,19 +34,56 @@ import numpy as np  # noqa: E402
 
 ALGO_BYTES_PER_SAMPLE = 2.0 + 2.0 / 32.0     # int8 I + int8 Q in, int16 PCM out at 1/32 rate
 HBM_PEAK_GBS = 8000.0                        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+METRIC = "IQ MSamples/s through WBFM chain at 1/2/4/8 GPUs; % HBM roofline"
+
+CONFIGS = {
+    1: dict(mode="wbfm", channels=1, log2=28, tag="wbfm_2p28",
+            what="BASELINE configs[1]: WBFM, 1 channel, 2^28-sample synthetic IQ"),
+    2: dict(mode="fm", channels=4096, log2=16, tag="fm_4096",
+            what="BASELINE configs[2]: 4096 concurrent FM channels, 2^16 samples (256 ms at 256 kS/s) each per step"),
+    3: dict(mode="mixed", channels=4096, log2=16, tag="mixed_4096",
+            what="BASELINE configs[3]: mixed AM/FM/WBFM/LSB/USB (channel % 5), 4096 channels per GPU = 32768 over 8 GPUs, "
+                 "2^16 samples each per step"),
+    4: dict(mode="ssb_stress", channels=8192, log2=16, tag="ssb_8192",
+            what="BASELINE configs[4]: LSB+USB alternating, rotation selector (the reference's only NCO: +Fs/4, none, -Fs/4) "
+                 "varying per channel, Harris AGC running, 8192 channels per GPU = 65536 over 8 GPUs, 2^16 samples each per step"),
+}
 
 
-def cpu_baseline(period_u8, seconds_target=12.0):
-    """Times the reference CPU chain (oracle/_ref, the unmodified reference sources) — or, where that
-    library is absent, the oracle port — on one host core over a bounded sample of the same signal."""
+# ---- CPU baseline --------------------------------------------------------------------------------------------
+def _cpu_chain(kind_mode):
     from oracle import bindings as B
     if B.have_ref():
         chain, kind = B.Reference().chain(), "reference"
     else:
         chain, kind = B.Oracle().chain(), "port"
-    chain.set_mode("wbfm")
+    chain.set_mode(kind_mode)
+    return chain, kind
+
+
+def _cpu_worker(mode, period_u8, seconds, q):
+    """One independent channel on one core for about `seconds`; reports (samples, elapsed)."""
+    chain, _ = _cpu_chain(mode)
+    piece = period_u8[: 2 << 20]                  # 2^20 samples per call: the clock is read often enough
+    chain.accept_stream(piece[: 1 << 18])         # warm the code and the tables
+    done, t0 = 0, time.perf_counter()
+    while True:
+        chain.accept_stream(piece)
+        done += len(piece) // 2
+        dt = time.perf_counter() - t0
+        if dt >= seconds:
+            break
+    q.put((done, dt))
+
+
+def cpu_baseline(period_u8, mode="wbfm", seconds_target=10.0, all_cores=True):
+    """The reference CPU chain itself (oracle/_ref: the unmodified reference sources; `kind` says "port" when that
+    library is absent and the oracle restatement is timed instead) on a bounded sample of the bench signal: one host
+    core, and every host core this process may use with one independent channel per process (the reference is
+    single-threaded per channel: src_diags/DataConsumer.cc:52)."""
+    cpu_mode = {"mixed": "wbfm", "ssb_stress": "lsb"}.get(mode, mode)
+    chain, kind = _cpu_chain(cpu_mode)
     n_period = len(period_u8) // 2
-    # calibrate on 2^21 samples, then run ~seconds_target
     t0 = time.perf_counter()
     chain.accept_stream(period_u8[: 2 << 21])
     rate = (1 << 21) / (time.perf_counter() - t0)
@@ -48,9 +92,27 @@ def cpu_baseline(period_u8, seconds_target=12.0):
     for _ in range(reps):
         chain.accept_stream(period_u8)
     dt = time.perf_counter() - t0
-    return {"value": round(reps * n_period / dt / 1e6, 3), "unit": "MSamples/s", "cores": 1, "kind": kind,
-            "sample": "WBFM, 1 channel, %d x 2^24 samples of the bench signal through "
-                      "IqDataProcessor::acceptIqData in 32768-byte blocks, 1 thread" % reps}
+    out = {"value": round(reps * n_period / dt / 1e6, 3), "unit": "MSamples/s", "cores": 1, "kind": kind,
+           "sample": "%s, 1 channel, %d x 2^%d samples of the bench signal through IqDataProcessor::acceptIqData in "
+                     "32768-byte blocks, 1 thread" % (cpu_mode.upper(), reps, int(np.log2(n_period)))}
+    if all_cores:
+        import multiprocessing as mp
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        ctx = mp.get_context("fork")
+        q = ctx.Queue()
+        procs = [ctx.Process(target=_cpu_worker, args=(cpu_mode, period_u8, 0.8 * seconds_target, q)) for _ in range(cores)]
+        t0 = time.perf_counter()
+        for p in procs:
+            p.start()
+        got = [q.get() for _ in procs]
+        for p in procs:
+            p.join()
+        wall = time.perf_counter() - t0
+        out["all_cores"] = {"value": round(sum(d for d, _ in got) / max(t for _, t in got) / 1e6, 3), "unit": "MSamples/s",
+                            "cores": cores, "kind": kind, "wall_s": round(wall, 2),
+                            "sample": "%d processes (one per usable host core), one independent %s channel each, 2^20-sample "
+                                      "calls of the bench signal for %.0f s" % (cores, cpu_mode.upper(), 0.8 * seconds_target)}
+    return out
 
 
 def host_path(eng, iq_dev, n, n_ch, reps=3):
@@ -72,33 +134,199 @@ def host_path(eng, iq_dev, n, n_ch, reps=3):
             "what": "iqd_accept_iq from page-locked host buffers (upload, kernels, PCM download), %d calls" % reps}
 
 
-def measured_traffic(mode, n_ch, log2_samples):
-    """HBM bytes per launch of the chain kernel from the committed rocprofv3 PMC summary of the same
-    workload (profiles/), or None: bench.py itself cannot collect PMC counters."""
-    path = os.path.join(ROOT, "profiles", "r1_wbfm_2p28_pmc.json")
-    if mode == "wbfm" and n_ch == 1 and log2_samples == 28 and os.path.exists(path):
-        with open(path) as f:
-            return json.load(f).get("traffic_bytes_per_launch")
-    return None
+def profile_summary(tag):
+    """Counter-derived figures of the same workload from the committed rocprofv3 summary (profiles/, written by
+    tools/profile.sh + tools/pmc_summary.py): bench.py itself cannot collect PMC counters."""
+    for rnd in (2, 1):
+        path = os.path.join(ROOT, "profiles", "r%d_%s_pmc.json" % (rnd, tag))
+        if os.path.exists(path):
+            with open(path) as f:
+                return json.load(f), os.path.relpath(path, ROOT)
+    return None, None
 
 
-def main():
+# ---- the workload --------------------------------------------------------------------------------------------
+def make_signal(synth, signal, period):
+    if signal == "fm_tone":
+        return synth.fm_tone(period, seed=1234)
+    if signal == "white":
+        return synth.white_u8(period, seed=1234)
+    if signal == "carrier":      # unmodulated, noiseless: every sample hits the same table cell
+        return synth.fm_tone(period, seed=1234, deviation=0.0, sigma=0.0)
+    if signal == "small":        # weak signal: the table accesses stay within a few cells
+        return synth.fm_tone(period, seed=1234, amplitude=6.0, sigma=1.0)
+    if signal == "large":        # strong signal: a wide ring through the table
+        return synth.fm_tone(period, seed=1234, amplitude=120.0)
+    return synth.fm_tone(period, seed=1234, deviation=3000.0)   # "quiet": speech-like deviation
+
+
+def configure(eng, mode, n_ch, first_global, squelch):
+    """Per-channel settings; `first_global` is this rank's first channel in the whole job, so that the mix is the
+    same however many ranks share it."""
+    if mode == "mixed":          # BASELINE configs[3]: channel % 5 -> {AM, FM, WBFM, LSB, USB}
+        for c in range(n_ch):
+            eng.set_mode(["am", "fm", "wbfm", "lsb", "usb"][(first_global + c) % 5], first=c, n=1)
+    elif mode == "ssb_stress":   # BASELINE configs[4]
+        for c in range(n_ch):
+            g = first_global + c
+            eng.set_mode("lsb" if g % 2 == 0 else "usb", first=c, n=1)
+            eng.set_rotation((1, 0, -1)[g % 3], first=c, n=1)
+        eng.agc_set_type(1)      # AGC_TYPE_HARRIS
+        eng.agc_enable(True)
+    else:
+        eng.set_mode(mode)
+    if squelch is not None:
+        eng.set_squelch(squelch)
+
+
+def rank_body(args, rank, world, dev, make_engine, dist, torch, order_streams=None):
+    """What one rank does: stage the input, W untimed steps, K timed steps between barriers, the slowest rank's
+    clock, and (rank 0) the result.  Engine, device and process group come from the caller, so that the CPU tests
+    drive the very same control flow with a stand-in engine over gloo (tests/test_shard_gloo.py)."""
+    from rtlsdrdiags_amd import shard, synth
+
+    n = 1 << args.log2_samples
+    n_ch = args.channels
+    period = min(n, 1 << 24)
+    period_u8 = make_signal(synth, args.signal, period)   # the same seeded signal on every rank and channel
+    iq = torch.from_numpy(period_u8).to(dev).repeat(n // period)
+    if n_ch > 1:
+        iq = iq.unsqueeze(0).repeat(n_ch, 1).contiguous()
+    pcm = torch.zeros(n_ch * (n // 32), dtype=torch.int16, device=dev)
+    cnt = torch.zeros(n_ch, dtype=torch.int32, device=dev)
+    mag = torch.zeros(n_ch * max(1, 2 * n // 32768), dtype=torch.int32, device=dev)
+    sync = (lambda: torch.cuda.synchronize()) if dev.type == "cuda" else (lambda: None)
+    sync()
+
+    flags = (1 if args.no_magnitude else 0) | {"tiles": 2, "stream": 4}.get(args.wbfm_path, 0)
+    eng = make_engine(n_channels=n_ch, flags=flags)
+    first_global, _ = shard.channel_range(rank, world, n_ch * world)
+    configure(eng, args.mode, n_ch, first_global, args.squelch)
+    gatherer = shard.PcmGatherer(n_ch, n // 32, dev) if (args.gather and dist is not None) else None
+
+    def step():
+        if args.no_magnitude:
+            eng.accept_device(iq.data_ptr(), 2 * n, pcm.data_ptr())
+        else:
+            eng.accept_device(iq.data_ptr(), 2 * n, pcm.data_ptr(), cnt.data_ptr(), mag.data_ptr())
+        if gatherer is not None:
+            if order_streams is not None:
+                order_streams(eng)          # the collective's stream waits for the engine's kernels (no host sync)
+            else:
+                eng.synchronize()
+            gatherer.gather(pcm.view(n_ch, -1), cnt)
+
+    for _ in range(args.warmup):
+        step()
+    eng.synchronize()
+    sync()
+    if dist is not None:
+        dist.barrier()
+    eng.set_profiling(True)
+    k0 = eng.stats()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    eng.synchronize()
+    sync()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    k1 = eng.stats()
+    eng.set_profiling(False)
+    if dist is not None:
+        elapsed = shard.max_over_ranks(elapsed, dev)
+
+    out = None
+    if rank == 0:
+        total_samples = float(n) * n_ch * args.steps * world
+        launches = max(1, k1["chain_kernel_count"] - k0["chain_kernel_count"])
+        kern_ms = (k1["chain_kernel_ms"] - k0["chain_kernel_ms"]) / launches
+        streamed = k1.get("stream_launches", 0) - k0.get("stream_launches", 0) > 0
+        if args.mode == "mixed":
+            timed, timed_samples = "the first demodulator family launched (WBFM's stream / chain kernel)", None
+        elif args.mode in ("am", "lsb", "usb", "ssb_stress"):
+            timed, timed_samples = "am_chain_kernel + its DC-removal kernels", n * n_ch
+        elif args.mode == "fm":
+            timed, timed_samples = "fm_chain_kernel", n * n_ch
+        else:
+            timed, timed_samples = ("wbfm_stream_kernel" if streamed else "wbfm_chain_kernel"), n * n_ch
+        prof, prof_path = profile_summary(args.tag) if args.tag else (None, None)
+        roof = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": timed, "kernel_ms": round(kern_ms, 4)}
+        if timed_samples is not None and kern_ms > 0:
+            achieved = ALGO_BYTES_PER_SAMPLE * timed_samples / (kern_ms * 1e-3) / 1e9
+            roof.update({"achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_SAMPLE * timed_samples})
+        else:   # several families side by side: price the whole step against the bytes it moves
+            achieved = ALGO_BYTES_PER_SAMPLE * n * n_ch / (elapsed / args.steps) / 1e9
+            roof.update({"achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_SAMPLE * n * n_ch,
+                         "note": "achieved = algorithmic bytes of the step / step time (all families' kernels)"})
+        roof["traffic"] = (prof.get("derived", {}).get("hbm_bytes_per_launch") or prof.get("traffic_bytes_per_launch")) if prof else None
+        if prof:   # the second ceiling: vector-ALU issue (SQ_ACTIVE_INST_VALU, 4 cycles per wave-instruction, 1024 SIMDs)
+            c = prof.get("counters_per_launch", {})
+            if c.get("SQ_ACTIVE_INST_VALU") and prof.get("kernel_ms_avg"):
+                busy_ms = c["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (prof.get("clock_ghz", 2.3) * 1e9) * 1e3
+                roof["valu_issue_frac"] = round(busy_ms / prof["kernel_ms_avg"], 3)
+                roof["valu_lane_ops_per_sample"] = round(prof.get("derived", {}).get("valu_lane_ops_per_sample", 0.0), 1)
+            roof["profile"] = prof_path
+        out = {
+            "metric": METRIC if args.mode == "wbfm" else METRIC.replace("WBFM chain", "%s chains" % args.mode.upper()),
+            "value": round(total_samples / elapsed / 1e6, 1), "unit": "MSamples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int8/int16 Q15 + f32", "data": "synthetic" if args.signal == "fm_tone" else "synthetic (%s)" % args.signal,
+            "config": {"workload": args.what or "%s, %d channel(s) per GPU, 2^%d IQ samples per channel per step, uint8 I/Q "
+                                                "resident in HBM (not a BASELINE configuration)"
+                                                % (args.mode.upper(), n_ch, args.log2_samples),
+                       "channels_per_gpu": n_ch, "log2_samples_per_channel": args.log2_samples,
+                       "sharding": "independent channels, contiguous range per rank, no data-path collective"
+                                   + ("; PCM gathered to rank 0 over RCCL" if args.gather else "")},
+            "roofline": roof,
+            "state_checks": k1["state_checks"] - k0["state_checks"],
+            "state_repairs": k1["state_repairs"] - k0["state_repairs"],
+            "segment_repairs": k1["segment_repairs"] - k0["segment_repairs"],
+        }
+        if world == 1 and not args.no_host_path and dev.type == "cuda":
+            out["host_path"] = host_path(eng, iq, n, n_ch)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(period_u8, args.mode, all_cores=not args.cpu_one_core_only)
+    eng.close()
+    return out
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--log2-samples", type=int, default=28, help="IQ samples per channel per step (default 2^28)")
-    ap.add_argument("--channels", type=int, default=1, help="channels per GPU")
-    ap.add_argument("--mode", default="wbfm")
+    ap.add_argument("--config", type=int, default=None, choices=sorted(CONFIGS), help="BASELINE.json configs[N] preset (default 1)")
+    ap.add_argument("--log2-samples", type=int, default=None, help="IQ samples per channel per step (overrides the preset)")
+    ap.add_argument("--channels", type=int, default=None, help="channels per GPU (overrides the preset)")
+    ap.add_argument("--mode", default=None, help="am|fm|wbfm|lsb|usb|mixed|ssb_stress (overrides the preset)")
     ap.add_argument("--signal", default="fm_tone", choices=["fm_tone", "white", "carrier", "quiet", "small", "large"],
-                    help="synthetic input: the FM test tone of SURVEY 8(d) (default) or uniform random bytes")
-    ap.add_argument("--no-magnitude", action="store_true", help="IQD_F_NO_MAGNITUDE: skip the per-block squelch magnitudes (nobody listens to them at the default threshold)")
+                    help="synthetic input: the FM test tone of SURVEY 8(d) (default) or uniform random bytes, ...")
+    ap.add_argument("--no-magnitude", action="store_true", help="IQD_F_NO_MAGNITUDE: skip the per-block squelch magnitudes")
     ap.add_argument("--squelch", type=int, default=None, help="squelch threshold in dBFS (default: the reference's -200, never closes)")
+    ap.add_argument("--wbfm-path", default="auto", choices=["auto", "tiles", "stream"], help="pin the WBFM kernel (A/B)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-one-core-only", action="store_true", help="skip the all-host-cores CPU baseline")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive iqd_accept_iq measurement")
     ap.add_argument("--gather", action="store_true", help="also gather the PCM to rank 0 over RCCL each step")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+    preset = CONFIGS[args.config or 1]
+    custom = args.mode is not None or args.channels is not None or args.log2_samples is not None
+    args.mode = args.mode or preset["mode"]
+    args.channels = args.channels or preset["channels"]
+    args.log2_samples = args.log2_samples or preset["log2"]
+    same = (args.mode, args.channels, args.log2_samples) == (preset["mode"], preset["channels"], preset["log2"])
+    args.what = preset["what"] if (same or not custom) else None
+    args.tag = preset["tag"] if (same or not custom) and args.signal == "fm_tone" and not args.no_magnitude else None
+    return args
 
+
+def main():
+    args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -116,104 +344,17 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from rtlsdrdiags_amd import capi, shard, synth
+    from rtlsdrdiags_amd import capi
 
-    n = 1 << args.log2_samples
-    n_ch = args.channels
-    period = min(n, 1 << 24)
-    dev = torch.device("cuda", local_rank)
-    # the same seeded signal on every rank, phase-continuous over the period
-    if args.signal == "fm_tone":
-        period_u8 = synth.fm_tone(period, seed=1234)
-    elif args.signal == "white":
-        period_u8 = synth.white_u8(period, seed=1234)
-    elif args.signal == "carrier":      # unmodulated, noiseless: every sample hits the same table cell
-        period_u8 = synth.fm_tone(period, seed=1234, deviation=0.0, sigma=0.0)
-    elif args.signal == "small":        # weak signal: the table accesses stay within a few cache lines
-        period_u8 = synth.fm_tone(period, seed=1234, amplitude=6.0, sigma=1.0)
-    elif args.signal == "large":        # strong signal: a wide ring through the table
-        period_u8 = synth.fm_tone(period, seed=1234, amplitude=120.0)
-    else:                               # speech-like: 3 kHz deviation
-        period_u8 = synth.fm_tone(period, seed=1234, deviation=3000.0)
-    iq = torch.from_numpy(period_u8).to(dev).repeat(n // period)
-    if n_ch > 1:
-        iq = iq.unsqueeze(0).repeat(n_ch, 1).contiguous()
-    pcm = torch.zeros(n_ch * (n // 32), dtype=torch.int16, device=dev)
-    cnt = torch.zeros(n_ch, dtype=torch.int32, device=dev)
-    mag = torch.zeros(n_ch * (2 * n // 32768), dtype=torch.int32, device=dev)
-    torch.cuda.synchronize()
+    def make_engine(n_channels, flags):
+        return capi.Engine(n_channels=n_channels, device=local_rank, flags=flags)
 
-    eng = capi.Engine(n_channels=n_ch, device=local_rank, flags=1 if args.no_magnitude else 0)
-    if args.mode == "mixed":     # BASELINE configs[3]: ch % 5 -> {AM, FM, WBFM, LSB, USB}
-        for c in range(n_ch):
-            eng.set_mode(["am", "fm", "wbfm", "lsb", "usb"][c % 5], first=c, n=1)
-    else:
-        eng.set_mode(args.mode)
+    def order_streams(eng):   # torch's current stream (where the collective is enqueued) waits for the engine's stream
+        torch.cuda.current_stream().wait_stream(torch.cuda.ExternalStream(eng.stream_handle()))
 
-    if args.squelch is not None:
-        eng.set_squelch(args.squelch)
-
-    def step():
-        if args.no_magnitude:
-            eng.accept_device(iq.data_ptr(), 2 * n, pcm.data_ptr())
-        else:
-            eng.accept_device(iq.data_ptr(), 2 * n, pcm.data_ptr(), cnt.data_ptr(), mag.data_ptr())
-        if args.gather and dist is not None:
-            shard.gather_pcm(pcm.view(n_ch, -1), cnt, dst=0)
-
-    for _ in range(args.warmup):
-        step()
-    eng.synchronize()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    eng.set_profiling(True)
-    k0 = eng.stats()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    eng.synchronize()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    k1 = eng.stats()
-    eng.set_profiling(False)
-    if dist is not None:
-        elapsed = shard.max_over_ranks(elapsed, dev)
-
-    total_samples = float(n) * n_ch * args.steps * world
-    value = total_samples / elapsed / 1e6
-    kern_ms = (k1["chain_kernel_ms"] - k0["chain_kernel_ms"]) / max(1, k1["chain_kernel_count"] - k0["chain_kernel_count"])
-    achieved = ALGO_BYTES_PER_SAMPLE * n * n_ch / (kern_ms * 1e-3) / 1e9 if kern_ms > 0 else 0.0
-
-    if rank == 0:
-        out = {
-            "metric": "IQ MSamples/s through WBFM chain at 1/2/4/8 GPUs; % HBM roofline",
-            "value": round(value, 1), "unit": "MSamples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int8/int16 Q15 + f32", "data": "synthetic" if args.signal == "fm_tone" else "synthetic (%s)" % args.signal,
-            "config": {"workload": "%s, %d channel(s) per GPU, 2^%d IQ samples per channel per step, "
-                                   "uint8 I/Q resident in HBM (BASELINE configs[1])"
-                                   % (args.mode.upper(), n_ch, args.log2_samples),
-                       "sharding": "independent channels, one per rank, no data-path collective"
-                                   + ("; PCM gathered to rank 0 over RCCL" if args.gather else "")},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": measured_traffic(args.mode, n_ch, args.log2_samples),
-                         "kernel": "%s_chain_kernel" % ("am" if args.mode in ("am", "lsb", "usb") else ("first family's" if args.mode == "mixed" else args.mode)), "kernel_ms": round(kern_ms, 4),
-                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_SAMPLE * n * n_ch},
-            "state_checks": k1["state_checks"] - k0["state_checks"],
-            "state_repairs": k1["state_repairs"] - k0["state_repairs"],
-            "segment_repairs": k1["segment_repairs"] - k0["segment_repairs"],
-        }
-        if world == 1 and not args.no_host_path:
-            out["host_path"] = host_path(eng, iq, n, n_ch)
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(period_u8)
+    out = rank_body(args, rank, world, torch.device("cuda", local_rank), make_engine, dist, torch, order_streams)
+    if out is not None:
         print(json.dumps(out))
-    eng.close()
     if dist is not None:
         dist.destroy_process_group()
 

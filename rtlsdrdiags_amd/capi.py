@@ -305,6 +305,10 @@ class Engine:
     def synchronize(self):
         self._check(self._L.iqd_synchronize(self._h))
 
+    def stream_handle(self):
+        """The hipStream_t the engine launches on (an integer, for torch.cuda.ExternalStream)."""
+        return int(self._L.iqd_stream(self._h) or 0)
+
     # ---- diagnostics / device helpers -------------------------------------------------------
     def stats(self):
         s = Stats()

@@ -67,7 +67,7 @@ struct iqd_engine {
     uint32_t list_first = 0, list_n = 0;
     std::vector<uint32_t> h_lists[FAM_COUNT + 1];  // per family; [FAM_COUNT] = mode None
     uint32_t n_cus = 256;
-    size_t dcr_layout[2] = {~(size_t)0, ~(size_t)0};   // where the DC redo flags of AM / SSB sit in their buffers
+    size_t dcr_layout[2][2] = {{~(size_t)0, 0}, {~(size_t)0, 0}};   // AM / SSB: where the DC redo flags sit in their buffer, and how many
     bool any_gated = false, any_agc = false;
     std::vector<AgcConfig> h_agc;           // per channel; the one-shot fields are cleared once applied
     std::vector<uint8_t> agc_touched;       // the device may have moved this channel's IF gain
@@ -1107,7 +1107,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
     std::sort(order, order + FAM_COUNT, [&](int x, int y) { return cost[x] > cost[y]; });
     float lane_load[3] = {0.f, 0.f, 0.f};   // 0: the engine's stream, 1 and 2: the side streams
     bool lane_used[3] = {false, false, false};
-    size_t *dcr_layout = e->dcr_layout;
+    size_t (*dcr_layout)[2] = e->dcr_layout;
     for (int oi = 0; oi < FAM_COUNT; oi++) {
         const int f = order[oi];
         const uint32_t n_list = (uint32_t)e->h_lists[f].size();
@@ -1198,9 +1198,11 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
                 HIP_TRY(e, dcr.ensure(rec_bytes + n_list * sizeof(uint32_t)));
                 a.dc_records = dcr.p;
                 // the flags sit behind the records, whose extent changes with the call: clear them whenever it may have
-                if (grown || dcr_layout[f == FAM_SSB] != rec_bytes) {
+                // (same offset but more channels than last time: the new flags lie over old record bytes)
+                if (grown || dcr_layout[f == FAM_SSB][0] != rec_bytes || dcr_layout[f == FAM_SSB][1] < n_list) {
                     HIP_TRY(e, hipMemsetAsync((char *)dcr.p + rec_bytes, 0, n_list * sizeof(uint32_t), s));
-                    dcr_layout[f == FAM_SSB] = rec_bytes;
+                    dcr_layout[f == FAM_SSB][0] = rec_bytes;
+                    dcr_layout[f == FAM_SSB][1] = n_list;
                 }
             }
             HIP_TRY(e, launch_am(a, f, gated, fused_mag, n_list * a.tiles_per_ch, s));

@@ -1,14 +1,24 @@
-"""CPU, world_size 2 over gloo: the N>1 path of the benchmark / sharded deployment — channel ranges,
-the PCM gather and the max-over-ranks clock.  (The data path itself has no collective.)"""
+"""CPU, world_size 2 over gloo: the N>1 path of the benchmark / sharded deployment.
+
+The rank body is bench.py's own (`bench.rank_body`: staging, warm-up, barriers, K timed steps, the PCM gather with
+its persistent buffers, the max-over-ranks clock, the result line); only the engine is a stand-in that works on
+host memory, so the control flow the driver's multi-GPU runs depend on is exactly what runs here.  The data path
+itself has no collective."""
+import ctypes
 import os
 import socket
+import sys
 
 import numpy as np
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from rtlsdrdiags_amd import shard
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from rtlsdrdiags_amd import shard  # noqa: E402
 
 
 def test_channel_ranges_cover_everything():
@@ -23,40 +33,149 @@ def test_channel_ranges_cover_everything():
             assert max(sizes) - min(sizes) <= 1
 
 
-def _worker(rank, world, port, n_channels, q):
+class FakeEngine:
+    """Stand-in for capi.Engine over host memory: 'PCM' of channel c is a function of the channel's global index,
+    its mode and its input bytes, so that the gathered result proves which rank produced which rows."""
+
+    def __init__(self, n_channels, flags, rank):
+        self.n, self.flags, self.rank = n_channels, flags, rank
+        self.modes = ["none"] * n_channels
+        self.rot = [1] * n_channels
+        self.calls = 0
+        self.profiling = False
+        self.agc = False
+
+    def set_mode(self, mode, first=0, n=None):
+        for c in range(first, first + (self.n - first if n is None else n)):
+            self.modes[c] = mode
+
+    def set_rotation(self, r, first=0, n=None):
+        for c in range(first, first + (self.n - first if n is None else n)):
+            self.rot[c] = r
+
+    def set_squelch(self, t, first=0, n=None):
+        pass
+
+    def agc_set_type(self, t, first=0, n=None):
+        pass
+
+    def agc_enable(self, on=True, first=0, n=None):
+        self.agc = on
+
+    def accept_device(self, iq_ptr, bytes_per_ch, pcm_ptr, cnt_ptr=0, mag_ptr=0, allowed_ptr=0):
+        n_pcm = bytes_per_ch // 64
+        iq = np.frombuffer((ctypes.c_uint8 * (self.n * bytes_per_ch)).from_address(iq_ptr), dtype=np.uint8).reshape(self.n, -1)
+        pcm = np.frombuffer((ctypes.c_int16 * (self.n * n_pcm)).from_address(pcm_ptr), dtype=np.int16).reshape(self.n, -1)
+        for c in range(self.n):
+            tagv = ["none", "am", "fm", "wbfm", "lsb", "usb"].index(self.modes[c]) * 1000 + int(iq[c, :64].sum()) % 1000
+            pcm[c, :] = np.int16(tagv % 30000)
+            pcm[c, 0] = np.int16(self.rot[c])
+        if cnt_ptr:
+            cnt = np.frombuffer((ctypes.c_int32 * self.n).from_address(cnt_ptr), dtype=np.int32)
+            cnt[:] = n_pcm
+        self.calls += 1
+
+    def synchronize(self):
+        pass
+
+    def set_profiling(self, on):
+        self.profiling = on
+
+    def stats(self):
+        return {"chain_kernel_ms": 0.25 * self.calls, "chain_kernel_count": self.calls, "state_checks": 0,
+                "state_repairs": 0, "segment_repairs": 0, "stream_launches": 0}
+
+    def close(self):
+        pass
+
+
+def _worker(rank, world, port, argv, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    first, cnt = shard.channel_range(rank, world, n_channels)
-    # stand-in for the engine's output: channel c's PCM row is filled with c, count = c + 1
-    rows = torch.stack([torch.full((16,), c, dtype=torch.int16) for c in range(first, first + cnt)])
-    counts = torch.tensor([c + 1 for c in range(first, first + cnt)], dtype=torch.int32)
-    pcm, cnts = shard.gather_pcm(rows, counts, dst=0)
-    slow = shard.max_over_ranks(0.5 + rank, torch.device("cpu"))
+    import bench
+    args = bench.parse_args(argv)
+    engines = []
+
+    def make_engine(n_channels, flags):
+        engines.append(FakeEngine(n_channels, flags, rank))
+        return engines[-1]
+
+    captured = {}
+    real_gatherer = shard.PcmGatherer
+
+    class Spy(real_gatherer):   # keeps a handle on the gatherer bench.py builds, to read what arrived on rank 0
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            captured["g"] = self
+
+    shard.PcmGatherer = Spy
+    out = bench.rank_body(args, rank, world, torch.device("cpu"), make_engine, dist, torch)
+    shard.PcmGatherer = real_gatherer
+    eng = engines[0]
+    assert eng.calls == args.warmup + args.steps
     if rank == 0:
-        allp = torch.cat(pcm).numpy()
-        allc = torch.cat(cnts).numpy()
-        q.put((allp[:, 0].tolist(), allc.tolist(), slow))
+        pcm, cnts = captured["g"].result()
+        rows = torch.cat(pcm).numpy()
+        q.put((out, rows[:, 0].tolist(), rows[:, 1].tolist(), torch.cat(cnts).numpy().tolist(),
+               captured["g"].sizes, eng.modes, eng.agc))
     else:
-        assert pcm is None and cnts is None
+        assert out is None
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_gather_and_clock_world_size_2():
+def _run(argv, world=2):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
-    n_channels = 5   # uneven split: 3 + 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_channels, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, argv, q)) for r in range(world)]
     for p in procs:
         p.start()
-    first_col, counts, slow = q.get(timeout=120)
+    res = q.get(timeout=180)
     for p in procs:
-        p.join(timeout=120)
+        p.join(timeout=180)
         assert p.exitcode == 0
-    assert first_col == list(range(n_channels))
-    assert counts == [c + 1 for c in range(n_channels)]
-    assert abs(slow - 1.5) < 1e-9
+    return res
+
+
+def test_bench_rank_body_mixed_channels_world_size_2():
+    """configs[3] shape (mixed modes), 5 channels per rank: channel g of the job runs mode g % 5 whichever rank owns it."""
+    argv = ["--gpus", "2", "--steps", "3", "--warmup", "1", "--mode", "mixed", "--channels", "5", "--log2-samples", "12",
+            "--gather", "--no-cpu-baseline", "--no-host-path"]
+    out, rot_col, tag_col, counts, sizes, modes0, agc0 = _run(argv)
+    assert sizes == [5, 5] and len(tag_col) == 10
+    names = ["am", "fm", "wbfm", "lsb", "usb"]
+    assert modes0 == names                                     # rank 0 owns job channels 0..4
+    idx = {"am": 1, "fm": 2, "wbfm": 3, "lsb": 4, "usb": 5}
+    assert [t // 1000 for t in tag_col] == [idx[names[g % 5]] for g in range(10)]   # rank 1's rows continue the pattern
+    assert counts == [(1 << 12) // 32] * 10 and not agc0
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["config"]["channels_per_gpu"] == 5 and "gathered" in out["config"]["sharding"]
+    # value = samples of ALL ranks / the slowest rank's time
+    assert abs(out["value"] - 2 * 5 * 4096 * 3 / (out["ms_per_step"] * 3e-3) / 1e6) / out["value"] < 2e-2   # (both figures are rounded in the line)
+    assert out["roofline"]["kernel_ms"] == 0.25 and "cpu_baseline" not in out
+
+
+def test_bench_rank_body_ssb_stress_world_size_2():
+    """configs[4] shape: LSB/USB alternate and the rotation selector cycles with the JOB-wide channel index."""
+    argv = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--mode", "ssb_stress", "--channels", "3", "--log2-samples", "12",
+            "--gather", "--no-cpu-baseline", "--no-host-path"]
+    out, rot_col, tag_col, counts, sizes, modes0, agc0 = _run(argv)
+    assert [t // 1000 for t in tag_col] == [4 if g % 2 == 0 else 5 for g in range(6)]
+    assert rot_col == [(1, 0, -1)[g % 3] for g in range(6)]
+    assert agc0 and out["metric"].startswith("IQ MSamples/s through SSB_STRESS chains")
+
+
+def test_presets_name_the_baseline_configurations():
+    import bench
+    a = bench.parse_args([])
+    assert (a.mode, a.channels, a.log2_samples) == ("wbfm", 1, 28) and "configs[1]" in a.what
+    a = bench.parse_args(["--config", "2"])
+    assert (a.mode, a.channels, a.log2_samples) == ("fm", 4096, 16) and "configs[2]" in a.what
+    a = bench.parse_args(["--config", "4"])
+    assert (a.mode, a.channels) == ("ssb_stress", 8192) and "65536" in a.what
+    a = bench.parse_args(["--mode", "am", "--channels", "64"])
+    assert a.what is None and a.tag is None                    # not a BASELINE configuration: labelled as such
