@@ -97,11 +97,13 @@ struct iqd_engine {
     bool stream_ok = false;              // the half table's symmetry holds on this host's libm
     std::vector<float> wbfm_kmax;        // [n_ch]: largest |K| a channel has run with since creation (casts stay bounded)
     StreamArgs stream_args{};
+    uint64_t stream_handoffs = 0;        // cold segments launched so far (their verification counts only mismatches)
     uint32_t *d_counters = nullptr;      // cumulative, read by iqd_get_stats
     unsigned long long *d_stamps = nullptr;
     uint32_t *h_counters = nullptr;  // pinned
 
     // per-call scratch
+    DevBuf stream_hist;   // boundary records of the streaming WBFM kernel, one StHist per segment
     DevBuf lists[FAM_COUNT + 1], mag_sums, blk_lists, vlen, records, base8k, gain_trace, freq_trace, dc_records, dc_records2, repair_flags;
     DevBuf st_iq, st_pcm, st_count, st_mag, st_allowed;  // staging for host-pointer accepts
     // sliced host-pointer accepts: two staging sets, so that slice k+1 crosses PCIe while slice k runs
@@ -313,7 +315,7 @@ void iqd_destroy(iqd_t *e)
         if (p) (void)hipFree(p);
     if (e->h_counters) (void)hipHostFree(e->h_counters);
     for (auto &b : e->lists) b.release();
-    DevBuf *bufs[] = {&e->mag_sums, &e->blk_lists, &e->vlen, &e->records, &e->base8k, &e->gain_trace, &e->freq_trace, &e->dc_records, &e->dc_records2, &e->repair_flags,
+    DevBuf *bufs[] = {&e->stream_hist, &e->mag_sums, &e->blk_lists, &e->vlen, &e->records, &e->base8k, &e->gain_trace, &e->freq_trace, &e->dc_records, &e->dc_records2, &e->repair_flags,
                       &e->st_iq, &e->st_pcm, &e->st_count, &e->st_mag, &e->st_allowed};
     for (DevBuf *b : bufs) b->release();
     for (int b = 0; b < 2; b++) {
@@ -693,7 +695,7 @@ int iqd_get_stats(iqd_t *e, iqd_stats *out)
         e->ev_free_pairs.push_back(pr);
     }
     e->ev_pending.clear();
-    e->stats.state_checks = e->h_counters[CNT_TILE_CHECKS];
+    e->stats.state_checks = e->h_counters[CNT_TILE_CHECKS] + e->stream_handoffs - e->h_counters[CNT_STREAM_MISMATCH];
     e->stats.segment_repairs = e->h_counters[CNT_SEG_REPAIRS];
     e->stats.state_repairs = (uint64_t)e->h_counters[CNT_TILE_REPAIRS] + e->h_counters[CNT_DC_REDO];
     *out = e->stats;
@@ -1180,7 +1182,12 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
                 const uint32_t wgs_needed = (sa.n_segments + ST_SEGS - 1) / ST_SEGS;
                 const uint32_t grid = wgs_needed < e->n_cus ? wgs_needed : e->n_cus;
                 sa.rounds = (wgs_needed + grid - 1) / grid;
+                HIP_TRY(e, e->stream_hist.ensure((size_t)sa.n_segments * sizeof(StHist)));
+                sa.hist = e->stream_hist.as<StHist>();
+                a.verify_at_end = 1;
                 HIP_TRY(e, launch_wbfm_stream(a, sa, stream_rot, fused_mag, grid, s));
+                HIP_TRY(e, launch_wbfm_stream_fixup(a, sa, s));
+                e->stream_handoffs += (uint64_t)n_list * ((vlen + a.tile_len - 1) / a.tile_len - 1);
                 e->stats.stream_launches++;
             } else {
                 HIP_TRY(e, launch_wbfm(a, gated, fused_mag, n_list * a.tiles_per_ch, s));
@@ -1214,8 +1221,9 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         }
         e->stats.kernel_launches++;
         if (f == FAM_WBFM) {
-            // hand-off verification, repair of what it flags (normally an immediate exit), then state commit + tail
-            HIP_TRY(e, launch_wbfm_verify(a, s));
+            // hand-off verification (streaming launches: done by their fix-up kernel), repair of what it flags
+            // (normally an immediate exit), then state commit + tail
+            if (!use_stream) HIP_TRY(e, launch_wbfm_verify(a, s));
             HIP_TRY(e, launch_wbfm_repair(a, gated, s));
             HIP_TRY(e, launch_tail_update(a, FAM_WBFM, s));
         } else {

@@ -11,7 +11,7 @@ namespace iqd {
 struct WbfmStart;
 struct WbfmRecord;
 
-enum Counter { CNT_TILE_MISMATCH = 0, CNT_TILE_CHECKS = 1, CNT_SEG_REPAIRS = 2, CNT_DC_REDO = 3, CNT_TILE_REPAIRS = 4, CNT_COUNT = 8 };
+enum Counter { CNT_TILE_MISMATCH = 0, CNT_TILE_CHECKS = 1, CNT_SEG_REPAIRS = 2, CNT_DC_REDO = 3, CNT_TILE_REPAIRS = 4, CNT_STREAM_MISMATCH = 5, CNT_COUNT = 8 };
 constexpr uint32_t MAX_MISMATCH_LIST = 1024;
 
 // One chain launch = the channels of one demodulator family inside one accept call.
@@ -39,6 +39,8 @@ struct ChainLaunch {
     uint32_t *mag_sums;           // [n_ch][n_blocks]
     WbfmRecord *records;          // [n_list][tiles_per_ch]
     uint32_t *repair_flags;       // [n_list]: set by the verification, cleared by the repair (zero between calls)
+    uint32_t verify_at_end;       // streaming launches: a cold segment's y_in is its state at its own start, to be compared
+                                  // with its predecessor's y_end (tile launches: both taken FORCED_BACK earlier, y_out)
     uint32_t *counters;           // [CNT_COUNT]
     int32_t *base8k;              // AM/SSB detector input at 8 kS/s, n_ch_call * pcm_stride ints
     size_t base_stride_ch, base_stride_t;   // its layout: channel-major or time-major
@@ -76,6 +78,7 @@ hipError_t launch_reset(uint8_t *tails, WbfmCarry *wc, DcCarry *dc, uint32_t fir
 hipError_t launch_wbfm_verify(const ChainLaunch &a, hipStream_t s);
 struct StreamArgs;
 hipError_t launch_wbfm_stream(const ChainLaunch &a, const StreamArgs &sa, int rotation, bool mag, uint32_t grid, hipStream_t s);
+hipError_t launch_wbfm_stream_fixup(const ChainLaunch &a, const StreamArgs &sa, hipStream_t s);
 hipError_t launch_retail(uint8_t *tails, const ChanParams *params, uint32_t n_ch, hipStream_t s);
 // kind: 0 float decimator, 1 float interpolator, 2 int16 interpolator
 hipError_t launch_resample(int kind, const void *in, void *out, const void *hist, void *hist_next, const void *taps,

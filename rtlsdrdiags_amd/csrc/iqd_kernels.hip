@@ -157,9 +157,13 @@ __global__ __launch_bounds__(WB_THREADS, IQD_WBFM_MIN_WAVES) void wbfm_repair_ke
     const uint32_t vlen = GATED ? a.vlen_gated[ch] : a.vlen;
     const uint32_t ntiles = (vlen + a.tile_len - 1) / a.tile_len;
     WbfmRecord *r = a.records + (size_t)li * a.tiles_per_ch;
+    bool redo_next = false;   // streaming launches: the tile after a re-run one took its first PCM samples from histories
+                              // that the failed run may have left inexact - it is re-run too
     for (uint32_t tile = 1; tile < ntiles; tile++) {
         const WbfmRecord prev = r[tile - 1];
-        if (iir_states_agree(r[tile].y_in, prev.y_out, a.params[a.first_ch + ch].wbfm_k >= 1.0f)) continue;
+        const bool ok = iir_states_agree(r[tile].y_in, a.verify_at_end ? prev.y_end : prev.y_out, a.params[a.first_ch + ch].wbfm_k >= 1.0f);
+        if (ok && !redo_next) continue;
+        redo_next = a.verify_at_end && !ok;
         WbfmStart start;
         start.y = prev.y_out; start.u = prev.u_out; start.back = prev.back_out; start.cold = 0;
         wbfm_run_tile<GATED, false>(a, lds, li, tile, ch, vlen, start);
@@ -361,7 +365,7 @@ __global__ void wbfm_verify_kernel(const ChainLaunch a)
     if (tile >= ntiles) return;
     const WbfmRecord *r = a.records + (size_t)li * a.tiles_per_ch;
     if (tile > 0) {
-        if (!iir_states_agree(r[tile].y_in, r[tile - 1].y_out, a.params[a.first_ch + ch].wbfm_k >= 1.0f)) {
+        if (!iir_states_agree(r[tile].y_in, a.verify_at_end ? r[tile - 1].y_end : r[tile - 1].y_out, a.params[a.first_ch + ch].wbfm_k >= 1.0f)) {
             atomicAdd(&a.counters[CNT_TILE_MISMATCH], 1u);
             a.repair_flags[li] = 1;
         } else {

@@ -1,0 +1,78 @@
+// Device-only building blocks shared by the chain kernels that run their first FIR stage on the matrix cores
+// (v_mfma_i32_16x16x64_i8): the byte-level front end and the squelch magnitude.  gfx950 only (no host twin).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "iqd_prims.h"
+
+namespace iqd {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+
+// ---- small device helpers -----------------------------------------------------------------------
+// byte B of x replaced by its two's-complement negation, the other bytes kept (v_sub_u32_sdwa): int8
+// wrap, so -(-128) stays -128 like the reference's rotation (IqDataProcessor.cc:594-607)
+#define ST_NEG_BYTE(x, B)                                                                                     \
+    asm("v_sub_u32_sdwa %0, %1, %0 dst_sel:BYTE_" #B " dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_" #B \
+        : "+v"(x) : "v"(zero))
+
+// raw offset-binary bytes of 8 samples -> signed bytes with the rotation's SIGNS applied in place (which
+// byte feeds which rail is folded into the tap matrices).  +Fs/4: I' = {I0,-Q1,-I2,Q3}, Q' = {Q0,I1,-Q2,-I3};
+// -Fs/4: I' = {I0,Q1,-I2,-Q3}, Q' = {Q0,-I1,-Q2,I3} (IqDataProcessor.cc:567-611).
+template <int ROT>
+__device__ __forceinline__ uint4 st_front(uint4 raw, uint32_t zero)
+{
+    uint32_t d[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+    for (int h = 0; h < 4; h += 2) {
+        uint32_t d0 = d[h], d1 = d[h + 1];
+        if (ROT == 0) {
+            d0 ^= 0x80808080u;
+            d1 ^= 0x80808080u;
+        } else if (ROT > 0) {
+            d0 = (d0 ^ 0x7f808080u) + 0x01000000u;   // byte 3 (Q1): ~s + 1, the carry leaves the register
+            d1 ^= 0x80808080u;
+            ST_NEG_BYTE(d1, 0);
+            ST_NEG_BYTE(d1, 1);
+            ST_NEG_BYTE(d1, 2);
+        } else {
+            d0 ^= 0x80808080u;
+            ST_NEG_BYTE(d0, 2);
+            d1 = (d1 ^ 0x7f808080u) + 0x01000000u;   // byte 3 (Q3)
+            ST_NEG_BYTE(d1, 0);
+            ST_NEG_BYTE(d1, 1);
+        }
+        d[h] = d0;
+        d[h + 1] = d1;
+    }
+    return uint4{d[0], d[1], d[2], d[3]};
+}
+
+// sum over the 2 samples of a dword of signed bytes of max(|I|,|Q|) + min(|I|,|Q|)/2, added into two 16-bit
+// lanes of acc (SignalDetector.cc:227-247).  |x| of all four bytes at once: (x ^ m) + t with t the sign bits.
+__device__ __forceinline__ uint32_t st_mag_dword(uint32_t sx, uint32_t acc)
+{
+    const uint32_t t = (sx >> 7) & 0x01010101u;
+    uint32_t t8 = t << 8;
+    asm("" : "+v"(t8));                                    // (else hipcc folds this into a quarter-rate v_mul_lo_u32 by 255)
+    const uint32_t m = t8 - t;
+    const uint32_t ab = (sx ^ m) + t;                      // bytes |I0| |Q0| |I1| |Q1|, each <= 128
+    const us2 a = __builtin_bit_cast(us2, ab & 0x00ff00ffu);
+    const us2 b = __builtin_bit_cast(us2, (ab >> 8) & 0x00ff00ffu);
+    const us2 mx = __builtin_elementwise_max(a, b), mn = __builtin_elementwise_min(a, b);
+    return acc + __builtin_bit_cast(uint32_t, mx) + __builtin_bit_cast(uint32_t, (us2)(mn >> 1));
+}
+
+
+__device__ __forceinline__ uint32_t st_mag_chunk(const uint4 &s)   // 8 samples of signed bytes
+{
+    uint32_t m16 = st_mag_dword(s.x, 0u);
+    m16 = st_mag_dword(s.y, m16);
+    m16 = st_mag_dword(s.z, m16);
+    m16 = st_mag_dword(s.w, m16);
+    return (m16 & 0xffffu) + (m16 >> 16);
+}
+
+}  // namespace iqd

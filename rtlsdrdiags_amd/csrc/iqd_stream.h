@@ -26,8 +26,14 @@ constexpr int ST_THREADS = 64 * ST_WAVES;
 constexpr int ST_RINGS = 3;                 // = IIR waves
 constexpr int ST_P_PER_RING = 4;            // P waves feeding one ring (16 segments each)
 constexpr int ST_SEGS = 64 * ST_RINGS;      // segments per workgroup and round
-constexpr int ST_HALO = 1408;               // lead-in of a cold segment: 640 samples for the de-emphasis state to
-                                            // become exact, then FORCED_BACK = 768 of exact decimator history
+constexpr int ST_HALO = FORCED_BACK;         // lead-in of every segment, 768 samples.  A warm segment (a call's first) runs
+                                            // them from the carried exact state, which also rebuilds its decimator
+                                            // histories.  A cold one uses them for the de-emphasis state to become exact
+                                            // (checked against its predecessor's end state) and starts its decimators
+                                            // with unknown histories: the 21 PCM samples those reach into are recomputed
+                                            // from the boundary records (StHist) by wbfm_stream_fixup_kernel.
+constexpr int ST_MIN_TILE = 768;            // a segment's own end histories must not reach back before its start
+constexpr int ST_FIX_PCM = 21;              // PCM samples of a cold segment that depend on its predecessor's histories
 constexpr int ST_ROW_FLOATS = 260;          // half-table row stride (1040 B: bank = x + 4 r)
 constexpr int ST_TABLE_BYTES = 129 * ST_ROW_FLOATS * 4;
 constexpr int ST_SLOT_BYTES = 64 * 16 * 4;  // one window of one ring: 64 segments x 16 samples, f32
@@ -37,7 +43,20 @@ constexpr int ST_LDS_BYTES = ST_TABLE_BYTES + ST_RINGS * ST_RING_SLOTS * ST_SLOT
 static_assert(ST_LDS_BYTES <= 160 * 1024, "table + rings must fit the CU's LDS");
 static_assert(ST_HALO % 128 == 0 && ST_HALO + 32 <= TAIL, "the lead-in is whole 128-sample units inside the kept tail");
 
+// What a segment leaves for the boundary with its neighbours (int16 values in pairs, older sample in the low half).
+struct StHist {
+    uint32_t w_first[2];      // (int16)y of its samples 0..3
+    uint32_t y1_first[6];     // stage-1 outputs 0..11  (output 0 reaches into the predecessor: recomputed)
+    uint32_t y2_first[21];    // stage-2 outputs 0..41  (outputs 0..2 likewise)
+    uint32_t w_last[2];       // (int16)y of its last 4 samples
+    uint32_t y1_last[4];      // its last 8 stage-1 outputs
+    uint32_t y2_last[20];     // its last 40 stage-2 outputs
+    uint32_t pad[9];
+};
+static_assert(sizeof(StHist) == 256, "one boundary record per segment, 256 bytes");
+
 struct StreamArgs {
+    StHist *hist;             // [n_segments]
     const uint32_t *amat;     // [8][64][4]: tap matrices as MFMA A operands, see build_stream_amat()
     const float *half_lut;    // [129][ST_ROW_FLOATS]: |atan2(-r, x - 128)|
     uint32_t n_segments;      // n_list * tiles_per_ch

@@ -5,65 +5,9 @@
 #include "iqd_kernels.h"
 #include "iqd_stream.h"
 #include "iqd_wbfm.h"
+#include "iqd_mfma.h"
 
 namespace iqd {
-
-typedef int v4i __attribute__((ext_vector_type(4)));
-typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-
-// ---- small device helpers -----------------------------------------------------------------------
-// byte B of x replaced by its two's-complement negation, the other bytes kept (v_sub_u32_sdwa): int8
-// wrap, so -(-128) stays -128 like the reference's rotation (IqDataProcessor.cc:594-607)
-#define ST_NEG_BYTE(x, B)                                                                                     \
-    asm("v_sub_u32_sdwa %0, %1, %0 dst_sel:BYTE_" #B " dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:BYTE_" #B \
-        : "+v"(x) : "v"(zero))
-
-// raw offset-binary bytes of 8 samples -> signed bytes with the rotation's SIGNS applied in place (which
-// byte feeds which rail is folded into the tap matrices).  +Fs/4: I' = {I0,-Q1,-I2,Q3}, Q' = {Q0,I1,-Q2,-I3};
-// -Fs/4: I' = {I0,Q1,-I2,-Q3}, Q' = {Q0,-I1,-Q2,I3} (IqDataProcessor.cc:567-611).
-template <int ROT>
-__device__ __forceinline__ uint4 st_front(uint4 raw, uint32_t zero)
-{
-    uint32_t d[4] = {raw.x, raw.y, raw.z, raw.w};
-#pragma unroll
-    for (int h = 0; h < 4; h += 2) {
-        uint32_t d0 = d[h], d1 = d[h + 1];
-        if (ROT == 0) {
-            d0 ^= 0x80808080u;
-            d1 ^= 0x80808080u;
-        } else if (ROT > 0) {
-            d0 = (d0 ^ 0x7f808080u) + 0x01000000u;   // byte 3 (Q1): ~s + 1, the carry leaves the register
-            d1 ^= 0x80808080u;
-            ST_NEG_BYTE(d1, 0);
-            ST_NEG_BYTE(d1, 1);
-            ST_NEG_BYTE(d1, 2);
-        } else {
-            d0 ^= 0x80808080u;
-            ST_NEG_BYTE(d0, 2);
-            d1 = (d1 ^ 0x7f808080u) + 0x01000000u;   // byte 3 (Q3)
-            ST_NEG_BYTE(d1, 0);
-            ST_NEG_BYTE(d1, 1);
-        }
-        d[h] = d0;
-        d[h + 1] = d1;
-    }
-    return uint4{d[0], d[1], d[2], d[3]};
-}
-
-// sum over the 2 samples of a dword of signed bytes of max(|I|,|Q|) + min(|I|,|Q|)/2, added into two 16-bit
-// lanes of acc (SignalDetector.cc:227-247).  |x| of all four bytes at once: (x ^ m) + t with t the sign bits.
-__device__ __forceinline__ uint32_t st_mag_dword(uint32_t sx, uint32_t acc)
-{
-    const uint32_t t = (sx >> 7) & 0x01010101u;
-    uint32_t t8 = t << 8;
-    asm("" : "+v"(t8));                                    // (else hipcc folds this into a quarter-rate v_mul_lo_u32 by 255)
-    const uint32_t m = t8 - t;
-    const uint32_t ab = (sx ^ m) + t;                      // bytes |I0| |Q0| |I1| |Q1|, each <= 128
-    const us2 a = __builtin_bit_cast(us2, ab & 0x00ff00ffu);
-    const us2 b = __builtin_bit_cast(us2, (ab >> 8) & 0x00ff00ffu);
-    const us2 mx = __builtin_elementwise_max(a, b), mn = __builtin_elementwise_min(a, b);
-    return acc + __builtin_bit_cast(uint32_t, mx) + __builtin_bit_cast(uint32_t, (us2)(mn >> 1));
-}
 
 __device__ __forceinline__ uint32_t lds_load_relaxed(const uint32_t *p)
 {
@@ -158,9 +102,23 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
             return *(const uint4 *)(base + 2 * (int64_t)pc);
         };
 
-        float last_prev = 0.f;                                   // theta'[3] of this lane's previous window
         uint4 prev = st_front<ROT>(load_piece(-ST_HALO - 32), zero);
         uint4 raw_next = load_piece(-ST_HALO);
+        // theta' of the sample before the lead-in (a warm segment's carried state applies from the lead-in's very first
+        // sample, whose delta theta needs it): the last output of the piece before, from that piece's "N" window
+        float last_prev;                                         // theta'[3] of this lane's previous window
+        {
+            const v4i bn = v4i{(int)prev.x, (int)prev.y, (int)prev.z, (int)prev.w};
+            const v4i ilo = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[0], bn, cbias, 0, 0, 0);
+            const v4i ihi = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[1], bn, czero, 0, 0, 0);
+            const v4i qlo = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[2], bn, cbias, 0, 0, 0);
+            const v4i qhi = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[3], bn, czero, 0, 0, 0);
+            const uint32_t ti = (uint32_t)ilo[3] + ((uint32_t)ihi[3] << 8), tq = (uint32_t)qlo[3] + ((uint32_t)qhi[3] << 8);
+            uint32_t rr;
+            asm("v_msad_u8 %0, %1, %2, 0" : "=v"(rr) : "v"(tq), "s"(0x00800000u));
+            const uint32_t t = *(const uint32_t *)(lds + rr * (uint32_t)(ST_ROW_FLOATS * 4) + (bfe(ti, 16, 8) << 2));
+            last_prev = u2f((t & 0x7fffffffu) | ((tq << 8) & 0x80000000u));
+        }
         for (int q = 0; q < n_pieces; q++) {
             const int pos = -ST_HALO + 32 * q;
             const uint4 cur = st_front<ROT>(raw_next, zero);
@@ -263,6 +221,7 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
 struct StIir {
     float y, up;
     uint32_t wlast[2];     // the last 4 (int16)y
+    uint32_t wq0[2];       // the first 4 (int16)y of the window just processed
     uint32_t y1h[4];       // the last 8 stage-1 outputs
     uint32_t y2p[24];      // stage-2 outputs as pairs; variant V of a piece uses [V+1 .. V+20]
     uint32_t y2lo;         // first stage-2 output of the current piece
@@ -290,6 +249,8 @@ __device__ __forceinline__ int st_iir_window(const StreamArgs &sa, StIir &s, con
     for (int k = 0; k < 8; k++) wq[2 + k] = pack_lo16(wv[2 * k], wv[2 * k + 1]);
     s.wlast[0] = wq[8];
     s.wlast[1] = wq[9];
+    s.wq0[0] = wq[2];
+    s.wq0[1] = wq[3];
     uint32_t y1[4];
 #pragma unroll
     for (int o = 0; o < 4; o++) {                      // window x[4m-4 .. 4m+3] <-> taps h[7 .. 0]
@@ -338,6 +299,7 @@ struct StIirSeg {
     int32_t rec_pos;
     WbfmRecord rec;
     int16_t *pcm_row;
+    StHist *hist;          // this segment's boundary record
 };
 
 __device__ __forceinline__ void st_iir_marks(StIirSeg &q, StIir &s, int pos)
@@ -345,11 +307,22 @@ __device__ __forceinline__ void st_iir_marks(StIirSeg &q, StIir &s, int pos)
     if (q.back >= 0) {                                 // warm segment: silence before the carried state applies
         if (pos == -q.back) { s.y = q.cy_y; s.up = q.cy_u; }
         else if (pos < -q.back) { s.y = 0.f; s.up = 0.f; }
-    } else if (pos == -FORCED_BACK) {
+    } else if (pos == 0) {                             // cold segment: the warmed-up state, checked against the predecessor's end
         q.rec.y_in = s.y;
     }
     if (pos == q.rec_pos) { q.rec.y_out = s.y; q.rec.u_out = s.up; }
-    if (pos == q.sg.tlen) { q.rec.y_end = s.y; q.rec.u_end = s.up; }
+    if (pos == q.sg.tlen) {                            // (a multiple of 128: the pair history sits in y2p[0..19] here)
+        q.rec.y_end = s.y;
+        q.rec.u_end = s.up;
+        if (q.sg.valid) {
+            q.hist->w_last[0] = s.wlast[0];
+            q.hist->w_last[1] = s.wlast[1];
+#pragma unroll
+            for (int k = 0; k < 4; k++) q.hist->y1_last[k] = s.y1h[k];
+#pragma unroll
+            for (int k = 0; k < 20; k++) q.hist->y2_last[k] = s.y2p[k];
+        }
+    }
 }
 
 template <int V>
@@ -374,11 +347,17 @@ __device__ __forceinline__ int st_iir_piece(const StreamArgs &sa, uint8_t *ring_
         wg++;
         st_iir_marks(q, s, wpos);
         const int y2 = st_iir_window(sa, s, u);
+        if (wpos >= 0 && wpos < 48 && q.sg.valid) {    // (uniform) the segment's first values, for the boundary fix-up
+            if (wpos == 0) { q.hist->w_first[0] = s.wq0[0]; q.hist->w_first[1] = s.wq0[1]; }
+            q.hist->y1_first[wpos >> 3] = s.y1h[2];
+            q.hist->y1_first[(wpos >> 3) + 1] = s.y1h[3];
+        }
         const uint32_t mag = (uint32_t)(y2 < 0 ? -y2 : y2);
         if (mag > (uint32_t)AUDIO40_SAFE) s.loud = 21;
         if (half == 0) s.y2lo = (uint32_t)y2;
         else s.y2p[V + 20] = pack_lo16(s.y2lo, (uint32_t)y2);
     }
+    if (pos >= 0 && pos < 32 * ST_FIX_PCM && q.sg.valid) q.hist->y2_first[pos >> 5] = s.y2p[V + 20];
     const bool quiet = !__any(s.loud > 0);
     const int pcm = quiet ? st_audio<V>(sa, s, true) : st_audio<V>(sa, s, false);
     if (s.loud > 0) s.loud--;
@@ -399,6 +378,7 @@ __device__ __forceinline__ void st_iir_wave(const ChainLaunch &a, const StreamAr
         StIirSeg q;
         q.sg = st_segment(a, sid, sa.n_segments);
         q.pcm_row = a.pcm + (size_t)q.sg.ch * a.pcm_stride;
+        q.hist = sa.hist + (q.sg.valid ? (size_t)q.sg.li * a.tiles_per_ch + q.sg.tile : 0);
         q.back = -1;
         q.cy_y = q.cy_u = 0.f;
         int32_t halo = ST_HALO;
@@ -421,6 +401,7 @@ __device__ __forceinline__ void st_iir_wave(const ChainLaunch &a, const StreamAr
         StIir s;
         s.y = 0.f; s.up = 0.f;
         s.wlast[0] = s.wlast[1] = 0;
+        s.wq0[0] = s.wq0[1] = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) s.y1h[k] = 0;
 #pragma unroll
@@ -456,6 +437,84 @@ __global__ __launch_bounds__(ST_THREADS, 4) void wbfm_stream_kernel(const ChainL
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     if (wave < ST_RINGS) st_iir_wave(a, sa, st_lds, sync, wave, lane);
     else st_p_wave<ROT, MAG>(a, sa, st_lds, sync, wave - ST_RINGS, lane);
+}
+
+// The first ST_FIX_PCM PCM samples of every cold segment, recomputed with the exact histories its predecessor left
+// (StHist): stage-1 output 0, stage-2 outputs 0..2, then the 40-tap audio decimator in the reference's MAC order with
+// the clamp after every MAC (Decimator_int16.cc:176-238) - which is also what the clamp-free fast path equals when
+// no clamp can fire.  A workgroup takes 8 consecutive segments: their 9 records (the predecessor of the first
+// included) are one contiguous 2304-byte read into LDS; then one thread per segment and PCM sample.
+constexpr int FIX_SEGS = 8;
+__global__ __launch_bounds__(32 * FIX_SEGS) void wbfm_stream_fixup_kernel(const ChainLaunch a, const StreamArgs sa)
+{
+    __shared__ uint32_t rec[(FIX_SEGS + 1) * 64];
+    __shared__ uint32_t y2x[FIX_SEGS][41];             // per segment: stage-2 pairs -40 .. 41 with the boundary ones exact
+    const uint32_t sid0 = blockIdx.x * FIX_SEGS;
+    const int tid = (int)threadIdx.x, sl = tid >> 5, i = tid & 31;
+    {
+        const uint32_t *src = (const uint32_t *)sa.hist + ((size_t)sid0 - (sid0 ? 1 : 0)) * 64;
+        const uint32_t n_avail = (sa.n_segments - sid0 < (uint32_t)FIX_SEGS ? sa.n_segments - sid0 : (uint32_t)FIX_SEGS) + (sid0 ? 1u : 0u);
+        for (uint32_t k = (uint32_t)tid; k < n_avail * 64; k += 32 * FIX_SEGS) rec[k + (sid0 ? 0 : 64)] = src[k];
+    }
+    __syncthreads();
+    const uint32_t sid = sid0 + (uint32_t)sl;
+    const StSeg sg = st_segment(a, sid < sa.n_segments ? sid : 0u, sa.n_segments);
+    const bool live = sid < sa.n_segments && sg.valid && sg.tile != 0;
+    const StHist &prev = *(const StHist *)&rec[sl * 64], &own = *(const StHist *)&rec[(sl + 1) * 64];
+    if (live && i < 3) {                               // stage-2 output i (0..2) of the segment, from y1[4i-8 .. 4i+3]
+        int acc = 1 << 14;                             // stage-1 output 0: w[-4 .. 3]
+        acc = dot2(prev.w_last[0], sa.d1p[0], acc);
+        acc = dot2(prev.w_last[1], sa.d1p[1], acc);
+        acc = dot2(own.w_first[0], sa.d1p[2], acc);
+        acc = dot2(own.w_first[1], sa.d1p[3], acc);
+        uint32_t y1[10];                               // pairs: outputs -8 .. 11
+#pragma unroll
+        for (int k = 0; k < 4; k++) y1[k] = prev.y1_last[k];
+#pragma unroll
+        for (int k = 0; k < 6; k++) y1[4 + k] = own.y1_first[k];
+        y1[4] = (y1[4] & 0xffff0000u) | ((uint32_t)(acc >> 15) & 0xffffu);
+        int s2 = 1 << 14;
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            const uint32_t d = i == 0 ? y1[5 - q] : (i == 1 ? y1[7 - q] : y1[9 - q]);   // pairs 2i .. 2i+5, newest first
+            s2 = dot2(d, sa.p12p[q], s2);
+        }
+        ((int16_t *)&y2x[sl][20])[i] = (int16_t)(s2 >> 15);   // outputs 0, 1 -> pair 20; output 2 -> low half of pair 21
+    } else if (live) {                                 // the other pairs as they are (each thread a few)
+        for (int p = i - 3; p < 41; p += 29) {
+            if (p == 20) continue;
+            if (p == 21) ((int16_t *)&y2x[sl][21])[1] = (int16_t)(own.y2_first[1] >> 16);
+            else y2x[sl][p] = p < 20 ? prev.y2_last[p] : own.y2_first[p - 20];
+        }
+    }
+    // Hand-off verification of the same segments (what wbfm_verify_kernel does for tile launches): a cold segment's
+    // warmed-up state at its start must be its predecessor's end state, bit for bit.  Only mismatches touch the
+    // device counters (thousands of workgroups adding to one word would cost more than the whole kernel); the host
+    // knows how many hand-offs a launch has.
+    if (live && i == 31) {
+        const WbfmRecord *r = a.records + (size_t)sg.li * a.tiles_per_ch;
+        if (!iir_states_agree(r[sg.tile].y_in, r[sg.tile - 1].y_end, a.params[sg.ech].wbfm_k >= 1.0f)) {
+            atomicAdd(&a.counters[CNT_TILE_MISMATCH], 1u);
+            atomicAdd(&a.counters[CNT_STREAM_MISMATCH], 1u);
+            a.repair_flags[sg.li] = 1;
+        }
+    }
+    if (!live || i >= ST_FIX_PCM || i >= sg.tlen / 32) return;
+    // PCM i from stage-2 outputs 2i-38 .. 2i+1: pairs i+1 .. i+20, newest first
+    int s3 = 1 << 14;
+#pragma unroll
+    for (int q = 0; q < 20; q++) {
+        const uint32_t pair = y2x[sl][20 + i - q];
+        s3 = clamp_q30(dot2(pair, sa.a40p[q] & 0xffff0000u, s3));
+        s3 = clamp_q30(dot2(pair, sa.a40p[q] & 0x0000ffffu, s3));
+    }
+    a.pcm[(size_t)sg.ch * a.pcm_stride + (sg.v0 >> 5) + i] = (int16_t)(s3 >> 15);
+}
+
+hipError_t launch_wbfm_stream_fixup(const ChainLaunch &a, const StreamArgs &sa, hipStream_t s)
+{
+    hipLaunchKernelGGL(wbfm_stream_fixup_kernel, dim3((sa.n_segments + FIX_SEGS - 1) / FIX_SEGS), dim3(32 * FIX_SEGS), 0, s, a, sa);
+    return hipGetLastError();
 }
 
 hipError_t launch_wbfm_stream(const ChainLaunch &a, const StreamArgs &sa, int rotation, bool mag, uint32_t grid, hipStream_t s)
