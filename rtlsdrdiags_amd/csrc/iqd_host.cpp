@@ -256,7 +256,7 @@ TilePlan plan_stream(uint32_t vlen, uint32_t n_channels, uint32_t streams)
     uint32_t per_ch = n_channels ? (streams + n_channels - 1) / n_channels : 1;
     if (per_ch == 0) per_ch = 1;
     uint64_t len = ((uint64_t)vlen + per_ch - 1) / per_ch;
-    len = (len + 127) / 128 * 128;
+    len = (len + 511) / 512 * 512;              // whole 32-byte PCM sectors per segment (16 PCM samples)
     if (len < ST_MIN_TILE) len = ST_MIN_TILE;   // a segment's end histories must be its own
     p.tile_len = (uint32_t)len;
     p.tiles_per_ch = (uint32_t)(((uint64_t)vlen + len - 1) / len);

@@ -44,14 +44,14 @@ static_assert(ST_LDS_BYTES <= 160 * 1024, "table + rings must fit the CU's LDS")
 static_assert(ST_HALO % 128 == 0 && ST_HALO + 32 <= TAIL, "the lead-in is whole 128-sample units inside the kept tail");
 
 // What a segment leaves for the boundary with its neighbours (int16 values in pairs, older sample in the low half).
-struct StHist {
+struct StHist {               // (every member 16-byte aligned: the IIR lanes write it with a few wide stores)
     uint32_t w_first[2];      // (int16)y of its samples 0..3
     uint32_t y1_first[6];     // stage-1 outputs 0..11  (output 0 reaches into the predecessor: recomputed)
-    uint32_t y2_first[21];    // stage-2 outputs 0..41  (outputs 0..2 likewise)
-    uint32_t w_last[2];       // (int16)y of its last 4 samples
+    uint32_t y2_first[24];    // stage-2 outputs 0..47  (outputs 0..2 likewise; 0..41 are used)
     uint32_t y1_last[4];      // its last 8 stage-1 outputs
+    uint32_t w_last[2];       // (int16)y of its last 4 samples
+    uint32_t pad[6];
     uint32_t y2_last[20];     // its last 40 stage-2 outputs
-    uint32_t pad[9];
 };
 static_assert(sizeof(StHist) == 256, "one boundary record per segment, 256 bytes");
 

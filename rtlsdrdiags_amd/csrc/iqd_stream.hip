@@ -315,12 +315,10 @@ __device__ __forceinline__ void st_iir_marks(StIirSeg &q, StIir &s, int pos)
         q.rec.y_end = s.y;
         q.rec.u_end = s.up;
         if (q.sg.valid) {
-            q.hist->w_last[0] = s.wlast[0];
-            q.hist->w_last[1] = s.wlast[1];
+            *(u32x4 *)q.hist->y1_last = u32x4{s.y1h[0], s.y1h[1], s.y1h[2], s.y1h[3]};
+            *(u32x2 *)q.hist->w_last = u32x2{s.wlast[0], s.wlast[1]};
 #pragma unroll
-            for (int k = 0; k < 4; k++) q.hist->y1_last[k] = s.y1h[k];
-#pragma unroll
-            for (int k = 0; k < 20; k++) q.hist->y2_last[k] = s.y2p[k];
+            for (int k = 0; k < 20; k += 4) *(u32x4 *)&q.hist->y2_last[k] = u32x4{s.y2p[k], s.y2p[k + 1], s.y2p[k + 2], s.y2p[k + 3]};
         }
     }
 }
@@ -348,16 +346,16 @@ __device__ __forceinline__ int st_iir_piece(const StreamArgs &sa, uint8_t *ring_
         st_iir_marks(q, s, wpos);
         const int y2 = st_iir_window(sa, s, u);
         if (wpos >= 0 && wpos < 48 && q.sg.valid) {    // (uniform) the segment's first values, for the boundary fix-up
-            if (wpos == 0) { q.hist->w_first[0] = s.wq0[0]; q.hist->w_first[1] = s.wq0[1]; }
-            q.hist->y1_first[wpos >> 3] = s.y1h[2];
-            q.hist->y1_first[(wpos >> 3) + 1] = s.y1h[3];
+            if (wpos == 0) *(u32x4 *)q.hist->w_first = u32x4{s.wq0[0], s.wq0[1], s.y1h[2], s.y1h[3]};   // (w_first, y1_first[0..1])
+            else *(u32x2 *)&q.hist->y1_first[wpos >> 3] = u32x2{s.y1h[2], s.y1h[3]};
         }
         const uint32_t mag = (uint32_t)(y2 < 0 ? -y2 : y2);
         if (mag > (uint32_t)AUDIO40_SAFE) s.loud = 21;
         if (half == 0) s.y2lo = (uint32_t)y2;
         else s.y2p[V + 20] = pack_lo16(s.y2lo, (uint32_t)y2);
     }
-    if (pos >= 0 && pos < 32 * ST_FIX_PCM && q.sg.valid) q.hist->y2_first[pos >> 5] = s.y2p[V + 20];
+    if (V == 3 && pos >= 96 && pos < 768 && q.sg.valid)   // the four pairs of this run of 128 samples (pos = its last piece)
+        *(u32x4 *)&q.hist->y2_first[(pos - 96) >> 5] = u32x4{s.y2p[20], s.y2p[21], s.y2p[22], s.y2p[23]};
     const bool quiet = !__any(s.loud > 0);
     const int pcm = quiet ? st_audio<V>(sa, s, true) : st_audio<V>(sa, s, false);
     if (s.loud > 0) s.loud--;
@@ -408,15 +406,40 @@ __device__ __forceinline__ void st_iir_wave(const ChainLaunch &a, const StreamAr
         for (int k = 0; k < 24; k++) s.y2p[k] = 0;
         s.y2lo = 0;
         s.loud = 0;
+        uint32_t pbuf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        // wide stores need whole 512-sample groups per lane (tile_len a multiple of 512) and 32-byte aligned rows
+        const bool wide = (a.tile_len & 511u) == 0 && (((uintptr_t)a.pcm | (a.pcm_stride * 2)) & 31u) == 0;
         for (int pq = 0; pq < n_pieces; pq += 4) {
             const int pos = -ST_HALO + 32 * pq;
             const int p0 = st_iir_piece<0>(sa, ring_base, full, consumed, wg, q, s, pos, rd_off0, rd_swz, lane);
             const int p1 = st_iir_piece<1>(sa, ring_base, full, consumed, wg, q, s, pos + 32, rd_off0, rd_swz, lane);
             const int p2 = st_iir_piece<2>(sa, ring_base, full, consumed, wg, q, s, pos + 64, rd_off0, rd_swz, lane);
             const int p3 = st_iir_piece<3>(sa, ring_base, full, consumed, wg, q, s, pos + 96, rd_off0, rd_swz, lane);
-            // 128 samples = 4 PCM samples = one 8-byte store (segments start and end on multiples of 128)
-            if (q.sg.valid && pos >= 0 && pos < q.sg.tlen)
-                *(u32x2 *)(q.pcm_row + ((q.sg.v0 + pos) >> 5)) = u32x2{pack_lo16((uint32_t)p0, (uint32_t)p1), pack_lo16((uint32_t)p2, (uint32_t)p3)};
+            // 128 samples = 4 PCM samples = 8 bytes.  Where the row allows it they are collected over 512 samples and
+            // leave as one aligned 32-byte sector (segments start on multiples of 512 samples of their channel's
+            // stream, so the phase below is the same for every lane); else 8 bytes at a time.
+            const uint32_t w0 = pack_lo16((uint32_t)p0, (uint32_t)p1), w1 = pack_lo16((uint32_t)p2, (uint32_t)p3);
+            const int phase = (pos >> 7) & 3;
+            if (phase == 0) { pbuf[0] = w0; pbuf[1] = w1; }
+            else if (phase == 1) { pbuf[2] = w0; pbuf[3] = w1; }
+            else if (phase == 2) { pbuf[4] = w0; pbuf[5] = w1; }
+            else { pbuf[6] = w0; pbuf[7] = w1; }
+            if (q.sg.valid) {
+                if (!wide) {
+                    if (pos >= 0 && pos < q.sg.tlen) *(u32x2 *)(q.pcm_row + ((q.sg.v0 + pos) >> 5)) = u32x2{w0, w1};
+                } else if (phase == 3) {
+                    const int g0 = pos - 384;                    // the group [g0, g0 + 512)
+                    int16_t *dst = q.pcm_row + ((q.sg.v0 + g0) >> 5);
+                    if (g0 >= 0 && g0 + 512 <= q.sg.tlen) {
+                        ((u32x4 *)dst)[0] = u32x4{pbuf[0], pbuf[1], pbuf[2], pbuf[3]};
+                        ((u32x4 *)dst)[1] = u32x4{pbuf[4], pbuf[5], pbuf[6], pbuf[7]};
+                    } else {                                     // a segment's ragged end (or the lead-in): quarter by quarter
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                            if (g0 + 128 * k >= 0 && g0 + 128 * k < q.sg.tlen) ((u32x2 *)dst)[k] = u32x2{pbuf[2 * k], pbuf[2 * k + 1]};
+                    }
+                }
+            }
 #pragma unroll
             for (int k = 0; k < 20; k++) s.y2p[k] = s.y2p[k + 4];
         }

@@ -66,9 +66,16 @@ def main():
                 d[k + "_over_WAVE_CYCLES"] = counters[k] / wc
     if "SQ_LDS_BANK_CONFLICT" in counters and counters.get("SQ_LDS_IDX_ACTIVE"):
         d["lds_conflict_share"] = counters["SQ_LDS_BANK_CONFLICT"] / counters["SQ_LDS_IDX_ACTIVE"]
-    if "SQ_ACTIVE_INST_VALU" in counters and "SQ_BUSY_CYCLES" in counters and res.get("kernel_ms_avg"):
+    if counters.get("GRBM_GUI_ACTIVE") and res.get("kernel_ms_avg"):
+        # rocprofv3 sums the 8 XCDs (MI355X_MICROARCH.md, DVFS give-back); the PMC passes run a little slower than the trace
+        res["clock_ghz"] = round(counters["GRBM_GUI_ACTIVE"] / 8 / (res["kernel_ms_avg"] * 1e-3) / 1e9, 3)
+    if "SQ_ACTIVE_INST_VALU" in counters and res.get("kernel_ms_avg"):
         # SQ_ACTIVE_INST_VALU counts quad-cycles over all SIMDs; 1024 SIMDs on the chip
-        d["valu_busy_ms_at_2p3GHz_per_simd"] = counters["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / 2.3e9 * 1e3
+        ghz = res.get("clock_ghz", 2.3)
+        d["valu_busy_ms_per_simd"] = counters["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (ghz * 1e9) * 1e3
+        d["valu_issue_frac"] = d["valu_busy_ms_per_simd"] / res["kernel_ms_avg"]
+    if counters.get("SQ_INSTS_MFMA"):
+        d["mfma_per_kilosample"] = counters["SQ_INSTS_MFMA"] / samples * 1000
     res["derived"] = d
     txt = json.dumps(res, indent=1)
     if out:
