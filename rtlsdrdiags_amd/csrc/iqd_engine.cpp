@@ -66,6 +66,7 @@ struct iqd_engine {
     bool lists_dirty = true;
     uint32_t list_first = 0, list_n = 0;
     std::vector<uint32_t> h_lists[FAM_COUNT + 1];  // per family; [FAM_COUNT] = mode None
+    uint32_t rot_count[FAM_COUNT][3] = {};         // channels of each family per rotation group (+Fs/4, none, -Fs/4)
     uint32_t n_cus = 256;
     size_t dcr_layout[2][2] = {{~(size_t)0, 0}, {~(size_t)0, 0}};   // AM / SSB: where the DC redo flags sit in their buffer, and how many
     bool any_gated = false, any_agc = false;
@@ -94,6 +95,9 @@ struct iqd_engine {
     float *d_atan = nullptr, *d_fmlut = nullptr;
     float *d_half_lut = nullptr;         // streaming WBFM kernel: |atan2| half table, tap matrices per rotation (-1, 0, +1)
     uint32_t *d_amat[3] = {nullptr, nullptr, nullptr};
+    uint32_t *d_amat4 = nullptr;         // FM tuner / AM-SSB stage 1 as MFMA operands: [fm: 3 rotations][am: 3 rotations][4][64][4]
+    D4Args d4_args{};
+    std::vector<float> fm_kmax;          // [n_ch]: like wbfm_kmax, for the FM chain
     bool stream_ok = false;              // the half table's symmetry holds on this host's libm
     std::vector<float> wbfm_kmax;        // [n_ch]: largest |K| a channel has run with since creation (casts stay bounded)
     StreamArgs stream_args{};
@@ -247,6 +251,14 @@ int iqd_create(const iqd_config *cfg, iqd_t **out)
             build_stream_amat(r - 1, pre, amat[r].data());
         }
     }
+    std::vector<uint32_t> amat4((size_t)2 * 3 * 4 * 64 * 4, 0u);
+    for (int r = 0; r < 3; r++) {
+        build_decim4_amat(r - 1, e->consts.fm_tuner, 32, amat4.data() + (size_t)r * 4 * 64 * 4);
+        build_decim4_amat(r - 1, e->consts.am_s1, 8, amat4.data() + (size_t)(3 + r) * 4 * 64 * 4);
+    }
+    build_d4_taps(e->consts, e->d4_args);
+    e->fm_kmax.resize(e->n_ch);
+    for (uint32_t c = 0; c < e->n_ch; c++) e->fm_kmax[c] = fabsf(e->h_params[c].fm_k);
     build_stream_taps(e->consts.wbfm_d1, e->consts.post12, e->consts.audio40, e->stream_args);
     e->stream_args.b0 = e->consts.deemph_b0;
     e->stream_args.a1 = e->consts.deemph_a1;
@@ -269,6 +281,7 @@ int iqd_create(const iqd_config *cfg, iqd_t **out)
     ok = ok && hipMalloc((void **)&e->d_fmlut, fm_lut.size() * sizeof(float)) == hipSuccess;
     ok = ok && hipMalloc((void **)&e->d_half_lut, half_lut.size() * sizeof(float)) == hipSuccess;
     for (int r = 0; r < 3; r++) ok = ok && hipMalloc((void **)&e->d_amat[r], amat[r].size() * sizeof(uint32_t)) == hipSuccess;
+    ok = ok && hipMalloc((void **)&e->d_amat4, amat4.size() * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc((void **)&e->d_counters, CNT_COUNT * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMemset(e->d_counters, 0, CNT_COUNT * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc((void **)&e->d_stamps, 16 * sizeof(unsigned long long)) == hipSuccess;
@@ -293,6 +306,8 @@ int iqd_create(const iqd_config *cfg, iqd_t **out)
         for (int r = 0; r < 3; r++)
             ok = ok && hipMemcpyAsync(e->d_amat[r], amat[r].data(), amat[r].size() * sizeof(uint32_t),
                                       hipMemcpyHostToDevice, e->stream) == hipSuccess;
+        ok = ok && hipMemcpyAsync(e->d_amat4, amat4.data(), amat4.size() * sizeof(uint32_t), hipMemcpyHostToDevice,
+                                  e->stream) == hipSuccess;
         ok = ok && upload_consts(e->consts, e->stream) == hipSuccess;
         ok = ok && hipStreamSynchronize(e->stream) == hipSuccess;
     }
@@ -310,7 +325,7 @@ void iqd_destroy(iqd_t *e)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     void *ptrs[] = {e->d_params, e->d_tails, e->d_wcarry, e->d_dc, e->d_tracker, e->d_agc_cfg, e->d_agc, e->d_epochs, e->d_scan_cfg, e->d_scan,
-                    e->d_atan, e->d_fmlut, e->d_counters, e->d_stamps, e->d_half_lut, e->d_amat[0], e->d_amat[1], e->d_amat[2]};
+                    e->d_atan, e->d_fmlut, e->d_counters, e->d_stamps, e->d_half_lut, e->d_amat[0], e->d_amat[1], e->d_amat[2], e->d_amat4};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     if (e->h_counters) (void)hipHostFree(e->h_counters);
@@ -358,8 +373,9 @@ int iqd_set_gain(iqd_t *e, uint32_t first_ch, uint32_t n_ch, int demod, float ga
     for (uint32_t c = first_ch; c < first_ch + n_ch; c++) {
         e->h_params[c].gain[fam[demod]] = gain;
         derive_params(e->h_params[c]);
-        const float ak = fabsf(e->h_params[c].wbfm_k);
+        const float ak = fabsf(e->h_params[c].wbfm_k), fk = fabsf(e->h_params[c].fm_k);
         if (!(ak <= e->wbfm_kmax[c])) e->wbfm_kmax[c] = ak;   // (NaN included: never "bounded" again)
+        if (!(fk <= e->fm_kmax[c])) e->fm_kmax[c] = fk;
     }
     e->params_dirty = true;
     return IQD_OK;
@@ -974,6 +990,15 @@ static void rebuild_lists(iqd_t *e, uint32_t first_ch, uint32_t n_ch)
         if (!squelch_always_open(worst, e->consts)) e->any_gated = true;
         if (e->h_agc[first_ch + c].enabled) e->any_agc = true;
     }
+    // Each family's channels in the order +Fs/4, no rotation, -Fs/4: the streaming kernels want the segments of one
+    // rotation selector next to each other (a P wave's 16 segments share tap matrices); nothing else minds the order.
+    for (int f = 0; f < FAM_COUNT; f++) {
+        auto &l = e->h_lists[f];
+        auto grp = [&](uint32_t c) { return 1 - e->h_params[first_ch + c].rotation; };
+        std::stable_sort(l.begin(), l.end(), [&](uint32_t x, uint32_t y) { return grp(x) < grp(y); });
+        for (int r = 0; r < 3; r++) e->rot_count[f][r] = 0;
+        for (uint32_t c : l) e->rot_count[f][grp(c)]++;
+    }
     e->list_first = first_ch;
     e->list_n = n_ch;
     e->lists_dirty = false;
@@ -1155,6 +1180,42 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
                 use_stream = true;
             }
         }
+        // FM / AM / SSB: the streaming pipelines of iqd_stream2.hip under the same conditions (channels of different
+        // rotation selectors are fine here: the list is sorted by selector and the groups are padded)
+        bool use_d4 = false;
+        uint32_t d4_wgs = e->n_cus;
+        D4Args d4 = e->d4_args;
+        if (f != FAM_WBFM && !gated && !(e->flags & IQD_F_WBFM_TILES) && vlen % 128 == 0 && (f == FAM_FM || vlen / 32 > 512)) {
+            bool ok = true;
+            if (f == FAM_FM)
+                for (uint32_t c : e->h_lists[f]) ok = ok && e->fm_kmax[first_ch + c] * 6.35f < 2147483648.0f;
+            int want = 0;
+            if (e->flags & IQD_F_WBFM_STREAM) want = 1;
+            if (const char *env = getenv("IQD_WBFM_PATH")) want = env[0] == 's' ? 1 : env[0] == 't' ? -1 : want;
+            const uint64_t work = (uint64_t)vlen * n_list;
+            if (ok && want >= 0 && (want > 0 || work >= (uint64_t)e->n_cus * ST_SEGS * 2048)) {
+                d4_wgs = e->n_cus;
+                for (uint32_t spare = 0;; spare += 48) {   // (the rotation groups' padding may push an exact fit into a second round)
+                    const TilePlan sp = plan_stream(vlen, n_list, d4_wgs * ST_SEGS - spare);
+                    a.tile_len = sp.tile_len;
+                    a.tiles_per_ch = sp.tiles_per_ch;
+                    uint32_t at = 0, li0 = 0;
+                    for (int r = 0; r < 3; r++) {
+                        d4.group_start[r] = at;
+                        d4.group_li0[r] = li0;
+                        d4.group_nseg[r] = e->rot_count[f][r] * a.tiles_per_ch;
+                        at += (d4.group_nseg[r] + 15u) / 16u * 16u;
+                        li0 += e->rot_count[f][r];
+                    }
+                    d4.group_start[3] = at;
+                    if (at <= d4_wgs * ST_SEGS || spare >= 48 || n_list * 1u >= d4_wgs * ST_SEGS) break;
+                }
+                d4.amat = e->d_amat4 + (size_t)(f == FAM_FM ? 0 : 3) * 4 * 64 * 4;
+                d4.fm_lut = e->d_fmlut;
+                d4.halo = f == FAM_FM ? D4_HALO_FM : (f == FAM_AM ? D4_HALO_AM : D4_HALO_SSB);
+                use_d4 = true;
+            }
+        }
         if (e->profiling && !timed) {
             if (e->ev_free_pairs.empty()) {
                 hipEvent_t a0, a1;
@@ -1193,7 +1254,39 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
                 HIP_TRY(e, launch_wbfm(a, gated, fused_mag, n_list * a.tiles_per_ch, s));
             }
         } else if (f == FAM_FM) {
-            HIP_TRY(e, launch_fm(a, gated, fused_mag, n_list * a.tiles_per_ch, s));
+            if (use_d4) {
+                const uint32_t wgs_needed = (d4.group_start[3] + ST_SEGS - 1) / ST_SEGS;
+                const uint32_t grid = wgs_needed < d4_wgs ? wgs_needed : d4_wgs;
+                d4.rounds = (wgs_needed + grid - 1) / grid;
+                HIP_TRY(e, launch_d4_stream(a, d4, D4_FM, fused_mag, grid, s));
+                e->stats.stream_launches++;
+            } else {
+                HIP_TRY(e, launch_fm(a, gated, fused_mag, n_list * a.tiles_per_ch, s));
+            }
+        } else if (use_d4) {
+            HIP_TRY(e, e->base8k.ensure((size_t)n_ch * base.pcm_stride * sizeof(int32_t)));
+            a.base8k = e->base8k.as<int32_t>();
+            a.base_stride_ch = base.pcm_stride;   // channel-major (rows longer than 512 PCM samples)
+            a.base_stride_t = 1;
+            a.dc_tiles = (uint32_t)((base.pcm_stride + DC_TILE - 1) / DC_TILE);
+            DevBuf &dcr = f == FAM_SSB ? e->dc_records2 : e->dc_records;
+            {
+                const size_t rec_bytes = (size_t)n_list * a.dc_tiles * sizeof(DcRecord);
+                const bool grown = dcr.cap < rec_bytes + n_list * sizeof(uint32_t);
+                HIP_TRY(e, dcr.ensure(rec_bytes + n_list * sizeof(uint32_t)));
+                a.dc_records = dcr.p;
+                if (grown || dcr_layout[f == FAM_SSB][0] != rec_bytes || dcr_layout[f == FAM_SSB][1] < n_list) {
+                    HIP_TRY(e, hipMemsetAsync((char *)dcr.p + rec_bytes, 0, n_list * sizeof(uint32_t), s));
+                    dcr_layout[f == FAM_SSB][0] = rec_bytes;
+                    dcr_layout[f == FAM_SSB][1] = n_list;
+                }
+            }
+            const uint32_t wgs_needed = (d4.group_start[3] + ST_SEGS - 1) / ST_SEGS;
+            const uint32_t grid = wgs_needed < d4_wgs ? wgs_needed : d4_wgs;
+            d4.rounds = (wgs_needed + grid - 1) / grid;
+            HIP_TRY(e, launch_d4_stream(a, d4, f == FAM_AM ? D4_AM : D4_SSB, fused_mag, grid, s));
+            HIP_TRY(e, launch_am_dc(a, f, s));
+            e->stats.stream_launches++;
         } else {
             HIP_TRY(e, e->base8k.ensure((size_t)n_ch * base.pcm_stride * sizeof(int32_t)));
             a.base8k = e->base8k.as<int32_t>();

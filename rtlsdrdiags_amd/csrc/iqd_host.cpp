@@ -219,6 +219,46 @@ void build_stream_amat(int rotation, const int16_t *pre_q15, uint32_t *out)
             }
 }
 
+// A operands of the /4 first stages of the FM (32 taps) and AM/SSB (8 taps) chains (iqd_stream2.hip).  Output row
+// 4 g' + r of the MFMA is output m = 2 g' + (r >> 1) of the 32-sample piece, rail r & 1 (0 = I', 1 = Q'); byte j of
+// lane group g of the data operand is sample 8 g + j / 2, component j & 1, of this piece ([0], [1]) or of the
+// previous one ([2], [3]).
+void build_decim4_amat(int rotation, const int16_t *taps_q15, int ntaps, uint32_t *out)
+{
+    for (int which = 0; which < 2; which++)
+        for (int plane = 0; plane < 2; plane++) {
+            uint32_t *m = out + (size_t)(2 * which + plane) * 64 * 4;
+            for (int lane = 0; lane < 64; lane++) {
+                const int rho = lane & 15, g = lane >> 4;
+                const int mo = 2 * (rho >> 2) + ((rho & 3) >> 1), rail = rho & 1;
+                for (int j = 0; j < 16; j++) {
+                    const int i_rel = 8 * g + (j >> 1) - (which ? 32 : 0);
+                    const int k = 4 * mo + 3 - i_rel;                 // y[m] = sum h[k] x[4m+3-k]
+                    const int phase = ((i_rel % 4) + 4) % 4, comp = j & 1;
+                    const bool feeds_i = rotation == 0 ? comp == 0 : comp == (phase & 1);
+                    int8_t v = 0;
+                    if (k >= 0 && k < ntaps && feeds_i == (rail == 0)) {
+                        const int tap = taps_q15[k];
+                        const int8_t lo = (int8_t)(tap & 0xff);
+                        v = plane == 0 ? lo : (int8_t)((tap - lo) / 256);
+                    }
+                    m[lane * 4 + (j >> 2)] &= ~(0xffu << (8 * (j & 3)));
+                    m[lane * 4 + (j >> 2)] |= (uint32_t)(uint8_t)v << (8 * (j & 3));
+                }
+            }
+        }
+}
+
+void build_d4_taps(const Consts &c, D4Args &da)
+{
+    auto pair = [](int16_t lo, int16_t hi) { return (uint32_t)(uint16_t)lo | ((uint32_t)(uint16_t)hi << 16); };
+    for (int q = 0; q < 6; q++) da.s2p[q] = pair(c.am_s2[2 * q + 1], c.am_s2[2 * q]);
+    for (int q = 0; q < 8; q++) da.s3p[q] = pair(c.am_s3[2 * q + 1], c.am_s3[2 * q]);
+    for (int j = 0; j < 16; j++) da.hilb[j] = (uint32_t)(uint16_t)c.ssb_hilbert[2 * j];
+    for (int q = 0; q < 6; q++) da.p12p[q] = pair(c.post12[2 * q + 1], c.post12[2 * q]);
+    for (int q = 0; q < 20; q++) da.a40p[q] = pair(c.audio40[2 * q + 1], c.audio40[2 * q]);
+}
+
 // |atan2(-r, x - 128)| for r = 0..128.  The kernel negates every angle (theta' = -theta, with -K), so that the
 // sign bit of theta' is simply bit 7 of the y index: y < 0 -> theta < 0 -> theta' = +|theta|; y >= 0 ->
 // theta' = -|theta| (y = 0: -0 or -pi).  Valid because the reference's table is odd in y bit for bit; checked here.
@@ -253,7 +293,9 @@ void build_stream_taps(const int16_t *d1, const int16_t *post12, const int16_t *
 TilePlan plan_stream(uint32_t vlen, uint32_t n_channels, uint32_t streams)
 {
     TilePlan p;
-    uint32_t per_ch = n_channels ? (streams + n_channels - 1) / n_channels : 1;
+    // As many segments as fit ONE round of the persistent workgroups (all segments of a round advance in lock step,
+    // so a second round with a handful of stragglers would cost as much as the first).
+    uint32_t per_ch = n_channels ? streams / n_channels : 1;
     if (per_ch == 0) per_ch = 1;
     uint64_t len = ((uint64_t)vlen + per_ch - 1) / per_ch;
     len = (len + 511) / 512 * 512;              // whole 32-byte PCM sectors per segment (16 PCM samples)

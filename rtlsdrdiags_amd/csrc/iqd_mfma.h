@@ -75,4 +75,23 @@ __device__ __forceinline__ uint32_t st_mag_chunk(const uint4 &s)   // 8 samples 
     return (m16 & 0xffffu) + (m16 >> 16);
 }
 
+// ---- producer / consumer plumbing of the streaming kernels (waves of one workgroup talking through LDS rings) ----
+__device__ __forceinline__ uint32_t lds_load_relaxed(const uint32_t *p)
+{
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// lane 0 adds 1 to an LDS word (exec is all ones wherever this is used); the plain HIP form costs a dozen
+// instructions of "which lane is first" bookkeeping per call
+__device__ __forceinline__ void lds_signal(const uint32_t *p)
+{
+    const uint32_t addr = (uint32_t)(uintptr_t)p, one = 1u;
+    asm volatile("s_mov_b64 exec, 1\n\tds_add_u32 %0, %1\n\ts_mov_b64 exec, -1" :: "v"(addr), "v"(one) : "memory");
+}
+
+// byte offset of granule q (4 samples) of ring row j inside a slot: XOR swizzle, conflict-free for the
+// P waves' ds_write_b128 and the IIR lanes' ds_read_b128
+__device__ __forceinline__ uint32_t st_slot_off(uint32_t j, uint32_t q) { return j * 64u + ((q ^ ((j >> 2) & 3u)) << 4); }
+
+
 }  // namespace iqd

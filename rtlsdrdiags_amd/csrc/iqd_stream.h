@@ -67,6 +67,26 @@ struct StreamArgs {
     float b0, a1;
 };
 
+// FM / AM / SSB as streaming pipelines (iqd_stream2.hip): the chain's first /4 decimator on the matrix cores in
+// P waves, everything behind it in consumer lanes.
+enum { D4_AM = 0, D4_SSB = 1, D4_FM = 2 };
+constexpr int D4_HALO_AM = 384, D4_HALO_SSB = 1280, D4_HALO_FM = 768;   // lead-in samples (the chains need 260 / 1220 / 684)
+struct D4Args {
+    const uint32_t *amat;        // [3 rotation selectors -1, 0, +1][4][64][4]: build_decim4_amat()
+    const float *fm_lut;         // 283 x 283 phase angles
+    uint32_t group_start[4];     // segment ids of the rotation groups (+Fs/4, none, -Fs/4), each padded to 16; [3] = end
+    uint32_t group_li0[3];       // first channel-list index of each group (the list is sorted by group)
+    uint32_t group_nseg[3];      // real segments in each group
+    uint32_t rounds;
+    int32_t halo;
+    uint32_t s2p[6], s3p[8];     // AM/SSB stage 2 (12 taps) and stage 3 (16 taps) as v_dot2 pairs, newest pair first
+    uint32_t hilb[16];           // SSB: the nonzero Hilbert taps h[0], h[2], ..., h[30] (int16 in the low half)
+    uint32_t p12p[6], a40p[20];  // FM post-discriminator decimators
+};
+// [0] this piece, low tap byte; [1] this piece, high byte; [2] previous piece, low; [3] previous piece, high
+void build_decim4_amat(int rotation, const int16_t *taps_q15, int ntaps, uint32_t *out /* [4*64*4] */);
+void build_d4_taps(const Consts &c, D4Args &da);
+
 // A operands of v_mfma_i32_16x16x64_i8 for the pre-demodulation FIR of one rotation selector.
 // Matrix index = 4 * window_type + 2 * rail + plane; window_type 0 = "N" (the 16 outputs of the second
 // half of a 32-sample piece, operand = the piece), 1 = "S" (first half: lanes 0-31 hold the piece's first

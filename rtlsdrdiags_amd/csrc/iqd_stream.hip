@@ -9,23 +9,6 @@
 
 namespace iqd {
 
-__device__ __forceinline__ uint32_t lds_load_relaxed(const uint32_t *p)
-{
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-
-// lane 0 adds 1 to an LDS word (exec is all ones wherever this is used); the plain HIP form costs a dozen
-// instructions of "which lane is first" bookkeeping per call
-__device__ __forceinline__ void lds_signal(const uint32_t *p)
-{
-    const uint32_t addr = (uint32_t)(uintptr_t)p, one = 1u;
-    asm volatile("s_mov_b64 exec, 1\n\tds_add_u32 %0, %1\n\ts_mov_b64 exec, -1" :: "v"(addr), "v"(one) : "memory");
-}
-
-// byte offset of granule q (4 samples) of ring row j inside a slot: XOR swizzle, conflict-free for the
-// P waves' ds_write_b128 and the IIR lanes' ds_read_b128
-__device__ __forceinline__ uint32_t st_slot_off(uint32_t j, uint32_t q) { return j * 64u + ((q ^ ((j >> 2) & 3u)) << 4); }
-
 struct StSeg {           // what a lane knows about its segment
     uint32_t valid, li, tile, ch, ech;
     int32_t v0, tlen;
@@ -73,6 +56,7 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
     const int n_pieces = (ST_HALO + (int)a.tile_len) >> 5;
     uint32_t wg = 0;                                             // windows this ring has seen (all rounds)
     for (uint32_t round = 0; round < sa.rounds; round++) {
+        if ((round * gridDim.x + blockIdx.x) * ST_SEGS >= sa.n_segments) break;   // nothing left for this workgroup
         const uint32_t sid = (round * gridDim.x + blockIdx.x) * ST_SEGS + ring * 64 + row;
         const StSeg sg = st_segment(a, sid, sa.n_segments);
         const ChanParams &p = a.params[sg.ech];
@@ -372,6 +356,7 @@ __device__ __forceinline__ void st_iir_wave(const ChainLaunch &a, const StreamAr
     const int n_pieces = (ST_HALO + (int)a.tile_len) >> 5;       // a multiple of 4
     uint32_t wg = 0;
     for (uint32_t round = 0; round < sa.rounds; round++) {
+        if ((round * gridDim.x + blockIdx.x) * ST_SEGS >= sa.n_segments) break;
         const uint32_t sid = (round * gridDim.x + blockIdx.x) * ST_SEGS + ring * 64 + lane;
         StIirSeg q;
         q.sg = st_segment(a, sid, sa.n_segments);

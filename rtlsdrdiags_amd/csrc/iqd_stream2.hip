@@ -1,0 +1,517 @@
+// FM, AM and SSB chains as streaming pipelines (gfx950), the shape of iqd_stream.hip without the table and without
+// a full-rate recurrence: one persistent 15-wave workgroup per CU, 192 segments in lock step, 32 samples (a piece)
+// at a time.
+//
+//   12 P waves, 16 segments each: raw bytes -> signed, rotation signs (SDWA) -> squelch magnitude -> the chain's
+//       first /4 decimator on both rails as v_mfma_i32_16x16x64_i8 (FM: 32-tap tuner filter, AM/SSB: 8 taps; the
+//       part of the window that lies in the previous piece through a second, chained MFMA) ->
+//       AM/SSB: 8 + 8 int16 outputs per piece into the ring;  FM: the exact phase angle of each of the 8 outputs
+//       (283 x 283 table in global memory, L2-resident) into the ring
+//   3 consumer waves, 64 segments each (one per lane): the remaining stages with their histories in registers
+//       AM   /4 (12 taps) /2 (16 taps) on both rails -> max + min/2 -> detector input at 8 kS/s
+//       SSB  the same -> -i[n-15] -+ Hilbert31(q) -> detector input at 8 kS/s
+//       FM   theta[n-2] - theta[n-4], branch cut, K, (int16) -> /4 (12 taps) -> /2 (40 taps) -> PCM
+//   AM/SSB stop in front of the 8 kS/s DC-removal IIR like the tile kernel does (dc_* kernels run it exactly).
+//
+// Every stage is a FIR: a segment rebuilds its histories over a lead-in (AM 384, FM 768, SSB 1280 samples) and is
+// exact by construction - no verification, no records.  Segments of channels with different rotation selectors sit
+// in groups padded to 16, so that a P wave's 16 segments always share one (its tap matrices and byte negations).
+//
+// Reference: FmDemodulator.cc:376-560, AmDemodulator.cc:339-504, SsbDemodulator.cc:462-598 behind
+// IqDataProcessor.cc:735-749.  hipcc --offload-arch=gfx950 -ffp-contract=off.
+#include <hip/hip_runtime.h>
+
+#include "iqd_kernels.h"
+#include "iqd_stream.h"
+#include "iqd_wbfm.h"
+#include "iqd_mfma.h"
+
+// build-time experiments (tools/variant.sh): all off in the shipped library
+#ifndef IQD_D4_SPLIT
+#define IQD_D4_SPLIT 0
+#endif
+#ifndef IQD_D4_PRIO
+#define IQD_D4_PRIO 0
+#endif
+#ifndef IQD_D4_WAITSTAT
+#define IQD_D4_WAITSTAT 0
+#endif
+
+namespace iqd {
+
+constexpr int D4_SLOTS = 4;                       // ring depth in pieces
+constexpr int D4_SLOT_BYTES = 64 * 32;            // 64 segments x (4 lanes x 8 bytes) per piece
+constexpr int D4_LDS_BYTES = ST_RINGS * D4_SLOTS * D4_SLOT_BYTES + ST_SYNC_WORDS * 4 * 2;
+
+struct D4Seg {
+    uint32_t valid, li, tile, ch, ech;
+    int32_t v0, tlen;
+    int rot;
+};
+
+// segment id -> (rotation group, channel, tile).  Groups in the order +Fs/4, none, -Fs/4, each padded to 16 ids.
+__device__ __forceinline__ D4Seg d4_segment(const ChainLaunch &a, const D4Args &da, uint32_t sid)
+{
+    D4Seg s;
+    const uint32_t r = (sid >= da.group_start[1] ? 1u : 0u) + (sid >= da.group_start[2] ? 1u : 0u);
+    const uint32_t local = sid - da.group_start[r];
+    s.rot = 1 - (int)r;
+    s.valid = sid < da.group_start[3] && local < da.group_nseg[r] ? 1u : 0u;
+    const uint32_t id = s.valid ? local : 0u;
+    s.li = da.group_li0[r] + id / a.tiles_per_ch;
+    if (!s.valid) s.li = 0;
+    s.tile = id % a.tiles_per_ch;
+    s.ch = a.ch_list[s.li];
+    s.ech = a.first_ch + s.ch;
+    const int64_t v0 = (int64_t)s.tile * a.tile_len;
+    if (v0 >= (int64_t)a.vlen) { s.valid = 0; s.v0 = 0; s.tlen = 0; return s; }
+    s.v0 = (int32_t)v0;
+    const int64_t rest = (int64_t)a.vlen - v0;
+    s.tlen = s.valid ? (int32_t)(rest < (int64_t)a.tile_len ? rest : (int64_t)a.tile_len) : 0;
+    return s;
+}
+
+__device__ __forceinline__ uint32_t d4_ring_off(uint32_t row, uint32_t g) { return row * 32u + ((g ^ (row & 3u)) << 3); }
+
+// ---- P wave ---------------------------------------------------------------------------------------------
+template <int MODE, bool MAG>
+__device__ __forceinline__ void d4_p_wave(const ChainLaunch &a, const D4Args &da, uint8_t *lds, uint32_t *sync, int pw, int lane)
+{
+    const int ring = pw / ST_P_PER_RING, cg = pw % ST_P_PER_RING;
+    const int g = lane >> 4, c = lane & 15;
+    const uint32_t row = (uint32_t)(16 * cg + c);
+    uint8_t *ring_base = lds + ring * (D4_SLOTS * D4_SLOT_BYTES);
+    const uint32_t *full = sync + ring * D4_SLOTS;
+    const uint32_t *consumed = sync + 16 + ring;
+    const uint32_t wr_off = d4_ring_off(row, (uint32_t)g);
+    const v4i cround = {1 << 14, 1 << 14, 1 << 14, 1 << 14}, czero = {0, 0, 0, 0};
+    uint32_t zero = 0;
+    asm volatile("" : "+v"(zero));
+    const int n_pieces = (da.halo + (int)a.tile_len) >> 5;
+    uint32_t pg = 0;                                           // pieces this ring has seen (all rounds)
+    for (uint32_t round = 0; round < da.rounds; round++) {
+        if ((round * gridDim.x + blockIdx.x) * ST_SEGS >= da.group_start[3]) break;   // nothing left for this workgroup
+        const uint32_t sid = (round * gridDim.x + blockIdx.x) * ST_SEGS + ring * 64 + row;
+        const D4Seg sg = d4_segment(a, da, sid);
+        const int rot = __builtin_amdgcn_readfirstlane(sg.rot);   // one rotation per wave (groups are padded to 16)
+        const v4i *am = (const v4i *)da.amat + (size_t)(rot + 1) * 4 * 64;
+        const v4i A0 = am[0 * 64 + lane], A1 = am[1 * 64 + lane], A2 = am[2 * 64 + lane], A3 = am[3 * 64 + lane];
+        const uint8_t *iq_ch = a.iq + (size_t)sg.ch * a.ch_stride_bytes;
+        const int fam = MODE == D4_FM ? FAM_FM : (MODE == D4_AM ? FAM_AM : FAM_SSB);
+        const uint8_t *tail = a.tails + ((size_t)sg.ech * FAM_COUNT + fam) * TAIL_BYTES + TAIL_BYTES;
+        const int32_t vlane = sg.v0 + 8 * g;
+        const uint8_t *base_iq = iq_ch + 2 * (int64_t)vlane, *base_tail = tail + 2 * (int64_t)vlane;
+        const int32_t pos_max = (int32_t)a.vlen - 8 - vlane;
+        auto load_piece = [&](int pos) -> uint4 {
+            const int32_t pc = pos < pos_max ? pos : pos_max;
+            const uint8_t *base = pc < -vlane ? base_tail : base_iq;
+            return *(const uint4 *)(base + 2 * (int64_t)pc);
+        };
+        auto front = [&](uint4 raw) -> uint4 {
+            if (rot == 0) return st_front<0>(raw, zero);
+            if (rot > 0) return st_front<1>(raw, zero);
+            return st_front<-1>(raw, zero);
+        };
+        uint32_t *mag_row = MAG ? a.mag_sums + (size_t)sg.ch * a.n_blocks : nullptr;
+        const bool mcount = MAG && sg.valid;
+        const int32_t mlimit = sg.tlen - 8 * g;
+        uint32_t macc = 0;
+        uint32_t mblk = (uint32_t)(sg.v0 + 8 * g) / a.block_samples;
+        uint32_t minblk = (uint32_t)(sg.v0 + 8 * g) - mblk * a.block_samples;
+
+        uint4 prev = front(load_piece(-da.halo - 32));
+        uint4 raw_next = load_piece(-da.halo), raw_n2 = load_piece(-da.halo + 32), raw_n3 = load_piece(-da.halo + 64);
+        for (int q = 0; q < n_pieces; q++) {
+            const int pos = -da.halo + 32 * q;
+            const uint4 cur = front(raw_next);
+            raw_next = raw_n2;                                   // three pieces in flight: a piece's arithmetic is
+            raw_n2 = raw_n3;                                     // shorter than a trip to HBM
+            raw_n3 = load_piece(pos + 96);
+            const v4i bc = {(int)cur.x, (int)cur.y, (int)cur.z, (int)cur.w};
+            const v4i bp = {(int)prev.x, (int)prev.y, (int)prev.z, (int)prev.w};
+            v4i lo = __builtin_amdgcn_mfma_i32_16x16x64_i8(A0, bc, cround, 0, 0, 0);
+            v4i hi = __builtin_amdgcn_mfma_i32_16x16x64_i8(A1, bc, czero, 0, 0, 0);
+            lo = __builtin_amdgcn_mfma_i32_16x16x64_i8(A2, bp, lo, 0, 0, 0);
+            hi = __builtin_amdgcn_mfma_i32_16x16x64_i8(A3, bp, hi, 0, 0, 0);
+            uint32_t seen = lds_load_relaxed(consumed);
+            if (MAG && pos >= 0) {
+                const uint32_t m = st_mag_chunk(cur);
+                macc += mcount && pos < mlimit ? m : 0u;
+                minblk += 32;
+                if (minblk >= a.block_samples) {
+                    if (macc) atomicAdd(&mag_row[mblk], macc);
+                    macc = 0;
+                    mblk++;
+                    minblk -= a.block_samples;
+                }
+            }
+            // rows 4g'+r: r even = I' rail, odd = Q' rail, output 2g' + (r >> 1) of the piece
+            int y[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) y[r] = (lo[r] + (int)((uint32_t)hi[r] << 8)) >> 15;
+            u32x2 payload;
+            if (MODE == D4_FM) {   // |y| <= 141: the exact theta table (FmDemodulator.cc:476)
+                payload.x = f2u(da.fm_lut[(y[1] + FM_LUT_R) * FM_LUT_W + (y[0] + FM_LUT_R)]);
+                payload.y = f2u(da.fm_lut[(y[3] + FM_LUT_R) * FM_LUT_W + (y[2] + FM_LUT_R)]);
+            } else {
+                payload.x = pack_lo16((uint32_t)y[0], (uint32_t)y[2]);   // I' outputs 2g, 2g+1
+                payload.y = pack_lo16((uint32_t)y[1], (uint32_t)y[3]);   // Q'
+            }
+            if (pg >= (uint32_t)D4_SLOTS)
+                while ((int32_t)(seen - (pg - (D4_SLOTS - 1))) < 0) {
+#if IQD_D4_WAITSTAT
+                    if (lane == 0) atomicAdd(&sync[24], 1u);
+#endif
+                    __builtin_amdgcn_s_sleep(1);
+                    seen = lds_load_relaxed(consumed);
+                }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            *(u32x2 *)(ring_base + (pg & (D4_SLOTS - 1)) * D4_SLOT_BYTES + wr_off) = payload;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            lds_signal(&full[pg & (D4_SLOTS - 1)]);
+            pg++;
+            prev = cur;
+        }
+        if (MAG && macc) atomicAdd(&mag_row[mblk], macc);
+    }
+}
+
+// ---- consumer waves ---------------------------------------------------------------------------------------
+// one ring row: the 4 P lanes' payloads of this lane's segment, un-swizzled
+__device__ __forceinline__ void d4_read_row(const uint8_t *slot, uint32_t row, u32x2 (&p)[4])
+{
+#pragma unroll
+    for (int g = 0; g < 4; g++) p[g] = *(const u32x2 *)(slot + d4_ring_off(row, (uint32_t)g));
+}
+
+#if IQD_D4_WAITSTAT
+__device__ __forceinline__ uint32_t *d4_stat_word(int i)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t d4_lds[];
+    return (uint32_t *)(d4_lds + ST_RINGS * D4_SLOTS * D4_SLOT_BYTES) + i;
+}
+#endif
+__device__ __forceinline__ void d4_wait_piece(const uint32_t *full, uint32_t pg)
+{
+    const uint32_t target = 4u * ((pg / D4_SLOTS) + 1u);
+    while ((int32_t)(lds_load_relaxed(&full[pg & (D4_SLOTS - 1)]) - target) < 0) {
+#if IQD_D4_WAITSTAT
+        if ((threadIdx.x & 63) == 0) atomicAdd(d4_stat_word(25), 1u);
+#endif
+        __builtin_amdgcn_s_sleep(1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// AM / SSB -----------------------------------------------------------------------------------------------
+struct D4Rail {
+    uint32_t y1h[4];      // the last 8 stage-1 outputs of the rail
+    uint32_t y2[11];      // stage-2 outputs as pairs; variant V of a piece uses [V .. V+7], its new pair is [V+7]
+};
+
+// one piece of one rail: 8 stage-1 outputs in, 2 stage-2 outputs (a pair) kept, 1 stage-3 output returned
+template <int V>
+__device__ __forceinline__ int d4_am_rail(const D4Args &da, D4Rail &r, const uint32_t (&n1)[4])
+{
+    const uint32_t w[8] = {r.y1h[0], r.y1h[1], r.y1h[2], r.y1h[3], n1[0], n1[1], n1[2], n1[3]};
+    int a0 = 1 << 14, a1 = 1 << 14;                    // /4, 12 taps: output k from y1[4k-8 .. 4k+3]
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+        a0 = dot2(w[5 - q], da.s2p[q], a0);
+        a1 = dot2(w[7 - q], da.s2p[q], a1);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) r.y1h[k] = n1[k];
+    r.y2[V + 7] = pack_lo16((uint32_t)(a0 >> 15), (uint32_t)(a1 >> 15));
+    int s3 = 1 << 14;                                  // /2, 16 taps: from y2[2i-14 .. 2i+1]
+#if IQD_D4_SPLIT
+    int s3b = 0;                                       // (two half-length chains: int32 sums wrap, so any order is exact)
+#pragma unroll
+    for (int q = 0; q < 4; q++) { s3 = dot2(r.y2[V + 7 - q], da.s3p[q], s3); s3b = dot2(r.y2[V + 3 - q], da.s3p[q + 4], s3b); }
+    s3 += s3b;
+#else
+#pragma unroll
+    for (int q = 0; q < 8; q++) s3 = dot2(r.y2[V + 7 - q], da.s3p[q], s3);
+#endif
+    return s3 >> 15;
+}
+
+struct D4Ssb {             // 8 kS/s histories of the phasing detector, split by sample parity (the Hilbert taps at odd
+    uint32_t qe[9], qo[9]; // distances are zero): pairs of same-parity samples, older in the low half, newest pair last
+    uint32_t ie[5], io[5];
+};
+
+// Hilbert transformer over one parity stream whose newest sample sits in the HIGH half of p[8] (full == true) or in
+// the LOW half of p[8] (full == false: that pair's high half is not there yet).  taps t[j] = h[2j], j = 0..15.
+template <bool FULL>
+__device__ __forceinline__ int d4_hilbert(const D4Args &da, const uint32_t (&p)[9])
+{
+    int acc = 1 << 14;
+    if (FULL) {
+#pragma unroll
+        for (int i = 0; i < 8; i++)   // pair p[8-i] = (S[m-2i-1], S[m-2i]): taps (t[2i+1], t[2i])
+            acc = dot2(p[8 - i], (da.hilb[2 * i + 1] & 0xffffu) | (da.hilb[2 * i] << 16), acc);
+    } else {
+        acc = dot2(p[8], da.hilb[0] & 0xffffu, acc);   // S[m] alone in the low half
+#pragma unroll
+        for (int i = 1; i <= 8; i++)  // pair p[8-i] = (S[m-2i], S[m-2i+1]): taps (t[2i], t[2i-1])
+            acc = dot2(p[8 - i], ((2 * i < 16 ? da.hilb[2 * i] : 0u) & 0xffffu) | (da.hilb[2 * i - 1] << 16), acc);
+    }
+    return acc >> 15;
+}
+
+template <int MODE, int V>
+__device__ __forceinline__ int d4_am_piece(const D4Args &da, const uint8_t *ring_base, const uint32_t *full, uint32_t *consumed,
+                                           uint32_t &pg, uint32_t row, int lane, D4Rail &ri, D4Rail &rq, D4Ssb &sb, int lsb)
+{
+    d4_wait_piece(full, pg);
+    u32x2 p[4];
+    d4_read_row(ring_base + (pg & (D4_SLOTS - 1)) * D4_SLOT_BYTES, row, p);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    lds_signal(consumed);
+    pg++;
+    const uint32_t ni[4] = {p[0].x, p[1].x, p[2].x, p[3].x}, nq[4] = {p[0].y, p[1].y, p[2].y, p[3].y};
+    const int iv = d4_am_rail<V>(da, ri, ni), qv = d4_am_rail<V>(da, rq, nq);
+    if (MODE == D4_AM) {   // AmDemodulator.cc:446-459: max(|i|,|q|) + min(|i|,|q|)/2 in int16 arithmetic
+        const int im = (int)(int16_t)(iv < 0 ? -iv : iv), qm = (int)(int16_t)(qv < 0 ? -qv : qv);
+        return (int)(int16_t)((im > qm) ? im + (qm >> 1) : qm + (im >> 1));
+    }
+    // SSB (SsbDemodulator.cc:574-588): delayed I - the 1.0 tap is -32768 in Q15, so (16384 - 32768 i[n-15]) >> 15 =
+    // -i[n-15] - and the 31-tap Hilbert transformer on Q; sample n of this piece has parity V & 1, and within its
+    // parity stream it is the low (V < 2) or the high (V >= 2) half of the newest pair.
+    int idl, qh;
+    if ((V & 1) == 0) {
+        if (V < 2) { sb.qe[8] = (uint32_t)qv & 0xffffu; sb.ie[4] = (uint32_t)iv & 0xffffu; }
+        else { sb.qe[8] = pack_lo16(sb.qe[8], (uint32_t)qv); sb.ie[4] = pack_lo16(sb.ie[4], (uint32_t)iv); }
+        qh = V < 2 ? d4_hilbert<false>(da, sb.qe) : d4_hilbert<true>(da, sb.qe);
+        // i[n-15] lies in the odd stream, 7 samples before its newest one (n-1): that one is the high half of io[3]
+        // when V == 0 (the pair completed in the previous run of 4 pieces), the low half of io[4] when V == 2
+        idl = V < 2 ? -(int)(int16_t)(sb.io[0] & 0xffffu) : -(int)(int16_t)(sb.io[0] >> 16);
+    } else {
+        if (V < 2) { sb.qo[8] = (uint32_t)qv & 0xffffu; sb.io[4] = (uint32_t)iv & 0xffffu; }
+        else { sb.qo[8] = pack_lo16(sb.qo[8], (uint32_t)qv); sb.io[4] = pack_lo16(sb.io[4], (uint32_t)iv); }
+        qh = V < 2 ? d4_hilbert<false>(da, sb.qo) : d4_hilbert<true>(da, sb.qo);
+        // even stream, 7 before its newest sample (n-1): the low half of ie[4] when V == 1, the high half of ie[4] when V == 3
+        idl = V < 2 ? -(int)(int16_t)(sb.ie[0] >> 16) : -(int)(int16_t)(sb.ie[1] & 0xffffu);
+    }
+    return lsb ? (int)(int16_t)idl - (int)(int16_t)qh : (int)(int16_t)idl + (int)(int16_t)qh;
+}
+
+template <int MODE>
+__device__ __forceinline__ void d4_am_wave(const ChainLaunch &a, const D4Args &da, uint8_t *lds, uint32_t *sync, int ring, int lane)
+{
+    const uint8_t *ring_base = lds + ring * (D4_SLOTS * D4_SLOT_BYTES);
+    const uint32_t *full = sync + ring * D4_SLOTS;
+    uint32_t *consumed = sync + 16 + ring;
+    const int n_pieces = (da.halo + (int)a.tile_len) >> 5;
+    uint32_t pg = 0;
+    for (uint32_t round = 0; round < da.rounds; round++) {
+        if ((round * gridDim.x + blockIdx.x) * ST_SEGS >= da.group_start[3]) break;
+        const uint32_t sid = (round * gridDim.x + blockIdx.x) * ST_SEGS + ring * 64 + lane;
+        const D4Seg sg = d4_segment(a, da, sid);
+        const int lsb = a.params[sg.ech].ssb_lsb;
+        int32_t *base_row = a.base8k + (size_t)sg.ch * a.base_stride_ch;
+        D4Rail ri, rq;
+        D4Ssb sb;
+#pragma unroll
+        for (int k = 0; k < 4; k++) ri.y1h[k] = rq.y1h[k] = 0;
+#pragma unroll
+        for (int k = 0; k < 11; k++) ri.y2[k] = rq.y2[k] = 0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) sb.qe[k] = sb.qo[k] = 0;
+#pragma unroll
+        for (int k = 0; k < 5; k++) sb.ie[k] = sb.io[k] = 0;
+        for (int pq = 0; pq < n_pieces; pq += 4) {
+            const int pos = -da.halo + 32 * pq;
+            const int x0 = d4_am_piece<MODE, 0>(da, ring_base, full, consumed, pg, (uint32_t)lane, lane, ri, rq, sb, lsb);
+            const int x1 = d4_am_piece<MODE, 1>(da, ring_base, full, consumed, pg, (uint32_t)lane, lane, ri, rq, sb, lsb);
+            const int x2 = d4_am_piece<MODE, 2>(da, ring_base, full, consumed, pg, (uint32_t)lane, lane, ri, rq, sb, lsb);
+            const int x3 = d4_am_piece<MODE, 3>(da, ring_base, full, consumed, pg, (uint32_t)lane, lane, ri, rq, sb, lsb);
+            // 128 samples = 4 detector inputs = one 16-byte store (segments start and end on multiples of 128)
+            if (sg.valid && pos >= 0 && pos < sg.tlen)
+                *(u32x4 *)(base_row + ((sg.v0 + pos) >> 5)) = u32x4{(uint32_t)x0, (uint32_t)x1, (uint32_t)x2, (uint32_t)x3};
+#pragma unroll
+            for (int k = 0; k < 7; k++) { ri.y2[k] = ri.y2[k + 4]; rq.y2[k] = rq.y2[k + 4]; }
+            if (MODE == D4_SSB) {   // each parity stream gained one pair
+#pragma unroll
+                for (int k = 0; k < 8; k++) { sb.qe[k] = sb.qe[k + 1]; sb.qo[k] = sb.qo[k + 1]; }
+#pragma unroll
+                for (int k = 0; k < 4; k++) { sb.ie[k] = sb.ie[k + 1]; sb.io[k] = sb.io[k + 1]; }
+            }
+        }
+    }
+}
+
+// FM -----------------------------------------------------------------------------------------------------
+struct D4Fm {
+    float th[4];           // theta of the last 4 tuner outputs
+    uint32_t eh[4];        // the last 8 (int16)(K dtheta)
+    uint32_t y2p[24];      // /4 outputs as pairs; variant V of a piece uses [V+1 .. V+20]
+    int loud_e, loud_y2;   // pieces for which a value above the clamp-free bound stays in a window's reach
+};
+
+template <int V>
+__device__ __forceinline__ int d4_fm_piece(const D4Args &da, const uint8_t *ring_base, const uint32_t *full, uint32_t *consumed,
+                                           uint32_t &pg, uint32_t row, D4Fm &s, float k)
+{
+    d4_wait_piece(full, pg);
+    u32x2 p[4];
+    d4_read_row(ring_base + (pg & (D4_SLOTS - 1)) * D4_SLOT_BYTES, row, p);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    lds_signal(consumed);
+    pg++;
+    const float th[12] = {s.th[0], s.th[1], s.th[2], s.th[3], u2f(p[0].x), u2f(p[0].y), u2f(p[1].x), u2f(p[1].y),
+                          u2f(p[2].x), u2f(p[2].y), u2f(p[3].x), u2f(p[3].y)};
+    uint32_t e[8];
+    uint32_t peak = 0;
+#pragma unroll
+    for (int m = 0; m < 8; m++) {   // output m: theta[m-2] - theta[m-4] (FmDemodulator.cc:113-122, 479), branch cut, K, (int16)
+        const float d = wrap_delta(th[m + 2] - th[m]);
+        const int ev = (int)(int16_t)(uint16_t)cast_i16_bounded(k * d);
+        e[m] = (uint32_t)ev;
+        const uint32_t mg = (uint32_t)(ev < 0 ? -ev : ev);
+        peak = mg > peak ? mg : peak;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) s.th[j] = th[8 + j];
+    if (peak > (uint32_t)POST12_SAFE) s.loud_e = 4;   // stays inside a 12-sample window for this piece and the next
+    const uint32_t w[8] = {s.eh[0], s.eh[1], s.eh[2], s.eh[3], pack_lo16(e[0], e[1]), pack_lo16(e[2], e[3]),
+                           pack_lo16(e[4], e[5]), pack_lo16(e[6], e[7])};
+    int a0 = 1 << 14, a1 = 1 << 14;                    // /4, 12 taps (FmDemodulator.cc:545): output j from e[4j-8 .. 4j+3]
+    if (!__any(s.loud_e > 0)) {
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            a0 = dot2(w[5 - q], da.p12p[q], a0);
+            a1 = dot2(w[7 - q], da.p12p[q], a1);
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            a0 = clamp_q30(dot2(w[5 - q], da.p12p[q] & 0xffff0000u, a0));
+            a0 = clamp_q30(dot2(w[5 - q], da.p12p[q] & 0x0000ffffu, a0));
+            a1 = clamp_q30(dot2(w[7 - q], da.p12p[q] & 0xffff0000u, a1));
+            a1 = clamp_q30(dot2(w[7 - q], da.p12p[q] & 0x0000ffffu, a1));
+        }
+    }
+    if (s.loud_e > 0) s.loud_e--;
+#pragma unroll
+    for (int j = 0; j < 4; j++) s.eh[j] = w[4 + j];
+    const int y0 = a0 >> 15, y1 = a1 >> 15;
+    const uint32_t m0 = (uint32_t)(y0 < 0 ? -y0 : y0), m1 = (uint32_t)(y1 < 0 ? -y1 : y1);
+    if ((m0 > m1 ? m0 : m1) > (uint32_t)AUDIO40_SAFE) s.loud_y2 = 21;
+    s.y2p[V + 20] = pack_lo16((uint32_t)y0, (uint32_t)y1);
+    int acc = 1 << 14;                                 // /2, 40 taps -> PCM
+    if (!__any(s.loud_y2 > 0)) {
+#if IQD_D4_SPLIT
+        int accb = 0, accc = 0, accd = 0;              // (four chains of 5: without the clamps int32 sums wrap, any order is exact)
+#pragma unroll
+        for (int q = 0; q < 5; q++) {
+            acc = dot2(s.y2p[V + 20 - q], da.a40p[q], acc);
+            accb = dot2(s.y2p[V + 15 - q], da.a40p[q + 5], accb);
+            accc = dot2(s.y2p[V + 10 - q], da.a40p[q + 10], accc);
+            accd = dot2(s.y2p[V + 5 - q], da.a40p[q + 15], accd);
+        }
+        acc = (acc + accb) + (accc + accd);
+#else
+#pragma unroll
+        for (int q = 0; q < 20; q++) acc = dot2(s.y2p[V + 20 - q], da.a40p[q], acc);
+#endif
+    } else {
+#pragma unroll
+        for (int q = 0; q < 20; q++) {
+            acc = clamp_q30(dot2(s.y2p[V + 20 - q], da.a40p[q] & 0xffff0000u, acc));
+            acc = clamp_q30(dot2(s.y2p[V + 20 - q], da.a40p[q] & 0x0000ffffu, acc));
+        }
+    }
+    if (s.loud_y2 > 0) s.loud_y2--;
+    return acc >> 15;
+}
+
+__device__ __forceinline__ void d4_fm_wave(const ChainLaunch &a, const D4Args &da, uint8_t *lds, uint32_t *sync, int ring, int lane)
+{
+    const uint8_t *ring_base = lds + ring * (D4_SLOTS * D4_SLOT_BYTES);
+    const uint32_t *full = sync + ring * D4_SLOTS;
+    uint32_t *consumed = sync + 16 + ring;
+    const int n_pieces = (da.halo + (int)a.tile_len) >> 5;
+    uint32_t pg = 0;
+    for (uint32_t round = 0; round < da.rounds; round++) {
+        if ((round * gridDim.x + blockIdx.x) * ST_SEGS >= da.group_start[3]) break;
+        const uint32_t sid = (round * gridDim.x + blockIdx.x) * ST_SEGS + ring * 64 + lane;
+        const D4Seg sg = d4_segment(a, da, sid);
+        const float k_now = a.params[sg.ech].fm_k;
+        const GainEpochList *ep = &a.epochs[sg.ech].fm;
+        const bool ep_reach = ep->since[0] < (uint32_t)TAIL && (int64_t)sg.v0 - da.halo - 32 < -(int64_t)ep->since[0];
+        int16_t *pcm_row = a.pcm + (size_t)sg.ch * a.pcm_stride;
+        D4Fm s;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { s.th[j] = 0.f; s.eh[j] = 0; }
+#pragma unroll
+        for (int j = 0; j < 24; j++) s.y2p[j] = 0;
+        s.loud_e = s.loud_y2 = 0;
+        for (int pq = 0; pq < n_pieces; pq += 4) {
+            const int pos = -da.halo + 32 * pq;
+            float k = k_now;
+            int pcm[4];
+            // (a segment whose lead-in reaches back before a gain change runs that part with the gain of the time;
+            // changes fall on call boundaries = multiples of 128 samples, and a piece's differences reach 4 tuner
+            // outputs = 16 samples back, which the next chunk of 128 re-derives nothing from: per piece is exact)
+            if (ep_reach) k = epoch_gain(ep, k_now, sg.v0 + pos);
+            pcm[0] = d4_fm_piece<0>(da, ring_base, full, consumed, pg, (uint32_t)lane, s, k);
+            if (ep_reach) k = epoch_gain(ep, k_now, sg.v0 + pos + 32);
+            pcm[1] = d4_fm_piece<1>(da, ring_base, full, consumed, pg, (uint32_t)lane, s, k);
+            if (ep_reach) k = epoch_gain(ep, k_now, sg.v0 + pos + 64);
+            pcm[2] = d4_fm_piece<2>(da, ring_base, full, consumed, pg, (uint32_t)lane, s, k);
+            if (ep_reach) k = epoch_gain(ep, k_now, sg.v0 + pos + 96);
+            pcm[3] = d4_fm_piece<3>(da, ring_base, full, consumed, pg, (uint32_t)lane, s, k);
+            if (sg.valid && pos >= 0 && pos < sg.tlen)
+                *(u32x2 *)(pcm_row + ((sg.v0 + pos) >> 5)) = u32x2{pack_lo16((uint32_t)pcm[0], (uint32_t)pcm[1]), pack_lo16((uint32_t)pcm[2], (uint32_t)pcm[3])};
+#pragma unroll
+            for (int j = 0; j < 20; j++) s.y2p[j] = s.y2p[j + 4];
+        }
+    }
+}
+
+#ifndef IQD_D4_AM_TWO_WGS
+#define IQD_D4_AM_TWO_WGS 0
+#endif
+#define D4_WAVES_PER_SIMD(MODE) ((MODE) == D4_AM && IQD_D4_AM_TWO_WGS ? 8 : 4)
+template <int MODE, bool MAG>
+__global__ __launch_bounds__(ST_THREADS, D4_WAVES_PER_SIMD(MODE)) void d4_stream_kernel(const ChainLaunch a, const D4Args da)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t d4_lds[];
+    uint32_t *sync = (uint32_t *)(d4_lds + ST_RINGS * D4_SLOTS * D4_SLOT_BYTES);
+    const int tid = (int)threadIdx.x;
+    if (tid < ST_SYNC_WORDS * 2) sync[tid] = 0;
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    if (wave < ST_RINGS) {
+        if (IQD_D4_PRIO) __builtin_amdgcn_s_setprio(IQD_D4_PRIO);
+        if (MODE == D4_FM) d4_fm_wave(a, da, d4_lds, sync, wave, lane);
+        else d4_am_wave<MODE>(a, da, d4_lds, sync, wave, lane);
+    } else {
+        d4_p_wave<MODE, MAG>(a, da, d4_lds, sync, wave - ST_RINGS, lane);
+    }
+#if IQD_D4_WAITSTAT
+    __syncthreads();
+    if (tid == 0 && (blockIdx.x & 63) == 5)
+        printf("wg %u: P sleeps %u (12 waves), consumer sleeps %u (3 waves), pieces %d\n", blockIdx.x, sync[24], sync[25], (da.halo + (int)a.tile_len) >> 5);
+#endif
+}
+
+hipError_t launch_d4_stream(const ChainLaunch &a, const D4Args &da, int mode, bool mag, uint32_t grid, hipStream_t s)
+{
+    const dim3 g(grid), b(ST_THREADS);
+    if (mode == D4_AM) {
+        if (mag) hipLaunchKernelGGL((d4_stream_kernel<D4_AM, true>), g, b, D4_LDS_BYTES, s, a, da);
+        else hipLaunchKernelGGL((d4_stream_kernel<D4_AM, false>), g, b, D4_LDS_BYTES, s, a, da);
+    } else if (mode == D4_SSB) {
+        if (mag) hipLaunchKernelGGL((d4_stream_kernel<D4_SSB, true>), g, b, D4_LDS_BYTES, s, a, da);
+        else hipLaunchKernelGGL((d4_stream_kernel<D4_SSB, false>), g, b, D4_LDS_BYTES, s, a, da);
+    } else {
+        if (mag) hipLaunchKernelGGL((d4_stream_kernel<D4_FM, true>), g, b, D4_LDS_BYTES, s, a, da);
+        else hipLaunchKernelGGL((d4_stream_kernel<D4_FM, false>), g, b, D4_LDS_BYTES, s, a, da);
+    }
+    return hipGetLastError();
+}
+
+}  // namespace iqd

@@ -1,0 +1,121 @@
+"""GPU (MI355X): the FM / AM / SSB streaming pipelines (iqd_stream2.hip) pinned on by IQD_F_WBFM_STREAM, against the
+oracle and the golden vectors, sample for sample - the cases the tile kernels are held to in test_gpu_modes.py."""
+import numpy as np
+import pytest
+
+from rtlsdrdiags_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+STREAM = 0x4
+MODES = ["am", "fm", "lsb", "usb"]
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from rtlsdrdiags_amd import capi as c
+    return c
+
+
+def oracle_run(oracle, mode, u8, rotation=1, gain=None, block_bytes=32768):
+    c = oracle.chain()
+    c.set_mode(mode)
+    c.set_rotation(rotation)
+    if gain is not None:
+        c.set_gain({"am": 1, "fm": 2, "lsb": 4, "usb": 4}[mode], gain)
+    return c.accept_stream(u8, block_bytes)
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("name", ["fm_tone", "am_tone", "white", "rails"])
+def test_golden(capi, golden, mode, name):
+    g = golden[name]
+    if g["iq"].size < 2 * 16384 * 2:
+        pytest.skip("row shorter than two blocks: AM/SSB take the batched DC path, not the stream kernel")
+    eng = capi.Engine(1, flags=STREAM)
+    eng.set_mode(mode)
+    pcm, cnt, mag, allowed = eng.accept(g["iq"])
+    assert eng.stats()["stream_launches"] == 1
+    assert np.array_equal(pcm[0, :cnt[0]], g["pcm_" + mode])
+    assert np.array_equal(mag[0], g["magnitude"])
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_mixed_rotations_white_bytes_and_calls(capi, oracle, mode):
+    """9 channels whose rotation selector cycles +1, 0, -1 (groups padded to 16 segments inside one launch), uniform
+    random bytes with runs of 0x00 (-128), three calls."""
+    n_ch = 9
+    rng = np.random.default_rng(11)
+    u8 = rng.integers(0, 256, size=(n_ch, 6 * 32768), dtype=np.uint8)
+    u8[:, 200:328] = 0
+    eng = capi.Engine(n_ch, flags=STREAM)
+    eng.set_mode(mode)
+    for c in range(n_ch):
+        eng.set_rotation((1, 0, -1)[c % 3], first=c, n=1)
+    outs, mags = [], []
+    for k in range(3):
+        pcm, cnt, mag, _ = eng.accept(u8[:, k * 65536:(k + 1) * 65536])
+        outs.append(pcm)
+        mags.append(mag)
+    assert eng.stats()["stream_launches"] == 3
+    got, gmag = np.concatenate(outs, axis=1), np.concatenate(mags, axis=1)
+    for c in range(n_ch):
+        ref, ref_mag, _ = oracle_run(oracle, mode, u8[c], rotation=(1, 0, -1)[c % 3])
+        assert np.array_equal(got[c], ref), (mode, c)
+        assert np.array_equal(gmag[c], ref_mag), (mode, c)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_many_channels_and_long_rows(capi, oracle, mode):
+    n_ch = 70
+    make = synth.am_tone if mode == "am" else synth.fm_tone
+    u8 = np.stack([make(4 * 16384, seed=500 + c) for c in range(n_ch)])
+    eng = capi.Engine(n_ch, flags=STREAM)
+    eng.set_mode(mode)
+    pcm, cnt, mag, _ = eng.accept(u8)
+    for c in range(0, n_ch, 3):
+        ref, ref_mag, _ = oracle_run(oracle, mode, u8[c])
+        assert np.array_equal(pcm[c, :cnt[c]], ref), (mode, c)
+        assert np.array_equal(mag[c], ref_mag), (mode, c)
+    long_u8 = make(1 << 21, seed=9)
+    eng1 = capi.Engine(1, flags=STREAM)
+    eng1.set_mode(mode)
+    pcm, cnt, _, _ = eng1.accept(long_u8)
+    assert eng1.stats()["stream_launches"] == 1
+    assert np.array_equal(pcm[0, :cnt[0]], oracle_run(oracle, mode, long_u8)[0]), mode
+
+
+def test_fm_gain_changes_and_loud_path(capi, oracle):
+    u8 = synth.fm_tone(12 * 16384, seed=21, deviation=70e3)
+    c = oracle.chain()
+    c.set_mode("fm")
+    eng = capi.Engine(1, flags=STREAM)
+    eng.set_mode("fm")
+    ref, out = [], []
+    for k, gain in enumerate([None, 4.0e5, 900.0, 3.0e6, None, 10185.9]):   # 3e6: |y2| far above the clamp-free bound
+        if gain is not None:
+            c.set_gain(2, gain)
+            eng.set_gain("fm", gain)
+        piece = u8[k * 65536:(k + 1) * 65536]
+        ref.append(c.accept_stream(piece)[0])
+        pcm, cnt, _, _ = eng.accept(piece)
+        out.append(pcm[0, :cnt[0]])
+    assert eng.stats()["stream_launches"] == 6
+    for k in range(6):
+        assert np.array_equal(out[k], ref[k]), k
+
+
+def test_alternating_with_the_tile_kernels(capi, oracle):
+    """Both kernels read the same carried state (raw tails, DC-removal state): the path may change from call to call."""
+    u8 = synth.am_tone(8 * 16384, seed=77)
+    for mode in MODES:
+        ref = oracle_run(oracle, mode, u8)[0]
+        a, b = capi.Engine(1, flags=STREAM), capi.Engine(1, flags=0x2)
+        for e in (a, b):
+            e.set_mode(mode)
+        outs = [[], []]
+        for off in range(0, len(u8), 4 * 32768):
+            for k, e in enumerate((a, b)):
+                pcm, cnt, _, _ = e.accept(u8[off:off + 4 * 32768])
+                outs[k].append(pcm[0, :cnt[0]])
+        assert np.array_equal(np.concatenate(outs[0]), ref) and np.array_equal(np.concatenate(outs[1]), ref), mode
