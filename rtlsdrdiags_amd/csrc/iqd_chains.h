@@ -445,71 +445,104 @@ IQD_DEV void dc_block_run(const int32_t *x, int n, float gain, float a1, DcCarry
 }
 
 
-// ---- the same IIR for long streams: one wave per channel, 64 segments of SEG samples at a time ----
-// Same scheme as the WBFM de-emphasis (iqd_wbfm.h): every lane warms up over the previous
-// segment from a guessed state and is accepted only if it reproduces its left neighbour's exact
-// end state bit for bit; otherwise it restarts from that state.
-constexpr int DC_SUPER = 64 * SEG;          // PCM samples per pass of the wave
+// ---- the same IIR for long streams: one wave per channel, 64 segments of DC_S samples at a time ----
+// Same idea as the WBFM de-emphasis (iqd_wbfm.h): every lane first rebuilds the state at the start of its segment
+// over the DC_WSEG segments in front of it from a close guess - two trajectories of this contraction (pole 0.95) that
+// start a fraction of a unit in the last place apart become bit-identical within those 128 steps - and is accepted
+// only if it reproduces its left neighbour's exact end state bit for bit; otherwise it restarts from that state.
+// The input differences x[n] - x[n-1] are formed once (they are exact), and the PCM leaves through LDS as whole
+// dwords: per pass of 2048 samples a lane runs 32 + 128 + 32 steps.
+constexpr int DC_S = 32;                    // samples per segment
+constexpr int DC_WSEG = 4;                  // segments of warm-up
+constexpr int DC_GUESS = 12;                // zero-state responses summed for the guess (0.95^(32*12) ~ 3e-9)
+constexpr int DC_SUPER = 64 * DC_S;         // PCM samples per pass of the wave
 struct DcLds {
-    int32_t x[64 * (SEG + 1)];              // detector input, one padded row per segment
-    float z[64 + 4], g[64], e[64];
+    float tn[64 * (DC_S + 1)];              // x[n] - x[n-1], one padded row per segment
+    uint32_t out[64 * (DC_S / 2 + 1)];      // PCM pairs of the pass, one padded row per segment
+    float z[DC_GUESS + 64], g[64], e[64];
     float x_carry, y_carry;                 // state entering the pass
 };
 
-IQD_DEV float dc_x_before(const DcLds &lds, int seg)
+IQD_DEV void dc_fill(DcLds &lds, const int32_t *x, int at, int nseg, int lane)
 {
-    return seg == 0 ? lds.x_carry : (float)lds.x[(seg - 1) * (SEG + 1) + SEG - 1];
+    // a lane takes 4 consecutive samples out of every 256; all of a pass's loads are issued before the first use
+    // (one after the other they cost a trip to memory each, which was most of this pass's time)
+    u32x4 v[DC_SUPER / 256];
+    int32_t before[DC_SUPER / 256];
+#pragma unroll
+    for (int k = 0; k < DC_SUPER / 256; k++) {        // (clamped, not predicated: nothing to wait for in between)
+        const int i = 4 * lane + 256 * k, ic = i < nseg * DC_S ? i : nseg * DC_S - 4;
+#if IQD_ON_DEVICE
+        v[k] = *(const u32x4 *)(x + at + ic);         // rows and passes start on multiples of 4 samples
+#else
+        memcpy(&v[k], x + at + ic, 16);
+#endif
+        before[k] = x[at + ic > 0 ? at + ic - 1 : 0];
+    }
+#if IQD_ON_DEVICE
+    __builtin_amdgcn_sched_barrier(0);                // keep the loads together, ahead of the first use
+#endif
+#pragma unroll
+    for (int k = 0; k < DC_SUPER / 256; k++) {
+        const int i = 4 * lane + 256 * k;
+        if (i >= nseg * DC_S) break;
+        float *dst = &lds.tn[(i / DC_S) * (DC_S + 1) + (i % DC_S)];
+        const float f0 = (float)(int32_t)v[k].x, f1 = (float)(int32_t)v[k].y, f2 = (float)(int32_t)v[k].z, f3 = (float)(int32_t)v[k].w;
+        dst[0] = f0 - (at + i == 0 ? lds.x_carry : (float)before[k]);
+        dst[1] = f1 - f0;
+        dst[2] = f2 - f1;
+        dst[3] = f3 - f2;
+    }
+    if (lane < DC_GUESS) lds.z[lane] = lane == DC_GUESS - 1 ? lds.y_carry : 0.f;
 }
 
 IQD_DEV void dc_guess(const Consts &c, DcLds &lds, int nseg, int lane)
 {
-    if (lane == 0) lds.z[3] = lds.y_carry, lds.z[2] = 0.f, lds.z[1] = 0.f, lds.z[0] = 0.f;
     if (lane >= nseg) return;
     const float cc = -c.dc_a1;
-    const int32_t *src = &lds.x[lane * (SEG + 1)];
-    float xp = dc_x_before(lds, lane), z = 0.f;
-    for (int i = 0; i < SEG; i++) {
-        const float xf = (float)src[i];
-        z = __builtin_fmaf(cc, z, xf - xp);
-        xp = xf;
-    }
-    lds.z[4 + lane] = z;
+    const float *src = &lds.tn[lane * (DC_S + 1)];
+    float z = 0.f;
+    for (int i = 0; i < DC_S; i++) z = __builtin_fmaf(cc, z, src[i]);
+    lds.z[DC_GUESS + lane] = z;
 }
 
 IQD_DEV void dc_warm(const Consts &c, DcLds &lds, int nseg, int lane)
 {
     if (lane >= nseg) return;
     if (lane == 0) { lds.g[0] = lds.y_carry; return; }
-    const float a = c.dc_c128;
-    const float *zz = &lds.z[4 + lane - 2];
-    float y = zz[0] + a * (zz[-1] + a * (zz[-2] + a * zz[-3]));
-    if (lane == 1) y = lds.y_carry;
-    const int32_t *src = &lds.x[(lane - 1) * (SEG + 1)];
-    float xp = dc_x_before(lds, lane - 1);
+    const int m = lane > DC_WSEG ? lane - DC_WSEG : 0;       // first segment of the warm-up
+    float y = lds.y_carry;
+    if (m > 0) {                                             // state entering segment m, to float rounding
+        const float a = c.dc_cseg;
+        const float *zz = &lds.z[DC_GUESS + m - 1];
+        y = zz[-(DC_GUESS - 1)];
+        for (int j = DC_GUESS - 2; j >= 0; j--) y = __builtin_fmaf(a, y, zz[-j]);
+    }
     const float a1 = c.dc_a1;
-    for (int i = 0; i < SEG; i++) {
-        const float xf = (float)src[i];
-        const float tn = xf - xp;
-        const float r = a1 * y;
-        y = tn - r;
-        xp = xf;
+    for (int sgm = m; sgm < lane; sgm++) {
+        const float *src = &lds.tn[sgm * (DC_S + 1)];
+        for (int i = 0; i < DC_S; i++) {
+            const float r = a1 * y;
+            y = src[i] - r;
+        }
     }
     lds.g[lane] = y;
 }
 
-IQD_DEV void dc_real(const Consts &c, DcLds &lds, int nseg, int lane, float gain, int16_t *pcm /* of the pass */)
+IQD_DEV void dc_real(const Consts &c, DcLds &lds, int nseg, int lane, float gain)
 {
     if (lane >= nseg) return;
-    const int32_t *src = &lds.x[lane * (SEG + 1)];
-    float xp = dc_x_before(lds, lane), y = lds.g[lane];
+    const float *src = &lds.tn[lane * (DC_S + 1)];
+    uint32_t *dst = &lds.out[lane * (DC_S / 2 + 1)];
+    float y = lds.g[lane];
     const float a1 = c.dc_a1;
-    for (int i = 0; i < SEG; i++) {
-        const float xf = (float)src[i];
-        const float tn = xf - xp;
-        const float r = a1 * y;
-        y = tn - r;
-        if (pcm) pcm[lane * SEG + i] = (int16_t)cast_i16(gain * y);
-        xp = xf;
+    for (int i = 0; i < DC_S; i += 2) {
+        float r = a1 * y;
+        y = src[i] - r;
+        const uint32_t lo = (uint32_t)cast_i16(gain * y);
+        r = a1 * y;
+        y = src[i + 1] - r;
+        dst[i / 2] = pack_lo16(lo, (uint32_t)cast_i16(gain * y));
     }
     lds.e[lane] = y;
 }
@@ -526,6 +559,12 @@ IQD_DEV bool dc_check(DcLds &lds, int nseg, int lane, bool tiny_ok = false)
     return false;
 }
 
+IQD_DEV void dc_store(const DcLds &lds, int nseg, int lane, int16_t *pcm /* of the pass, 4-byte aligned */)
+{
+    uint32_t *dst = (uint32_t *)pcm;
+    for (int d = lane; d < nseg * (DC_S / 2); d += 64) dst[d] = lds.out[(d / (DC_S / 2)) * (DC_S / 2 + 1) + (d % (DC_S / 2))];
+}
+
 // One channel, n PCM samples (multiple of 4; the last pass may be partial, its last segment too).
 template <class Exec>
 IQD_DEV void dc_block_wave(Exec &ex, const Consts &c, DcLds &lds, const int32_t *x, int n, float gain,
@@ -534,29 +573,28 @@ IQD_DEV void dc_block_wave(Exec &ex, const Consts &c, DcLds &lds, const int32_t 
     ex.wave0([&](int lane) { if (lane == 0) { lds.x_carry = st.x_prev; lds.y_carry = st.y_prev; } });
     for (int base = 0; base < n; base += DC_SUPER) {
         const int len = n - base < DC_SUPER ? n - base : DC_SUPER;
-        const int nfull = len / SEG;              // whole segments: the segmented scheme
-        ex.wave0([&](int lane) {
-            for (int i = lane; i < nfull * SEG; i += 64) lds.x[(i / SEG) * (SEG + 1) + (i % SEG)] = x[base + i];
-        });
+        const int nfull = len / DC_S;             // whole segments: the segmented scheme
         if (nfull > 0) {
+            ex.wave0([&](int lane) { dc_fill(lds, x, base, nfull, lane); });
             ex.wave0([&](int lane) { dc_guess(c, lds, nfull, lane); });
             ex.wave0([&](int lane) { dc_warm(c, lds, nfull, lane); });
             do {
-                ex.wave0([&](int lane) { dc_real(c, lds, nfull, lane, gain, pcm ? pcm + base : nullptr); });
+                ex.wave0([&](int lane) { dc_real(c, lds, nfull, lane, gain); });
             } while (!ex.wave0_all([&](int lane) { return dc_check(lds, nfull, lane, __builtin_fabsf(gain) <= 1e6f); }));
             ex.wave0([&](int lane) {
+                if (pcm) dc_store(lds, nfull, lane, pcm + base);
                 if (lane == 0) {
                     lds.y_carry = lds.e[nfull - 1];
-                    lds.x_carry = (float)lds.x[(nfull - 1) * (SEG + 1) + SEG - 1];
+                    lds.x_carry = (float)x[base + nfull * DC_S - 1];
                 }
             });
         }
-        const int rest = len - nfull * SEG;       // a tail shorter than a segment: one lane, serial
+        const int rest = len - nfull * DC_S;      // a tail shorter than a segment: one lane, serial
         if (rest > 0) {
             ex.wave0([&](int lane) {
                 if (lane != 0) return;
                 DcCarry t2{lds.x_carry, lds.y_carry};
-                dc_block_run(x + base + nfull * SEG, rest, gain, c.dc_a1, t2, pcm ? pcm + base + nfull * SEG : nullptr);
+                dc_block_run(x + base + nfull * DC_S, rest, gain, c.dc_a1, t2, pcm ? pcm + base + nfull * DC_S : nullptr);
                 lds.x_carry = t2.x_prev;
                 lds.y_carry = t2.y_prev;
             });
@@ -574,7 +612,7 @@ IQD_DEV void dc_block_wave(Exec &ex, const Consts &c, DcLds &lds, const int32_t 
 // only if every tile's start state agrees with its predecessor's end state (dc_chainup_kernel), which by
 // induction from tile 0 makes every tile the serial result.  Otherwise (e.g. a decaying tail that has not reached zero)
 // the one-wave pass above redoes the channel from the carried state.
-constexpr int DC_TILE = DC_SUPER;     // 8192
+constexpr int DC_TILE = 8192;
 constexpr int DC_WARM = 2048;
 struct DcRecord { float y_start, y_end, x_end; uint32_t pad; };
 

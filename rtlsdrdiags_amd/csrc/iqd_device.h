@@ -115,7 +115,7 @@ struct Consts {
     float deemph_b0, deemph_a1;     // 0.0253863, -0.9492274
     float deemph_c, deemph_c16, deemph_c127, deemph_c128, deemph_cinv;  // powers of -a1 (state guess only)
     float dc_a1;                    // -0.95
-    float dc_c128;                  // 0.95^128 (state guess only)
+    float dc_cseg;                  // 0.95^32: decay over one DC segment (state guess only)
 };
 
 }  // namespace iqd

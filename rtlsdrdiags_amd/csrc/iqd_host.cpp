@@ -98,7 +98,7 @@ void build_consts(Consts &c)
     c.deemph_c128 = (float)pow(cc, 128.0);
     c.deemph_cinv = (float)(1.0 / cc);
     c.dc_a1 = taps::DCBLOCK_A1;
-    c.dc_c128 = (float)pow(-(double)taps::DCBLOCK_A1, 128.0);
+    c.dc_cseg = (float)pow(-(double)taps::DCBLOCK_A1, 32.0);
 }
 
 void build_atan2_lut(std::vector<float> &lut)

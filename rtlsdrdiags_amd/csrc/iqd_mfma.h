@@ -75,6 +75,27 @@ __device__ __forceinline__ uint32_t st_mag_chunk(const uint4 &s)   // 8 samples 
     return (m16 & 0xffffu) + (m16 >> 16);
 }
 
+// ---- input prefetch of the streaming kernels ----
+// A 16-byte global load the compiler does not track, and the matching wait.  With ordinary loads the compiler's
+// own s_waitcnt placement joins the loop's entry and back edge conservatively (vmcnt(0) at the header, i.e. a wait
+// for the load issued one piece ago) and hands buffers on with register moves that wait for the youngest load;
+// a P wave then pays a trip to HBM per piece however many pieces it asked for in advance.  Loads return in order,
+// so "at most N younger loads outstanding" is exactly "this one has arrived"; other memory operations issued in
+// between (magnitude atomics) only make the wait stricter.
+typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4u gload16_untracked(const void *p)
+{
+    v4u r;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(p));
+    return r;
+}
+template <int N_YOUNGER>
+__device__ __forceinline__ uint4 gload_arrived(v4u r)
+{
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r) : "n"(N_YOUNGER));
+    return uint4{r.x, r.y, r.z, r.w};
+}
+
 // ---- producer / consumer plumbing of the streaming kernels (waves of one workgroup talking through LDS rings) ----
 __device__ __forceinline__ uint32_t lds_load_relaxed(const uint32_t *p)
 {

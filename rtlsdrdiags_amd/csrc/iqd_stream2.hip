@@ -40,6 +40,7 @@
 namespace iqd {
 
 constexpr int D4_SLOTS = 4;                       // ring depth in pieces
+constexpr int D4_AHEAD = 4;                       // pieces of input a P wave keeps in flight
 constexpr int D4_SLOT_BYTES = 64 * 32;            // 64 segments x (4 lanes x 8 bytes) per piece
 constexpr int D4_LDS_BYTES = ST_RINGS * D4_SLOTS * D4_SLOT_BYTES + ST_SYNC_WORDS * 4 * 2;
 
@@ -74,26 +75,18 @@ __device__ __forceinline__ D4Seg d4_segment(const ChainLaunch &a, const D4Args &
 __device__ __forceinline__ uint32_t d4_ring_off(uint32_t row, uint32_t g) { return row * 32u + ((g ^ (row & 3u)) << 3); }
 
 // ---- P wave ---------------------------------------------------------------------------------------------
-template <int MODE, bool MAG>
-__device__ __forceinline__ void d4_p_wave(const ChainLaunch &a, const D4Args &da, uint8_t *lds, uint32_t *sync, int pw, int lane)
+// One round of one P wave: its 16 segments from lead-in to end, with the rotation as a template parameter so that the
+// piece loop is straight-line code (the selector is uniform over the wave: groups are padded to 16).
+template <int MODE, bool MAG, int ROT>
+__device__ __forceinline__ void d4_p_round(const ChainLaunch &a, const D4Args &da, const D4Seg &sg, uint8_t *ring_base,
+                                           const uint32_t *full, const uint32_t *consumed, uint32_t *sync, uint32_t wr_off,
+                                           int g, int lane, uint32_t &pg)
 {
-    const int ring = pw / ST_P_PER_RING, cg = pw % ST_P_PER_RING;
-    const int g = lane >> 4, c = lane & 15;
-    const uint32_t row = (uint32_t)(16 * cg + c);
-    uint8_t *ring_base = lds + ring * (D4_SLOTS * D4_SLOT_BYTES);
-    const uint32_t *full = sync + ring * D4_SLOTS;
-    const uint32_t *consumed = sync + 16 + ring;
-    const uint32_t wr_off = d4_ring_off(row, (uint32_t)g);
-    const v4i cround = {1 << 14, 1 << 14, 1 << 14, 1 << 14}, czero = {0, 0, 0, 0};
-    uint32_t zero = 0;
-    asm volatile("" : "+v"(zero));
-    const int n_pieces = (da.halo + (int)a.tile_len) >> 5;
-    uint32_t pg = 0;                                           // pieces this ring has seen (all rounds)
-    for (uint32_t round = 0; round < da.rounds; round++) {
-        if ((round * gridDim.x + blockIdx.x) * ST_SEGS >= da.group_start[3]) break;   // nothing left for this workgroup
-        const uint32_t sid = (round * gridDim.x + blockIdx.x) * ST_SEGS + ring * 64 + row;
-        const D4Seg sg = d4_segment(a, da, sid);
-        const int rot = __builtin_amdgcn_readfirstlane(sg.rot);   // one rotation per wave (groups are padded to 16)
+        const int rot = ROT;
+        const v4i cround = {1 << 14, 1 << 14, 1 << 14, 1 << 14}, czero = {0, 0, 0, 0};
+        uint32_t zero = 0;
+        asm volatile("" : "+v"(zero));
+        const int n_pieces = (da.halo + (int)a.tile_len) >> 5;
         const v4i *am = (const v4i *)da.amat + (size_t)(rot + 1) * 4 * 64;
         const v4i A0 = am[0 * 64 + lane], A1 = am[1 * 64 + lane], A2 = am[2 * 64 + lane], A3 = am[3 * 64 + lane];
         const uint8_t *iq_ch = a.iq + (size_t)sg.ch * a.ch_stride_bytes;
@@ -102,16 +95,12 @@ __device__ __forceinline__ void d4_p_wave(const ChainLaunch &a, const D4Args &da
         const int32_t vlane = sg.v0 + 8 * g;
         const uint8_t *base_iq = iq_ch + 2 * (int64_t)vlane, *base_tail = tail + 2 * (int64_t)vlane;
         const int32_t pos_max = (int32_t)a.vlen - 8 - vlane;
-        auto load_piece = [&](int pos) -> uint4 {
+        auto load_piece = [&](int pos) -> v4u {
             const int32_t pc = pos < pos_max ? pos : pos_max;
             const uint8_t *base = pc < -vlane ? base_tail : base_iq;
-            return *(const uint4 *)(base + 2 * (int64_t)pc);
+            return gload16_untracked(base + 2 * (int64_t)pc);
         };
-        auto front = [&](uint4 raw) -> uint4 {
-            if (rot == 0) return st_front<0>(raw, zero);
-            if (rot > 0) return st_front<1>(raw, zero);
-            return st_front<-1>(raw, zero);
-        };
+        auto front = [&](uint4 raw) -> uint4 { return st_front<ROT>(raw, zero); };
         uint32_t *mag_row = MAG ? a.mag_sums + (size_t)sg.ch * a.n_blocks : nullptr;
         const bool mcount = MAG && sg.valid;
         const int32_t mlimit = sg.tlen - 8 * g;
@@ -119,14 +108,19 @@ __device__ __forceinline__ void d4_p_wave(const ChainLaunch &a, const D4Args &da
         uint32_t mblk = (uint32_t)(sg.v0 + 8 * g) / a.block_samples;
         uint32_t minblk = (uint32_t)(sg.v0 + 8 * g) - mblk * a.block_samples;
 
-        uint4 prev = front(load_piece(-da.halo - 32));
-        uint4 raw_next = load_piece(-da.halo), raw_n2 = load_piece(-da.halo + 32), raw_n3 = load_piece(-da.halo + 64);
-        for (int q = 0; q < n_pieces; q++) {
-            const int pos = -da.halo + 32 * q;
-            const uint4 cur = front(raw_next);
-            raw_next = raw_n2;                                   // three pieces in flight: a piece's arithmetic is
-            raw_n2 = raw_n3;                                     // shorter than a trip to HBM
-            raw_n3 = load_piece(pos + 96);
+        // Four pieces in flight - a piece's arithmetic is much shorter than a trip to HBM - in four named buffers of
+        // a loop unrolled by four: handing a buffer on with register moves would wait for the load it has just issued.
+        const v4u raw_before = load_piece(-da.halo - 32);
+        v4u raw[D4_AHEAD];
+#pragma unroll
+        for (int j = 0; j < D4_AHEAD; j++) raw[j] = load_piece(-da.halo + 32 * j);
+        uint4 prev = front(gload_arrived<D4_AHEAD>(raw_before));
+        for (int q0 = 0; q0 < n_pieces; q0 += D4_AHEAD) {       // (n_pieces is a multiple of 4)
+#pragma unroll
+          for (int j = 0; j < D4_AHEAD; j++) {
+            const int pos = -da.halo + 32 * (q0 + j);
+            const uint4 cur = front(gload_arrived<D4_AHEAD - 1>(raw[j]));
+            raw[j] = load_piece(pos + 32 * D4_AHEAD);
             const v4i bc = {(int)cur.x, (int)cur.y, (int)cur.z, (int)cur.w};
             const v4i bp = {(int)prev.x, (int)prev.y, (int)prev.z, (int)prev.w};
             v4i lo = __builtin_amdgcn_mfma_i32_16x16x64_i8(A0, bc, cround, 0, 0, 0);
@@ -171,8 +165,30 @@ __device__ __forceinline__ void d4_p_wave(const ChainLaunch &a, const D4Args &da
             lds_signal(&full[pg & (D4_SLOTS - 1)]);
             pg++;
             prev = cur;
+          }
         }
         if (MAG && macc) atomicAdd(&mag_row[mblk], macc);
+}
+
+template <int MODE, bool MAG>
+__device__ __forceinline__ void d4_p_wave(const ChainLaunch &a, const D4Args &da, uint8_t *lds, uint32_t *sync, int pw, int lane)
+{
+    const int ring = pw / ST_P_PER_RING, cg = pw % ST_P_PER_RING;
+    const int g = lane >> 4, c = lane & 15;
+    const uint32_t row = (uint32_t)(16 * cg + c);
+    uint8_t *ring_base = lds + ring * (D4_SLOTS * D4_SLOT_BYTES);
+    const uint32_t *full = sync + ring * D4_SLOTS;
+    const uint32_t *consumed = sync + 16 + ring;
+    const uint32_t wr_off = d4_ring_off(row, (uint32_t)g);
+    uint32_t pg = 0;                                           // pieces this ring has seen (all rounds)
+    for (uint32_t round = 0; round < da.rounds; round++) {
+        if ((round * gridDim.x + blockIdx.x) * ST_SEGS >= da.group_start[3]) break;   // nothing left for this workgroup
+        const uint32_t sid = (round * gridDim.x + blockIdx.x) * ST_SEGS + ring * 64 + row;
+        const D4Seg sg = d4_segment(a, da, sid);
+        const int rot = __builtin_amdgcn_readfirstlane(sg.rot);
+        if (rot == 0) d4_p_round<MODE, MAG, 0>(a, da, sg, ring_base, full, consumed, sync, wr_off, g, lane, pg);
+        else if (rot > 0) d4_p_round<MODE, MAG, 1>(a, da, sg, ring_base, full, consumed, sync, wr_off, g, lane, pg);
+        else d4_p_round<MODE, MAG, -1>(a, da, sg, ring_base, full, consumed, sync, wr_off, g, lane, pg);
     }
 }
 
