@@ -33,16 +33,24 @@
 #ifndef IQD_D4_PRIO
 #define IQD_D4_PRIO 0
 #endif
+#ifndef IQD_D4_MAGLUT
+#define IQD_D4_MAGLUT 1
+#endif
 #ifndef IQD_D4_WAITSTAT
 #define IQD_D4_WAITSTAT 0
 #endif
 
 namespace iqd {
 
-constexpr int D4_SLOTS = 4;                       // ring depth in pieces
+#ifndef IQD_D4_SLOTS
+#define IQD_D4_SLOTS 8
+#endif
+constexpr int D4_SLOTS = IQD_D4_SLOTS;            // ring depth in pieces (a power of two)
+constexpr int D4_SYNC_WORDS = ST_RINGS * D4_SLOTS + 8;   // per ring: a "full" counter per slot; then a "consumed" counter per ring
 constexpr int D4_AHEAD = 4;                       // pieces of input a P wave keeps in flight
 constexpr int D4_SLOT_BYTES = 64 * 32;            // 64 segments x (4 lanes x 8 bytes) per piece
-constexpr int D4_LDS_BYTES = ST_RINGS * D4_SLOTS * D4_SLOT_BYTES + ST_SYNC_WORDS * 4 * 2;
+constexpr int D4_MAGLUT_OFF = (ST_RINGS * D4_SLOTS * D4_SLOT_BYTES + D4_SYNC_WORDS * 4 + 15) & ~15;   // squelch magnitude table (iqd_mfma.h)
+constexpr int D4_LDS_BYTES = D4_MAGLUT_OFF + ST_MAGLUT_BYTES;
 
 struct D4Seg {
     uint32_t valid, li, tile, ch, ech;
@@ -84,8 +92,9 @@ __device__ __forceinline__ void d4_p_round(const ChainLaunch &a, const D4Args &d
 {
         const int rot = ROT;
         const v4i cround = {1 << 14, 1 << 14, 1 << 14, 1 << 14}, czero = {0, 0, 0, 0};
-        uint32_t zero = 0;
-        asm volatile("" : "+v"(zero));
+        uint32_t zero = 0, four = 4;
+        asm volatile("" : "+v"(zero), "+v"(four));
+        const uint8_t *maglut = (const uint8_t *)sync + (D4_MAGLUT_OFF - ST_RINGS * D4_SLOTS * D4_SLOT_BYTES);
         const int n_pieces = (da.halo + (int)a.tile_len) >> 5;
         const v4i *am = (const v4i *)da.amat + (size_t)(rot + 1) * 4 * 64;
         const v4i A0 = am[0 * 64 + lane], A1 = am[1 * 64 + lane], A2 = am[2 * 64 + lane], A3 = am[3 * 64 + lane];
@@ -108,8 +117,58 @@ __device__ __forceinline__ void d4_p_round(const ChainLaunch &a, const D4Args &d
         uint32_t mblk = (uint32_t)(sg.v0 + 8 * g) / a.block_samples;
         uint32_t minblk = (uint32_t)(sg.v0 + 8 * g) - mblk * a.block_samples;
 
-        // Four pieces in flight - a piece's arithmetic is much shorter than a trip to HBM - in four named buffers of
-        // a loop unrolled by four: handing a buffer on with register moves would wait for the load it has just issued.
+        // the piece's ring slot: wait until the consumer has freed it, store, signal
+        auto hand_over = [&](u32x2 payload, uint32_t seen) {
+            if (pg >= (uint32_t)D4_SLOTS)
+                while ((int32_t)(seen - (pg - (D4_SLOTS - 1))) < 0) {
+#if IQD_D4_WAITSTAT
+                    if (lane == 0) atomicAdd(&sync[D4_SYNC_WORDS - 2], 1u);
+#endif
+                    __builtin_amdgcn_s_sleep(1);
+                    seen = lds_load_relaxed(consumed);
+                }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (MODE == D4_FM) *(uint32_t *)(ring_base + (pg & (D4_SLOTS - 1)) * D4_SLOT_BYTES + wr_off) = payload.x;
+            else *(u32x2 *)(ring_base + (pg & (D4_SLOTS - 1)) * D4_SLOT_BYTES + wr_off) = payload;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            lds_signal(&full[pg & (D4_SLOTS - 1)]);
+            pg++;
+        };
+        // FM: the discriminator runs here too, two outputs per lane (theta[m] - theta[m-2]: the lane 16 below holds
+        // theta[m-2], for the first lane group it is what the last one held a piece ago).  The two angles come from the
+        // 283 x 283 table in L2, a long way off for an in-order wave: a piece asks for its angles and finishes the
+        // piece before it, whose angles have had a whole piece's arithmetic to arrive.
+        const int src_lane4 = ((lane - 16) & 63) << 2;
+        float last_a = 0.f, last_b = 0.f;
+        const float k_now = MODE == D4_FM ? a.params[sg.ech].fm_k : 0.f;
+        const GainEpochList *ep = &a.epochs[sg.ech].fm;
+        const bool ep_reach = MODE == D4_FM && ep->since[0] < (uint32_t)TAIL && (int64_t)sg.v0 - da.halo - 32 < -(int64_t)ep->since[0];
+        {   // have these arrive now: a first use inside the piece loop would put a wait for everything in flight there
+            const uint32_t reach = ep_reach;
+            asm volatile("" :: "v"(k_now), "v"(reach));
+        }
+        uint32_t asked_a[2] = {0, 0}, asked_b[2] = {0, 0};
+        auto fm_finish = [&](int pos, uint32_t ta_bits, uint32_t tb_bits, uint32_t seen) {
+            const float ta = u2f(ta_bits), tb = u2f(tb_bits);
+            const float give_a = g == 3 ? last_a : ta, give_b = g == 3 ? last_b : tb;
+            const float before_a = u2f((uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)f2u(give_a)));
+            const float before_b = u2f((uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)f2u(give_b)));
+            last_a = ta;
+            last_b = tb;
+            // theta[m] - theta[m-2] is the reference's discriminator output two tuner samples later
+            // (theta[n-2] - theta[n-4], FmDemodulator.cc:113-122, 479): the last lane group's pair belongs to the
+            // next piece, gain included.  (A segment whose lead-in reaches back before a gain change runs that part
+            // with the gain of the time; changes fall on call boundaries = multiples of 128 samples.)
+            float kk = k_now;
+            if (ep_reach) kk = epoch_gain(ep, k_now, sg.v0 + pos + (g == 3 ? 32 : 0));
+            const uint32_t ea = cast_i16_bounded(kk * wrap_delta(ta - before_a));   // branch cut, K, cast; (int16) = the low half
+            const uint32_t eb = cast_i16_bounded(kk * wrap_delta(tb - before_b));
+            hand_over(u32x2{pack_lo16(ea, eb), 0u}, seen);
+        };
+        // Four pieces of input in flight - a piece's arithmetic is much shorter than a trip to HBM - in four named
+        // buffers of a loop unrolled by four: handing a buffer on with register moves would wait for the load it has
+        // just issued.  Waits count the loads issued since (iqd_mfma.h): per piece one of these, for FM two angles more.
+        constexpr int PER_PIECE = MODE == D4_FM ? 3 : 1;
         const v4u raw_before = load_piece(-da.halo - 32);
         v4u raw[D4_AHEAD];
 #pragma unroll
@@ -119,17 +178,25 @@ __device__ __forceinline__ void d4_p_round(const ChainLaunch &a, const D4Args &d
 #pragma unroll
           for (int j = 0; j < D4_AHEAD; j++) {
             const int pos = -da.halo + 32 * (q0 + j);
-            const uint4 cur = front(gload_arrived<D4_AHEAD - 1>(raw[j]));
-            raw[j] = load_piece(pos + 32 * D4_AHEAD);
+            // younger than raw[j]: the other three buffers' loads, plus the angles asked for since its own issue (in
+            // the first trip: since the start)
+            uint4 rawj;
+            if (PER_PIECE == 1 || q0 > 0) rawj = gload_arrived<D4_AHEAD - 1 + (PER_PIECE - 1) * D4_AHEAD>(raw[j]);
+            else rawj = gload_arrived_n(raw[j], D4_AHEAD - 1 + (PER_PIECE - 1) * j);
+            const uint4 cur = front(rawj);
             const v4i bc = {(int)cur.x, (int)cur.y, (int)cur.z, (int)cur.w};
             const v4i bp = {(int)prev.x, (int)prev.y, (int)prev.z, (int)prev.w};
             v4i lo = __builtin_amdgcn_mfma_i32_16x16x64_i8(A0, bc, cround, 0, 0, 0);
             v4i hi = __builtin_amdgcn_mfma_i32_16x16x64_i8(A1, bc, czero, 0, 0, 0);
             lo = __builtin_amdgcn_mfma_i32_16x16x64_i8(A2, bp, lo, 0, 0, 0);
             hi = __builtin_amdgcn_mfma_i32_16x16x64_i8(A3, bp, hi, 0, 0, 0);
-            uint32_t seen = lds_load_relaxed(consumed);
+            const uint32_t seen = lds_load_relaxed(consumed);
             if (MAG && pos >= 0) {
+#if IQD_D4_MAGLUT
+                const uint32_t m = st_maglut_chunk(maglut, rawj, four);
+#else
                 const uint32_t m = st_mag_chunk(cur);
+#endif
                 macc += mcount && pos < mlimit ? m : 0u;
                 minblk += 32;
                 if (minblk >= a.block_samples) {
@@ -139,33 +206,35 @@ __device__ __forceinline__ void d4_p_round(const ChainLaunch &a, const D4Args &d
                     minblk -= a.block_samples;
                 }
             }
+            // the buffer's next load only now, after the last use of its old contents: while those are live the new
+            // load would get other registers and the loop would have to move it back - reading registers in flight
+            raw[j] = load_piece(pos + 32 * D4_AHEAD);
             // rows 4g'+r: r even = I' rail, odd = Q' rail, output 2g' + (r >> 1) of the piece
             int y[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) y[r] = (lo[r] + (int)((uint32_t)hi[r] << 8)) >> 15;
-            u32x2 payload;
             if (MODE == D4_FM) {   // |y| <= 141: the exact theta table (FmDemodulator.cc:476)
-                payload.x = f2u(da.fm_lut[(y[1] + FM_LUT_R) * FM_LUT_W + (y[0] + FM_LUT_R)]);
-                payload.y = f2u(da.fm_lut[(y[3] + FM_LUT_R) * FM_LUT_W + (y[2] + FM_LUT_R)]);
-            } else {
-                payload.x = pack_lo16((uint32_t)y[0], (uint32_t)y[2]);   // I' outputs 2g, 2g+1
-                payload.y = pack_lo16((uint32_t)y[1], (uint32_t)y[3]);   // Q'
-            }
-            if (pg >= (uint32_t)D4_SLOTS)
-                while ((int32_t)(seen - (pg - (D4_SLOTS - 1))) < 0) {
-#if IQD_D4_WAITSTAT
-                    if (lane == 0) atomicAdd(&sync[24], 1u);
+#if IQD_D4_FAKE_LUT   // timing experiment only: all lookups inside one 1 KiB corner of the table
+                asked_a[j & 1] = gload4_untracked(&da.fm_lut[((y[1] + FM_LUT_R) * FM_LUT_W + (y[0] + FM_LUT_R)) & 255]);
+                asked_b[j & 1] = gload4_untracked(&da.fm_lut[((y[3] + FM_LUT_R) * FM_LUT_W + (y[2] + FM_LUT_R)) & 255]);
+#else
+                asked_a[j & 1] = gload4_untracked(&da.fm_lut[(y[1] + FM_LUT_R) * FM_LUT_W + (y[0] + FM_LUT_R)]);
+                asked_b[j & 1] = gload4_untracked(&da.fm_lut[(y[3] + FM_LUT_R) * FM_LUT_W + (y[2] + FM_LUT_R)]);
 #endif
-                    __builtin_amdgcn_s_sleep(1);
-                    seen = lds_load_relaxed(consumed);
+                if (q0 + j > 0) {  // the piece before: younger than its second angle are this piece's input load and two angles
+                    const uint32_t ta = gload_arrived<3>(asked_a[(j & 1) ^ 1]), tb = gload_arrived<3>(asked_b[(j & 1) ^ 1]);
+                    fm_finish(pos - 32, ta, tb, seen);
                 }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            *(u32x2 *)(ring_base + (pg & (D4_SLOTS - 1)) * D4_SLOT_BYTES + wr_off) = payload;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            lds_signal(&full[pg & (D4_SLOTS - 1)]);
-            pg++;
+            } else {
+                // I' outputs 2g, 2g+1 | Q'
+                hand_over(u32x2{pack_lo16((uint32_t)y[0], (uint32_t)y[2]), pack_lo16((uint32_t)y[1], (uint32_t)y[3])}, seen);
+            }
             prev = cur;
           }
+        }
+        if (MODE == D4_FM) {       // the last piece
+            const uint32_t ta = gload_arrived<0>(asked_a[(D4_AHEAD - 1) & 1]), tb = gload_arrived<0>(asked_b[(D4_AHEAD - 1) & 1]);
+            fm_finish(-da.halo + 32 * (n_pieces - 1), ta, tb, lds_load_relaxed(consumed));
         }
         if (MAG && macc) atomicAdd(&mag_row[mblk], macc);
 }
@@ -178,8 +247,8 @@ __device__ __forceinline__ void d4_p_wave(const ChainLaunch &a, const D4Args &da
     const uint32_t row = (uint32_t)(16 * cg + c);
     uint8_t *ring_base = lds + ring * (D4_SLOTS * D4_SLOT_BYTES);
     const uint32_t *full = sync + ring * D4_SLOTS;
-    const uint32_t *consumed = sync + 16 + ring;
-    const uint32_t wr_off = d4_ring_off(row, (uint32_t)g);
+    const uint32_t *consumed = sync + ST_RINGS * D4_SLOTS + ring;
+    const uint32_t wr_off = MODE == D4_FM ? row * 16u + 4u * (uint32_t)g : d4_ring_off(row, (uint32_t)g);   // FM: one dword per lane
     uint32_t pg = 0;                                           // pieces this ring has seen (all rounds)
     for (uint32_t round = 0; round < da.rounds; round++) {
         if ((round * gridDim.x + blockIdx.x) * ST_SEGS >= da.group_start[3]) break;   // nothing left for this workgroup
@@ -190,6 +259,20 @@ __device__ __forceinline__ void d4_p_wave(const ChainLaunch &a, const D4Args &da
         else if (rot > 0) d4_p_round<MODE, MAG, 1>(a, da, sg, ring_base, full, consumed, sync, wr_off, g, lane, pg);
         else d4_p_round<MODE, MAG, -1>(a, da, sg, ring_base, full, consumed, sync, wr_off, g, lane, pg);
     }
+}
+
+__device__ __forceinline__ uint32_t pk_abs_i16(uint32_t v)
+{
+    uint32_t n, r;
+    asm("v_pk_sub_i16 %0, 0, %1" : "=v"(n) : "v"(v));
+    asm("v_pk_max_i16 %0, %1, %2" : "=v"(r) : "v"(v), "v"(n));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_pk_max_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
 
 // ---- consumer waves ---------------------------------------------------------------------------------------
@@ -212,7 +295,7 @@ __device__ __forceinline__ void d4_wait_piece(const uint32_t *full, uint32_t pg)
     const uint32_t target = 4u * ((pg / D4_SLOTS) + 1u);
     while ((int32_t)(lds_load_relaxed(&full[pg & (D4_SLOTS - 1)]) - target) < 0) {
 #if IQD_D4_WAITSTAT
-        if ((threadIdx.x & 63) == 0) atomicAdd(d4_stat_word(25), 1u);
+        if ((threadIdx.x & 63) == 0) atomicAdd(d4_stat_word(D4_SYNC_WORDS - 1), 1u);
 #endif
         __builtin_amdgcn_s_sleep(1);
     }
@@ -318,7 +401,7 @@ __device__ __forceinline__ void d4_am_wave(const ChainLaunch &a, const D4Args &d
 {
     const uint8_t *ring_base = lds + ring * (D4_SLOTS * D4_SLOT_BYTES);
     const uint32_t *full = sync + ring * D4_SLOTS;
-    uint32_t *consumed = sync + 16 + ring;
+    uint32_t *consumed = sync + ST_RINGS * D4_SLOTS + ring;
     const int n_pieces = (da.halo + (int)a.tile_len) >> 5;
     uint32_t pg = 0;
     for (uint32_t round = 0; round < da.rounds; round++) {
@@ -360,39 +443,29 @@ __device__ __forceinline__ void d4_am_wave(const ChainLaunch &a, const D4Args &d
 
 // FM -----------------------------------------------------------------------------------------------------
 struct D4Fm {
-    float th[4];           // theta of the last 4 tuner outputs
-    uint32_t eh[4];        // the last 8 (int16)(K dtheta)
+    uint32_t eh[4];        // the last 8 (int16)(K dtheta) of the previous piece
+    uint32_t early;        // the pair the P waves delivered a piece ahead (their stream runs two samples early)
     uint32_t y2p[24];      // /4 outputs as pairs; variant V of a piece uses [V+1 .. V+20]
     int loud_e, loud_y2;   // pieces for which a value above the clamp-free bound stays in a window's reach
 };
 
 template <int V>
 __device__ __forceinline__ int d4_fm_piece(const D4Args &da, const uint8_t *ring_base, const uint32_t *full, uint32_t *consumed,
-                                           uint32_t &pg, uint32_t row, D4Fm &s, float k)
+                                           uint32_t &pg, uint32_t row, D4Fm &s)
 {
     d4_wait_piece(full, pg);
-    u32x2 p[4];
-    d4_read_row(ring_base + (pg & (D4_SLOTS - 1)) * D4_SLOT_BYTES, row, p);
+    const u32x4 n = *(const u32x4 *)(ring_base + (pg & (D4_SLOTS - 1)) * D4_SLOT_BYTES + row * 16u);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     lds_signal(consumed);
     pg++;
-    const float th[12] = {s.th[0], s.th[1], s.th[2], s.th[3], u2f(p[0].x), u2f(p[0].y), u2f(p[1].x), u2f(p[1].y),
-                          u2f(p[2].x), u2f(p[2].y), u2f(p[3].x), u2f(p[3].y)};
-    uint32_t e[8];
-    uint32_t peak = 0;
+    // this piece's 8 discriminator outputs: the pair that came early with the previous piece, then three of the four new
+    const uint32_t w[8] = {s.eh[0], s.eh[1], s.eh[2], s.eh[3], s.early, n.x, n.y, n.z};
+    s.early = n.w;
+    uint32_t peak = 0;     // max |e| of the piece, on the pairs (|-32768| stays 0x8000 = 32768 unsigned)
 #pragma unroll
-    for (int m = 0; m < 8; m++) {   // output m: theta[m-2] - theta[m-4] (FmDemodulator.cc:113-122, 479), branch cut, K, (int16)
-        const float d = wrap_delta(th[m + 2] - th[m]);
-        const int ev = (int)(int16_t)(uint16_t)cast_i16_bounded(k * d);
-        e[m] = (uint32_t)ev;
-        const uint32_t mg = (uint32_t)(ev < 0 ? -ev : ev);
-        peak = mg > peak ? mg : peak;
-    }
-#pragma unroll
-    for (int j = 0; j < 4; j++) s.th[j] = th[8 + j];
+    for (int j = 4; j < 8; j++) peak = pk_max_u16(peak, pk_abs_i16(w[j]));
+    peak = (peak & 0xffffu) > (peak >> 16) ? (peak & 0xffffu) : (peak >> 16);
     if (peak > (uint32_t)POST12_SAFE) s.loud_e = 4;   // stays inside a 12-sample window for this piece and the next
-    const uint32_t w[8] = {s.eh[0], s.eh[1], s.eh[2], s.eh[3], pack_lo16(e[0], e[1]), pack_lo16(e[2], e[3]),
-                           pack_lo16(e[4], e[5]), pack_lo16(e[6], e[7])};
     int a0 = 1 << 14, a1 = 1 << 14;                    // /4, 12 taps (FmDemodulator.cc:545): output j from e[4j-8 .. 4j+3]
     if (!__any(s.loud_e > 0)) {
 #pragma unroll
@@ -447,38 +520,28 @@ __device__ __forceinline__ void d4_fm_wave(const ChainLaunch &a, const D4Args &d
 {
     const uint8_t *ring_base = lds + ring * (D4_SLOTS * D4_SLOT_BYTES);
     const uint32_t *full = sync + ring * D4_SLOTS;
-    uint32_t *consumed = sync + 16 + ring;
+    uint32_t *consumed = sync + ST_RINGS * D4_SLOTS + ring;
     const int n_pieces = (da.halo + (int)a.tile_len) >> 5;
     uint32_t pg = 0;
     for (uint32_t round = 0; round < da.rounds; round++) {
         if ((round * gridDim.x + blockIdx.x) * ST_SEGS >= da.group_start[3]) break;
         const uint32_t sid = (round * gridDim.x + blockIdx.x) * ST_SEGS + ring * 64 + lane;
         const D4Seg sg = d4_segment(a, da, sid);
-        const float k_now = a.params[sg.ech].fm_k;
-        const GainEpochList *ep = &a.epochs[sg.ech].fm;
-        const bool ep_reach = ep->since[0] < (uint32_t)TAIL && (int64_t)sg.v0 - da.halo - 32 < -(int64_t)ep->since[0];
         int16_t *pcm_row = a.pcm + (size_t)sg.ch * a.pcm_stride;
         D4Fm s;
 #pragma unroll
-        for (int j = 0; j < 4; j++) { s.th[j] = 0.f; s.eh[j] = 0; }
+        for (int j = 0; j < 4; j++) s.eh[j] = 0;
+        s.early = 0;
 #pragma unroll
         for (int j = 0; j < 24; j++) s.y2p[j] = 0;
         s.loud_e = s.loud_y2 = 0;
         for (int pq = 0; pq < n_pieces; pq += 4) {
             const int pos = -da.halo + 32 * pq;
-            float k = k_now;
             int pcm[4];
-            // (a segment whose lead-in reaches back before a gain change runs that part with the gain of the time;
-            // changes fall on call boundaries = multiples of 128 samples, and a piece's differences reach 4 tuner
-            // outputs = 16 samples back, which the next chunk of 128 re-derives nothing from: per piece is exact)
-            if (ep_reach) k = epoch_gain(ep, k_now, sg.v0 + pos);
-            pcm[0] = d4_fm_piece<0>(da, ring_base, full, consumed, pg, (uint32_t)lane, s, k);
-            if (ep_reach) k = epoch_gain(ep, k_now, sg.v0 + pos + 32);
-            pcm[1] = d4_fm_piece<1>(da, ring_base, full, consumed, pg, (uint32_t)lane, s, k);
-            if (ep_reach) k = epoch_gain(ep, k_now, sg.v0 + pos + 64);
-            pcm[2] = d4_fm_piece<2>(da, ring_base, full, consumed, pg, (uint32_t)lane, s, k);
-            if (ep_reach) k = epoch_gain(ep, k_now, sg.v0 + pos + 96);
-            pcm[3] = d4_fm_piece<3>(da, ring_base, full, consumed, pg, (uint32_t)lane, s, k);
+            pcm[0] = d4_fm_piece<0>(da, ring_base, full, consumed, pg, (uint32_t)lane, s);
+            pcm[1] = d4_fm_piece<1>(da, ring_base, full, consumed, pg, (uint32_t)lane, s);
+            pcm[2] = d4_fm_piece<2>(da, ring_base, full, consumed, pg, (uint32_t)lane, s);
+            pcm[3] = d4_fm_piece<3>(da, ring_base, full, consumed, pg, (uint32_t)lane, s);
             if (sg.valid && pos >= 0 && pos < sg.tlen)
                 *(u32x2 *)(pcm_row + ((sg.v0 + pos) >> 5)) = u32x2{pack_lo16((uint32_t)pcm[0], (uint32_t)pcm[1]), pack_lo16((uint32_t)pcm[2], (uint32_t)pcm[3])};
 #pragma unroll
@@ -497,7 +560,8 @@ __global__ __launch_bounds__(ST_THREADS, D4_WAVES_PER_SIMD(MODE)) void d4_stream
     extern __shared__ __attribute__((aligned(16))) uint8_t d4_lds[];
     uint32_t *sync = (uint32_t *)(d4_lds + ST_RINGS * D4_SLOTS * D4_SLOT_BYTES);
     const int tid = (int)threadIdx.x;
-    if (tid < ST_SYNC_WORDS * 2) sync[tid] = 0;
+    if (tid < D4_SYNC_WORDS) sync[tid] = 0;
+    if (MAG) st_maglut_build(d4_lds + D4_MAGLUT_OFF, tid, ST_THREADS);
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     if (wave < ST_RINGS) {
@@ -510,23 +574,27 @@ __global__ __launch_bounds__(ST_THREADS, D4_WAVES_PER_SIMD(MODE)) void d4_stream
 #if IQD_D4_WAITSTAT
     __syncthreads();
     if (tid == 0 && (blockIdx.x & 63) == 5)
-        printf("wg %u: P sleeps %u (12 waves), consumer sleeps %u (3 waves), pieces %d\n", blockIdx.x, sync[24], sync[25], (da.halo + (int)a.tile_len) >> 5);
+        printf("wg %u: P sleeps %u (12 waves), consumer sleeps %u (3 waves), pieces %d\n", blockIdx.x, sync[D4_SYNC_WORDS - 2], sync[D4_SYNC_WORDS - 1], (da.halo + (int)a.tile_len) >> 5);
 #endif
 }
 
 hipError_t launch_d4_stream(const ChainLaunch &a, const D4Args &da, int mode, bool mag, uint32_t grid, hipStream_t s)
 {
-    const dim3 g(grid), b(ST_THREADS);
-    if (mode == D4_AM) {
-        if (mag) hipLaunchKernelGGL((d4_stream_kernel<D4_AM, true>), g, b, D4_LDS_BYTES, s, a, da);
-        else hipLaunchKernelGGL((d4_stream_kernel<D4_AM, false>), g, b, D4_LDS_BYTES, s, a, da);
-    } else if (mode == D4_SSB) {
-        if (mag) hipLaunchKernelGGL((d4_stream_kernel<D4_SSB, true>), g, b, D4_LDS_BYTES, s, a, da);
-        else hipLaunchKernelGGL((d4_stream_kernel<D4_SSB, false>), g, b, D4_LDS_BYTES, s, a, da);
-    } else {
-        if (mag) hipLaunchKernelGGL((d4_stream_kernel<D4_FM, true>), g, b, D4_LDS_BYTES, s, a, da);
-        else hipLaunchKernelGGL((d4_stream_kernel<D4_FM, false>), g, b, D4_LDS_BYTES, s, a, da);
+    typedef void (*Kernel)(const ChainLaunch, const D4Args);
+    static const Kernel ks[3][2] = {{d4_stream_kernel<D4_AM, false>, d4_stream_kernel<D4_AM, true>},
+                                    {d4_stream_kernel<D4_SSB, false>, d4_stream_kernel<D4_SSB, true>},
+                                    {d4_stream_kernel<D4_FM, false>, d4_stream_kernel<D4_FM, true>}};
+    static bool attr_set = false;
+    if (!attr_set) {                                     // more than the 64 KiB a kernel gets without asking
+        for (int m = 0; m < 3; m++)
+            for (int g = 0; g < 2; g++) {
+                const hipError_t e = hipFuncSetAttribute((const void *)ks[m][g], hipFuncAttributeMaxDynamicSharedMemorySize, D4_LDS_BYTES);
+                if (e != hipSuccess) return e;
+            }
+        attr_set = true;
     }
+    const int m = mode == D4_AM ? 0 : (mode == D4_SSB ? 1 : 2);
+    hipLaunchKernelGGL(ks[m][mag ? 1 : 0], dim3(grid), dim3(ST_THREADS), D4_LDS_BYTES, s, a, da);
     return hipGetLastError();
 }
 
