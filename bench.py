@@ -246,9 +246,9 @@ def rank_body(args, rank, world, dev, make_engine, dist, torch, order_streams=No
         if args.mode == "mixed":
             timed, timed_samples = "the first demodulator family launched (WBFM's stream / chain kernel)", None
         elif args.mode in ("am", "lsb", "usb", "ssb_stress"):
-            timed, timed_samples = "am_chain_kernel + its DC-removal kernels", n * n_ch
+            timed, timed_samples = ("d4_stream_kernel" if streamed else "am_chain_kernel") + " + its DC-removal kernels", n * n_ch
         elif args.mode == "fm":
-            timed, timed_samples = "fm_chain_kernel", n * n_ch
+            timed, timed_samples = ("d4_stream_kernel" if streamed else "fm_chain_kernel"), n * n_ch
         else:
             timed, timed_samples = ("wbfm_stream_kernel" if streamed else "wbfm_chain_kernel"), n * n_ch
         prof, prof_path = profile_summary(args.tag) if args.tag else (None, None)

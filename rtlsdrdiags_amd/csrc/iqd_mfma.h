@@ -133,32 +133,33 @@ __device__ __forceinline__ v4u gload16_untracked(const void *p)
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(p));
     return r;
 }
+// (In place, on the variable the load was issued into: handing the value to the wait by copy invites the compiler to
+// make that copy - of registers still in flight - in front of the wait.  tools/isa_lint.py checks the generated code
+// for exactly this.)
 template <int N_YOUNGER>
-__device__ __forceinline__ uint4 gload_arrived(v4u r)
+__device__ __forceinline__ void gload_wait(v4u &r)
 {
     asm volatile("s_waitcnt vmcnt(%1) ; arrived %0" : "+v"(r) : "n"(N_YOUNGER));   // (the comment is for tools/isa_lint.py)
-    return uint4{r.x, r.y, r.z, r.w};
 }
-
 // the same with a count that is only known after unrolling (folds to one s_waitcnt)
-__device__ __forceinline__ uint4 gload_arrived_n(v4u r, int n_younger)
+__device__ __forceinline__ void gload_wait_n(v4u &r, int n_younger)
 {
     switch (n_younger) {
-    case 0: return gload_arrived<0>(r);
-    case 1: return gload_arrived<1>(r);
-    case 2: return gload_arrived<2>(r);
-    case 3: return gload_arrived<3>(r);
-    case 4: return gload_arrived<4>(r);
-    case 5: return gload_arrived<5>(r);
-    case 6: return gload_arrived<6>(r);
-    case 7: return gload_arrived<7>(r);
-    case 8: return gload_arrived<8>(r);
-    case 9: return gload_arrived<9>(r);
-    case 10: return gload_arrived<10>(r);
-    case 11: return gload_arrived<11>(r);
-    default: return gload_arrived<0>(r);
+    case 1: gload_wait<1>(r); break;
+    case 2: gload_wait<2>(r); break;
+    case 3: gload_wait<3>(r); break;
+    case 4: gload_wait<4>(r); break;
+    case 5: gload_wait<5>(r); break;
+    case 6: gload_wait<6>(r); break;
+    case 7: gload_wait<7>(r); break;
+    case 8: gload_wait<8>(r); break;
+    case 9: gload_wait<9>(r); break;
+    case 10: gload_wait<10>(r); break;
+    case 11: gload_wait<11>(r); break;
+    default: gload_wait<0>(r); break;
     }
 }
+__device__ __forceinline__ uint4 as_uint4(v4u r) { return uint4{r.x, r.y, r.z, r.w}; }
 __device__ __forceinline__ uint32_t gload4_untracked(const void *p)
 {
     uint32_t r;
@@ -166,10 +167,9 @@ __device__ __forceinline__ uint32_t gload4_untracked(const void *p)
     return r;
 }
 template <int N_YOUNGER>
-__device__ __forceinline__ uint32_t gload_arrived(uint32_t r)
+__device__ __forceinline__ void gload_wait(uint32_t &r)
 {
     asm volatile("s_waitcnt vmcnt(%1) ; arrived %0" : "+v"(r) : "n"(N_YOUNGER));
-    return r;
 }
 
 // ---- producer / consumer plumbing of the streaming kernels (waves of one workgroup talking through LDS rings) ----

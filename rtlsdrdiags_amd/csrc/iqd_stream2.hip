@@ -2,24 +2,30 @@
 // a full-rate recurrence: one persistent 15-wave workgroup per CU, 192 segments in lock step, 32 samples (a piece)
 // at a time.
 //
-//   12 P waves, 16 segments each: raw bytes -> signed, rotation signs (SDWA) -> squelch magnitude -> the chain's
-//       first /4 decimator on both rails as v_mfma_i32_16x16x64_i8 (FM: 32-tap tuner filter, AM/SSB: 8 taps; the
-//       part of the window that lies in the previous piece through a second, chained MFMA) ->
-//       AM/SSB: 8 + 8 int16 outputs per piece into the ring;  FM: the exact phase angle of each of the 8 outputs
-//       (283 x 283 table in global memory, L2-resident) into the ring
+//   12 P waves, 16 segments each: raw bytes (four pieces of input in flight per wave, iqd_mfma.h: gload16_untracked)
+//       -> squelch magnitude of the raw samples through a 68 KiB table in LDS -> signed, rotation signs (SDWA) -> the
+//       chain's first /4 decimator on both rails as v_mfma_i32_16x16x64_i8 (FM: 32-tap tuner filter, AM/SSB: 8 taps;
+//       the part of the window that lies in the previous piece through a second, chained MFMA) ->
+//       AM/SSB: 8 + 8 int16 outputs per piece into the ring
+//       FM: the exact phase angle of each output (283 x 283 table in global memory, L2-resident), then the
+//           discriminator right here, two outputs per lane: theta[m] - theta[m-2] (the lane 16 below holds theta[m-2]),
+//           branch cut, K, (int16) - one dword per lane into the ring
 //   3 consumer waves, 64 segments each (one per lane): the remaining stages with their histories in registers
 //       AM   /4 (12 taps) /2 (16 taps) on both rails -> max + min/2 -> detector input at 8 kS/s
 //       SSB  the same -> -i[n-15] -+ Hilbert31(q) -> detector input at 8 kS/s
-//       FM   theta[n-2] - theta[n-4], branch cut, K, (int16) -> /4 (12 taps) -> /2 (40 taps) -> PCM
+//       FM   /4 (12 taps) -> /2 (40 taps) -> PCM (the P waves' stream runs two samples early: one pair is kept a piece)
 //   AM/SSB stop in front of the 8 kS/s DC-removal IIR like the tile kernel does (dc_* kernels run it exactly).
 //
 // Every stage is a FIR: a segment rebuilds its histories over a lead-in (AM 384, FM 768, SSB 1280 samples) and is
 // exact by construction - no verification, no records.  Segments of channels with different rotation selectors sit
-// in groups padded to 16, so that a P wave's 16 segments always share one (its tap matrices and byte negations).
+// in groups padded to 16, so that a P wave's 16 segments always share one (its tap matrices and byte negations; the
+// piece loop is instantiated per selector).
 //
 // Reference: FmDemodulator.cc:376-560, AmDemodulator.cc:339-504, SsbDemodulator.cc:462-598 behind
 // IqDataProcessor.cc:735-749.  hipcc --offload-arch=gfx950 -ffp-contract=off.
 #include <hip/hip_runtime.h>
+
+#include <type_traits>
 
 #include "iqd_kernels.h"
 #include "iqd_stream.h"
@@ -169,20 +175,22 @@ __device__ __forceinline__ void d4_p_round(const ChainLaunch &a, const D4Args &d
         // buffers of a loop unrolled by four: handing a buffer on with register moves would wait for the load it has
         // just issued.  Waits count the loads issued since (iqd_mfma.h): per piece one of these, for FM two angles more.
         constexpr int PER_PIECE = MODE == D4_FM ? 3 : 1;
-        const v4u raw_before = load_piece(-da.halo - 32);
+        v4u raw_before = load_piece(-da.halo - 32);
         v4u raw[D4_AHEAD];
 #pragma unroll
         for (int j = 0; j < D4_AHEAD; j++) raw[j] = load_piece(-da.halo + 32 * j);
-        uint4 prev = front(gload_arrived<D4_AHEAD>(raw_before));
-        for (int q0 = 0; q0 < n_pieces; q0 += D4_AHEAD) {       // (n_pieces is a multiple of 4)
-#pragma unroll
-          for (int j = 0; j < D4_AHEAD; j++) {
+        gload_wait<D4_AHEAD>(raw_before);
+        uint4 prev = front(as_uint4(raw_before));
+        // One piece.  `first` (a type) says whether this is the first trip through the four buffers, where fewer loads
+        // have been issued since raw[j]'s: the two cases are separate instantiations, not a branch - a wait chosen at run
+        // time made the compiler copy the buffer, still in flight, in front of one of the two waits.
+        auto piece = [&](auto first, int q0, int j) {
             const int pos = -da.halo + 32 * (q0 + j);
             // younger than raw[j]: the other three buffers' loads, plus the angles asked for since its own issue (in
             // the first trip: since the start)
-            uint4 rawj;
-            if (PER_PIECE == 1 || q0 > 0) rawj = gload_arrived<D4_AHEAD - 1 + (PER_PIECE - 1) * D4_AHEAD>(raw[j]);
-            else rawj = gload_arrived_n(raw[j], D4_AHEAD - 1 + (PER_PIECE - 1) * j);
+            if (PER_PIECE == 1 || !decltype(first)::value) gload_wait<D4_AHEAD - 1 + (PER_PIECE - 1) * D4_AHEAD>(raw[j]);
+            else gload_wait_n(raw[j], D4_AHEAD - 1 + (PER_PIECE - 1) * j);
+            const uint4 rawj = as_uint4(raw[j]);
             const uint4 cur = front(rawj);
             const v4i bc = {(int)cur.x, (int)cur.y, (int)cur.z, (int)cur.w};
             const v4i bp = {(int)prev.x, (int)prev.y, (int)prev.z, (int)prev.w};
@@ -214,27 +222,36 @@ __device__ __forceinline__ void d4_p_round(const ChainLaunch &a, const D4Args &d
 #pragma unroll
             for (int r = 0; r < 4; r++) y[r] = (lo[r] + (int)((uint32_t)hi[r] << 8)) >> 15;
             if (MODE == D4_FM) {   // |y| <= 141: the exact theta table (FmDemodulator.cc:476)
-#if IQD_D4_FAKE_LUT   // timing experiment only: all lookups inside one 1 KiB corner of the table
-                asked_a[j & 1] = gload4_untracked(&da.fm_lut[((y[1] + FM_LUT_R) * FM_LUT_W + (y[0] + FM_LUT_R)) & 255]);
-                asked_b[j & 1] = gload4_untracked(&da.fm_lut[((y[3] + FM_LUT_R) * FM_LUT_W + (y[2] + FM_LUT_R)) & 255]);
-#else
                 asked_a[j & 1] = gload4_untracked(&da.fm_lut[(y[1] + FM_LUT_R) * FM_LUT_W + (y[0] + FM_LUT_R)]);
                 asked_b[j & 1] = gload4_untracked(&da.fm_lut[(y[3] + FM_LUT_R) * FM_LUT_W + (y[2] + FM_LUT_R)]);
-#endif
-                if (q0 + j > 0) {  // the piece before: younger than its second angle are this piece's input load and two angles
-                    const uint32_t ta = gload_arrived<3>(asked_a[(j & 1) ^ 1]), tb = gload_arrived<3>(asked_b[(j & 1) ^ 1]);
-                    fm_finish(pos - 32, ta, tb, seen);
+                if (!decltype(first)::value || j > 0) {  // the piece before: younger than its second angle are this piece's input load and two angles
+                    gload_wait<3>(asked_a[(j & 1) ^ 1]);
+                    gload_wait<3>(asked_b[(j & 1) ^ 1]);
+                    fm_finish(pos - 32, asked_a[(j & 1) ^ 1], asked_b[(j & 1) ^ 1], seen);
                 }
             } else {
                 // I' outputs 2g, 2g+1 | Q'
                 hand_over(u32x2{pack_lo16((uint32_t)y[0], (uint32_t)y[2]), pack_lo16((uint32_t)y[1], (uint32_t)y[3])}, seen);
             }
             prev = cur;
-          }
+        };
+        int q_start = 0;
+        if (PER_PIECE > 1) {                                    // (n_pieces is a multiple of 4 and at least 12)
+#pragma unroll
+            for (int j = 0; j < D4_AHEAD; j++) piece(std::true_type{}, 0, j);
+            q_start = D4_AHEAD;
         }
+        for (int q0 = q_start; q0 < n_pieces; q0 += D4_AHEAD) {
+#pragma unroll
+            for (int j = 0; j < D4_AHEAD; j++) piece(std::false_type{}, q0, j);
+        }
+        // the loads asked for beyond the last piece (clamped re-reads) must have landed before their registers move on
+#pragma unroll
+        for (int j = 0; j < D4_AHEAD; j++) gload_wait<0>(raw[j]);
         if (MODE == D4_FM) {       // the last piece
-            const uint32_t ta = gload_arrived<0>(asked_a[(D4_AHEAD - 1) & 1]), tb = gload_arrived<0>(asked_b[(D4_AHEAD - 1) & 1]);
-            fm_finish(-da.halo + 32 * (n_pieces - 1), ta, tb, lds_load_relaxed(consumed));
+            gload_wait<0>(asked_a[(D4_AHEAD - 1) & 1]);
+            gload_wait<0>(asked_b[(D4_AHEAD - 1) & 1]);
+            fm_finish(-da.halo + 32 * (n_pieces - 1), asked_a[(D4_AHEAD - 1) & 1], asked_b[(D4_AHEAD - 1) & 1], lds_load_relaxed(consumed));
         }
         if (MAG && macc) atomicAdd(&mag_row[mblk], macc);
 }

@@ -1,0 +1,18 @@
+"""CPU tier: the generated gfx950 code of the streaming kernels never touches a register that an untracked prefetch
+load (iqd_mfma.h: gload16_untracked) still owns - tools/isa_lint.py compiles the file and follows the control flow.
+(The hazard is silent on a quiet machine: the bytes usually have arrived long before.  It was found by this lint.)"""
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_untracked_loads_are_not_touched_before_they_arrive():
+    src = os.path.join(ROOT, "rtlsdrdiags_amd", "csrc", "iqd_stream2.hip")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_lint.py"), src], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-4000:]
+    last = r.stdout.strip().splitlines()[-1]
+    assert "0 finding(s)" in last and " 6 kernels" in last, last
+    n_loads = int(last.split(" global loads")[0].split()[-1])
+    assert n_loads > 100          # the lint saw the loads it is about

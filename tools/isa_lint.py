@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""Lint for the streaming kernels' untracked prefetch loads (rtlsdrdiags_amd/csrc/iqd_mfma.h: gload16_untracked).
+
+Those loads are inline assembly the compiler does not track: nothing may read or overwrite their destination
+registers between the load and the matching `s_waitcnt vmcnt(N) ; arrived v[..]` - a register move there (a loop
+hand-over the allocator decided on) would copy bytes that have not arrived yet.  This compiles a .hip file to gfx950
+assembly and runs a forward data flow over every kernel's control-flow graph (which registers may still be in flight):
+
+    python3 tools/isa_lint.py rtlsdrdiags_amd/csrc/iqd_stream2.hip
+
+Exit status 1 and a listing if a destination register of a pending untracked load is touched before its arrival."""
+import re
+import subprocess
+import sys
+import tempfile
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REG = re.compile(r"\bv\[(\d+):(\d+)\]|\bv(\d+)\b")
+
+
+def regs_of(text):
+    out = set()
+    for m in REG.finditer(text):
+        if m.group(3) is not None:
+            out.add(int(m.group(3)))
+        else:
+            out.update(range(int(m.group(1)), int(m.group(2)) + 1))
+    return out
+
+
+def compile_to_asm(src):
+    fd, path = tempfile.mkstemp(suffix=".s")
+    os.close(fd)
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-strict-aliasing",
+           "-w", "-I" + os.path.join(ROOT, "rtlsdrdiags_amd", "csrc"), "-I" + os.path.join(ROOT, "include"),
+           "-S", "--cuda-device-only", "-o", path, src]
+    subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    text = open(path).read()
+    os.unlink(path)
+    return text
+
+
+def parse(lines):
+    """-> list of (line_no, text, kind, regs, target): kind in load / arrived / settle / end / branch / cbranch / other"""
+    out, labels, in_asm = [], {}, False
+    for no, raw in lines:
+        line = raw.strip()
+        if line.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if line.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        m = re.match(r"^(\.LBB\w+):", line)
+        if m:
+            labels[m.group(1)] = len(out)
+            continue
+        if not line or line.startswith(";") or line.startswith("."):
+            continue
+        code, _, comment = line.partition(";")
+        code = code.strip()
+        op = code.split()[0] if code else ""
+        if in_asm and op.startswith("global_load_dword"):
+            out.append((no, line, "load", regs_of(code.split(",")[0]), None))
+        elif in_asm and op == "s_waitcnt" and "arrived" in comment:
+            out.append((no, line, "arrived", regs_of(comment), None))
+        elif op == "s_waitcnt" and "vmcnt(0)" in code:
+            out.append((no, line, "settle", set(), None))
+        elif op == "s_endpgm":
+            out.append((no, line, "end", set(), None))
+        elif op == "s_branch":
+            out.append((no, line, "branch", set(), code.split()[1]))
+        elif op.startswith("s_cbranch"):
+            out.append((no, line, "cbranch", set(), code.split()[1]))
+        else:
+            out.append((no, line, "other", regs_of(code), None))
+    return out, labels
+
+
+def lint_kernel(name, lines):
+    """Forward data flow over the kernel's control-flow graph: which registers may belong to an untracked load that has
+    not been waited for; any other instruction naming such a register is a finding."""
+    ins, labels = parse(lines)
+    n = len(ins)
+    succ = [[] for _ in range(n)]
+    for i, (no, text, kind, regs, target) in enumerate(ins):
+        if kind == "end":
+            continue
+        if kind in ("branch", "cbranch") and target in labels and labels[target] < n:
+            succ[i].append(labels[target])
+        if kind != "branch" and i + 1 < n:
+            succ[i].append(i + 1)
+    pend_in = [dict() for _ in range(n)]            # register -> line of the owning load
+    work = [0] if n else []
+    seen_once = [False] * n
+    while work:
+        i = work.pop()
+        no, text, kind, regs, target = ins[i]
+        cur = dict(pend_in[i])
+        if kind == "load":
+            for r in regs:
+                cur[r] = no
+        elif kind == "arrived":
+            for r in regs:
+                cur.pop(r, None)
+        elif kind in ("settle", "end"):
+            cur = {}
+        for j in succ[i]:
+            merged = dict(pend_in[j])
+            changed = not seen_once[j]
+            for r, owner in cur.items():
+                if r not in merged:
+                    merged[r] = owner
+                    changed = True
+            if changed:
+                pend_in[j] = merged
+                seen_once[j] = True
+                work.append(j)
+    findings = []
+    for i, (no, text, kind, regs, target) in enumerate(ins):
+        if kind != "other" and kind != "load":
+            continue
+        touched = regs & set(pend_in[i]) if kind == "other" else set()
+        if kind == "load":      # the address registers of a load may not be pending either; its own destination may
+            addr = regs_of(text.split(",", 1)[1]) if "," in text else set()
+            touched = addr & set(pend_in[i])
+        if touched:
+            findings.append((name, no, text, sorted(touched), sorted({pend_in[i][r] for r in touched})))
+    return findings
+
+
+def main():
+    src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "rtlsdrdiags_amd", "csrc", "iqd_stream2.hip")
+    text = compile_to_asm(src)
+    kernels = {}
+    cur = None
+    for no, line in enumerate(text.splitlines(), 1):
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            cur = m.group(1)
+            kernels[cur] = []
+            continue
+        if cur is not None:
+            kernels[cur].append((no, line))
+            if line.strip().startswith("s_endpgm"):
+                cur = None
+    findings = []
+    n_loads = 0
+    for name, lines in kernels.items():
+        n_loads += sum(1 for _, l in lines if "global_load_dword" in l)
+        findings += lint_kernel(name, lines)
+    seen = set()
+    for name, no, raw, regs, owners in findings:
+        key = (name, no)
+        if key in seen:
+            continue
+        seen.add(key)
+        print("%s: line %d touches v%s of the untracked load(s) at line(s) %s before arrival:\n    %s"
+              % (name, no, regs, owners, raw))
+    print("%s: %d kernels, %d global loads, %d finding(s)" % (os.path.basename(src), len(kernels), n_loads, len(seen)))
+    return 1 if seen else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

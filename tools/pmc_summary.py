@@ -68,7 +68,11 @@ def main():
         d["lds_conflict_share"] = counters["SQ_LDS_BANK_CONFLICT"] / counters["SQ_LDS_IDX_ACTIVE"]
     if counters.get("GRBM_GUI_ACTIVE") and res.get("kernel_ms_avg"):
         # rocprofv3 sums the 8 XCDs (MI355X_MICROARCH.md, DVFS give-back); the PMC passes run a little slower than the trace
-        res["clock_ghz"] = round(counters["GRBM_GUI_ACTIVE"] / 8 / (res["kernel_ms_avg"] * 1e-3) / 1e9, 3)
+        # (the counter pass is not the traced pass: when its kernel ran longer the quotient exceeds the 2.4 GHz the
+        # part can clock at - then the nominal peak is used, which can only understate the busy fraction)
+        raw = counters["GRBM_GUI_ACTIVE"] / 8 / (res["kernel_ms_avg"] * 1e-3) / 1e9
+        res["clock_ghz_raw"] = round(raw, 3)
+        res["clock_ghz"] = round(min(raw, 2.4), 3)
     if "SQ_ACTIVE_INST_VALU" in counters and res.get("kernel_ms_avg"):
         # SQ_ACTIVE_INST_VALU counts quad-cycles over all SIMDs; 1024 SIMDs on the chip
         ghz = res.get("clock_ghz", 2.3)

@@ -15,8 +15,8 @@ PY
 run r2_wbfm_2p28 wbfm_stream_kernel 268435456
 run r2_wbfm_2p28_tiles wbfm_chain_kernel 268435456 --wbfm-path tiles
 run r2_wbfm_2p28_white wbfm_stream_kernel 268435456 --signal white
-run r2_fm_4096 fm_chain_kernel 268435456 --config 2
-run r2_am_4096 am_chain_kernel 268435456 --mode am --channels 4096 --log2-samples 16
-run r2_usb_4096 am_chain_kernel 268435456 --mode usb --channels 4096 --log2-samples 16
-run r2_ssb_8192 am_chain_kernel 536870912 --config 4
+run r2_fm_4096 d4_stream_kernel 268435456 --config 2
+run r2_am_4096 d4_stream_kernel 268435456 --mode am --channels 4096 --log2-samples 16
+run r2_usb_4096 d4_stream_kernel 268435456 --mode usb --channels 4096 --log2-samples 16
+run r2_ssb_8192 d4_stream_kernel 536870912 --config 4
 run r2_mixed_4096 wbfm_stream_kernel 53673984 --config 3

@@ -86,6 +86,57 @@ static void run4(const uint8_t *d, uint32_t *o, size_t total, const char *what)
     printf("%-44s %.4f ms  %.2f TB/s\n", what, best, total / (best * 1e-3) / 1e12);
 }
 
+// SEGS segments per load instruction, 1024 / SEGS contiguous bytes each; a wave owns 16 segments
+template <int SEGS, int AHEAD>
+__global__ __launch_bounds__(768) void streams_n(const uint8_t *in, uint32_t *out, uint32_t seg_bytes, int n_steps)
+{
+    constexpr int LANES = 64 / SEGS, CHUNK = 16 * LANES, GROUPS = 16 / SEGS;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, sx = lane / LANES, lx = lane % LANES;
+    const uint32_t seg0 = (blockIdx.x * 12 + wave) * 16;
+    uint4 acc = {0, 0, 0, 0};
+    uint4 buf[AHEAD][GROUPS];
+    const uint8_t *p[GROUPS];
+#pragma unroll
+    for (int grp = 0; grp < GROUPS; grp++) p[grp] = in + (size_t)(seg0 + SEGS * grp + sx) * seg_bytes + 16 * lx;
+#pragma unroll
+    for (int j = 0; j < AHEAD; j++)
+#pragma unroll
+        for (int grp = 0; grp < GROUPS; grp++) buf[j][grp] = *(const uint4 *)(p[grp] + j * CHUNK);
+    for (int q = 0; q < n_steps; q += AHEAD) {
+#pragma unroll
+        for (int j = 0; j < AHEAD; j++) {
+#pragma unroll
+            for (int grp = 0; grp < GROUPS; grp++) {
+                const uint4 v = buf[j][grp];
+                acc.x ^= v.x; acc.y += v.y; acc.z ^= v.z; acc.w += v.w;
+                int nq = q + j + AHEAD;
+                nq = nq < n_steps ? nq : n_steps - 1;
+                buf[j][grp] = *(const uint4 *)(p[grp] + (size_t)nq * CHUNK);
+            }
+        }
+    }
+    out[blockIdx.x * 768 + threadIdx.x] = acc.x + acc.y + acc.z + acc.w;
+}
+
+template <int SEGS, int A>
+static void run_n(const uint8_t *d, uint32_t *o, const char *what)
+{
+    const uint32_t nseg = 256 * 12 * 16, seg_bytes = 11264;
+    const size_t total = (size_t)seg_bytes * nseg;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e9f;
+    for (int it = 0; it < 6; it++) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((streams_n<SEGS, A>), dim3(256), dim3(768), 0, 0, d, o, seg_bytes, (int)(seg_bytes / (1024 / SEGS)));
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (it && ms < best) best = ms;
+    }
+    printf("%-44s %.4f ms  %.2f TB/s\n", what, best, total / (best * 1e-3) / 1e12);
+}
+
 // the same bytes, fully coalesced: a workgroup streams through its contiguous share, a wave takes 1 KiB at a time
 template <int AHEAD>
 __global__ __launch_bounds__(768) void coalesced(const uint8_t *in, uint32_t *out, uint32_t wg_bytes)
@@ -167,6 +218,11 @@ int main()
         snprintf(what, sizeof what, "64 B pieces, segments %u bytes apart", sb);
         run<16, 4>(d, o, total, what, sb);
     }
+    run_n<16, 2>(d, o, "16 segments x 64 B per load, 2 ahead");
+    run_n<8, 1>(d, o, "8 segments x 128 B per load, 1 ahead");
+    run_n<8, 2>(d, o, "8 segments x 128 B per load, 2 ahead");
+    run_n<4, 2>(d, o, "4 segments x 256 B per load, 2 ahead");
+    run_n<2, 1>(d, o, "2 segments x 512 B per load, 1 ahead");
     run4<1>(d, o, total, "4 segments x 256 B per load, 1 step ahead");
     run4<2>(d, o, total, "4 segments x 256 B per load, 2 steps ahead");
     run_coalesced<4>(d, o, total, 256, "coalesced, 256 workgroups, 4 ahead");
