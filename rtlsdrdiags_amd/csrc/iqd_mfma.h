@@ -172,6 +172,10 @@ __device__ __forceinline__ void gload_wait(uint32_t &r)
     asm volatile("s_waitcnt vmcnt(%1) ; arrived %0" : "+v"(r) : "n"(N_YOUNGER));
 }
 
+#ifndef IQD_RINGS_IN_A_ROW
+#define IQD_RINGS_IN_A_ROW 0
+#endif
+
 // ---- producer / consumer plumbing of the streaming kernels (waves of one workgroup talking through LDS rings) ----
 __device__ __forceinline__ uint32_t lds_load_relaxed(const uint32_t *p)
 {

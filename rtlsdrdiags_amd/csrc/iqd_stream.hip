@@ -37,7 +37,14 @@ template <int ROT, bool MAG>
 __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs &sa, uint8_t *lds, uint32_t *sync,
                                           int pw, int lane)
 {
+    // a ring's four P waves are every third wave, not four in a row: the hardware issues oldest wave first, and with
+    // rings of neighbouring waves ring 0 ran a third ahead of ring 2 (per-wave end times 115 / 137 / 155 us), which left
+    // the last ring to finish on a nearly empty CU.  Now every ring has a wave of each age.
+#if IQD_RINGS_IN_A_ROW
     const int ring = pw / ST_P_PER_RING, cg = pw % ST_P_PER_RING;
+#else
+    const int ring = pw % ST_RINGS, cg = pw / ST_RINGS;
+#endif
     const int g = lane >> 4, c = lane & 15;
     const uint32_t row = (uint32_t)(16 * cg + c);                // ring row of this lane's segment
     uint8_t *ring_base = lds + ST_TABLE_BYTES + ring * (ST_RING_SLOTS * ST_SLOT_BYTES);

@@ -39,6 +39,12 @@
 #ifndef IQD_D4_PRIO
 #define IQD_D4_PRIO 0
 #endif
+#ifndef IQD_D4_TIMING
+#define IQD_D4_TIMING 0
+#endif
+#ifndef IQD_D4_TRANSPOSE
+#define IQD_D4_TRANSPOSE 0
+#endif
 #ifndef IQD_D4_MAGLUT
 #define IQD_D4_MAGLUT 1
 #endif
@@ -51,8 +57,12 @@ namespace iqd {
 #ifndef IQD_D4_SLOTS
 #define IQD_D4_SLOTS 8
 #endif
-constexpr int D4_SLOTS = IQD_D4_SLOTS;            // ring depth in pieces (a power of two)
-constexpr int D4_SYNC_WORDS = ST_RINGS * D4_SLOTS + 8;   // per ring: a "full" counter per slot; then a "consumed" counter per ring
+constexpr int D4_SLOTS = IQD_D4_SLOTS;            // ring depth in pieces: whole quads, a power of two of them
+constexpr int D4_QUADS = D4_SLOTS / 4;            // the waves shake hands once per quad (4 pieces = 128 samples), not per piece
+// per ring a "full" counter per quad of slots (each of the 4 P waves adds 1 when it has stored the quad's last piece), then
+// a "consumed" counter per ring (quads the consumer wave has read)
+constexpr int D4_SYNC_WORDS = ST_RINGS * D4_QUADS + 8;
+static_assert(D4_SLOTS % 4 == 0 && (D4_QUADS & (D4_QUADS - 1)) == 0 && D4_QUADS >= 2, "ring depth");
 constexpr int D4_AHEAD = 4;                       // pieces of input a P wave keeps in flight
 constexpr int D4_SLOT_BYTES = 64 * 32;            // 64 segments x (4 lanes x 8 bytes) per piece
 constexpr int D4_MAGLUT_OFF = (ST_RINGS * D4_SLOTS * D4_SLOT_BYTES + D4_SYNC_WORDS * 4 + 15) & ~15;   // squelch magnitude table (iqd_mfma.h)
@@ -91,11 +101,22 @@ __device__ __forceinline__ uint32_t d4_ring_off(uint32_t row, uint32_t g) { retu
 // ---- P wave ---------------------------------------------------------------------------------------------
 // One round of one P wave: its 16 segments from lead-in to end, with the rotation as a template parameter so that the
 // piece loop is straight-line code (the selector is uniform over the wave: groups are padded to 16).
+// A lane has two identities.  It LOADS as lane 4 c + k: bytes 16 k .. 16 k + 15 of segment c's piece, so that the four
+// lanes of a segment are neighbours and ask for 64 contiguous bytes (tools/ubench/streams.hip: 4.4 TB/s against 2.9
+// when they sit 16 lanes apart, which is how the matrix instruction wants them); squelch magnitudes are taken in this
+// arrangement.  Four ds_bpermute then put the bytes where v_mfma expects them - lane 16 k + c - and everything behind
+// the matrix instruction (sg, g) belongs to that arrangement.
 template <int MODE, bool MAG, int ROT>
-__device__ __forceinline__ void d4_p_round(const ChainLaunch &a, const D4Args &da, const D4Seg &sg, uint8_t *ring_base,
+__device__ __forceinline__ void d4_p_round(const ChainLaunch &a, const D4Args &da, const D4Seg &sg, const D4Seg &sgl, uint8_t *ring_base,
                                            const uint32_t *full, const uint32_t *consumed, uint32_t *sync, uint32_t wr_off,
                                            int g, int lane, uint32_t &pg)
 {
+#if IQD_D4_TRANSPOSE
+        const int gl = lane & 3;                                 // k group of the bytes this lane loads
+        const int from_lane4 = (4 * (lane & 15) + (lane >> 4)) << 2;   // ds_bpermute address: who loaded this lane's operand
+#else
+        const int gl = g;
+#endif
         const int rot = ROT;
         const v4i cround = {1 << 14, 1 << 14, 1 << 14, 1 << 14}, czero = {0, 0, 0, 0};
         uint32_t zero = 0, four = 4;
@@ -104,10 +125,10 @@ __device__ __forceinline__ void d4_p_round(const ChainLaunch &a, const D4Args &d
         const int n_pieces = (da.halo + (int)a.tile_len) >> 5;
         const v4i *am = (const v4i *)da.amat + (size_t)(rot + 1) * 4 * 64;
         const v4i A0 = am[0 * 64 + lane], A1 = am[1 * 64 + lane], A2 = am[2 * 64 + lane], A3 = am[3 * 64 + lane];
-        const uint8_t *iq_ch = a.iq + (size_t)sg.ch * a.ch_stride_bytes;
+        const uint8_t *iq_ch = a.iq + (size_t)sgl.ch * a.ch_stride_bytes;
         const int fam = MODE == D4_FM ? FAM_FM : (MODE == D4_AM ? FAM_AM : FAM_SSB);
-        const uint8_t *tail = a.tails + ((size_t)sg.ech * FAM_COUNT + fam) * TAIL_BYTES + TAIL_BYTES;
-        const int32_t vlane = sg.v0 + 8 * g;
+        const uint8_t *tail = a.tails + ((size_t)sgl.ech * FAM_COUNT + fam) * TAIL_BYTES + TAIL_BYTES;
+        const int32_t vlane = sgl.v0 + 8 * gl;
         const uint8_t *base_iq = iq_ch + 2 * (int64_t)vlane, *base_tail = tail + 2 * (int64_t)vlane;
         const int32_t pos_max = (int32_t)a.vlen - 8 - vlane;
         auto load_piece = [&](int pos) -> v4u {
@@ -115,30 +136,45 @@ __device__ __forceinline__ void d4_p_round(const ChainLaunch &a, const D4Args &d
             const uint8_t *base = pc < -vlane ? base_tail : base_iq;
             return gload16_untracked(base + 2 * (int64_t)pc);
         };
+#if IQD_D4_TRANSPOSE
+        auto front = [&](uint4 raw) -> uint4 {                   // signed bytes, rotation signs, then to the matrix arrangement
+            const uint4 f = st_front<ROT>(raw, zero);
+            return uint4{(uint32_t)__builtin_amdgcn_ds_bpermute(from_lane4, (int)f.x), (uint32_t)__builtin_amdgcn_ds_bpermute(from_lane4, (int)f.y),
+                         (uint32_t)__builtin_amdgcn_ds_bpermute(from_lane4, (int)f.z), (uint32_t)__builtin_amdgcn_ds_bpermute(from_lane4, (int)f.w)};
+        };
+#else
         auto front = [&](uint4 raw) -> uint4 { return st_front<ROT>(raw, zero); };
-        uint32_t *mag_row = MAG ? a.mag_sums + (size_t)sg.ch * a.n_blocks : nullptr;
-        const bool mcount = MAG && sg.valid;
-        const int32_t mlimit = sg.tlen - 8 * g;
+#endif
+        uint32_t *mag_row = MAG ? a.mag_sums + (size_t)sgl.ch * a.n_blocks : nullptr;
+        const bool mcount = MAG && sgl.valid;
+        const int32_t mlimit = sgl.tlen - 8 * gl;
         uint32_t macc = 0;
-        uint32_t mblk = (uint32_t)(sg.v0 + 8 * g) / a.block_samples;
-        uint32_t minblk = (uint32_t)(sg.v0 + 8 * g) - mblk * a.block_samples;
+        uint32_t mblk = (uint32_t)(sgl.v0 + 8 * gl) / a.block_samples;
+        uint32_t minblk = (uint32_t)(sgl.v0 + 8 * gl) - mblk * a.block_samples;
 
-        // the piece's ring slot: wait until the consumer has freed it, store, signal
-        auto hand_over = [&](u32x2 payload, uint32_t seen) {
-            if (pg >= (uint32_t)D4_SLOTS)
-                while ((int32_t)(seen - (pg - (D4_SLOTS - 1))) < 0) {
+        // A piece into its ring slot.  `sq` (known after unrolling) is the slot's place in its quad: room is checked
+        // before a quad's first store - its four slots are free once the consumer has read the quad D4_QUADS back - and
+        // the quad is published after its last.
+        auto hand_over = [&](u32x2 payload, int sq) {
+            if (sq == 0 && pg >= (uint32_t)D4_QUADS) {
+                uint32_t seen = lds_load_relaxed(consumed);
+                while ((int32_t)(seen - (pg - (D4_QUADS - 1))) < 0) {
 #if IQD_D4_WAITSTAT
                     if (lane == 0) atomicAdd(&sync[D4_SYNC_WORDS - 2], 1u);
 #endif
                     __builtin_amdgcn_s_sleep(1);
                     seen = lds_load_relaxed(consumed);
                 }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            if (MODE == D4_FM) *(uint32_t *)(ring_base + (pg & (D4_SLOTS - 1)) * D4_SLOT_BYTES + wr_off) = payload.x;
-            else *(u32x2 *)(ring_base + (pg & (D4_SLOTS - 1)) * D4_SLOT_BYTES + wr_off) = payload;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            lds_signal(&full[pg & (D4_SLOTS - 1)]);
-            pg++;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
+            uint8_t *slot = ring_base + ((pg & (D4_QUADS - 1)) * 4 + (uint32_t)sq) * D4_SLOT_BYTES + wr_off;
+            if (MODE == D4_FM) *(uint32_t *)slot = payload.x;
+            else *(u32x2 *)slot = payload;
+            if (sq == 3) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                lds_signal(&full[pg & (D4_QUADS - 1)]);
+                pg++;
+            }
         };
         // FM: the discriminator runs here too, two outputs per lane (theta[m] - theta[m-2]: the lane 16 below holds
         // theta[m-2], for the first lane group it is what the last one held a piece ago).  The two angles come from the
@@ -154,7 +190,10 @@ __device__ __forceinline__ void d4_p_round(const ChainLaunch &a, const D4Args &d
             asm volatile("" :: "v"(k_now), "v"(reach));
         }
         uint32_t asked_a[2] = {0, 0}, asked_b[2] = {0, 0};
-        auto fm_finish = [&](int pos, uint32_t ta_bits, uint32_t tb_bits, uint32_t seen) {
+#if IQD_D4_TIMING
+        long long t_wait_raw = 0, t_front_mag = 0, t_post_hand = 0;
+#endif
+        auto fm_finish = [&](int pos, uint32_t ta_bits, uint32_t tb_bits, int sq) {
             const float ta = u2f(ta_bits), tb = u2f(tb_bits);
             const float give_a = g == 3 ? last_a : ta, give_b = g == 3 ? last_b : tb;
             const float before_a = u2f((uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)f2u(give_a)));
@@ -169,7 +208,7 @@ __device__ __forceinline__ void d4_p_round(const ChainLaunch &a, const D4Args &d
             if (ep_reach) kk = epoch_gain(ep, k_now, sg.v0 + pos + (g == 3 ? 32 : 0));
             const uint32_t ea = cast_i16_bounded(kk * wrap_delta(ta - before_a));   // branch cut, K, cast; (int16) = the low half
             const uint32_t eb = cast_i16_bounded(kk * wrap_delta(tb - before_b));
-            hand_over(u32x2{pack_lo16(ea, eb), 0u}, seen);
+            hand_over(u32x2{pack_lo16(ea, eb), 0u}, sq);
         };
         // Four pieces of input in flight - a piece's arithmetic is much shorter than a trip to HBM - in four named
         // buffers of a loop unrolled by four: handing a buffer on with register moves would wait for the load it has
@@ -186,11 +225,18 @@ __device__ __forceinline__ void d4_p_round(const ChainLaunch &a, const D4Args &d
         // time made the compiler copy the buffer, still in flight, in front of one of the two waits.
         auto piece = [&](auto first, int q0, int j) {
             const int pos = -da.halo + 32 * (q0 + j);
+#if IQD_D4_TIMING
+            const long long tA = clock64();
+#endif
             // younger than raw[j]: the other three buffers' loads, plus the angles asked for since its own issue (in
             // the first trip: since the start)
             if (PER_PIECE == 1 || !decltype(first)::value) gload_wait<D4_AHEAD - 1 + (PER_PIECE - 1) * D4_AHEAD>(raw[j]);
             else gload_wait_n(raw[j], D4_AHEAD - 1 + (PER_PIECE - 1) * j);
             const uint4 rawj = as_uint4(raw[j]);
+#if IQD_D4_TIMING
+            const long long tB = clock64();
+            t_wait_raw += tB - tA;
+#endif
             const uint4 cur = front(rawj);
             const v4i bc = {(int)cur.x, (int)cur.y, (int)cur.z, (int)cur.w};
             const v4i bp = {(int)prev.x, (int)prev.y, (int)prev.z, (int)prev.w};
@@ -198,7 +244,6 @@ __device__ __forceinline__ void d4_p_round(const ChainLaunch &a, const D4Args &d
             v4i hi = __builtin_amdgcn_mfma_i32_16x16x64_i8(A1, bc, czero, 0, 0, 0);
             lo = __builtin_amdgcn_mfma_i32_16x16x64_i8(A2, bp, lo, 0, 0, 0);
             hi = __builtin_amdgcn_mfma_i32_16x16x64_i8(A3, bp, hi, 0, 0, 0);
-            const uint32_t seen = lds_load_relaxed(consumed);
             if (MAG && pos >= 0) {
 #if IQD_D4_MAGLUT
                 const uint32_t m = st_maglut_chunk(maglut, rawj, four);
@@ -206,14 +251,20 @@ __device__ __forceinline__ void d4_p_round(const ChainLaunch &a, const D4Args &d
                 const uint32_t m = st_mag_chunk(cur);
 #endif
                 macc += mcount && pos < mlimit ? m : 0u;
-                minblk += 32;
-                if (minblk >= a.block_samples) {
-                    if (macc) atomicAdd(&mag_row[mblk], macc);
-                    macc = 0;
-                    mblk++;
-                    minblk -= a.block_samples;
+                if (j == 3) {   // blocks, segments and lead-ins are whole quads: the boundary test once per quad
+                    minblk += 128;
+                    if (minblk >= a.block_samples) {
+                        if (macc) atomicAdd(&mag_row[mblk], macc);
+                        macc = 0;
+                        mblk++;
+                        minblk -= a.block_samples;
+                    }
                 }
             }
+#if IQD_D4_TIMING
+            const long long tC = clock64();
+            t_front_mag += tC - tB;
+#endif
             // the buffer's next load only now, after the last use of its old contents: while those are live the new
             // load would get other registers and the loop would have to move it back - reading registers in flight
             raw[j] = load_piece(pos + 32 * D4_AHEAD);
@@ -227,14 +278,21 @@ __device__ __forceinline__ void d4_p_round(const ChainLaunch &a, const D4Args &d
                 if (!decltype(first)::value || j > 0) {  // the piece before: younger than its second angle are this piece's input load and two angles
                     gload_wait<3>(asked_a[(j & 1) ^ 1]);
                     gload_wait<3>(asked_b[(j & 1) ^ 1]);
-                    fm_finish(pos - 32, asked_a[(j & 1) ^ 1], asked_b[(j & 1) ^ 1], seen);
+                    fm_finish(pos - 32, asked_a[(j & 1) ^ 1], asked_b[(j & 1) ^ 1], (j + 3) & 3);
                 }
             } else {
                 // I' outputs 2g, 2g+1 | Q'
-                hand_over(u32x2{pack_lo16((uint32_t)y[0], (uint32_t)y[2]), pack_lo16((uint32_t)y[1], (uint32_t)y[3])}, seen);
+                hand_over(u32x2{pack_lo16((uint32_t)y[0], (uint32_t)y[2]), pack_lo16((uint32_t)y[1], (uint32_t)y[3])}, j);
             }
             prev = cur;
+#if IQD_D4_TIMING
+            const long long tD = clock64();
+            t_post_hand += tD - tC;
+#endif
         };
+#if IQD_D4_TIMING
+        const long long t_round0 = clock64();
+#endif
         int q_start = 0;
         if (PER_PIECE > 1) {                                    // (n_pieces is a multiple of 4 and at least 12)
 #pragma unroll
@@ -251,30 +309,47 @@ __device__ __forceinline__ void d4_p_round(const ChainLaunch &a, const D4Args &d
         if (MODE == D4_FM) {       // the last piece
             gload_wait<0>(asked_a[(D4_AHEAD - 1) & 1]);
             gload_wait<0>(asked_b[(D4_AHEAD - 1) & 1]);
-            fm_finish(-da.halo + 32 * (n_pieces - 1), asked_a[(D4_AHEAD - 1) & 1], asked_b[(D4_AHEAD - 1) & 1], lds_load_relaxed(consumed));
+            fm_finish(-da.halo + 32 * (n_pieces - 1), asked_a[(D4_AHEAD - 1) & 1], asked_b[(D4_AHEAD - 1) & 1], 3);
         }
         if (MAG && macc) atomicAdd(&mag_row[mblk], macc);
+#if IQD_D4_TIMING
+        if ((blockIdx.x & 63) == 7 && lane == 0)
+            printf("wg %u P wave: round %lld cycles for %d pieces: wait_raw %lld front+mfma+mag %lld post+handover %lld\n", blockIdx.x,
+                   clock64() - t_round0, n_pieces, t_wait_raw, t_front_mag, t_post_hand);
+#endif
 }
 
 template <int MODE, bool MAG>
 __device__ __forceinline__ void d4_p_wave(const ChainLaunch &a, const D4Args &da, uint8_t *lds, uint32_t *sync, int pw, int lane)
 {
+    // a ring's four P waves are every third wave, not four in a row: the hardware issues oldest wave first, and with
+    // rings of neighbouring waves ring 0 ran a third ahead of ring 2 (per-wave end times 115 / 137 / 155 us), which left
+    // the last ring to finish on a nearly empty CU.  Now every ring has a wave of each age.
+#if IQD_RINGS_IN_A_ROW
     const int ring = pw / ST_P_PER_RING, cg = pw % ST_P_PER_RING;
+#else
+    const int ring = pw % ST_RINGS, cg = pw / ST_RINGS;
+#endif
     const int g = lane >> 4, c = lane & 15;
     const uint32_t row = (uint32_t)(16 * cg + c);
     uint8_t *ring_base = lds + ring * (D4_SLOTS * D4_SLOT_BYTES);
-    const uint32_t *full = sync + ring * D4_SLOTS;
-    const uint32_t *consumed = sync + ST_RINGS * D4_SLOTS + ring;
+    const uint32_t *full = sync + ring * D4_QUADS;
+    const uint32_t *consumed = sync + ST_RINGS * D4_QUADS + ring;
     const uint32_t wr_off = MODE == D4_FM ? row * 16u + 4u * (uint32_t)g : d4_ring_off(row, (uint32_t)g);   // FM: one dword per lane
-    uint32_t pg = 0;                                           // pieces this ring has seen (all rounds)
+    uint32_t pg = 0;                                           // quads this ring has seen (all rounds)
     for (uint32_t round = 0; round < da.rounds; round++) {
         if ((round * gridDim.x + blockIdx.x) * ST_SEGS >= da.group_start[3]) break;   // nothing left for this workgroup
-        const uint32_t sid = (round * gridDim.x + blockIdx.x) * ST_SEGS + ring * 64 + row;
-        const D4Seg sg = d4_segment(a, da, sid);
+        const uint32_t sid0 = (round * gridDim.x + blockIdx.x) * ST_SEGS + ring * 64 + 16 * cg;
+        const D4Seg sg = d4_segment(a, da, sid0 + (uint32_t)c);
+#if IQD_D4_TRANSPOSE
+        const D4Seg sgl = d4_segment(a, da, sid0 + (uint32_t)(lane >> 2));
+#else
+        const D4Seg &sgl = sg;
+#endif
         const int rot = __builtin_amdgcn_readfirstlane(sg.rot);
-        if (rot == 0) d4_p_round<MODE, MAG, 0>(a, da, sg, ring_base, full, consumed, sync, wr_off, g, lane, pg);
-        else if (rot > 0) d4_p_round<MODE, MAG, 1>(a, da, sg, ring_base, full, consumed, sync, wr_off, g, lane, pg);
-        else d4_p_round<MODE, MAG, -1>(a, da, sg, ring_base, full, consumed, sync, wr_off, g, lane, pg);
+        if (rot == 0) d4_p_round<MODE, MAG, 0>(a, da, sg, sgl, ring_base, full, consumed, sync, wr_off, g, lane, pg);
+        else if (rot > 0) d4_p_round<MODE, MAG, 1>(a, da, sg, sgl, ring_base, full, consumed, sync, wr_off, g, lane, pg);
+        else d4_p_round<MODE, MAG, -1>(a, da, sg, sgl, ring_base, full, consumed, sync, wr_off, g, lane, pg);
     }
 }
 
@@ -307,16 +382,32 @@ __device__ __forceinline__ uint32_t *d4_stat_word(int i)
     return (uint32_t *)(d4_lds + ST_RINGS * D4_SLOTS * D4_SLOT_BYTES) + i;
 }
 #endif
-__device__ __forceinline__ void d4_wait_piece(const uint32_t *full, uint32_t pg)
+__device__ __forceinline__ void d4_wait_quad(const uint32_t *full, uint32_t pg)   // all four P waves have stored quad pg
 {
-    const uint32_t target = 4u * ((pg / D4_SLOTS) + 1u);
-    while ((int32_t)(lds_load_relaxed(&full[pg & (D4_SLOTS - 1)]) - target) < 0) {
+    const uint32_t target = 4u * ((pg / D4_QUADS) + 1u);
+    while ((int32_t)(lds_load_relaxed(&full[pg & (D4_QUADS - 1)]) - target) < 0) {
 #if IQD_D4_WAITSTAT
         if ((threadIdx.x & 63) == 0) atomicAdd(d4_stat_word(D4_SYNC_WORDS - 1), 1u);
 #endif
         __builtin_amdgcn_s_sleep(1);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+// piece V of quad pg: its slot; the consumer waits before a quad's first piece and hands the quad back after its last
+template <int V>
+__device__ __forceinline__ const uint8_t *d4_take_piece(const uint8_t *ring_base, const uint32_t *full, uint32_t pg)
+{
+    if (V == 0) d4_wait_quad(full, pg);
+    return ring_base + ((pg & (D4_QUADS - 1)) * 4 + V) * D4_SLOT_BYTES;
+}
+template <int V>
+__device__ __forceinline__ void d4_piece_taken(uint32_t *consumed, uint32_t &pg)
+{
+    if (V == 3) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        lds_signal(consumed);
+        pg++;
+    }
 }
 
 // AM / SSB -----------------------------------------------------------------------------------------------
@@ -380,12 +471,9 @@ template <int MODE, int V>
 __device__ __forceinline__ int d4_am_piece(const D4Args &da, const uint8_t *ring_base, const uint32_t *full, uint32_t *consumed,
                                            uint32_t &pg, uint32_t row, int lane, D4Rail &ri, D4Rail &rq, D4Ssb &sb, int lsb)
 {
-    d4_wait_piece(full, pg);
     u32x2 p[4];
-    d4_read_row(ring_base + (pg & (D4_SLOTS - 1)) * D4_SLOT_BYTES, row, p);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    lds_signal(consumed);
-    pg++;
+    d4_read_row(d4_take_piece<V>(ring_base, full, pg), row, p);
+    d4_piece_taken<V>(consumed, pg);
     const uint32_t ni[4] = {p[0].x, p[1].x, p[2].x, p[3].x}, nq[4] = {p[0].y, p[1].y, p[2].y, p[3].y};
     const int iv = d4_am_rail<V>(da, ri, ni), qv = d4_am_rail<V>(da, rq, nq);
     if (MODE == D4_AM) {   // AmDemodulator.cc:446-459: max(|i|,|q|) + min(|i|,|q|)/2 in int16 arithmetic
@@ -417,8 +505,8 @@ template <int MODE>
 __device__ __forceinline__ void d4_am_wave(const ChainLaunch &a, const D4Args &da, uint8_t *lds, uint32_t *sync, int ring, int lane)
 {
     const uint8_t *ring_base = lds + ring * (D4_SLOTS * D4_SLOT_BYTES);
-    const uint32_t *full = sync + ring * D4_SLOTS;
-    uint32_t *consumed = sync + ST_RINGS * D4_SLOTS + ring;
+    const uint32_t *full = sync + ring * D4_QUADS;
+    uint32_t *consumed = sync + ST_RINGS * D4_QUADS + ring;
     const int n_pieces = (da.halo + (int)a.tile_len) >> 5;
     uint32_t pg = 0;
     for (uint32_t round = 0; round < da.rounds; round++) {
@@ -470,11 +558,8 @@ template <int V>
 __device__ __forceinline__ int d4_fm_piece(const D4Args &da, const uint8_t *ring_base, const uint32_t *full, uint32_t *consumed,
                                            uint32_t &pg, uint32_t row, D4Fm &s)
 {
-    d4_wait_piece(full, pg);
-    const u32x4 n = *(const u32x4 *)(ring_base + (pg & (D4_SLOTS - 1)) * D4_SLOT_BYTES + row * 16u);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    lds_signal(consumed);
-    pg++;
+    const u32x4 n = *(const u32x4 *)(d4_take_piece<V>(ring_base, full, pg) + row * 16u);
+    d4_piece_taken<V>(consumed, pg);
     // this piece's 8 discriminator outputs: the pair that came early with the previous piece, then three of the four new
     const uint32_t w[8] = {s.eh[0], s.eh[1], s.eh[2], s.eh[3], s.early, n.x, n.y, n.z};
     s.early = n.w;
@@ -536,8 +621,8 @@ __device__ __forceinline__ int d4_fm_piece(const D4Args &da, const uint8_t *ring
 __device__ __forceinline__ void d4_fm_wave(const ChainLaunch &a, const D4Args &da, uint8_t *lds, uint32_t *sync, int ring, int lane)
 {
     const uint8_t *ring_base = lds + ring * (D4_SLOTS * D4_SLOT_BYTES);
-    const uint32_t *full = sync + ring * D4_SLOTS;
-    uint32_t *consumed = sync + ST_RINGS * D4_SLOTS + ring;
+    const uint32_t *full = sync + ring * D4_QUADS;
+    uint32_t *consumed = sync + ST_RINGS * D4_QUADS + ring;
     const int n_pieces = (da.halo + (int)a.tile_len) >> 5;
     uint32_t pg = 0;
     for (uint32_t round = 0; round < da.rounds; round++) {
@@ -581,6 +666,10 @@ __global__ __launch_bounds__(ST_THREADS, D4_WAVES_PER_SIMD(MODE)) void d4_stream
     if (MAG) st_maglut_build(d4_lds + D4_MAGLUT_OFF, tid, ST_THREADS);
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+#if IQD_D4_TIMING == 2
+    const long long t_wave0 = clock64();
+    const long long t_real0 = wall_clock64();
+#endif
     if (wave < ST_RINGS) {
         if (IQD_D4_PRIO) __builtin_amdgcn_s_setprio(IQD_D4_PRIO);
         if (MODE == D4_FM) d4_fm_wave(a, da, d4_lds, sync, wave, lane);
@@ -588,6 +677,25 @@ __global__ __launch_bounds__(ST_THREADS, D4_WAVES_PER_SIMD(MODE)) void d4_stream
     } else {
         d4_p_wave<MODE, MAG>(a, da, d4_lds, sync, wave - ST_RINGS, lane);
     }
+#if IQD_D4_TIMING == 2
+    {
+        uint32_t hwid;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        const long long t_end = wall_clock64();
+        if (lane == 0) {
+            ((long long *)a.dc_records)[(blockIdx.x * 16 + wave) * 2] = t_end - t_real0;
+            ((long long *)a.dc_records)[(blockIdx.x * 16 + wave) * 2 + 1] = hwid;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            long long *r = (long long *)a.dc_records + blockIdx.x * 32;
+            unsigned long long simds = 0;
+            for (int w = 0; w < 15; w++) simds |= (unsigned long long)((r[2 * w + 1] >> 4) & 3) << (4 * w);
+            printf("T wg %u simds %llx cu %lld se %lld t %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld\n", blockIdx.x, simds,
+                   (r[1] >> 8) & 15, (r[1] >> 13) & 7, r[0], r[2], r[4], r[6], r[8], r[10], r[12], r[14], r[16], r[18], r[20], r[22], r[24], r[26], r[28]);
+        }
+    }
+#endif
 #if IQD_D4_WAITSTAT
     __syncthreads();
     if (tid == 0 && (blockIdx.x & 63) == 5)
