@@ -13,8 +13,10 @@ import sys
 
 
 def rows(pattern):
-    for path in glob.glob(pattern, recursive=True):
-        with open(path, newline="") as f:
+    # gpurun merges every call's output into the same local directories: only the newest file of a pass counts
+    paths = glob.glob(pattern, recursive=True)
+    if paths:
+        with open(max(paths, key=os.path.getmtime), newline="") as f:
             yield from csv.DictReader(f)
 
 

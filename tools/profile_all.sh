@@ -2,6 +2,7 @@
 # Round profiles of the bench configurations (run on the GPU box from the repo root); summaries land in
 # gpurun_out/<tag>/summary.json and the kernel stats in gpurun_out/<tag>/kt/**/_kernel_stats.csv.
 set -u
+# (copy what is to be judged into profiles/: <tag>/summary.json -> profiles/<tag>_pmc.json, the newest kt/**/_kernel_stats.csv beside it)
 run() { # tag needle samples args...
   local tag=$1 needle=$2 samples=$3; shift 3
   tools/profile.sh $tag "$@" > /dev/null
