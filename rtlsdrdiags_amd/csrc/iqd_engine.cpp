@@ -651,7 +651,7 @@ int iqd_set_rotation(iqd_t *e, uint32_t first_ch, uint32_t n_ch, int rotation)
     if (!range_ok(e, first_ch, n_ch) || rotation < -1 || rotation > 1) return IQD_EINVAL;
     std::lock_guard<std::mutex> lk(e->mu);
     for (uint32_t c = first_ch; c < first_ch + n_ch; c++) e->h_params[c].rotation = rotation;
-    e->params_dirty = true;
+    e->params_dirty = e->lists_dirty = true;   // (the families' channel lists are grouped by selector for the streaming kernels)
     return IQD_OK;
 }
 

@@ -119,3 +119,37 @@ def test_alternating_with_the_tile_kernels(capi, oracle):
                 pcm, cnt, _, _ = e.accept(u8[off:off + 4 * 32768])
                 outs[k].append(pcm[0, :cnt[0]])
         assert np.array_equal(np.concatenate(outs[0]), ref) and np.array_equal(np.concatenate(outs[1]), ref), mode
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_rotation_selector_changed_between_calls(capi, oracle, mode):
+    """The selector of some channels changes between two calls (found by tools/gpu_fuzz.py with the streaming path pinned:
+    the families' channel lists are grouped by selector, and the grouping has to follow the change).  The histories keep
+    the old rotation exactly, the new samples get the new one."""
+    n_ch = 5
+    rng = np.random.default_rng(17)
+    u8 = rng.integers(0, 256, size=(n_ch, 4 * 32768), dtype=np.uint8)
+    first = [1, 0, -1, 1, 1]
+    second = [-1, 0, 1, 0, 1]
+    eng = capi.Engine(n_ch, flags=STREAM)
+    eng.set_mode(mode)
+    chains = []
+    for c in range(n_ch):
+        eng.set_rotation(first[c], first=c, n=1)
+        o = oracle.chain()
+        o.set_mode(mode)
+        o.set_rotation(first[c])
+        chains.append(o)
+    half = 2 * 32768
+    pcm1, _, mag1, _ = eng.accept(u8[:, :half])
+    for c in range(n_ch):
+        eng.set_rotation(second[c], first=c, n=1)
+    pcm2, _, mag2, _ = eng.accept(u8[:, half:])
+    assert eng.stats()["stream_launches"] == 2
+    for c in range(n_ch):
+        r1 = chains[c].accept_stream(u8[c, :half], 32768)
+        chains[c].set_rotation(second[c])
+        r2 = chains[c].accept_stream(u8[c, half:], 32768)
+        assert np.array_equal(pcm1[c], r1[0]) and np.array_equal(mag1[c], r1[1]), (mode, c)
+        assert np.array_equal(pcm2[c], r2[0]), (mode, c)
+        assert np.array_equal(mag2[c], r2[1]), (mode, c)

@@ -95,6 +95,7 @@ def one_case(rng, O):
         iq[c] = signal(rng, n, bb // 2)
     cuts = sorted(set([0, nblk] + [int(x) for x in rng.integers(0, nblk + 1, int(rng.integers(0, 6)))]))
     got = [[] for _ in range(n_ch)]
+    ops_log = []
     got_allowed, got_mag = [], []
     ref_parts = [[[], [], []] for _ in range(n_ch)]
     for a, b in zip(cuts[:-1], cuts[1:]):
@@ -104,6 +105,7 @@ def one_case(rng, O):
                 what = int(rng.integers(0, 10))
                 if os.environ.get("FUZZ_OPS"):
                     what = int(rng.choice([int(x) for x in os.environ["FUZZ_OPS"].split(",")]))
+                ops_log.append((a, c, what))
                 if what == 0:
                     m = MODES[int(rng.integers(0, 6))]
                     chains[c].set_mode(m); eng.set_mode(m, first=c, n=1)
@@ -114,12 +116,14 @@ def one_case(rng, O):
                     # samples are still inside the 2048-sample tail: GainEpochList)
                     d, g = int(rng.integers(1, 5)), float(np.float32(10.0 ** rng.uniform(0, 6)))
                     chains[c].set_gain(d, g); eng.set_gain(d, g, first=c, n=1)
+                    ops_log[-1] += (d, g)
                 elif what == 3:
                     t = int(rng.choice([-200, -70, -50, -35]))
                     chains[c].set_squelch(t); eng.set_squelch(t, first=c, n=1)
                 elif what == 4:
                     r = int(rng.integers(-1, 2))
                     chains[c].set_rotation(r); eng.set_rotation(r, first=c, n=1)
+                    ops_log[-1] += (r,)
                 elif what == 5:
                     g = int(rng.integers(0, 47))
                     chains[c].set_rx_gain_db(g); eng.set_rx_gain_db(g, first=c, n=1)
@@ -183,6 +187,11 @@ def one_case(rng, O):
         if what:
             print("MISMATCH in %s: channel %d of %d, block_bytes %d, %d blocks, cuts %s, cfg %s" %
                   (what, c, n_ch, bb, nblk, cuts, cfg[c]))
+            if what == "pcm":
+                g, r = np.concatenate(got[c]), ref
+                bad = np.flatnonzero(g != r)
+                print("  first differing PCM sample %d of %d (%d differ, last %d): got %s, oracle %s; operations between calls: %s"
+                      % (bad[0], len(r), len(bad), bad[-1], g[bad[0]:bad[0] + 6], r[bad[0]:bad[0] + 6], ops_log))
             return False
     eng.close()
     return True
