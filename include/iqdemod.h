@@ -62,9 +62,10 @@ typedef struct iqd_config {
 
 #define IQD_F_NO_MAGNITUDE 0x1u /* do not produce per-block magnitudes when no channel's squelch can close
                                    (the reference only reports them through an optional callback) */
-/* The WBFM chain exists as two kernels with identical results: tiles (one workgroup per run of samples) and the
- * streaming pipeline (one persistent workgroup per CU, used for launches big enough to fill the chip).  These two
- * flags pin the choice (tests, A/B measurements); the environment variable IQD_WBFM_PATH=tiles|stream does the same. */
+/* Every chain (WBFM, FM, AM, SSB) exists as two kernels with identical results: tiles (one workgroup per run of
+ * samples) and a streaming pipeline (one persistent workgroup per CU, used for launches big enough to fill the chip
+ * that are not squelch-gated).  These two flags pin the choice for all chains (tests, A/B measurements; the names
+ * are from the round in which only WBFM had both); the environment variable IQD_WBFM_PATH=tiles|stream does the same. */
 #define IQD_F_WBFM_TILES  0x2u
 #define IQD_F_WBFM_STREAM 0x4u
 
@@ -218,7 +219,7 @@ typedef struct iqd_stats {
     uint64_t chain_kernel_count; /* launches covered by chain_kernel_ms */
     uint64_t segment_repairs;    /* extra in-kernel passes of the segmented de-emphasis (a segment's warm-up had not
                                     reached its neighbour's exact state yet) */
-    uint64_t stream_launches;    /* WBFM launches that ran as the streaming pipeline */
+    uint64_t stream_launches;    /* chain launches (any family) that ran as a streaming pipeline */
 } iqd_stats;
 
 int iqd_get_stats(iqd_t *e, iqd_stats *out);
