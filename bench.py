@@ -250,7 +250,7 @@ def rank_body(args, rank, world, dev, make_engine, dist, torch, order_streams=No
         elif args.mode == "fm":
             timed, timed_samples = ("d4_stream_kernel" if streamed else "fm_chain_kernel"), n * n_ch
         else:
-            timed, timed_samples = ("wbfm_stream_kernel" if streamed else "wbfm_chain_kernel"), n * n_ch
+            timed, timed_samples = ("wbfm_stream_kernel + wbfm_stream_fixup_kernel" if streamed else "wbfm_chain_kernel"), n * n_ch
         prof, prof_path = profile_summary(args.tag) if args.tag else (None, None)
         roof = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": timed, "kernel_ms": round(kern_ms, 4)}
         if timed_samples is not None and kern_ms > 0:
