@@ -109,6 +109,7 @@ struct iqd_engine {
     // per-call scratch
     DevBuf stream_hist;   // boundary records of the streaming WBFM kernel, one StHist per segment
     DevBuf lists[FAM_COUNT + 1], mag_sums, blk_lists, vlen, records, base8k, gain_trace, freq_trace, dc_records, dc_records2, repair_flags;
+    size_t mag_sums_zero = 0;            // leading elements of mag_sums known to be zero (left so by the last squelch pass)
     DevBuf st_iq, st_pcm, st_count, st_mag, st_allowed;  // staging for host-pointer accepts
     // sliced host-pointer accepts: two staging sets, so that slice k+1 crosses PCIe while slice k runs
     DevBuf sl_iq[2], sl_pcm[2], sl_count[2], sl_mag[2], sl_allowed[2];
@@ -1043,8 +1044,14 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
     }
     const bool want_mag = gated || any_agc || !(e->flags & IQD_F_NO_MAGNITUDE) || magnitude_dev;
 
-    HIP_TRY(e, e->mag_sums.ensure((size_t)n_ch * n_blocks * sizeof(uint32_t)));
-    if (want_mag) HIP_TRY(e, hipMemsetAsync(e->mag_sums.p, 0, (size_t)n_ch * n_blocks * sizeof(uint32_t), s));
+    {   // the sums start at zero: by memset, unless the previous call's squelch pass left this many of them zero
+        const void *before = e->mag_sums.p;
+        HIP_TRY(e, e->mag_sums.ensure((size_t)n_ch * n_blocks * sizeof(uint32_t)));
+        if (e->mag_sums.p != before) e->mag_sums_zero = 0;
+        if (want_mag && e->mag_sums_zero < (size_t)n_ch * n_blocks)
+            HIP_TRY(e, hipMemsetAsync(e->mag_sums.p, 0, (size_t)n_ch * n_blocks * sizeof(uint32_t), s));
+        e->mag_sums_zero = 0;   // from here on the call writes into them
+    }
 
     SquelchLaunch q{};
     q.n_ch = n_ch; q.first_ch = first_ch; q.n_blocks = n_blocks; q.block_samples = call_bs;
@@ -1335,7 +1342,11 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         HIP_TRY(e, launch_magnitude((const uint8_t *)iq_dev, bytes_per_ch, e->lists[FAM_COUNT].as<uint32_t>(),
                                     (uint32_t)e->h_lists[FAM_COUNT].size(), call_bs, n_blocks,
                                     e->mag_sums.as<uint32_t>(), s));
-    if (!gated && (want_mag || pcm_count_dev || signal_present_dev || e->trace_on)) HIP_TRY(e, launch_squelch(q, true, s));
+    if (!gated && (want_mag || pcm_count_dev || signal_present_dev || e->trace_on)) {
+        q.zero_sums_after = any_agc ? 0u : 1u;   // (a running AGC reads them again in the tracking pass)
+        HIP_TRY(e, launch_squelch(q, true, s));
+        if (q.zero_sums_after) e->mag_sums_zero = (size_t)n_ch * n_blocks;
+    }
 
     e->stats.accepts++;
     e->stats.samples += (uint64_t)vlen * n_ch;

@@ -67,6 +67,7 @@ struct SquelchLaunch {
     const ScanConfig *scan_cfg;   // [engine ch]
     ScanState *scan;              // [engine ch]
     unsigned long long *freq_trace;   // out, optional [n_ch][n_blocks]: the tuned frequency after each block
+    uint32_t zero_sums_after;     // squelch_block_kernel is the sums' only reader in this call: it clears them behind itself
 };
 
 hipError_t upload_consts(const Consts &c, hipStream_t s);

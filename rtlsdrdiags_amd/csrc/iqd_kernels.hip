@@ -449,6 +449,9 @@ __global__ void squelch_block_kernel(const SquelchLaunch q, int always_open)
     const uint32_t ech = q.first_ch + ch;
     const ChanParams &p = q.params[ech];
     if (q.magnitude) q.magnitude[idx] = q.mag_sums[idx] / q.block_samples;
+    // (the last reader of the sums when nothing tracks them block by block: leaves them zero for the next call's
+    // chain kernels to add into, which saves that call a memset launch)
+    if (q.zero_sums_after) const_cast<uint32_t *>(q.mag_sums)[idx] = 0;
     if (q.gain_trace) q.gain_trace[idx] = q.agc[ech].rx_gain;   // channels with a running AGC overwrite theirs
     if (q.freq_trace) q.freq_trace[idx] = q.scan[ech].current_hz;   // scanning, gated channels overwrite theirs
     if (always_open) {
