@@ -1324,8 +1324,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
             // hand-off verification (streaming launches: done by their fix-up kernel), repair of what it flags
             // (normally an immediate exit), then state commit + tail
             if (!use_stream) HIP_TRY(e, launch_wbfm_verify(a, s));
-            HIP_TRY(e, launch_wbfm_repair(a, gated, s));
-            HIP_TRY(e, launch_tail_update(a, FAM_WBFM, s));
+            HIP_TRY(e, launch_wbfm_repair(a, gated, s));   // (ends with the channels' state commit and tail update)
         } else {
             HIP_TRY(e, launch_tail_update(a, f, s));
         }

@@ -147,12 +147,20 @@ __global__ __launch_bounds__(WB_THREADS, IQD_WBFM_MIN_WAVES) void wbfm_chain_ker
 // two trajectories can stay one ulp apart for ever).  One workgroup per flagged channel walks its tiles in
 // order and re-runs every tile that does not chain up from its predecessor's recorded exact state, which makes
 // that tile's own record exact for the next comparison.  Magnitudes are not touched (the first run added them).
+__device__ __forceinline__ void tail_update_body(const ChainLaunch &a, int family, uint32_t li);
+static_assert(WB_THREADS == 256, "the repair kernel ends with the tail update, which moves 16 bytes per thread");
+
+// (The channel's state commit and new tail follow in the same launch: they need the repaired records, and a launch of
+// their own cost more than both together.)
 template <bool GATED>
 __global__ __launch_bounds__(WB_THREADS, IQD_WBFM_MIN_WAVES) void wbfm_repair_kernel(const ChainLaunch a)
 {
     __shared__ WbfmLds lds;
     const uint32_t li = blockIdx.x;
-    if (!a.repair_flags[li]) return;
+    if (!a.repair_flags[li]) {
+        tail_update_body(a, FAM_WBFM, li);
+        return;
+    }
     const uint32_t ch = a.ch_list[li];
     const uint32_t vlen = GATED ? a.vlen_gated[ch] : a.vlen;
     const uint32_t ntiles = (vlen + a.tile_len - 1) / a.tile_len;
@@ -172,6 +180,7 @@ __global__ __launch_bounds__(WB_THREADS, IQD_WBFM_MIN_WAVES) void wbfm_repair_ke
         if (threadIdx.x == 0) atomicAdd(&a.counters[CNT_TILE_REPAIRS], 1u);
     }
     if (threadIdx.x == 0) a.repair_flags[li] = 0;
+    tail_update_body(a, FAM_WBFM, li);
 }
 
 // Common tile set-up of the FM / AM / SSB kernels (no carried float state: FIR chains only).
@@ -376,9 +385,8 @@ __global__ void wbfm_verify_kernel(const ChainLaunch a)
 
 // New tail = last TAIL samples of [old tail | this call's open blocks] for one family.  For WBFM the
 // same launch commits the restart state of each channel's last tile (after verification and repair).
-__global__ __launch_bounds__(256) void tail_update_kernel(const ChainLaunch a, int family)
+__device__ __forceinline__ void tail_update_body(const ChainLaunch &a, int family, uint32_t li)
 {
-    const uint32_t li = blockIdx.x;
     const uint32_t ch = a.ch_list[li];
     const uint32_t ech = a.first_ch + ch;
     const uint32_t vlen = a.vlen_gated ? a.vlen_gated[ch] : a.vlen;
@@ -413,6 +421,11 @@ __global__ __launch_bounds__(256) void tail_update_kernel(const ChainLaunch a, i
     const uint4 val = *(const uint4 *)src;
     __syncthreads();
     ((uint4 *)tail)[threadIdx.x] = val;
+}
+
+__global__ __launch_bounds__(256) void tail_update_kernel(const ChainLaunch a, int family)
+{
+    tail_update_body(a, family, blockIdx.x);
 }
 
 // Per-block squelch magnitude sums for channels whose chain kernel does not produce them
