@@ -1142,6 +1142,9 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
     float lane_load[3] = {0.f, 0.f, 0.f};   // 0: the engine's stream, 1 and 2: the side streams
     bool lane_used[3] = {false, false, false};
     size_t (*dcr_layout)[2] = e->dcr_layout;
+    ChainLaunch tail_a{};
+    int tail_f = 0;
+    bool tail_pending = false;
     for (int oi = 0; oi < FAM_COUNT; oi++) {
         const int f = order[oi];
         const uint32_t n_list = (uint32_t)e->h_lists[f].size();
@@ -1325,6 +1328,10 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
             // (normally an immediate exit), then state commit + tail
             if (!use_stream) HIP_TRY(e, launch_wbfm_verify(a, s));
             HIP_TRY(e, launch_wbfm_repair(a, gated, s));   // (ends with the channels' state commit and tail update)
+        } else if (!forked && !gated && (want_mag || pcm_count_dev || signal_present_dev || e->trace_on)) {
+            tail_a = a;        // the only family of the call: its tail update rides in the squelch launch below
+            tail_f = f;
+            tail_pending = true;
         } else {
             HIP_TRY(e, launch_tail_update(a, f, s));
         }
@@ -1343,9 +1350,11 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
                                     e->mag_sums.as<uint32_t>(), s));
     if (!gated && (want_mag || pcm_count_dev || signal_present_dev || e->trace_on)) {
         q.zero_sums_after = any_agc ? 0u : 1u;   // (a running AGC reads them again in the tracking pass)
-        HIP_TRY(e, launch_squelch(q, true, s));
+        HIP_TRY(e, launch_squelch(q, true, s, tail_pending ? &tail_a : nullptr, tail_f));
+        tail_pending = false;
         if (q.zero_sums_after) e->mag_sums_zero = (size_t)n_ch * n_blocks;
     }
+    if (tail_pending) HIP_TRY(e, launch_tail_update(tail_a, tail_f, s));   // (no squelch launch to ride in)
 
     e->stats.accepts++;
     e->stats.samples += (uint64_t)vlen * n_ch;

@@ -454,9 +454,8 @@ __global__ __launch_bounds__(256) void magnitude_kernel(const uint8_t *iq, size_
 // Squelch, part 1 (SignalDetector.cc:249-271): per (channel, block) average magnitude.  When no channel's
 // squelch can close (always_open) this is the whole squelch: every block is allowed and the tracker ends in its
 // Tracking state.  Otherwise the decisions are taken per channel in block order by squelch_track_kernel.
-__global__ void squelch_block_kernel(const SquelchLaunch q, int always_open)
+__device__ __forceinline__ void squelch_block_body(const SquelchLaunch &q, int always_open, uint32_t idx)
 {
-    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= q.n_ch * q.n_blocks) return;
     const uint32_t ch = idx / q.n_blocks, b = idx - ch * q.n_blocks;
     const uint32_t ech = q.first_ch + ch;
@@ -472,6 +471,19 @@ __global__ void squelch_block_kernel(const SquelchLaunch q, int always_open)
         if (b == q.n_blocks - 1) q.tracker[ech] = 1u;
         if (b == 0 && q.pcm_count) q.pcm_count[ch] = p.mode == 0 ? 0u : q.n_blocks * q.block_samples / 32u;
     }
+}
+
+__global__ void squelch_block_kernel(const SquelchLaunch q, int always_open)
+{
+    squelch_block_body(q, always_open, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// A call with one demodulator family: the family's tail update (workgroups 0 .. n_list-1) and the squelch pass's first
+// part (the rest) share a launch - they are independent, tiny, and each launch of their own costs about as much as both.
+__global__ __launch_bounds__(256) void tail_squelch_kernel(const ChainLaunch a, int family, const SquelchLaunch q, int always_open)
+{
+    if (blockIdx.x < a.n_list) tail_update_body(a, family, blockIdx.x);
+    else squelch_block_body(q, always_open, (blockIdx.x - a.n_list) * 256u + threadIdx.x);
 }
 
 // Squelch, part 2, one thread per channel, blocks in order: the "signal present" comparison
@@ -905,10 +917,13 @@ hipError_t launch_magnitude(const uint8_t *iq, size_t ch_stride_bytes, const uin
     return hipGetLastError();
 }
 
-hipError_t launch_squelch(const SquelchLaunch &q, bool always_open, hipStream_t s)
+hipError_t launch_squelch(const SquelchLaunch &q, bool always_open, hipStream_t s, const ChainLaunch *tail_of, int tail_family)
 {
     const uint32_t n = q.n_ch * q.n_blocks;
-    hipLaunchKernelGGL(squelch_block_kernel, dim3((n + 255) / 256), dim3(256), 0, s, q, always_open ? 1 : 0);
+    if (tail_of)
+        hipLaunchKernelGGL(tail_squelch_kernel, dim3(tail_of->n_list + (n + 255) / 256), dim3(256), 0, s, *tail_of, tail_family, q, always_open ? 1 : 0);
+    else
+        hipLaunchKernelGGL(squelch_block_kernel, dim3((n + 255) / 256), dim3(256), 0, s, q, always_open ? 1 : 0);
     if (!always_open || q.any_agc) {
         if (q.n_blocks >= 32)   // long rows: one wave per channel
             hipLaunchKernelGGL(squelch_track_wave_kernel, dim3(q.n_ch), dim3(64), 0, s, q, always_open ? 1 : 0);
