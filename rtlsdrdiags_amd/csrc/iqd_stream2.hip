@@ -682,13 +682,14 @@ __global__ __launch_bounds__(ST_THREADS, D4_WAVES_PER_SIMD(MODE)) void d4_stream
         uint32_t hwid;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         const long long t_end = wall_clock64();
+        __shared__ long long t_rec[32];            // per wave: run time in 10 ns ticks, HW_ID (which SIMD it sat on)
         if (lane == 0) {
-            ((long long *)a.dc_records)[(blockIdx.x * 16 + wave) * 2] = t_end - t_real0;
-            ((long long *)a.dc_records)[(blockIdx.x * 16 + wave) * 2 + 1] = hwid;
+            t_rec[wave * 2] = t_end - t_real0;
+            t_rec[wave * 2 + 1] = hwid;
         }
         __syncthreads();
         if (tid == 0) {
-            long long *r = (long long *)a.dc_records + blockIdx.x * 32;
+            const long long *r = t_rec;
             unsigned long long simds = 0;
             for (int w = 0; w < 15; w++) simds |= (unsigned long long)((r[2 * w + 1] >> 4) & 3) << (4 * w);
             printf("T wg %u simds %llx cu %lld se %lld t %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld %lld\n", blockIdx.x, simds,
