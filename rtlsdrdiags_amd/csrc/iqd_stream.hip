@@ -534,7 +534,10 @@ hipError_t launch_wbfm_stream_fixup(const ChainLaunch &a, const StreamArgs &sa, 
 
 hipError_t launch_wbfm_stream(const ChainLaunch &a, const StreamArgs &sa, int rotation, bool mag, uint32_t grid, hipStream_t s)
 {
-    static bool attr_set = false;
+    static bool attr_set_on[64] = {};                    // per device: the attribute belongs to the device's code object
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    bool &attr_set = attr_set_on[dev];
     if (!attr_set) {
         const void *ks[] = {(const void *)wbfm_stream_kernel<0, false>, (const void *)wbfm_stream_kernel<0, true>,
                             (const void *)wbfm_stream_kernel<1, false>, (const void *)wbfm_stream_kernel<1, true>,

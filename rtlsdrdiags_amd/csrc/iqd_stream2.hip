@@ -710,7 +710,10 @@ hipError_t launch_d4_stream(const ChainLaunch &a, const D4Args &da, int mode, bo
     static const Kernel ks[3][2] = {{d4_stream_kernel<D4_AM, false>, d4_stream_kernel<D4_AM, true>},
                                     {d4_stream_kernel<D4_SSB, false>, d4_stream_kernel<D4_SSB, true>},
                                     {d4_stream_kernel<D4_FM, false>, d4_stream_kernel<D4_FM, true>}};
-    static bool attr_set = false;
+    static bool attr_set_on[64] = {};                    // per device: the attribute belongs to the device's code object
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+    bool &attr_set = attr_set_on[dev];
     if (!attr_set) {                                     // more than the 64 KiB a kernel gets without asking
         for (int m = 0; m < 3; m++)
             for (int g = 0; g < 2; g++) {
