@@ -125,7 +125,8 @@ __device__ __forceinline__ uint32_t st_maglut_chunk(const uint8_t *lut, const ui
 // for the load issued one piece ago) and hands buffers on with register moves that wait for the youngest load;
 // a P wave then pays a trip to HBM per piece however many pieces it asked for in advance.  Loads return in order,
 // so "at most N younger loads outstanding" is exactly "this one has arrived"; other memory operations issued in
-// between (magnitude atomics) only make the wait stricter.
+// between (magnitude atomics) only make the wait stricter.  Nothing that is not inlined may be called while such loads
+// are in flight: a callee uses registers as it pleases (tried: a noinline helper in the piece loop corrupted everything).
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ v4u gload16_untracked(const void *p)
 {

@@ -121,6 +121,10 @@ def lint_kernel(name, lines):
     for i, (no, text, kind, regs, target) in enumerate(ins):
         if kind != "other" and kind != "load":
             continue
+        if kind == "other" and pend_in[i] and text.split()[0] in ("s_swappc_b64", "s_setpc_b64", "s_call_b64"):
+            # a function call while loads are in flight: the callee knows nothing of the registers they will land in
+            findings.append((name, no, text, sorted(pend_in[i]), sorted(set(pend_in[i].values()))))
+            continue
         touched = regs & set(pend_in[i]) if kind == "other" else set()
         if kind == "load":      # the address registers of a load may not be pending either; its own destination may
             addr = regs_of(text.split(",", 1)[1]) if "," in text else set()
