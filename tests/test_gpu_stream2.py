@@ -153,3 +153,34 @@ def test_rotation_selector_changed_between_calls(capi, oracle, mode):
         assert np.array_equal(pcm1[c], r1[0]) and np.array_equal(mag1[c], r1[1]), (mode, c)
         assert np.array_equal(pcm2[c], r2[0]), (mode, c)
         assert np.array_equal(mag2[c], r2[1]), (mode, c)
+
+
+@pytest.mark.parametrize("mode", ["fm", "wbfm"])
+def test_more_segments_than_one_round_holds(capi, oracle, mode):
+    """60 000 channels of 2048 samples: one segment per channel, more than the 49 152 a round of the persistent workgroups
+    takes - the second round (ring counters running on, histories rebuilt) has to be as exact as the first."""
+    n_ch, n = 60000, 2048
+    rng = np.random.default_rng(5)
+    base = [synth.fm_tone(n, seed=900 + k) for k in range(7)]
+    pick = rng.integers(0, 7, n_ch)
+    u8 = np.stack([base[k] for k in pick])
+    u8[:, 100:116] = rng.integers(0, 256, size=(n_ch, 16), dtype=np.uint8)     # every channel its own few bytes
+    import torch
+    eng = capi.Engine(n_ch, flags=STREAM)
+    eng.set_mode(mode)
+    # (device pointers: a host-pointer call of this size would be cut into slices of a few thousand channels)
+    iq_d = torch.from_numpy(u8).cuda()
+    pcm_d = torch.zeros((n_ch, n // 32), dtype=torch.int16, device="cuda")
+    cnt_d = torch.zeros(n_ch, dtype=torch.int32, device="cuda")
+    mag_d = torch.zeros((n_ch, 1), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    eng.accept_device(iq_d.data_ptr(), 2 * n, pcm_d.data_ptr(), cnt_d.data_ptr(), mag_d.data_ptr())
+    eng.synchronize()
+    assert eng.stats()["stream_launches"] == 1
+    pcm, cnt, mag = pcm_d.cpu().numpy(), cnt_d.cpu().numpy(), mag_d.cpu().numpy().astype(np.uint32)
+    for c in list(range(0, 40)) + list(range(49100, 49200)) + list(range(n_ch - 40, n_ch)):
+        o = oracle.chain()
+        o.set_mode(mode)
+        ref = o.accept_stream(u8[c], 4096)
+        assert np.array_equal(pcm[c, :cnt[c]], ref[0]), (mode, c)
+        assert np.array_equal(mag[c], ref[1]), (mode, c)
