@@ -119,6 +119,7 @@ struct iqd_engine {
     hipEvent_t fam_fork = nullptr, fam_join[2] = {};
     hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
     uint32_t *h_slice_counts = nullptr;  // pinned, [2][n_ch of a slice]
+    uint32_t *d_closed = nullptr, *h_closed = nullptr;   // squelch-gated calls: did any channel lose a block? (device word, pinned copy)
     size_t h_slice_counts_cap = 0;
 
     bool profiling = false;
@@ -341,6 +342,8 @@ void iqd_destroy(iqd_t *e)
         if (e->ev_free[b]) (void)hipEventDestroy(e->ev_free[b]);
     }
     if (e->h_slice_counts) (void)hipHostFree(e->h_slice_counts);
+    if (e->d_closed) (void)hipFree(e->d_closed);
+    if (e->h_closed) (void)hipHostFree(e->h_closed);
     if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
     for (int f = 0; f < 2; f++) {
         if (e->fam_stream[f]) (void)hipStreamDestroy(e->fam_stream[f]);
@@ -1074,6 +1077,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         e->trace_first = first_ch; e->trace_n = n_ch; e->trace_blocks = n_blocks;
     }
 
+    bool chain_gated = gated;   // what the chain kernels are told: false as well when the squelch pass rejected nothing
     if (gated) {
         // pass 1: magnitudes of every block, then the squelch decisions and open-block lists
         HIP_TRY(e, e->blk_lists.ensure((size_t)n_ch * n_blocks * sizeof(uint32_t)));
@@ -1082,7 +1086,27 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
                                     n_blocks, e->mag_sums.as<uint32_t>(), s));
         q.blk_lists = e->blk_lists.as<uint32_t>();
         q.vlen_out = e->vlen.as<uint32_t>();
+        // A call big enough for the streaming kernels asks whether anything was rejected at all: if every block of every
+        // channel is open the chain kernels run exactly as in an ungated call (the squelch work is done either way),
+        // streaming kernels included.  One word comes back; the wait is a few microseconds against a third of the
+        // chain's time.
+        const bool probe = !(e->flags & IQD_F_WBFM_TILES) && vlen % 128 == 0 &&
+                           ((e->flags & IQD_F_WBFM_STREAM) || (uint64_t)vlen * n_ch >= (uint64_t)e->n_cus * ST_SEGS * 2048);
+        if (probe) {
+            if (!e->d_closed) {
+                HIP_TRY(e, hipMalloc((void **)&e->d_closed, sizeof(uint32_t)));
+                HIP_TRY(e, hipHostMalloc((void **)&e->h_closed, sizeof(uint32_t), hipHostMallocDefault));
+            }
+            HIP_TRY(e, hipMemsetAsync(e->d_closed, 0, sizeof(uint32_t), s));
+            q.closed_any = e->d_closed;
+        }
         HIP_TRY(e, launch_squelch(q, false, s));
+        if (probe) {
+            HIP_TRY(e, hipMemcpyAsync(e->h_closed, e->d_closed, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            HIP_TRY(e, hipStreamSynchronize(s));
+            chain_gated = *e->h_closed != 0;
+            q.closed_any = nullptr;
+        }
     }
 
     ChainLaunch base{};
@@ -1090,8 +1114,8 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
     base.ch_stride_bytes = bytes_per_ch;
     base.first_ch = first_ch;
     base.vlen = vlen;
-    base.vlen_gated = gated ? e->vlen.as<uint32_t>() : nullptr;
-    base.blk_lists = gated ? e->blk_lists.as<uint32_t>() : nullptr;
+    base.vlen_gated = chain_gated ? e->vlen.as<uint32_t>() : nullptr;
+    base.blk_lists = chain_gated ? e->blk_lists.as<uint32_t>() : nullptr;
     base.n_blocks = n_blocks;
     base.block_samples = call_bs;
     base.block_magic = block_magic(call_bs);
@@ -1171,7 +1195,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         // (int16)y can hit the "integer indefinite" value.  Results are identical either way.
         bool use_stream = false;
         int stream_rot = 0;
-        if (f == FAM_WBFM && e->stream_ok && !gated && !(e->flags & IQD_F_WBFM_TILES) && vlen % 128 == 0) {
+        if (f == FAM_WBFM && e->stream_ok && !chain_gated && !(e->flags & IQD_F_WBFM_TILES) && vlen % 128 == 0) {
             const auto &l = e->h_lists[FAM_WBFM];
             stream_rot = e->h_params[first_ch + l[0]].rotation;
             bool ok = true;
@@ -1195,7 +1219,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         bool use_d4 = false;
         uint32_t d4_wgs = e->n_cus;
         D4Args d4 = e->d4_args;
-        if (f != FAM_WBFM && !gated && !(e->flags & IQD_F_WBFM_TILES) && vlen % 128 == 0 && (f == FAM_FM || vlen / 32 > 512)) {
+        if (f != FAM_WBFM && !chain_gated && !(e->flags & IQD_F_WBFM_TILES) && vlen % 128 == 0 && (f == FAM_FM || vlen / 32 > 512)) {
             bool ok = true;
             if (f == FAM_FM)
                 for (uint32_t c : e->h_lists[f]) ok = ok && e->fm_kmax[first_ch + c] * 6.35f < 2147483648.0f;
@@ -1261,7 +1285,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
                 e->stream_handoffs += (uint64_t)n_list * ((vlen + a.tile_len - 1) / a.tile_len - 1);
                 e->stats.stream_launches++;
             } else {
-                HIP_TRY(e, launch_wbfm(a, gated, fused_mag, n_list * a.tiles_per_ch, s));
+                HIP_TRY(e, launch_wbfm(a, chain_gated, fused_mag, n_list * a.tiles_per_ch, s));
             }
         } else if (f == FAM_FM) {
             if (use_d4) {
@@ -1271,7 +1295,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
                 HIP_TRY(e, launch_d4_stream(a, d4, D4_FM, fused_mag, grid, s));
                 e->stats.stream_launches++;
             } else {
-                HIP_TRY(e, launch_fm(a, gated, fused_mag, n_list * a.tiles_per_ch, s));
+                HIP_TRY(e, launch_fm(a, chain_gated, fused_mag, n_list * a.tiles_per_ch, s));
             }
         } else if (use_d4) {
             HIP_TRY(e, e->base8k.ensure((size_t)n_ch * base.pcm_stride * sizeof(int32_t)));
@@ -1315,7 +1339,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
                     dcr_layout[f == FAM_SSB][1] = n_list;
                 }
             }
-            HIP_TRY(e, launch_am(a, f, gated, fused_mag, n_list * a.tiles_per_ch, s));
+            HIP_TRY(e, launch_am(a, f, chain_gated, fused_mag, n_list * a.tiles_per_ch, s));
         }
         if (e->profiling && !timed) {
             HIP_TRY(e, hipEventRecord(evp.second, s));
@@ -1327,7 +1351,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
             // hand-off verification (streaming launches: done by their fix-up kernel), repair of what it flags
             // (normally an immediate exit), then state commit + tail
             if (!use_stream) HIP_TRY(e, launch_wbfm_verify(a, s));
-            HIP_TRY(e, launch_wbfm_repair(a, gated, s));   // (ends with the channels' state commit and tail update)
+            HIP_TRY(e, launch_wbfm_repair(a, chain_gated, s));   // (ends with the channels' state commit and tail update)
         } else if (!forked && !gated && (want_mag || pcm_count_dev || signal_present_dev || e->trace_on)) {
             tail_a = a;        // the only family of the call: its tail update rides in the squelch launch below
             tail_f = f;

@@ -68,6 +68,7 @@ struct SquelchLaunch {
     ScanState *scan;              // [engine ch]
     unsigned long long *freq_trace;   // out, optional [n_ch][n_blocks]: the tuned frequency after each block
     uint32_t zero_sums_after;     // squelch_block_kernel is the sums' only reader in this call: it clears them behind itself
+    uint32_t *closed_any;         // optional: counts the channels of the call that had a block rejected
 };
 
 hipError_t upload_consts(const Consts &c, hipStream_t s);

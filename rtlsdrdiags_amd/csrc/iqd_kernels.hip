@@ -534,6 +534,7 @@ __global__ void squelch_track_kernel(const SquelchLaunch q, int always_open)
         const uint32_t vlen = (p.mode == 0) ? 0u : open * q.block_samples;
         q.vlen_out[ch] = vlen;
         if (q.pcm_count) q.pcm_count[ch] = vlen / 32u;
+        if (q.closed_any && p.mode != 0 && open != q.n_blocks) atomicAdd(q.closed_any, 1u);
     }
 }
 
@@ -622,6 +623,7 @@ __global__ __launch_bounds__(64) void squelch_track_wave_kernel(const SquelchLau
         const uint32_t vlen = (p.mode == 0) ? 0u : open * q.block_samples;
         q.vlen_out[ch] = vlen;
         if (q.pcm_count) q.pcm_count[ch] = vlen / 32u;
+        if (q.closed_any && p.mode != 0 && open != q.n_blocks) atomicAdd(q.closed_any, 1u);
     }
 }
 

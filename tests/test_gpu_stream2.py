@@ -184,3 +184,26 @@ def test_more_segments_than_one_round_holds(capi, oracle, mode):
         ref = o.accept_stream(u8[c], 4096)
         assert np.array_equal(pcm[c, :cnt[c]], ref[0]), (mode, c)
         assert np.array_equal(mag[c], ref[1]), (mode, c)
+
+
+@pytest.mark.parametrize("mode", ["wbfm", "fm", "usb"])
+def test_squelch_that_rejects_nothing_leaves_the_streaming_path_open(capi, oracle, mode):
+    """A threshold that could close the squelch makes the call a gated one (magnitude pass, decisions, open-block lists
+    first).  When the decisions reject nothing - one word read back - the chain runs through the streaming kernel as in
+    an ungated call; when they reject something, through the tile kernels.  Identical to the oracle either way."""
+    u8 = synth.fm_tone(8 * 16384, seed=33)
+    quiet = u8.copy().reshape(-1, 2)
+    quiet[3 * 16384:5 * 16384] = 128                         # two silent blocks: rejected at -40 dBFS
+    for data, threshold, streamed in ((u8, -60, True), (quiet.reshape(-1), -40, False)):
+        eng = capi.Engine(1, flags=STREAM)
+        eng.set_mode(mode)
+        eng.set_squelch(threshold)
+        o = oracle.chain()
+        o.set_mode(mode)
+        o.set_squelch(threshold)
+        pcm, cnt, mag, allowed = eng.accept(data)
+        ref = o.accept_stream(data, 32768)
+        assert (eng.stats()["stream_launches"] == 1) == streamed, (mode, threshold)
+        assert np.array_equal(allowed[0], ref[2]) and np.array_equal(mag[0], ref[1]), (mode, threshold)
+        assert bool(np.all(ref[2] == 1)) == streamed          # the case is what it claims to be
+        assert np.array_equal(pcm[0, :cnt[0]], ref[0]), (mode, threshold)
