@@ -27,6 +27,13 @@
 
 using namespace iqd;
 
+// A chain launch takes its streaming kernel when it brings this many samples per segment of the persistent workgroups
+// (n_cus x 192 segments): measured crossovers against the tile kernels lie at 50-60 M samples per launch on 256 CUs
+// (WBFM 2^25: 0.118 vs 0.139 ms, 2^26: 0.200 vs 0.171; AM 512 x 2^16: 0.047 vs 0.065, 1024 x 2^16: 0.077 vs 0.072;
+// USB 1024 x 2^16: 0.088 vs 0.083), and side by side with other families' launches the streaming kernels do better.
+static const uint64_t STREAM_MIN_PER_SEGMENT = 1024;
+
+
 namespace {
 
 struct DevBuf {
@@ -1091,7 +1098,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         // streaming kernels included.  One word comes back; the wait is a few microseconds against a third of the
         // chain's time.
         const bool probe = !(e->flags & IQD_F_WBFM_TILES) && vlen % 128 == 0 &&
-                           ((e->flags & IQD_F_WBFM_STREAM) || (uint64_t)vlen * n_ch >= (uint64_t)e->n_cus * ST_SEGS * 2048);
+                           ((e->flags & IQD_F_WBFM_STREAM) || (uint64_t)vlen * n_ch >= (uint64_t)e->n_cus * ST_SEGS * STREAM_MIN_PER_SEGMENT);
         if (probe) {
             if (!e->d_closed) {
                 HIP_TRY(e, hipMalloc((void **)&e->d_closed, sizeof(uint32_t)));
@@ -1207,7 +1214,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
             if (e->flags & IQD_F_WBFM_STREAM) want = 1;
             if (const char *env = getenv("IQD_WBFM_PATH")) want = env[0] == 's' ? 1 : env[0] == 't' ? -1 : want;
             const uint64_t work = (uint64_t)vlen * n_list;
-            if (ok && want >= 0 && (want > 0 || work >= (uint64_t)e->n_cus * ST_SEGS * 2048)) {
+            if (ok && want >= 0 && (want > 0 || work >= (uint64_t)e->n_cus * ST_SEGS * STREAM_MIN_PER_SEGMENT)) {
                 const TilePlan sp = plan_stream(vlen, n_list, e->n_cus * ST_SEGS);
                 a.tile_len = sp.tile_len;
                 a.tiles_per_ch = sp.tiles_per_ch;
@@ -1227,7 +1234,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
             if (e->flags & IQD_F_WBFM_STREAM) want = 1;
             if (const char *env = getenv("IQD_WBFM_PATH")) want = env[0] == 's' ? 1 : env[0] == 't' ? -1 : want;
             const uint64_t work = (uint64_t)vlen * n_list;
-            if (ok && want >= 0 && (want > 0 || work >= (uint64_t)e->n_cus * ST_SEGS * 2048)) {
+            if (ok && want >= 0 && (want > 0 || work >= (uint64_t)e->n_cus * ST_SEGS * STREAM_MIN_PER_SEGMENT)) {
                 d4_wgs = e->n_cus;
                 for (uint32_t spare = 0;; spare += 48) {   // (the rotation groups' padding may push an exact fit into a second round)
                     const TilePlan sp = plan_stream(vlen, n_list, d4_wgs * ST_SEGS - spare);
