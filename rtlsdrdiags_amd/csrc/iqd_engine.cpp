@@ -122,8 +122,8 @@ struct iqd_engine {
     DevBuf sl_iq[2], sl_pcm[2], sl_count[2], sl_mag[2], sl_allowed[2];
     hipStream_t copy_stream = nullptr;
     // mixed-mode calls: two side streams beside the engine's, so that the families' kernels share the GPU
-    hipStream_t fam_stream[2] = {};
-    hipEvent_t fam_fork = nullptr, fam_join[2] = {};
+    hipStream_t fam_stream[3] = {};     // side streams: with the engine's own, one lane per demodulator family
+    hipEvent_t fam_fork = nullptr, fam_join[3] = {};
     hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
     uint32_t *h_slice_counts = nullptr;  // pinned, [2][n_ch of a slice]
     uint32_t *d_closed = nullptr, *h_closed = nullptr;   // squelch-gated calls: did any channel lose a block? (device word, pinned copy)
@@ -352,7 +352,7 @@ void iqd_destroy(iqd_t *e)
     if (e->d_closed) (void)hipFree(e->d_closed);
     if (e->h_closed) (void)hipHostFree(e->h_closed);
     if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
-    for (int f = 0; f < 2; f++) {
+    for (int f = 0; f < 3; f++) {
         if (e->fam_stream[f]) (void)hipStreamDestroy(e->fam_stream[f]);
         if (e->fam_join[f]) (void)hipEventDestroy(e->fam_join[f]);
     }
@@ -1157,7 +1157,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
             int lo = 0, hi = 0;   // numerically lower = higher priority
             (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
             HIP_TRY(e, hipEventCreateWithFlags(&e->fam_fork, hipEventDisableTiming));
-            for (int k = 0; k < 2; k++) {
+            for (int k = 0; k < 3; k++) {
                 HIP_TRY(e, hipStreamCreateWithPriority(&e->fam_stream[k], hipStreamNonBlocking, k == 0 ? hi : lo));
                 HIP_TRY(e, hipEventCreateWithFlags(&e->fam_join[k], hipEventDisableTiming));
             }
@@ -1165,13 +1165,37 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         HIP_TRY(e, e->base8k.ensure((size_t)n_ch * base.pcm_stride * sizeof(int32_t)));   // before the fork: shared by AM and SSB
         HIP_TRY(e, hipEventRecord(e->fam_fork, s_main));
     }
-    static const float weight[FAM_COUNT] = {3.4f, 4.0f, 7.2f, 3.7f};   // measured ms per 2^28 samples: AM, FM, WBFM, SSB
+    static const float weight[FAM_COUNT] = {3.4f, 5.2f, 8.0f, 2.9f};   // relative cost per channel-sample: AM, FM, WBFM, SSB (streaming kernels side by side, 64 CUs each: 138 / 211 / 326 / 117 us per 820 channels x 2^16)
     int order[FAM_COUNT] = {0, 1, 2, 3};
     float cost[FAM_COUNT];
     for (int f = 0; f < FAM_COUNT; f++) cost[f] = weight[f] * (float)e->h_lists[f].size();
     std::sort(order, order + FAM_COUNT, [&](int x, int y) { return cost[x] > cost[y]; });
-    float lane_load[3] = {0.f, 0.f, 0.f};   // 0: the engine's stream, 1 and 2: the side streams
-    bool lane_used[3] = {false, false, false};
+    // Several families side by side: each one's persistent workgroups take a share of the CUs in proportion to its
+    // estimated cost, so that the families' streaming kernels run at the same time (a CU's LDS holds one such
+    // workgroup) on longer segments - less lead-in overhead, which is what small families pay most for.  (Mixed
+    // configuration, 4096 channels x 2^16: 0.45 ms per step with every family on all CUs in turn, 0.39 with shares.)
+    uint32_t fam_share[FAM_COUNT];
+    {
+        float total = 0.f;
+        for (int f = 0; f < FAM_COUNT; f++) total += cost[f];
+        uint32_t given = 0;
+        for (int f = 0; f < FAM_COUNT; f++) {
+            uint32_t w = e->n_cus;
+            if (forked && total > 0.f && !getenv("IQD_FULL_GRID")) {
+                // rounded down to whole multiples of 8: workgroups are dealt round-robin to the 8 XCDs, and the shares
+                // must fit side by side on every one of them - or a family's last workgroups wait for a whole kernel
+                // of another family (seen: 38 + 59 + 91 + 65 workgroups put 34 on one XCD of 32 CUs, AM took twice as long)
+                w = (uint32_t)((float)e->n_cus * cost[f] / total) & ~7u;
+                if (w < 8 && cost[f] > 0.f) w = 8;
+                given += cost[f] > 0.f ? w : 0u;
+            }
+            fam_share[f] = w;
+        }
+        if (forked && given > e->n_cus)                                  // (many tiny families: give up the plan)
+            for (int f = 0; f < FAM_COUNT; f++) fam_share[f] = e->n_cus;
+    }
+    float lane_load[4] = {0.f, 0.f, 0.f, 0.f};   // 0: the engine's stream, 1 to 3: the side streams
+    bool lane_used[4] = {false, false, false, false};
     size_t (*dcr_layout)[2] = e->dcr_layout;
     ChainLaunch tail_a{};
     int tail_f = 0;
@@ -1182,13 +1206,15 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         if (!n_list) continue;
         int lane = 0;
         if (forked) {
-            for (int k = 1; k < 3; k++)
+            for (int k = 1; k < 4; k++)
                 if (lane_load[k] < lane_load[lane]) lane = k;
             lane_load[lane] += cost[f];
         }
         s = lane == 0 ? s_main : e->fam_stream[lane - 1];
         if (lane != 0 && !lane_used[lane]) HIP_TRY(e, hipStreamWaitEvent(s, e->fam_fork, 0));
         lane_used[lane] = true;
+        uint32_t fam_wgs = fam_share[f];
+        if (const char *env = getenv("IQD_STREAM_WGS")) fam_wgs = (uint32_t)atoi(env) > 0 ? (uint32_t)atoi(env) : fam_wgs;   // (experiments)
         ChainLaunch a = base;
         a.ch_list = e->lists[f].as<uint32_t>();
         a.n_list = n_list;
@@ -1215,7 +1241,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
             if (const char *env = getenv("IQD_WBFM_PATH")) want = env[0] == 's' ? 1 : env[0] == 't' ? -1 : want;
             const uint64_t work = (uint64_t)vlen * n_list;
             if (ok && want >= 0 && (want > 0 || work >= (uint64_t)e->n_cus * ST_SEGS * STREAM_MIN_PER_SEGMENT)) {
-                const TilePlan sp = plan_stream(vlen, n_list, e->n_cus * ST_SEGS);
+                const TilePlan sp = plan_stream(vlen, n_list, fam_wgs * ST_SEGS);
                 a.tile_len = sp.tile_len;
                 a.tiles_per_ch = sp.tiles_per_ch;
                 use_stream = true;
@@ -1224,7 +1250,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         // FM / AM / SSB: the streaming pipelines of iqd_stream2.hip under the same conditions (channels of different
         // rotation selectors are fine here: the list is sorted by selector and the groups are padded)
         bool use_d4 = false;
-        uint32_t d4_wgs = e->n_cus;
+        uint32_t d4_wgs = fam_wgs;
         D4Args d4 = e->d4_args;
         if (f != FAM_WBFM && !chain_gated && !(e->flags & IQD_F_WBFM_TILES) && vlen % 128 == 0 && (f == FAM_FM || vlen / 32 > 512)) {
             bool ok = true;
@@ -1235,7 +1261,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
             if (const char *env = getenv("IQD_WBFM_PATH")) want = env[0] == 's' ? 1 : env[0] == 't' ? -1 : want;
             const uint64_t work = (uint64_t)vlen * n_list;
             if (ok && want >= 0 && (want > 0 || work >= (uint64_t)e->n_cus * ST_SEGS * STREAM_MIN_PER_SEGMENT)) {
-                d4_wgs = e->n_cus;
+                d4_wgs = fam_wgs;
                 for (uint32_t spare = 0;; spare += 48) {   // (the rotation groups' padding may push an exact fit into a second round)
                     const TilePlan sp = plan_stream(vlen, n_list, d4_wgs * ST_SEGS - spare);
                     a.tile_len = sp.tile_len;
@@ -1282,7 +1308,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
                 sa.half_lut = e->d_half_lut;
                 sa.n_segments = n_list * a.tiles_per_ch;
                 const uint32_t wgs_needed = (sa.n_segments + ST_SEGS - 1) / ST_SEGS;
-                const uint32_t grid = wgs_needed < e->n_cus ? wgs_needed : e->n_cus;
+                const uint32_t grid = wgs_needed < fam_wgs ? wgs_needed : fam_wgs;
                 sa.rounds = (wgs_needed + grid - 1) / grid;
                 HIP_TRY(e, e->stream_hist.ensure((size_t)sa.n_segments * sizeof(StHist)));
                 sa.hist = e->stream_hist.as<StHist>();
@@ -1368,7 +1394,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         }
     }
     s = s_main;
-    for (int k = 1; k < 3; k++)
+    for (int k = 1; k < 4; k++)
         if (lane_used[k]) {
             HIP_TRY(e, hipEventRecord(e->fam_join[k - 1], e->fam_stream[k - 1]));
             HIP_TRY(e, hipStreamWaitEvent(s_main, e->fam_join[k - 1], 0));
