@@ -1165,7 +1165,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         HIP_TRY(e, e->base8k.ensure((size_t)n_ch * base.pcm_stride * sizeof(int32_t)));   // before the fork: shared by AM and SSB
         HIP_TRY(e, hipEventRecord(e->fam_fork, s_main));
     }
-    static const float weight[FAM_COUNT] = {3.4f, 5.2f, 8.0f, 2.9f};   // relative cost per channel-sample: AM, FM, WBFM, SSB (streaming kernels side by side, 64 CUs each: 138 / 211 / 326 / 117 us per 820 channels x 2^16)
+    static const float weight[FAM_COUNT] = {3.4f, 5.2f, 9.0f, 2.9f};   // relative cost per channel-sample: AM, FM, WBFM, SSB (streaming kernels side by side, 64 CUs each: 138 / 211 / 326 / 117 us per 820 channels x 2^16)
     int order[FAM_COUNT] = {0, 1, 2, 3};
     float cost[FAM_COUNT];
     for (int f = 0; f < FAM_COUNT; f++) cost[f] = weight[f] * (float)e->h_lists[f].size();
@@ -1178,21 +1178,35 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
     {
         float total = 0.f;
         for (int f = 0; f < FAM_COUNT; f++) total += cost[f];
-        uint32_t given = 0;
-        for (int f = 0; f < FAM_COUNT; f++) {
-            uint32_t w = e->n_cus;
-            if (forked && total > 0.f && !getenv("IQD_FULL_GRID")) {
-                // rounded down to whole multiples of 8: workgroups are dealt round-robin to the 8 XCDs, and the shares
-                // must fit side by side on every one of them - or a family's last workgroups wait for a whole kernel
-                // of another family (seen: 38 + 59 + 91 + 65 workgroups put 34 on one XCD of 32 CUs, AM took twice as long)
-                w = (uint32_t)((float)e->n_cus * cost[f] / total) & ~7u;
+        for (int f = 0; f < FAM_COUNT; f++) fam_share[f] = e->n_cus;
+        if (forked && total > 0.f && e->n_cus >= 64 && !getenv("IQD_FULL_GRID")) {
+            // whole multiples of 8: workgroups are dealt round-robin to the 8 XCDs, and the shares must fit side by
+            // side on every one of them - or a family's last workgroups wait for a whole kernel of another family
+            // (seen: 38 + 59 + 91 + 65 workgroups put 34 on one XCD of 32 CUs, AM took twice as long)
+            // ... and two CUs per XCD stay free: with every CU spoken for, a workgroup that finds its CU still busy for
+            // a moment waits for a whole kernel (0.36 ms per step of the mixed configuration with 240 of 256 CUs planned,
+            // 0.42-0.45 with all 256)
+            const uint32_t budget = e->n_cus - 16;
+            float want[FAM_COUNT];
+            uint32_t given = 0;
+            for (int f = 0; f < FAM_COUNT; f++) {
+                want[f] = (float)budget * cost[f] / total;
+                uint32_t w = (uint32_t)want[f] & ~7u;
                 if (w < 8 && cost[f] > 0.f) w = 8;
+                fam_share[f] = cost[f] > 0.f ? w : e->n_cus;
                 given += cost[f] > 0.f ? w : 0u;
             }
-            fam_share[f] = w;
+            while (given + 8 <= budget) {                        // what the rounding left over: to whoever is furthest below its due
+                int best = -1;
+                for (int f = 0; f < FAM_COUNT; f++)
+                    if (cost[f] > 0.f && (best < 0 || want[f] - (float)fam_share[f] > want[best] - (float)fam_share[best])) best = f;
+                if (best < 0) break;
+                fam_share[best] += 8;
+                given += 8;
+            }
+            if (given > budget)                                  // (many tiny families: give up the plan)
+                for (int f = 0; f < FAM_COUNT; f++) fam_share[f] = e->n_cus;
         }
-        if (forked && given > e->n_cus)                                  // (many tiny families: give up the plan)
-            for (int f = 0; f < FAM_COUNT; f++) fam_share[f] = e->n_cus;
     }
     float lane_load[4] = {0.f, 0.f, 0.f, 0.f};   // 0: the engine's stream, 1 to 3: the side streams
     bool lane_used[4] = {false, false, false, false};

@@ -165,19 +165,20 @@ def test_more_segments_than_one_round_holds(capi, oracle, mode):
     pick = rng.integers(0, 7, n_ch)
     u8 = np.stack([base[k] for k in pick])
     u8[:, 100:116] = rng.integers(0, 256, size=(n_ch, 16), dtype=np.uint8)     # every channel its own few bytes
-    import torch
     eng = capi.Engine(n_ch, flags=STREAM)
     eng.set_mode(mode)
     # (device pointers: a host-pointer call of this size would be cut into slices of a few thousand channels)
-    iq_d = torch.from_numpy(u8).cuda()
-    pcm_d = torch.zeros((n_ch, n // 32), dtype=torch.int16, device="cuda")
-    cnt_d = torch.zeros(n_ch, dtype=torch.int32, device="cuda")
-    mag_d = torch.zeros((n_ch, 1), dtype=torch.int32, device="cuda")
-    torch.cuda.synchronize()
-    eng.accept_device(iq_d.data_ptr(), 2 * n, pcm_d.data_ptr(), cnt_d.data_ptr(), mag_d.data_ptr())
+    iq_d, pcm_d = eng.dev_alloc(u8.nbytes), eng.dev_alloc(n_ch * (n // 32) * 2)
+    cnt_d, mag_d = eng.dev_alloc(n_ch * 4), eng.dev_alloc(n_ch * 4)
+    eng.dev_upload(iq_d, u8)
+    eng.accept_device(iq_d, 2 * n, pcm_d, cnt_d, mag_d)
     eng.synchronize()
     assert eng.stats()["stream_launches"] == 1
-    pcm, cnt, mag = pcm_d.cpu().numpy(), cnt_d.cpu().numpy(), mag_d.cpu().numpy().astype(np.uint32)
+    pcm = eng.dev_download(pcm_d, n_ch * (n // 32) * 2, np.int16).reshape(n_ch, -1)
+    cnt = eng.dev_download(cnt_d, n_ch * 4, np.uint32)
+    mag = eng.dev_download(mag_d, n_ch * 4, np.uint32).reshape(n_ch, 1)
+    for p_ in (iq_d, pcm_d, cnt_d, mag_d):
+        eng.dev_free(p_)
     for c in list(range(0, 40)) + list(range(49100, 49200)) + list(range(n_ch - 40, n_ch)):
         o = oracle.chain()
         o.set_mode(mode)
