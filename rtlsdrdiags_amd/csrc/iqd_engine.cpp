@@ -1175,11 +1175,26 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
     // workgroup) on longer segments - less lead-in overhead, which is what small families pay most for.  (Mixed
     // configuration, 4096 channels x 2^16: 0.45 ms per step with every family on all CUs in turn, 0.39 with shares.)
     uint32_t fam_share[FAM_COUNT];
+    bool shares_on = false;   // the families of this call run their streaming kernels side by side, each on a share of the CUs
     {
         float total = 0.f;
         for (int f = 0; f < FAM_COUNT; f++) total += cost[f];
         for (int f = 0; f < FAM_COUNT; f++) fam_share[f] = e->n_cus;
-        if (forked && total > 0.f && e->n_cus >= 64 && !getenv("IQD_FULL_GRID")) {
+        // (only when every family of the call will take its streaming kernel - here that means: brings enough samples
+        // for ITS share of the CUs; tile kernels know nothing of shares, and a streaming kernel held to its share beside
+        // them lost 12-16 % at 2500-3000 mixed channels)
+        bool all_stream = !chain_gated && !(e->flags & IQD_F_WBFM_TILES) && vlen % 128 == 0;
+        if (const char *env = getenv("IQD_WBFM_PATH")) all_stream = all_stream && env[0] != 't';
+        for (int f = 0; f < FAM_COUNT && all_stream; f++) {
+            const uint64_t n_f = e->h_lists[f].size();
+            if (!n_f) continue;
+            const bool forced = (e->flags & IQD_F_WBFM_STREAM) != 0;
+            const float due = total > 0.f ? (float)(e->n_cus - 16) * cost[f] / total : (float)e->n_cus;
+            if (!forced && (float)((uint64_t)vlen * n_f) < due * (float)(ST_SEGS * STREAM_MIN_PER_SEGMENT)) all_stream = false;
+            if ((f == FAM_AM || f == FAM_SSB) && vlen / 32 <= 512) all_stream = false;
+        }
+        shares_on = forked && all_stream && total > 0.f && e->n_cus >= 64 && !getenv("IQD_FULL_GRID");
+        if (shares_on) {
             // whole multiples of 8: workgroups are dealt round-robin to the 8 XCDs, and the shares must fit side by
             // side on every one of them - or a family's last workgroups wait for a whole kernel of another family
             // (seen: 38 + 59 + 91 + 65 workgroups put 34 on one XCD of 32 CUs, AM took twice as long)
@@ -1254,7 +1269,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
             if (e->flags & IQD_F_WBFM_STREAM) want = 1;
             if (const char *env = getenv("IQD_WBFM_PATH")) want = env[0] == 's' ? 1 : env[0] == 't' ? -1 : want;
             const uint64_t work = (uint64_t)vlen * n_list;
-            if (ok && want >= 0 && (want > 0 || work >= (uint64_t)e->n_cus * ST_SEGS * STREAM_MIN_PER_SEGMENT)) {
+            if (ok && want >= 0 && (want > 0 || work >= (uint64_t)(shares_on ? fam_wgs : e->n_cus) * ST_SEGS * STREAM_MIN_PER_SEGMENT || shares_on)) {
                 const TilePlan sp = plan_stream(vlen, n_list, fam_wgs * ST_SEGS);
                 a.tile_len = sp.tile_len;
                 a.tiles_per_ch = sp.tiles_per_ch;
@@ -1274,7 +1289,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
             if (e->flags & IQD_F_WBFM_STREAM) want = 1;
             if (const char *env = getenv("IQD_WBFM_PATH")) want = env[0] == 's' ? 1 : env[0] == 't' ? -1 : want;
             const uint64_t work = (uint64_t)vlen * n_list;
-            if (ok && want >= 0 && (want > 0 || work >= (uint64_t)e->n_cus * ST_SEGS * STREAM_MIN_PER_SEGMENT)) {
+            if (ok && want >= 0 && (want > 0 || work >= (uint64_t)(shares_on ? fam_wgs : e->n_cus) * ST_SEGS * STREAM_MIN_PER_SEGMENT || shares_on)) {
                 d4_wgs = fam_wgs;
                 for (uint32_t spare = 0;; spare += 48) {   // (the rotation groups' padding may push an exact fit into a second round)
                     const TilePlan sp = plan_stream(vlen, n_list, d4_wgs * ST_SEGS - spare);
