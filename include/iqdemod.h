@@ -65,7 +65,9 @@ typedef struct iqd_config {
 /* Every chain (WBFM, FM, AM, SSB) exists as two kernels with identical results: tiles (one workgroup per run of
  * samples) and a streaming pipeline (one persistent workgroup per CU, used for launches big enough to fill the chip
  * that are not squelch-gated).  These two flags pin the choice for all chains (tests, A/B measurements; the names
- * are from the round in which only WBFM had both); the environment variable IQD_WBFM_PATH=tiles|stream does the same. */
+ * are from the round in which only WBFM had both); the environment variable IQD_WBFM_PATH=tiles|stream does the same.
+ * Two more environment variables exist for measurements only: IQD_FULL_GRID=1 gives every family of a multi-family call all
+ * CUs in turn instead of a share of them side by side, IQD_STREAM_WGS=<n> fixes the streaming kernels' workgroup count. */
 #define IQD_F_WBFM_TILES  0x2u
 #define IQD_F_WBFM_STREAM 0x4u
 
