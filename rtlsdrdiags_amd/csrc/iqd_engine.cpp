@@ -1194,34 +1194,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
             if ((f == FAM_AM || f == FAM_SSB) && vlen / 32 <= 512) all_stream = false;
         }
         shares_on = forked && all_stream && total > 0.f && e->n_cus >= 64 && !getenv("IQD_FULL_GRID");
-        if (shares_on) {
-            // whole multiples of 8: workgroups are dealt round-robin to the 8 XCDs, and the shares must fit side by
-            // side on every one of them - or a family's last workgroups wait for a whole kernel of another family
-            // (seen: 38 + 59 + 91 + 65 workgroups put 34 on one XCD of 32 CUs, AM took twice as long)
-            // ... and two CUs per XCD stay free: with every CU spoken for, a workgroup that finds its CU still busy for
-            // a moment waits for a whole kernel (0.36 ms per step of the mixed configuration with 240 of 256 CUs planned,
-            // 0.42-0.45 with all 256)
-            const uint32_t budget = e->n_cus - 16;
-            float want[FAM_COUNT];
-            uint32_t given = 0;
-            for (int f = 0; f < FAM_COUNT; f++) {
-                want[f] = (float)budget * cost[f] / total;
-                uint32_t w = (uint32_t)want[f] & ~7u;
-                if (w < 8 && cost[f] > 0.f) w = 8;
-                fam_share[f] = cost[f] > 0.f ? w : e->n_cus;
-                given += cost[f] > 0.f ? w : 0u;
-            }
-            while (given + 8 <= budget) {                        // what the rounding left over: to whoever is furthest below its due
-                int best = -1;
-                for (int f = 0; f < FAM_COUNT; f++)
-                    if (cost[f] > 0.f && (best < 0 || want[f] - (float)fam_share[f] > want[best] - (float)fam_share[best])) best = f;
-                if (best < 0) break;
-                fam_share[best] += 8;
-                given += 8;
-            }
-            if (given > budget)                                  // (many tiny families: give up the plan)
-                for (int f = 0; f < FAM_COUNT; f++) fam_share[f] = e->n_cus;
-        }
+        if (shares_on && !plan_family_shares(cost, FAM_COUNT, e->n_cus, fam_share)) shares_on = false;
     }
     float lane_load[4] = {0.f, 0.f, 0.f, 0.f};   // 0: the engine's stream, 1 to 3: the side streams
     bool lane_used[4] = {false, false, false, false};

@@ -290,6 +290,46 @@ void build_stream_taps(const int16_t *d1, const int16_t *post12, const int16_t *
 }
 
 // Segments of the streaming kernel: about `streams` of them in all, whole 128-sample units.
+// A CU's LDS holds one persistent workgroup, so families that stream side by side have to share the CUs.
+//  - whole multiples of 8: workgroups are dealt round-robin to the 8 XCDs, and the shares must fit side by side on every
+//    one of them - or a family's last workgroups wait for a whole kernel of another family (seen: 38 + 59 + 91 + 65
+//    workgroups put 34 on one XCD of 32 CUs, AM took twice as long);
+//  - two CUs per XCD stay unplanned: with every CU spoken for, a workgroup that finds its CU still busy for a moment
+//    waits for a whole kernel (0.35 ms per step of the mixed bench configuration with 240 of 256 CUs planned, 0.42-0.45
+//    with all 256);
+//  - what the rounding leaves over goes, 8 at a time, to whoever is furthest below its due.
+bool plan_family_shares(const float *cost, int n, uint32_t n_cus, uint32_t *share)
+{
+    for (int f = 0; f < n; f++) share[f] = n_cus;
+    float total = 0.f;
+    for (int f = 0; f < n; f++) total += cost[f] > 0.f ? cost[f] : 0.f;
+    if (n_cus < 64 || n > 8 || total <= 0.f) return false;
+    const uint32_t budget = n_cus - 16;
+    float want[8];
+    uint32_t given = 0;
+    for (int f = 0; f < n; f++) {
+        if (!(cost[f] > 0.f)) { want[f] = 0.f; continue; }
+        want[f] = (float)budget * cost[f] / total;
+        uint32_t w = (uint32_t)want[f] & ~7u;
+        if (w < 8) w = 8;
+        share[f] = w;
+        given += w;
+    }
+    while (given + 8 <= budget) {
+        int best = -1;
+        for (int f = 0; f < n; f++)
+            if (cost[f] > 0.f && (best < 0 || want[f] - (float)share[f] > want[best] - (float)share[best])) best = f;
+        if (best < 0) break;
+        share[best] += 8;
+        given += 8;
+    }
+    if (given > budget) {                                    // (many tiny families: no plan)
+        for (int f = 0; f < n; f++) share[f] = n_cus;
+        return false;
+    }
+    return true;
+}
+
 TilePlan plan_stream(uint32_t vlen, uint32_t n_channels, uint32_t streams)
 {
     TilePlan p;

@@ -31,6 +31,10 @@ struct TilePlan { uint32_t tile_len, tiles_per_ch; };
 TilePlan plan_tiles(uint32_t vlen, uint32_t n_channels, uint32_t chunk, uint32_t halo, uint32_t resident_wgs);
 
 TilePlan plan_stream(uint32_t vlen, uint32_t n_channels, uint32_t streams);
+// Several demodulator families in one call, each with its streaming kernel: the CUs each family's persistent workgroups
+// get, in proportion to cost[f] (0 = family absent: its entry becomes n_cus).  Whole multiples of 8, at least 8, two CUs
+// per XCD left unplanned; false (and every entry n_cus) when that cannot be had.  See iqd_host.cpp.
+bool plan_family_shares(const float *cost, int n, uint32_t n_cus, uint32_t *share);
 
 uint32_t block_magic(uint32_t block_samples);
 

@@ -232,4 +232,17 @@ void emu_agc_run(uint32_t type, int32_t operating_point, int32_t deadband, float
     *rx_gain = gain; *if_gain = st.if_gain; *filtered = st.filtered; *blank_ctr = st.blank_ctr; *adjusted = st.adjusted;
 }
 
+// host planning logic of the engine, for the CPU tier
+int emu_plan_family_shares(const float *cost, int n, uint32_t n_cus, uint32_t *share)
+{
+    return iqd::plan_family_shares(cost, n, n_cus, share) ? 1 : 0;
+}
+
+void emu_plan_stream(uint32_t vlen, uint32_t n_channels, uint32_t streams, uint32_t *tile_len, uint32_t *tiles_per_ch)
+{
+    const iqd::TilePlan p = iqd::plan_stream(vlen, n_channels, streams);
+    *tile_len = p.tile_len;
+    *tiles_per_ch = p.tiles_per_ch;
+}
+
 }  // extern "C"
