@@ -2,16 +2,21 @@
 """bench.py — IQ MSamples/s through the demodulator chains on N MI355X GPUs, with the HBM roofline fraction
 of the dominant kernel and the CPU baseline timed beside it.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 1|2|3|4]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config 0|1|2|3|4]
+
+`python bench.py --gpus N` with N > 1 starts its own ranks (torch.distributed.run as a CHILD process, one rank per GPU
+over RCCL) when it was not itself started by a launcher, and relays rank 0's line and the exit code.
 
 Default workload (BASELINE.json configs[1]): WBFM, 1 channel per GPU, 2^28 synthetic IQ samples
 (512 MiB of uint8 I/Q) resident in HBM before the timed region.  `--config N` selects BASELINE.json configs[N]:
 
+    0  one FM channel, 2^20 samples from a file through the C++ IqDataProcessor::acceptIqData in 32768-byte blocks
+       (the reference's own operating point: one 64 ms block per call; reports us per block beside MS/s)
     1  WBFM, 1 channel x 2^28 samples                                   (the metric's configuration)
     2  FM, 4096 channels x 2^16 samples (256 ms of signal each)
     3  mixed AM/FM/WBFM/LSB/USB, 4096 channels per GPU x 2^16 samples    (32768 channels over 8 GPUs)
-    4  LSB+USB, rotation selector varying per channel, Harris AGC running, 8192 channels per GPU x 2^16 samples
-                                                                         (65536 channels over 8 GPUs)
+    4  LSB+USB, rotation selector varying per channel, Harris AGC running, squelch threshold raised so that blocks
+       gate (loud / quiet blocks per channel), 8192 channels per GPU x 2^16 samples  (65536 channels over 8 GPUs)
 
 A "step" is one iqd_accept_iq_device() call over the whole batch: the chain kernel(s), the hand-off verification, the
 squelch / AGC bookkeeping and the state update.  With N > 1 every rank runs its own channels on its own GPU
@@ -37,6 +42,9 @@ HBM_PEAK_GBS = 8000.0                        # MI355X HBM3E spec peak (MI355X_MI
 METRIC = "IQ MSamples/s through WBFM chain at 1/2/4/8 GPUs; % HBM roofline"
 
 CONFIGS = {
+    0: dict(mode="fm", channels=1, log2=20, tag="fm_file",
+            what="BASELINE configs[0]: single FM channel, 256 kS/s uint8 IQ from a file through IqDataProcessor::acceptIqData "
+                 "in 32768-byte blocks (C++ class over the C ABI; one 64 ms block per call)"),
     1: dict(mode="wbfm", channels=1, log2=28, tag="wbfm_2p28",
             what="BASELINE configs[1]: WBFM, 1 channel, 2^28-sample synthetic IQ"),
     2: dict(mode="fm", channels=4096, log2=16, tag="fm_4096",
@@ -46,7 +54,8 @@ CONFIGS = {
                  "2^16 samples each per step"),
     4: dict(mode="ssb_stress", channels=8192, log2=16, tag="ssb_8192",
             what="BASELINE configs[4]: LSB+USB alternating, rotation selector (the reference's only NCO: +Fs/4, none, -Fs/4) "
-                 "varying per channel, Harris AGC running, 8192 channels per GPU = 65536 over 8 GPUs, 2^16 samples each per step"),
+                 "varying per channel, Harris AGC running, squelch threshold raised so that blocks gate, 8192 channels per GPU = "
+                 "65536 over 8 GPUs, 2^16 samples each per step"),
 }
 
 
@@ -160,6 +169,27 @@ def make_signal(synth, signal, period):
     return synth.fm_tone(period, seed=1234, deviation=3000.0)   # "quiet": speech-like deviation
 
 
+# BASELINE configs[4] ("squelch threshold raised so blocks gate", SURVEY 8(d) Config 5): every channel's row is made of
+# loud (carrier amplitude 60) and quiet (amplitude 2) blocks in a pattern that depends on its job-wide index, period 4
+# blocks, and the threshold sits at -60 dBFS.  With the Harris AGC running (it raises the IF gain over quiet stretches,
+# and the squelch compares level - gain) the steady state is: class 0 (LLLL) always open, class 1 (LQQL) loses one block
+# in four, class 2 (QQQL) two, class 3 (LLQQ) one: a quarter of all blocks is rejected, and every channel keeps running -
+# the filters see the concatenation of the allowed blocks (IqDataProcessor.cc:793; oracle-checked in tests/test_gpu_scale.py).
+GATE_PATTERNS = ((1, 1, 1, 1), (1, 0, 0, 1), (0, 0, 0, 1), (1, 1, 0, 0))
+GATE_THRESHOLD_DBFS = -60
+
+
+def gating_rows(synth, n, block_samples=16384):
+    """The four row classes of configs[4] as uint8 arrays of n samples each."""
+    loud = synth.fm_tone(n, seed=1234)
+    quiet = synth.fm_tone(n, seed=1234, amplitude=2.0, sigma=1.0)
+    bb = 2 * block_samples
+    rows = []
+    for pat in GATE_PATTERNS:
+        rows.append(np.concatenate([(loud if pat[b % 4] else quiet)[b * bb:(b + 1) * bb] for b in range(max(1, 2 * n // bb))]))
+    return rows
+
+
 def configure(eng, mode, n_ch, first_global, squelch):
     """Per-channel settings; `first_global` is this rank's first channel in the whole job, so that the mix is the
     same however many ranks share it."""
@@ -173,6 +203,8 @@ def configure(eng, mode, n_ch, first_global, squelch):
             eng.set_rotation((1, 0, -1)[g % 3], first=c, n=1)
         eng.agc_set_type(1)      # AGC_TYPE_HARRIS
         eng.agc_enable(True)
+        if squelch is None:
+            squelch = GATE_THRESHOLD_DBFS
     else:
         eng.set_mode(mode)
     if squelch is not None:
@@ -189,18 +221,27 @@ def rank_body(args, rank, world, dev, make_engine, dist, torch, order_streams=No
     n_ch = args.channels
     period = min(n, 1 << 24)
     period_u8 = make_signal(synth, args.signal, period)   # the same seeded signal on every rank and channel
-    iq = torch.from_numpy(period_u8).to(dev).repeat(n // period)
-    if n_ch > 1:
-        iq = iq.unsqueeze(0).repeat(n_ch, 1).contiguous()
+    first_global, _ = shard.channel_range(rank, world, n_ch * world)
+    gating = args.mode == "ssb_stress" and args.signal == "fm_tone" and n == period
+    if gating:   # configs[4]: loud / quiet blocks per channel class, so that the raised squelch really rejects blocks
+        classes = torch.from_numpy(np.stack(gating_rows(synth, n))).to(dev)
+        which = (torch.arange(n_ch, device=dev) + first_global) % len(GATE_PATTERNS)
+        iq = classes.index_select(0, which).contiguous()
+        del classes
+    else:
+        iq = torch.from_numpy(period_u8).to(dev).repeat(n // period)
+        if n_ch > 1:
+            iq = iq.unsqueeze(0).repeat(n_ch, 1).contiguous()
+    n_blocks = max(1, 2 * n // 32768)
     pcm = torch.zeros(n_ch * (n // 32), dtype=torch.int16, device=dev)
     cnt = torch.zeros(n_ch, dtype=torch.int32, device=dev)
-    mag = torch.zeros(n_ch * max(1, 2 * n // 32768), dtype=torch.int32, device=dev)
+    mag = torch.zeros(n_ch * n_blocks, dtype=torch.int32, device=dev)
+    allowed = torch.zeros(n_ch * n_blocks, dtype=torch.uint8, device=dev)
     sync = (lambda: torch.cuda.synchronize()) if dev.type == "cuda" else (lambda: None)
     sync()
 
     flags = (1 if args.no_magnitude else 0) | {"tiles": 2, "stream": 4}.get(args.wbfm_path, 0)
     eng = make_engine(n_channels=n_ch, flags=flags)
-    first_global, _ = shard.channel_range(rank, world, n_ch * world)
     configure(eng, args.mode, n_ch, first_global, args.squelch)
     gatherer = shard.PcmGatherer(n_ch, n // 32, dev) if (args.gather and dist is not None) else None
 
@@ -208,13 +249,15 @@ def rank_body(args, rank, world, dev, make_engine, dist, torch, order_streams=No
         if args.no_magnitude:
             eng.accept_device(iq.data_ptr(), 2 * n, pcm.data_ptr())
         else:
-            eng.accept_device(iq.data_ptr(), 2 * n, pcm.data_ptr(), cnt.data_ptr(), mag.data_ptr())
+            eng.accept_device(iq.data_ptr(), 2 * n, pcm.data_ptr(), cnt.data_ptr(), mag.data_ptr(), allowed.data_ptr())
         if gatherer is not None:
             if order_streams is not None:
-                order_streams(eng)          # the collective's stream waits for the engine's kernels (no host sync)
+                order_streams(eng, True)    # the collective's stream waits for the engine's kernels (no host sync)
             else:
                 eng.synchronize()
             gatherer.gather(pcm.view(n_ch, -1), cnt)
+            if order_streams is not None:
+                order_streams(eng, False)   # and the engine's next step waits for the gatherer's copies out of pcm / cnt
 
     for _ in range(args.warmup):
         step()
@@ -243,6 +286,11 @@ def rank_body(args, rank, world, dev, make_engine, dist, torch, order_streams=No
         launches = max(1, k1["chain_kernel_count"] - k0["chain_kernel_count"])
         kern_ms = (k1["chain_kernel_ms"] - k0["chain_kernel_ms"]) / launches
         streamed = k1.get("stream_launches", 0) - k0.get("stream_launches", 0) > 0
+        st_launches = k1.get("stream_launches", 0) - k0.get("stream_launches", 0)
+        ch_launches = k1.get("kernel_launches", 0) - k0.get("kernel_launches", 0)
+        kernels_ran = ("streaming pipelines" if st_launches == ch_launches and ch_launches else
+                       "tile kernels" if st_launches == 0 else
+                       "%d of %d chain launches as streaming pipelines, the rest as tile kernels" % (st_launches, ch_launches))
         if args.mode == "mixed":
             timed, timed_samples = "the first demodulator family launched (WBFM's stream / chain kernel)", None
         elif args.mode in ("am", "lsb", "usb", "ssb_stress"):
@@ -279,7 +327,7 @@ def rank_body(args, rank, world, dev, make_engine, dist, torch, order_streams=No
             "config": {"workload": args.what or "%s, %d channel(s) per GPU, 2^%d IQ samples per channel per step, uint8 I/Q "
                                                 "resident in HBM (not a BASELINE configuration)"
                                                 % (args.mode.upper(), n_ch, args.log2_samples),
-                       "channels_per_gpu": n_ch, "log2_samples_per_channel": args.log2_samples,
+                       "channels_per_gpu": n_ch, "log2_samples_per_channel": args.log2_samples, "kernels": kernels_ran,
                        "sharding": "independent channels, contiguous range per rank, no data-path collective"
                                    + ("; PCM gathered to rank 0 over RCCL" if args.gather else "")},
             "roofline": roof,
@@ -287,6 +335,11 @@ def rank_body(args, rank, world, dev, make_engine, dist, torch, order_streams=No
             "state_repairs": k1["state_repairs"] - k0["state_repairs"],
             "segment_repairs": k1["segment_repairs"] - k0["segment_repairs"],
         }
+        if not args.no_magnitude:   # what the squelch did in the last step (rank 0's channels)
+            open_frac = float(allowed.float().mean().item())
+            out["config"]["squelch"] = {"threshold_dbfs": GATE_THRESHOLD_DBFS if (args.squelch is None and args.mode == "ssb_stress") else args.squelch,
+                                        "blocks_rejected_frac": round(1.0 - open_frac, 4),
+                                        "pcm_samples_per_channel_mean": round(float(cnt.float().mean().item()), 1)}
         if world == 1 and not args.no_host_path and dev.type == "cuda":
             out["host_path"] = host_path(eng, iq, n, n_ch)
         if world == 1 and not args.no_cpu_baseline:
@@ -313,8 +366,11 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-one-core-only", action="store_true", help="skip the all-host-cores CPU baseline")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive iqd_accept_iq measurement")
     ap.add_argument("--gather", action="store_true", help="also gather the PCM to rank 0 over RCCL each step")
+    ap.add_argument("--standin", default=None, help=argparse.SUPPRESS)   # module:Class of a host-memory engine (CPU tests of the launcher)
     args = ap.parse_args(argv)
-    preset = CONFIGS[args.config or 1]
+    preset = CONFIGS[1 if args.config is None else args.config]
+    if args.config == 0 and args.steps == 20 and args.warmup == 3:
+        args.steps, args.warmup = 61, 3          # 64 blocks = 2^20 samples, SURVEY 8(d) Config 1
     custom = args.mode is not None or args.channels is not None or args.log2_samples is not None
     args.mode = args.mode or preset["mode"]
     args.channels = args.channels or preset["channels"]
@@ -325,17 +381,117 @@ def parse_args(argv=None):
     return args
 
 
+def self_launch(argv, n_gpus):
+    """`python bench.py --gpus N` outside a launcher: start the ranks as a CHILD process (never exec: a process that
+    has touched the GPU must not be replaced, and this one must stay to relay the result), one rank per GPU, and pass
+    on rank 0's line and the exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    line = None
+    for ln in p.stdout.decode(errors="replace").splitlines():
+        if ln.startswith('{"metric"'):
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line)
+    sys.stdout.flush()
+    return p.returncode if (p.returncode != 0 or line is not None) else 1
+
+
+def config0(args):
+    """BASELINE configs[0]: one FM channel from a FILE through the C++ IqDataProcessor::acceptIqData in 32768-byte
+    blocks (rtlsdrdiags_amd/bin/iqdemod_file: the reference's radioApp.cc / demod.cc shape), one block per call - the
+    reference's real operating point (DataConsumer.cc:333-346).  A step is one block; the first `warmup` blocks of the
+    file are not timed.  The PCM is held to the CPU chain's, which is timed beside it on the same file."""
+    import subprocess
+    import tempfile
+    from rtlsdrdiags_amd import synth
+    tool = os.path.join(ROOT, "rtlsdrdiags_amd", "bin", "iqdemod_file")
+    n_blocks = args.warmup + args.steps
+    u8 = synth.fm_tone(n_blocks * 16384, seed=1)
+    with tempfile.TemporaryDirectory() as tmp:
+        src, timing = os.path.join(tmp, "fm_u8.iq"), os.path.join(tmp, "timing.txt")
+        u8.tofile(src)
+        with open(src, "rb") as fin:
+            r = subprocess.run([tool, "2", "timing=" + timing], stdin=fin, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        if r.returncode != 0:
+            sys.exit("iqdemod_file failed (%d): %s" % (r.returncode, r.stderr.decode(errors="replace")))
+        pcm = np.frombuffer(r.stdout, dtype=np.int16)
+        with open(timing) as f:
+            head = f.readline().split()
+            us = np.array([float(x) for x in f.read().split()])
+    counts = dict(zip(head[0::2], map(int, head[1::2])))
+    t = us[args.warmup:]
+    out = {
+        "metric": METRIC.replace("WBFM chain", "FM chain (file source, one block per call)"),
+        "value": round(16384 * len(t) / t.sum(), 3), "unit": "MSamples/s", "n_gpus": 1, "steps": int(len(t)), "warmup": args.warmup,
+        "ms_per_step": round(float(t.mean()) / 1e3, 5), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "int8/int16 Q15 + f32", "data": "synthetic",
+        "config": {"workload": args.what, "channels_per_gpu": 1, "block_bytes": 32768,
+                   "host_path": "file -> fread -> IqDataProcessor::acceptIqData (C++) -> iqd_accept_iq (upload, kernels, PCM download) "
+                                "-> PCM callback -> fwrite; PCIe-inclusive by nature"},
+        "block_latency_us": {"p50": round(float(np.percentile(t, 50)), 1), "p99": round(float(np.percentile(t, 99)), 1),
+                             "max": round(float(t.max()), 1), "first_block": round(float(us[0]), 1)},
+        "device_ops_per_block": {"kernel_launch_calls": round(counts["launches"] / counts["blocks"], 2),
+                                 "copies_and_fills": round(counts["copies"] / counts["blocks"], 2)},
+        "real_time_factor": round(16384 * len(t) / t.sum() / 0.256, 1),
+        "roofline": {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "achieved": round(2.0625 * 16384 * len(t) / t.sum() / 1e3, 3),
+                     "frac": round(2.0625 * 16384 * len(t) / t.sum() / 1e3 / HBM_PEAK_GBS, 6), "traffic": None,
+                     "note": "one 32 KiB block per call: latency-bound by construction (a 64 ms block every 64 ms is the "
+                             "reference's operating point); the throughput roofline is configs[1]'s business"},
+    }
+    if not args.no_cpu_baseline:
+        chain, kind = _cpu_chain("fm")
+        t0 = time.perf_counter()
+        ref, _, _ = chain.accept_stream(u8)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": round(len(u8) / 2 / dt / 1e6, 3), "unit": "MSamples/s", "cores": 1, "kind": kind,
+                               "us_per_block": round(1e6 * dt / n_blocks, 1),
+                               "sample": "the same %d blocks through IqDataProcessor::acceptIqData on one host core" % n_blocks}
+        out["parity"] = "PCM identical to the CPU chain" if np.array_equal(pcm, ref) else "PCM DIFFERS from the CPU chain"
+        if not np.array_equal(pcm, ref):
+            print(json.dumps(out))
+            sys.exit("bench.py --config 0: PCM differs from the CPU chain")
+    print(json.dumps(out))
+
+
 def main():
     args = parse_args()
+    if args.config == 0:
+        return config0(args)
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        sys.exit(self_launch(sys.argv[1:], args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one rank per GPU)" % args.gpus)
-        args.gpus = world
+    world = int(world_env or "1")
+    args.gpus = world
 
     import torch
+    if args.standin:
+        # CPU test of the launcher and the rank body (tests/test_shard_gloo.py): a stand-in engine over host memory,
+        # gloo instead of RCCL.  The line says so in `data`; nothing here measures the product.
+        import importlib
+        import torch.distributed as dist
+        mod, cls = args.standin.split(":")
+        factory = getattr(importlib.import_module(mod), cls)
+        dist.init_process_group("gloo")
+        out = rank_body(args, rank, world, torch.device("cpu"), lambda n_channels, flags: factory(n_channels, flags, rank), dist, torch)
+        if out is not None:
+            out["data"] = "STAND-IN ENGINE on the CPU (launcher test, not a measurement)"
+            print(json.dumps(out))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU (the engine has no CPU path)")
     torch.cuda.set_device(local_rank)
@@ -349,8 +505,15 @@ def main():
     def make_engine(n_channels, flags):
         return capi.Engine(n_channels=n_channels, device=local_rank, flags=flags)
 
-    def order_streams(eng):   # torch's current stream (where the collective is enqueued) waits for the engine's stream
-        torch.cuda.current_stream().wait_stream(torch.cuda.ExternalStream(eng.stream_handle()))
+    def order_streams(eng, engine_first):
+        """engine_first: torch's current stream (where the gatherer's copies and the collective are enqueued) waits
+        for the engine's stream; else the engine's stream waits for torch's (the next step must not overwrite pcm / cnt
+        while the gatherer is still copying out of them: ADVICE r2)."""
+        ext = torch.cuda.ExternalStream(eng.stream_handle())
+        if engine_first:
+            torch.cuda.current_stream().wait_stream(ext)
+        else:
+            ext.wait_stream(torch.cuda.current_stream())
 
     out = rank_body(args, rank, world, torch.device("cuda", local_rank), make_engine, dist, torch, order_streams)
     if out is not None:

@@ -83,9 +83,10 @@ void iqd_destroy(iqd_t *e);
 int iqd_set_mode(iqd_t *e, uint32_t first_ch, uint32_t n_ch, int mode);
 
 /* Replaces {Am,Fm,WbFm,Ssb}Demodulator::setDemodulatorGain (e.g. WbFmDemodulator.cc:341-348).  Takes effect with the
- * first sample of the next accept; what the filters already hold keeps the old gain, as in the reference (the engine
- * remembers one earlier gain per demodulator for that: changes of the same gain less than 2048 samples - 8 ms - apart
- * are reproduced from the more recent one only). */
+ * first sample of the next accept; what the filters already hold keeps the gain it was made with, exactly as in the
+ * reference, for ANY sequence of changes: the engine keeps every change whose samples can still reach a filter
+ * history (up to 16 per channel and demodulator - a change needs an accept of >= 128 samples in between, and the
+ * histories reach back 2048 samples). */
 int iqd_set_gain(iqd_t *e, uint32_t first_ch, uint32_t n_ch, int demod, float gain);
 
 /* Replaces IqDataProcessor::setSignalDetectThreshold, IqDataProcessor.cc:284-295. */
@@ -222,6 +223,8 @@ typedef struct iqd_stats {
     uint64_t segment_repairs;    /* extra in-kernel passes of the segmented de-emphasis (a segment's warm-up had not
                                     reached its neighbour's exact state yet) */
     uint64_t stream_launches;    /* chain launches (any family) that ran as a streaming pipeline */
+    uint64_t device_launches;    /* kernel-launch calls queued by iqd_accept_* (all kinds) */
+    uint64_t device_copies;      /* memcpy / memset operations queued by iqd_accept_* */
 } iqd_stats;
 
 int iqd_get_stats(iqd_t *e, iqd_stats *out);

@@ -183,6 +183,15 @@ void IqDataProcessor::displayInternalInformation(void)
   fprintf(stderr, "Engine                   : %s\n", engine != 0 ? "MI355X (HIP)" : "unavailable");
 }
 
+void IqDataProcessor::deviceOperationCounts(unsigned long long *launches, unsigned long long *copies) const
+{
+  iqd_stats st;
+  memset(&st, 0, sizeof(st));
+  if (engine != 0) (void)iqd_get_stats(engine, &st);
+  if (launches != 0) *launches = st.device_launches;
+  if (copies != 0) *copies = st.device_copies;
+}
+
 // ---- AutomaticGainControl ---------------------------------------------------------------------------
 AutomaticGainControl::AutomaticGainControl(IqDataProcessor *processorPtr, int32_t operatingPointInDbFs)
 {

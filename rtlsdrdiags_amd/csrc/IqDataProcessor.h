@@ -115,6 +115,8 @@ class IqDataProcessor
   const char *lastError(void) const;
   int lastStatusCode(void) const { return lastStatus; }     // IQD_OK or the failure of the most recent call
   unsigned long rejectedBlockCount(void) const { return rejectedBlocks; }   // acceptIqData calls that could not be processed
+  // what the engine has queued on the device so far: kernel-launch calls and copy / fill operations (diagnostics)
+  void deviceOperationCounts(unsigned long long *launches, unsigned long long *copies) const;
 
   private:
   friend class AutomaticGainControl;

@@ -75,6 +75,11 @@ struct iqd_engine {
     std::vector<uint32_t> h_lists[FAM_COUNT + 1];  // per family; [FAM_COUNT] = mode None
     uint32_t rot_count[FAM_COUNT][3] = {};         // channels of each family per rotation group (+Fs/4, none, -Fs/4)
     uint32_t n_cus = 256;
+    // measurement knobs, read from the environment ONCE at creation (include/iqdemod.h): IQD_WBFM_PATH=stream|tiles
+    // (+1 / -1, 0 = choose), IQD_FULL_GRID, IQD_STREAM_WGS=<n>, IQD_PLAN_CHUNKS=<k>
+    int env_path = 0;
+    bool env_full_grid = false;
+    uint32_t env_stream_wgs = 0, env_plan_chunks = 0;
     size_t dcr_layout[2][2] = {{~(size_t)0, 0}, {~(size_t)0, 0}};   // AM / SSB: where the DC redo flags sit in their buffer, and how many
     bool any_gated = false, any_agc = false;
     std::vector<AgcConfig> h_agc;           // per channel; the one-shot fields are cleared once applied
@@ -155,6 +160,11 @@ struct iqd_engine {
                              __FILE__, __LINE__);                                                 \
     } while (0)
 
+// the same, counting what is queued on the device (iqd_stats.device_launches / device_copies: launch_* calls and
+// memcpy / memset operations; bench.py --config 0 reports them per block)
+#define HIP_LAUNCH(e, call) do { (e)->stats.device_launches++; HIP_TRY(e, call); } while (0)
+#define HIP_COPY(e, call) do { (e)->stats.device_copies++; HIP_TRY(e, call); } while (0)
+
 static int family_of_mode(int mode)
 {
     switch (mode) {
@@ -215,6 +225,10 @@ int iqd_create(const iqd_config *cfg, iqd_t **out)
     e->block_bytes = bb;
     e->block_samples = bb / 2;
     e->flags = cfg->flags;
+    if (const char *env = getenv("IQD_WBFM_PATH")) e->env_path = env[0] == 's' ? 1 : env[0] == 't' ? -1 : 0;
+    e->env_full_grid = getenv("IQD_FULL_GRID") != nullptr;
+    if (const char *env = getenv("IQD_STREAM_WGS")) e->env_stream_wgs = atoi(env) > 0 ? (uint32_t)atoi(env) : 0u;
+    if (const char *env = getenv("IQD_PLAN_CHUNKS")) e->env_plan_chunks = atoi(env) > 0 ? (uint32_t)atoi(env) : 0u;
     build_consts(e->consts);
     e->h_params.resize(e->n_ch);
     for (auto &p : e->h_params) default_params(p);
@@ -276,6 +290,11 @@ int iqd_create(const iqd_config *cfg, iqd_t **out)
 
     const size_t n = e->n_ch;
     bool ok = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) == hipSuccess;
+    {
+        static std::mutex attr_mu;   // engines may be created from several threads
+        std::lock_guard<std::mutex> lk(attr_mu);
+        ok = ok && init_wbfm_stream_kernels() == hipSuccess && init_d4_stream_kernels() == hipSuccess;
+    }
     ok = ok && hipMalloc((void **)&e->d_params, n * sizeof(ChanParams)) == hipSuccess;
     ok = ok && hipMalloc((void **)&e->d_tails, n * FAM_COUNT * TAIL_BYTES) == hipSuccess;
     ok = ok && hipMalloc((void **)&e->d_wcarry, n * sizeof(WbfmCarry)) == hipSuccess;
@@ -1042,7 +1061,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
                 const auto &l = e->h_lists[f];
                 if (l.empty()) continue;
                 HIP_TRY(e, e->lists[f].ensure(l.size() * sizeof(uint32_t)));
-                HIP_TRY(e, hipMemcpyAsync(e->lists[f].p, l.data(), l.size() * sizeof(uint32_t),
+                HIP_COPY(e, hipMemcpyAsync(e->lists[f].p, l.data(), l.size() * sizeof(uint32_t),
                                           hipMemcpyHostToDevice, s));
             }
             HIP_TRY(e, hipStreamSynchronize(s));
@@ -1059,7 +1078,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         HIP_TRY(e, e->mag_sums.ensure((size_t)n_ch * n_blocks * sizeof(uint32_t)));
         if (e->mag_sums.p != before) e->mag_sums_zero = 0;
         if (want_mag && e->mag_sums_zero < (size_t)n_ch * n_blocks)
-            HIP_TRY(e, hipMemsetAsync(e->mag_sums.p, 0, (size_t)n_ch * n_blocks * sizeof(uint32_t), s));
+            HIP_COPY(e, hipMemsetAsync(e->mag_sums.p, 0, (size_t)n_ch * n_blocks * sizeof(uint32_t), s));
         e->mag_sums_zero = 0;   // from here on the call writes into them
     }
 
@@ -1089,7 +1108,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         // pass 1: magnitudes of every block, then the squelch decisions and open-block lists
         HIP_TRY(e, e->blk_lists.ensure((size_t)n_ch * n_blocks * sizeof(uint32_t)));
         HIP_TRY(e, e->vlen.ensure((size_t)n_ch * sizeof(uint32_t)));
-        HIP_TRY(e, launch_magnitude((const uint8_t *)iq_dev, bytes_per_ch, nullptr, n_ch, call_bs,
+        HIP_LAUNCH(e, launch_magnitude((const uint8_t *)iq_dev, bytes_per_ch, nullptr, n_ch, call_bs,
                                     n_blocks, e->mag_sums.as<uint32_t>(), s));
         q.blk_lists = e->blk_lists.as<uint32_t>();
         q.vlen_out = e->vlen.as<uint32_t>();
@@ -1097,19 +1116,19 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         // channel is open the chain kernels run exactly as in an ungated call (the squelch work is done either way),
         // streaming kernels included.  One word comes back; the wait is a few microseconds against a third of the
         // chain's time.
-        const bool probe = !(e->flags & IQD_F_WBFM_TILES) && vlen % 128 == 0 &&
+        const bool probe = !(e->flags & IQD_F_WBFM_TILES) && e->env_path >= 0 && vlen % 128 == 0 &&
                            ((e->flags & IQD_F_WBFM_STREAM) || (uint64_t)vlen * n_ch >= (uint64_t)e->n_cus * ST_SEGS * STREAM_MIN_PER_SEGMENT);
         if (probe) {
             if (!e->d_closed) {
                 HIP_TRY(e, hipMalloc((void **)&e->d_closed, sizeof(uint32_t)));
                 HIP_TRY(e, hipHostMalloc((void **)&e->h_closed, sizeof(uint32_t), hipHostMallocDefault));
             }
-            HIP_TRY(e, hipMemsetAsync(e->d_closed, 0, sizeof(uint32_t), s));
+            HIP_COPY(e, hipMemsetAsync(e->d_closed, 0, sizeof(uint32_t), s));
             q.closed_any = e->d_closed;
         }
-        HIP_TRY(e, launch_squelch(q, false, s));
+        HIP_LAUNCH(e, launch_squelch(q, false, s));
         if (probe) {
-            HIP_TRY(e, hipMemcpyAsync(e->h_closed, e->d_closed, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+            HIP_COPY(e, hipMemcpyAsync(e->h_closed, e->d_closed, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
             HIP_TRY(e, hipStreamSynchronize(s));
             chain_gated = *e->h_closed != 0;
             q.closed_any = nullptr;
@@ -1184,7 +1203,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         // for ITS share of the CUs; tile kernels know nothing of shares, and a streaming kernel held to its share beside
         // them lost 12-16 % at 2500-3000 mixed channels)
         bool all_stream = !chain_gated && !(e->flags & IQD_F_WBFM_TILES) && vlen % 128 == 0;
-        if (const char *env = getenv("IQD_WBFM_PATH")) all_stream = all_stream && env[0] != 't';
+        all_stream = all_stream && e->env_path >= 0;
         for (int f = 0; f < FAM_COUNT && all_stream; f++) {
             const uint64_t n_f = e->h_lists[f].size();
             if (!n_f) continue;
@@ -1193,7 +1212,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
             if (!forced && (float)((uint64_t)vlen * n_f) < due * (float)(ST_SEGS * STREAM_MIN_PER_SEGMENT)) all_stream = false;
             if ((f == FAM_AM || f == FAM_SSB) && vlen / 32 <= 512) all_stream = false;
         }
-        shares_on = forked && all_stream && total > 0.f && e->n_cus >= 64 && !getenv("IQD_FULL_GRID");
+        shares_on = forked && all_stream && total > 0.f && e->n_cus >= 64 && !e->env_full_grid;
         if (shares_on && !plan_family_shares(cost, FAM_COUNT, e->n_cus, fam_share)) shares_on = false;
     }
     float lane_load[4] = {0.f, 0.f, 0.f, 0.f};   // 0: the engine's stream, 1 to 3: the side streams
@@ -1216,13 +1235,13 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         if (lane != 0 && !lane_used[lane]) HIP_TRY(e, hipStreamWaitEvent(s, e->fam_fork, 0));
         lane_used[lane] = true;
         uint32_t fam_wgs = fam_share[f];
-        if (const char *env = getenv("IQD_STREAM_WGS")) fam_wgs = (uint32_t)atoi(env) > 0 ? (uint32_t)atoi(env) : fam_wgs;   // (experiments)
+        if (e->env_stream_wgs) fam_wgs = e->env_stream_wgs;   // (experiments)
         ChainLaunch a = base;
         a.ch_list = e->lists[f].as<uint32_t>();
         a.n_list = n_list;
         // workgroups a CU holds at once: WBFM 3 (LDS), the others 4 (registers)
-        const TilePlan plan = f == FAM_WBFM ? plan_tiles(vlen, n_list, WBFM_CHUNK, COLD_HALO, 3 * e->n_cus)
-                                            : plan_tiles(vlen, n_list, CH_CHUNK, FIR_HALO, 4 * e->n_cus);
+        const TilePlan plan = f == FAM_WBFM ? plan_tiles(vlen, n_list, WBFM_CHUNK, COLD_HALO, 3 * e->n_cus, e->env_plan_chunks)
+                                            : plan_tiles(vlen, n_list, CH_CHUNK, FIR_HALO, 4 * e->n_cus, e->env_plan_chunks);
         a.tile_len = plan.tile_len;
         a.tiles_per_ch = plan.tiles_per_ch;
         // WBFM: the streaming pipeline (iqd_stream.hip) when the launch can fill the chip with it and nothing it does
@@ -1240,7 +1259,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
             }
             int want = 0;   // 0 auto, 1 stream, -1 tiles
             if (e->flags & IQD_F_WBFM_STREAM) want = 1;
-            if (const char *env = getenv("IQD_WBFM_PATH")) want = env[0] == 's' ? 1 : env[0] == 't' ? -1 : want;
+            if (e->env_path) want = e->env_path;
             const uint64_t work = (uint64_t)vlen * n_list;
             if (ok && want >= 0 && (want > 0 || work >= (uint64_t)(shares_on ? fam_wgs : e->n_cus) * ST_SEGS * STREAM_MIN_PER_SEGMENT || shares_on)) {
                 const TilePlan sp = plan_stream(vlen, n_list, fam_wgs * ST_SEGS);
@@ -1260,7 +1279,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
                 for (uint32_t c : e->h_lists[f]) ok = ok && e->fm_kmax[first_ch + c] * 6.35f < 2147483648.0f;
             int want = 0;
             if (e->flags & IQD_F_WBFM_STREAM) want = 1;
-            if (const char *env = getenv("IQD_WBFM_PATH")) want = env[0] == 's' ? 1 : env[0] == 't' ? -1 : want;
+            if (e->env_path) want = e->env_path;
             const uint64_t work = (uint64_t)vlen * n_list;
             if (ok && want >= 0 && (want > 0 || work >= (uint64_t)(shares_on ? fam_wgs : e->n_cus) * ST_SEGS * STREAM_MIN_PER_SEGMENT || shares_on)) {
                 d4_wgs = fam_wgs;
@@ -1301,7 +1320,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
             a.records = e->records.as<WbfmRecord>();
             if (e->repair_flags.cap < n_list * sizeof(uint32_t)) {   // zero between calls: the repair kernel clears what it used
                 HIP_TRY(e, e->repair_flags.ensure(n_list * sizeof(uint32_t)));
-                HIP_TRY(e, hipMemsetAsync(e->repair_flags.p, 0, e->repair_flags.cap, s));
+                HIP_COPY(e, hipMemsetAsync(e->repair_flags.p, 0, e->repair_flags.cap, s));
             }
             a.repair_flags = e->repair_flags.as<uint32_t>();
             if (use_stream) {
@@ -1315,22 +1334,22 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
                 HIP_TRY(e, e->stream_hist.ensure((size_t)sa.n_segments * sizeof(StHist)));
                 sa.hist = e->stream_hist.as<StHist>();
                 a.verify_at_end = 1;
-                HIP_TRY(e, launch_wbfm_stream(a, sa, stream_rot, fused_mag, grid, s));
-                HIP_TRY(e, launch_wbfm_stream_fixup(a, sa, s));
+                HIP_LAUNCH(e, launch_wbfm_stream(a, sa, stream_rot, fused_mag, grid, s));
+                HIP_LAUNCH(e, launch_wbfm_stream_fixup(a, sa, s));
                 e->stream_handoffs += (uint64_t)n_list * ((vlen + a.tile_len - 1) / a.tile_len - 1);
                 e->stats.stream_launches++;
             } else {
-                HIP_TRY(e, launch_wbfm(a, chain_gated, fused_mag, n_list * a.tiles_per_ch, s));
+                HIP_LAUNCH(e, launch_wbfm(a, chain_gated, fused_mag, n_list * a.tiles_per_ch, s));
             }
         } else if (f == FAM_FM) {
             if (use_d4) {
                 const uint32_t wgs_needed = (d4.group_start[3] + ST_SEGS - 1) / ST_SEGS;
                 const uint32_t grid = wgs_needed < d4_wgs ? wgs_needed : d4_wgs;
                 d4.rounds = (wgs_needed + grid - 1) / grid;
-                HIP_TRY(e, launch_d4_stream(a, d4, D4_FM, fused_mag, grid, s));
+                HIP_LAUNCH(e, launch_d4_stream(a, d4, D4_FM, fused_mag, grid, s));
                 e->stats.stream_launches++;
             } else {
-                HIP_TRY(e, launch_fm(a, chain_gated, fused_mag, n_list * a.tiles_per_ch, s));
+                HIP_LAUNCH(e, launch_fm(a, chain_gated, fused_mag, n_list * a.tiles_per_ch, s));
             }
         } else if (use_d4) {
             HIP_TRY(e, e->base8k.ensure((size_t)n_ch * base.pcm_stride * sizeof(int32_t)));
@@ -1345,7 +1364,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
                 HIP_TRY(e, dcr.ensure(rec_bytes + n_list * sizeof(uint32_t)));
                 a.dc_records = dcr.p;
                 if (grown || dcr_layout[f == FAM_SSB][0] != rec_bytes || dcr_layout[f == FAM_SSB][1] < n_list) {
-                    HIP_TRY(e, hipMemsetAsync((char *)dcr.p + rec_bytes, 0, n_list * sizeof(uint32_t), s));
+                    HIP_COPY(e, hipMemsetAsync((char *)dcr.p + rec_bytes, 0, n_list * sizeof(uint32_t), s));
                     dcr_layout[f == FAM_SSB][0] = rec_bytes;
                     dcr_layout[f == FAM_SSB][1] = n_list;
                 }
@@ -1353,8 +1372,8 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
             const uint32_t wgs_needed = (d4.group_start[3] + ST_SEGS - 1) / ST_SEGS;
             const uint32_t grid = wgs_needed < d4_wgs ? wgs_needed : d4_wgs;
             d4.rounds = (wgs_needed + grid - 1) / grid;
-            HIP_TRY(e, launch_d4_stream(a, d4, f == FAM_AM ? D4_AM : D4_SSB, fused_mag, grid, s));
-            HIP_TRY(e, launch_am_dc(a, f, s));
+            HIP_LAUNCH(e, launch_d4_stream(a, d4, f == FAM_AM ? D4_AM : D4_SSB, fused_mag, grid, s));
+            HIP_LAUNCH(e, launch_am_dc(a, f, s));
             e->stats.stream_launches++;
         } else {
             HIP_TRY(e, e->base8k.ensure((size_t)n_ch * base.pcm_stride * sizeof(int32_t)));
@@ -1369,12 +1388,12 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
                 // the flags sit behind the records, whose extent changes with the call: clear them whenever it may have
                 // (same offset but more channels than last time: the new flags lie over old record bytes)
                 if (grown || dcr_layout[f == FAM_SSB][0] != rec_bytes || dcr_layout[f == FAM_SSB][1] < n_list) {
-                    HIP_TRY(e, hipMemsetAsync((char *)dcr.p + rec_bytes, 0, n_list * sizeof(uint32_t), s));
+                    HIP_COPY(e, hipMemsetAsync((char *)dcr.p + rec_bytes, 0, n_list * sizeof(uint32_t), s));
                     dcr_layout[f == FAM_SSB][0] = rec_bytes;
                     dcr_layout[f == FAM_SSB][1] = n_list;
                 }
             }
-            HIP_TRY(e, launch_am(a, f, chain_gated, fused_mag, n_list * a.tiles_per_ch, s));
+            HIP_LAUNCH(e, launch_am(a, f, chain_gated, fused_mag, n_list * a.tiles_per_ch, s));
         }
         if (e->profiling && !timed) {
             HIP_TRY(e, hipEventRecord(evp.second, s));
@@ -1385,14 +1404,14 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         if (f == FAM_WBFM) {
             // hand-off verification (streaming launches: done by their fix-up kernel), repair of what it flags
             // (normally an immediate exit), then state commit + tail
-            if (!use_stream) HIP_TRY(e, launch_wbfm_verify(a, s));
-            HIP_TRY(e, launch_wbfm_repair(a, chain_gated, s));   // (ends with the channels' state commit and tail update)
+            if (!use_stream) HIP_LAUNCH(e, launch_wbfm_verify(a, s));
+            HIP_LAUNCH(e, launch_wbfm_repair(a, chain_gated, s));   // (ends with the channels' state commit and tail update)
         } else if (!forked && !gated && (want_mag || pcm_count_dev || signal_present_dev || e->trace_on)) {
             tail_a = a;        // the only family of the call: its tail update rides in the squelch launch below
             tail_f = f;
             tail_pending = true;
         } else {
-            HIP_TRY(e, launch_tail_update(a, f, s));
+            HIP_LAUNCH(e, launch_tail_update(a, f, s));
         }
     }
     s = s_main;
@@ -1404,16 +1423,16 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
 
     // channels in mode None still report their magnitudes
     if (fused_mag && !e->h_lists[FAM_COUNT].empty())
-        HIP_TRY(e, launch_magnitude((const uint8_t *)iq_dev, bytes_per_ch, e->lists[FAM_COUNT].as<uint32_t>(),
+        HIP_LAUNCH(e, launch_magnitude((const uint8_t *)iq_dev, bytes_per_ch, e->lists[FAM_COUNT].as<uint32_t>(),
                                     (uint32_t)e->h_lists[FAM_COUNT].size(), call_bs, n_blocks,
                                     e->mag_sums.as<uint32_t>(), s));
     if (!gated && (want_mag || pcm_count_dev || signal_present_dev || e->trace_on)) {
         q.zero_sums_after = any_agc ? 0u : 1u;   // (a running AGC reads them again in the tracking pass)
-        HIP_TRY(e, launch_squelch(q, true, s, tail_pending ? &tail_a : nullptr, tail_f));
+        HIP_LAUNCH(e, launch_squelch(q, true, s, tail_pending ? &tail_a : nullptr, tail_f));
         tail_pending = false;
         if (q.zero_sums_after) e->mag_sums_zero = (size_t)n_ch * n_blocks;
     }
-    if (tail_pending) HIP_TRY(e, launch_tail_update(tail_a, tail_f, s));   // (no squelch launch to ride in)
+    if (tail_pending) HIP_LAUNCH(e, launch_tail_update(tail_a, tail_f, s));   // (no squelch launch to ride in)
 
     e->stats.accepts++;
     e->stats.samples += (uint64_t)vlen * n_ch;
@@ -1427,7 +1446,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
 // to the next, so the result equals the unsliced call; squelch-gated rows are compacted on the host at the end.
 static const size_t SLICE_BYTES = (size_t)32 << 20;
 
-static int accept_sliced(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const uint8_t *iq, size_t bytes_per_ch,
+static int accept_sliced(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const uint8_t *iq, size_t bytes_per_ch, uint32_t call_bb,
                          int16_t *pcm, uint32_t *pcm_count, uint32_t *magnitude, uint8_t *signal_present)
 {
     hipStream_t s = e->stream;
@@ -1438,7 +1457,7 @@ static int accept_sliced(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const uint8
             HIP_TRY(e, hipEventCreateWithFlags(&e->ev_free[b], hipEventDisableTiming));
         }
     }
-    const size_t bb = e->block_bytes;
+    const size_t bb = call_bb;   // the block size in force for THIS call: one short block has bb = bytes_per_ch
     const size_t row_blocks = bytes_per_ch / bb;
     // slice shape: sc channels x st bytes of each row
     size_t sc, st;
@@ -1483,7 +1502,7 @@ static int accept_sliced(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const uint8
         const Slice x = slice_at(k);
         const int b = (int)(k & 1);
         if (k >= 2) HIP_TRY(e, hipStreamWaitEvent(e->copy_stream, e->ev_free[b], 0));
-        HIP_TRY(e, hipMemcpy2DAsync(e->sl_iq[b].p, x.tb, iq + x.c0 * bytes_per_ch + x.t0, bytes_per_ch, x.tb, x.nc,
+        HIP_COPY(e, hipMemcpy2DAsync(e->sl_iq[b].p, x.tb, iq + x.c0 * bytes_per_ch + x.t0, bytes_per_ch, x.tb, x.nc,
                                     hipMemcpyHostToDevice, e->copy_stream));
         HIP_TRY(e, hipEventRecord(e->ev_in[b], e->copy_stream));
         return IQD_OK;
@@ -1508,7 +1527,7 @@ static int accept_sliced(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const uint8
         const int b = (int)(k & 1);
         if (k + 1 < n_slices && (rc = upload(k + 1)) != IQD_OK) return rc;
         HIP_TRY(e, hipStreamWaitEvent(s, e->ev_in[b], 0));
-        HIP_TRY(e, hipMemsetAsync(e->sl_pcm[b].p, 0, x.nc * (x.tb / 64) * sizeof(int16_t), s));
+        HIP_COPY(e, hipMemsetAsync(e->sl_pcm[b].p, 0, x.nc * (x.tb / 64) * sizeof(int16_t), s));
         rc = iqd_accept_iq_device(e, first_ch + (uint32_t)x.c0, (uint32_t)x.nc, e->sl_iq[b].p, x.tb, e->sl_pcm[b].p,
                                   e->sl_count[b].p, magnitude ? e->sl_mag[b].p : nullptr,
                                   signal_present ? e->sl_allowed[b].p : nullptr);
@@ -1518,16 +1537,16 @@ static int accept_sliced(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const uint8
             settle(k - 1);
         }
         const size_t tpcm = x.tb / 64, tblk = x.tb / bb;
-        HIP_TRY(e, hipMemcpy2DAsync(pcm + x.c0 * row_pcm + x.t0 / 64, row_pcm * sizeof(int16_t), e->sl_pcm[b].p,
+        HIP_COPY(e, hipMemcpy2DAsync(pcm + x.c0 * row_pcm + x.t0 / 64, row_pcm * sizeof(int16_t), e->sl_pcm[b].p,
                                     tpcm * sizeof(int16_t), tpcm * sizeof(int16_t), x.nc, hipMemcpyDeviceToHost, s));
         if (magnitude)
-            HIP_TRY(e, hipMemcpy2DAsync(magnitude + x.c0 * row_blocks + x.t0 / bb, row_blocks * sizeof(uint32_t),
+            HIP_COPY(e, hipMemcpy2DAsync(magnitude + x.c0 * row_blocks + x.t0 / bb, row_blocks * sizeof(uint32_t),
                                         e->sl_mag[b].p, tblk * sizeof(uint32_t), tblk * sizeof(uint32_t), x.nc,
                                         hipMemcpyDeviceToHost, s));
         if (signal_present)
-            HIP_TRY(e, hipMemcpy2DAsync(signal_present + x.c0 * row_blocks + x.t0 / bb, row_blocks, e->sl_allowed[b].p,
+            HIP_COPY(e, hipMemcpy2DAsync(signal_present + x.c0 * row_blocks + x.t0 / bb, row_blocks, e->sl_allowed[b].p,
                                         tblk, tblk, x.nc, hipMemcpyDeviceToHost, s));
-        HIP_TRY(e, hipMemcpyAsync(e->h_slice_counts + b * sc, e->sl_count[b].p, x.nc * sizeof(uint32_t),
+        HIP_COPY(e, hipMemcpyAsync(e->h_slice_counts + b * sc, e->sl_count[b].p, x.nc * sizeof(uint32_t),
                                   hipMemcpyDeviceToHost, s));
         HIP_TRY(e, hipEventRecord(e->ev_free[b], s));
     }
@@ -1551,21 +1570,21 @@ int iqd_accept_iq(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const uint8_t *iq,
     const size_t pcm_bytes = (size_t)n_ch * (bytes_per_ch / 64) * sizeof(int16_t);
     const size_t nb = (size_t)n_ch * (bytes_per_ch / call_bb);
     if (in_bytes >= 2 * SLICE_BYTES)
-        return accept_sliced(e, first_ch, n_ch, iq, bytes_per_ch, pcm, pcm_count, magnitude, signal_present);
+        return accept_sliced(e, first_ch, n_ch, iq, bytes_per_ch, call_bb, pcm, pcm_count, magnitude, signal_present);
     HIP_TRY(e, e->st_iq.ensure(in_bytes));
     HIP_TRY(e, e->st_pcm.ensure(pcm_bytes));
     HIP_TRY(e, e->st_count.ensure(n_ch * sizeof(uint32_t)));
     HIP_TRY(e, e->st_mag.ensure(nb * sizeof(uint32_t)));
     HIP_TRY(e, e->st_allowed.ensure(nb));
-    HIP_TRY(e, hipMemcpyAsync(e->st_iq.p, iq, in_bytes, hipMemcpyHostToDevice, s));
-    HIP_TRY(e, hipMemsetAsync(e->st_pcm.p, 0, pcm_bytes, s));
+    HIP_COPY(e, hipMemcpyAsync(e->st_iq.p, iq, in_bytes, hipMemcpyHostToDevice, s));
+    HIP_COPY(e, hipMemsetAsync(e->st_pcm.p, 0, pcm_bytes, s));
     int rc = iqd_accept_iq_device(e, first_ch, n_ch, e->st_iq.p, bytes_per_ch, e->st_pcm.p, e->st_count.p,
                                   magnitude ? e->st_mag.p : nullptr, signal_present ? e->st_allowed.p : nullptr);
     if (rc != IQD_OK) return rc;
-    HIP_TRY(e, hipMemcpyAsync(pcm, e->st_pcm.p, pcm_bytes, hipMemcpyDeviceToHost, s));
-    if (pcm_count) HIP_TRY(e, hipMemcpyAsync(pcm_count, e->st_count.p, n_ch * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    if (magnitude) HIP_TRY(e, hipMemcpyAsync(magnitude, e->st_mag.p, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-    if (signal_present) HIP_TRY(e, hipMemcpyAsync(signal_present, e->st_allowed.p, nb, hipMemcpyDeviceToHost, s));
+    HIP_COPY(e, hipMemcpyAsync(pcm, e->st_pcm.p, pcm_bytes, hipMemcpyDeviceToHost, s));
+    if (pcm_count) HIP_COPY(e, hipMemcpyAsync(pcm_count, e->st_count.p, n_ch * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    if (magnitude) HIP_COPY(e, hipMemcpyAsync(magnitude, e->st_mag.p, nb * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    if (signal_present) HIP_COPY(e, hipMemcpyAsync(signal_present, e->st_allowed.p, nb, hipMemcpyDeviceToHost, s));
     HIP_TRY(e, hipStreamSynchronize(s));
     return IQD_OK;
 }

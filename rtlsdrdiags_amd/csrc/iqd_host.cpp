@@ -154,7 +154,7 @@ bool squelch_always_open(const ChanParams &p, const Consts &c)
     return true;
 }
 
-TilePlan plan_tiles(uint32_t vlen, uint32_t n_channels, uint32_t chunk, uint32_t halo, uint32_t resident_wgs)
+TilePlan plan_tiles(uint32_t vlen, uint32_t n_channels, uint32_t chunk, uint32_t halo, uint32_t resident_wgs, uint32_t force_chunks)
 {
     // One workgroup per tile, a tile = k whole chunks.  The launch runs in "rounds" of resident_wgs workgroups;
     // each round costs the tile plus its lead-in, and a partly filled last round costs as much as a full one.
@@ -179,9 +179,9 @@ TilePlan plan_tiles(uint32_t vlen, uint32_t n_channels, uint32_t chunk, uint32_t
         }
         if (len >= vlen) break;
     }
-    if (const char *ov = getenv("IQD_PLAN_CHUNKS")) {   // experiments: force k chunks per tile
-        const uint32_t k = (uint32_t)atoi(ov);
-        if (k) { p.tile_len = k * chunk; p.tiles_per_ch = (vlen + p.tile_len - 1) / p.tile_len; }
+    if (force_chunks) {   // experiments (IQD_PLAN_CHUNKS, read once by iqd_create): k chunks per tile
+        p.tile_len = force_chunks * chunk;
+        p.tiles_per_ch = (vlen + p.tile_len - 1) / p.tile_len;
     }
     return p;
 }

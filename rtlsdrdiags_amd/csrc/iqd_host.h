@@ -28,7 +28,8 @@ void derive_params(ChanParams &p);   // wbfm_k / fm_k from the gains, in binary3
 bool squelch_always_open(const ChanParams &p, const Consts &c);
 
 struct TilePlan { uint32_t tile_len, tiles_per_ch; };
-TilePlan plan_tiles(uint32_t vlen, uint32_t n_channels, uint32_t chunk, uint32_t halo, uint32_t resident_wgs);
+TilePlan plan_tiles(uint32_t vlen, uint32_t n_channels, uint32_t chunk, uint32_t halo, uint32_t resident_wgs,
+                    uint32_t force_chunks = 0 /* experiments: k chunks per tile */);
 
 TilePlan plan_stream(uint32_t vlen, uint32_t n_channels, uint32_t streams);
 // Several demodulator families in one call, each with its streaming kernel: the CUs each family's persistent workgroups

@@ -514,6 +514,7 @@ __global__ __launch_bounds__(32 * FIX_SEGS) void wbfm_stream_fixup_kernel(const 
             a.repair_flags[sg.li] = 1;
         }
     }
+    __syncthreads();   // y2x[sl] was written by this segment's 32 threads, each reads the others' entries (uniform control flow up to here)
     if (!live || i >= ST_FIX_PCM || i >= sg.tlen / 32) return;
     // PCM i from stage-2 outputs 2i-38 .. 2i+1: pairs i+1 .. i+20, newest first
     int s3 = 1 << 14;
@@ -532,33 +533,27 @@ hipError_t launch_wbfm_stream_fixup(const ChainLaunch &a, const StreamArgs &sa, 
     return hipGetLastError();
 }
 
-hipError_t launch_wbfm_stream(const ChainLaunch &a, const StreamArgs &sa, int rotation, bool mag, uint32_t grid, hipStream_t s)
+typedef void (*StKernel)(const ChainLaunch, const StreamArgs);
+// [rotation selector -1, 0, +1][squelch magnitudes in the kernel]
+static const StKernel st_kernels[3][2] = {{wbfm_stream_kernel<-1, false>, wbfm_stream_kernel<-1, true>},
+                                          {wbfm_stream_kernel<0, false>, wbfm_stream_kernel<0, true>},
+                                          {wbfm_stream_kernel<1, false>, wbfm_stream_kernel<1, true>}};
+
+// One workgroup takes nearly all of a CU's LDS; the attribute belongs to the current device's code object and is set
+// once per engine by iqd_create (serialised there).
+hipError_t init_wbfm_stream_kernels()
 {
-    static bool attr_set_on[64] = {};                    // per device: the attribute belongs to the device's code object
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    bool &attr_set = attr_set_on[dev];
-    if (!attr_set) {
-        const void *ks[] = {(const void *)wbfm_stream_kernel<0, false>, (const void *)wbfm_stream_kernel<0, true>,
-                            (const void *)wbfm_stream_kernel<1, false>, (const void *)wbfm_stream_kernel<1, true>,
-                            (const void *)wbfm_stream_kernel<-1, false>, (const void *)wbfm_stream_kernel<-1, true>};
-        for (const void *k : ks) {
-            hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS_BYTES);
+    for (int r = 0; r < 3; r++)
+        for (int g = 0; g < 2; g++) {
+            const hipError_t e = hipFuncSetAttribute((const void *)st_kernels[r][g], hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS_BYTES);
             if (e != hipSuccess) return e;
         }
-        attr_set = true;
-    }
-    const dim3 g(grid), b(ST_THREADS);
-    if (rotation == 0) {
-        if (mag) hipLaunchKernelGGL((wbfm_stream_kernel<0, true>), g, b, ST_LDS_BYTES, s, a, sa);
-        else hipLaunchKernelGGL((wbfm_stream_kernel<0, false>), g, b, ST_LDS_BYTES, s, a, sa);
-    } else if (rotation > 0) {
-        if (mag) hipLaunchKernelGGL((wbfm_stream_kernel<1, true>), g, b, ST_LDS_BYTES, s, a, sa);
-        else hipLaunchKernelGGL((wbfm_stream_kernel<1, false>), g, b, ST_LDS_BYTES, s, a, sa);
-    } else {
-        if (mag) hipLaunchKernelGGL((wbfm_stream_kernel<-1, true>), g, b, ST_LDS_BYTES, s, a, sa);
-        else hipLaunchKernelGGL((wbfm_stream_kernel<-1, false>), g, b, ST_LDS_BYTES, s, a, sa);
-    }
+    return hipSuccess;
+}
+
+hipError_t launch_wbfm_stream(const ChainLaunch &a, const StreamArgs &sa, int rotation, bool mag, uint32_t grid, hipStream_t s)
+{
+    hipLaunchKernelGGL(st_kernels[rotation < 0 ? 0 : rotation > 0 ? 2 : 1][mag ? 1 : 0], dim3(grid), dim3(ST_THREADS), ST_LDS_BYTES, s, a, sa);
     return hipGetLastError();
 }
 

@@ -704,24 +704,27 @@ __global__ __launch_bounds__(ST_THREADS, D4_WAVES_PER_SIMD(MODE)) void d4_stream
 #endif
 }
 
+typedef void (*D4Kernel)(const ChainLaunch, const D4Args);
+static const D4Kernel d4_kernels[3][2] = {{d4_stream_kernel<D4_AM, false>, d4_stream_kernel<D4_AM, true>},
+                                          {d4_stream_kernel<D4_SSB, false>, d4_stream_kernel<D4_SSB, true>},
+                                          {d4_stream_kernel<D4_FM, false>, d4_stream_kernel<D4_FM, true>}};
+
+// The streaming kernels want more LDS than the 64 KiB a kernel gets without asking.  The attribute belongs to the
+// current device's code object: iqd_create calls this once per engine, serialised (no unsynchronised statics
+// on the launch path).
+hipError_t init_d4_stream_kernels()
+{
+    for (int m = 0; m < 3; m++)
+        for (int g = 0; g < 2; g++) {
+            const hipError_t e = hipFuncSetAttribute((const void *)d4_kernels[m][g], hipFuncAttributeMaxDynamicSharedMemorySize, D4_LDS_BYTES);
+            if (e != hipSuccess) return e;
+        }
+    return hipSuccess;
+}
+
 hipError_t launch_d4_stream(const ChainLaunch &a, const D4Args &da, int mode, bool mag, uint32_t grid, hipStream_t s)
 {
-    typedef void (*Kernel)(const ChainLaunch, const D4Args);
-    static const Kernel ks[3][2] = {{d4_stream_kernel<D4_AM, false>, d4_stream_kernel<D4_AM, true>},
-                                    {d4_stream_kernel<D4_SSB, false>, d4_stream_kernel<D4_SSB, true>},
-                                    {d4_stream_kernel<D4_FM, false>, d4_stream_kernel<D4_FM, true>}};
-    static bool attr_set_on[64] = {};                    // per device: the attribute belongs to the device's code object
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-    bool &attr_set = attr_set_on[dev];
-    if (!attr_set) {                                     // more than the 64 KiB a kernel gets without asking
-        for (int m = 0; m < 3; m++)
-            for (int g = 0; g < 2; g++) {
-                const hipError_t e = hipFuncSetAttribute((const void *)ks[m][g], hipFuncAttributeMaxDynamicSharedMemorySize, D4_LDS_BYTES);
-                if (e != hipSuccess) return e;
-            }
-        attr_set = true;
-    }
+    const D4Kernel (&ks)[3][2] = d4_kernels;
     const int m = mode == D4_AM ? 0 : (mode == D4_SSB ? 1 : 2);
     hipLaunchKernelGGL(ks[m][mag ? 1 : 0], dim3(grid), dim3(ST_THREADS), D4_LDS_BYTES, s, a, da);
     return hipGetLastError();

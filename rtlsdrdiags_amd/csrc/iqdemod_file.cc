@@ -9,9 +9,14 @@
 //     scan=<start>:<end>:<increment>   run the channel's FrequencyScanner (Hz); its last tuning command is reported
 //     dump=<file>                      IQ dump tap: the rotated signed bytes of every block go to <file>
 //     blocks=<n1,n2,...>               read blocks of these sizes in turn (default 32768): short reads
+//     timing=<file>                    wall time of every acceptIqData call (microseconds, one per line) and the
+//                                      device operations the engine queued, for bench.py --config 0
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+
+#include <vector>
 
 #include "IqDataProcessor.h"
 
@@ -31,13 +36,14 @@ int main(int argc, char **argv)
     fprintf(stderr, "usage: %s <mode: 0 none 1 am 2 fm 3 wbfm 4 lsb 5 usb> [squelch threshold dBFS [agc type: 0 lowpass 1 harris]]\n", argv[0]);
     return 2;
   }
-  const char *scanSpec = 0, *dumpPath = 0, *blockSpec = 0;
+  const char *scanSpec = 0, *dumpPath = 0, *blockSpec = 0, *timingPath = 0;
   int npos = 0;
   char *pos[8];
   for (int i = 1; i < argc && npos < 8; i++) {
     if (strncmp(argv[i], "scan=", 5) == 0) scanSpec = argv[i] + 5;
     else if (strncmp(argv[i], "dump=", 5) == 0) dumpPath = argv[i] + 5;
     else if (strncmp(argv[i], "blocks=", 7) == 0) blockSpec = argv[i] + 7;
+    else if (strncmp(argv[i], "timing=", 7) == 0) timingPath = argv[i] + 7;
     else pos[npos++] = argv[i];
   }
   argc = npos + 1;
@@ -95,15 +101,29 @@ int main(int argc, char **argv)
       sizes[nsizes++] = (size_t)strtoul(q, (char **)&q, 10);
       if (*q == ',') q++;
     }
+  std::vector<double> blockMicroseconds;
   for (;;) {
     size_t want = nsizes ? sizes[next++ % nsizes] : sizeof(block);
     if (want == 0 || want > sizeof(block)) want = sizeof(block);
     const size_t got = fread(block, 1, want, stdin);
     if (got == 0) break;
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
     processor.acceptIqData(timeStamp++, block, got);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    if (timingPath != 0) blockMicroseconds.push_back(1e6 * (double)(t1.tv_sec - t0.tv_sec) + 1e-3 * (double)(t1.tv_nsec - t0.tv_nsec));
     if (got < want) break;
   }
   fflush(stdout);
+  if (timingPath != 0) {
+    FILE *tf = fopen(timingPath, "w");
+    if (tf == 0) { perror(timingPath); return 2; }
+    unsigned long long launches = 0, copies = 0;
+    processor.deviceOperationCounts(&launches, &copies);
+    fprintf(tf, "blocks %zu launches %llu copies %llu\n", blockMicroseconds.size(), launches, copies);
+    for (size_t i = 0; i < blockMicroseconds.size(); i++) fprintf(tf, "%.3f\n", blockMicroseconds[i]);
+    fclose(tf);
+  }
   if (processor.rejectedBlockCount() != 0)
     fprintf(stderr, "iqdemod_file: %lu block(s) could not be processed (%s)\n", processor.rejectedBlockCount(), processor.lastError());
   if (argc > 3) fprintf(stderr, "IF gain: %u dB\n", agc.getReceiveIfGainInDb());

@@ -79,3 +79,24 @@ def test_channel_slices_many_short_rows(capi, oracle):
         ref, rmag, _ = o.accept_stream(iq[c])
         assert np.array_equal(pcm[c], ref), c
         assert mag[c, 0] == rmag[0], c
+
+
+def test_channel_slices_of_one_short_block_per_row(capi, oracle):
+    """4096 rows of 16384 bytes = ONE short block each (block_bytes is 32768), 64 MiB: the sliced path has to size its
+    magnitude / flag staging by the call's own block length (it used block_bytes and got 0 blocks per row)."""
+    n_ch, nbytes = 4096, 16384
+    order = ["fm", "am", "wbfm", "usb"]
+    base = [synth.fm_tone(nbytes // 2, seed=300 + k, amplitude=20.0 + 9 * k) for k in range(7)]
+    iq = np.stack([np.roll(base[c % 7], 2 * (c % 97)) for c in range(n_ch)])
+    eng = capi.Engine(n_ch)
+    for c0 in range(0, n_ch, 32):
+        eng.set_mode(order[(c0 // 32) % 4], first=c0, n=32)
+    pcm, cnt, mag, allowed = eng.accept(iq)
+    assert pcm.shape == (n_ch, nbytes // 64) and mag.shape == (n_ch, 1)
+    assert (cnt == nbytes // 64).all() and allowed.all()
+    for c in list(range(0, n_ch, 311)) + [2047, 2048, n_ch - 1]:
+        o = oracle.chain()
+        o.set_mode(order[(c // 32) % 4])
+        ref, rmag, _ = o.accept_stream(iq[c], nbytes)          # one acceptIqData call of 16384 bytes
+        assert np.array_equal(pcm[c], ref), c
+        assert mag[c, 0] == rmag[0], c

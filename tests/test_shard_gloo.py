@@ -179,3 +179,35 @@ def test_presets_name_the_baseline_configurations():
     assert (a.mode, a.channels) == ("ssb_stress", 8192) and "65536" in a.what
     a = bench.parse_args(["--mode", "am", "--channels", "64"])
     assert a.what is None and a.tag is None                    # not a BASELINE configuration: labelled as such
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it: bench.py starts torch.distributed.run as a child process,
+    relays rank 0's one JSON line and the exit code (the driver calls it exactly like this).  Here with the
+    stand-in engine over gloo; on a GPU box the same entry runs one rank per GPU over RCCL."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                           "TORCHELASTIC_RUN_ID")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--mode", "mixed", "--channels", "5", "--log2-samples", "12", "--gather", "--no-cpu-baseline",
+                        "--no-host-path", "--standin", "tests.test_shard_gloo:FakeEngine"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines                               # ONE line on stdout, whatever the ranks printed
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert "STAND-IN" in out["data"] and out["config"]["channels_per_gpu"] == 5
+
+
+def test_bench_relays_a_failing_rank():
+    """A rank that dies must not look like success: the launcher's exit code comes back."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                           "TORCHELASTIC_RUN_ID")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                        "--channels", "2", "--log2-samples", "12", "--no-cpu-baseline", "--no-host-path",
+                        "--standin", "tests.test_shard_gloo:NoSuchEngine"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=300)
+    assert r.returncode != 0 and not r.stdout.decode().strip()
