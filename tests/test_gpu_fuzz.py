@@ -25,3 +25,12 @@ def test_random_long_rows_match_the_oracle(oracle, monkeypatch):
     rng = np.random.default_rng(9003)
     for case in range(40):
         assert gpu_fuzz.one_case(rng, oracle), case
+
+
+def test_random_wide_batches_match_the_oracle(oracle):
+    """Hundreds to thousands of channels per launch from a few templates: every row of every case against the oracle
+    (nothing randomised covered the many-channel launch geometry)."""
+    import gpu_fuzz
+    rng = np.random.default_rng(9004)
+    for case in range(10):
+        assert gpu_fuzz.wide_case(rng, oracle), case

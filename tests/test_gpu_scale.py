@@ -208,3 +208,105 @@ def test_bench_workload_at_full_size_is_the_oracles_pcm(capi, oracle):
     assert st["state_checks"] > 1000 and st["state_repairs"] == 0
     eng.dev_free(iq)
     eng.dev_free(pcm_dev)
+
+
+# ---- BASELINE configs[3] at its per-GPU size, on the path bench.py --config 3 times -------------------------------
+def _mixed_rows(n_ch, n, seed):
+    """n_ch distinct rows of n samples without n_ch synthesiser runs: 35 seeded FM tones, each row one of them rolled by
+    its own offset with a few bytes of its own."""
+    rng = np.random.default_rng(seed)
+    base = [synth.fm_tone(n, seed=600 + k, deviation=2000.0 + 800.0 * (k % 11), amplitude=25.0 + 2 * k) for k in range(35)]
+    u8 = np.empty((n_ch, 2 * n), np.uint8)
+    for c in range(n_ch):
+        u8[c] = np.roll(base[c % 35], 2 * ((c * 37) % 1009))
+    u8[:, 4000:4032] = rng.integers(0, 256, size=(n_ch, 32), dtype=np.uint8)
+    return u8
+
+
+def _mixed_setup(eng, n_ch, wbfm_every=5):
+    """channel % 5 -> {AM, FM, WBFM, LSB, USB}; the rotation selector cycles over the channels of the AM / FM / SSB
+    families (the WBFM streaming kernel takes one selector per launch).  Returns (mode, rotation) per channel."""
+    modes, rots = [], []
+    for c in range(n_ch):
+        m = ORDER[c % 5]
+        if m == "wbfm" and (c // 5) % wbfm_every:
+            m = "fm"                                          # (thinned-out WBFM family for the "too small to stream" case)
+        r = 1 if m == "wbfm" else (1, 0, -1)[(c // 5) % 3]
+        modes.append(m)
+        rots.append(r)
+    # runs of equal settings go down in one call each
+    for arr, setter in ((modes, eng.set_mode), (rots, eng.set_rotation)):
+        c0 = 0
+        for c in range(1, n_ch + 1):
+            if c == n_ch or arr[c] != arr[c0]:
+                setter(arr[c0], first=c0, n=c - c0)
+                c0 = c
+    return modes, rots
+
+
+def _sample_channels(modes, rots, extra=24, seed=3):
+    """first and last channel of every (mode, rotation) class, plus a few at random"""
+    first, last = {}, {}
+    for c, key in enumerate(zip(modes, rots)):
+        first.setdefault(key, c)
+        last[key] = c
+    rng = np.random.default_rng(seed)
+    picks = set(first.values()) | set(last.values()) | set(int(x) for x in rng.integers(0, len(modes), extra))
+    return sorted(picks)
+
+
+def _run_mixed_on_device(capi, oracle, n_ch, log2, expect_streams, wbfm_every=1, calls=2, extra=24):
+    n = 1 << log2
+    u8 = _mixed_rows(n_ch, n, seed=n_ch)
+    eng = capi.Engine(n_ch)
+    modes, rots = _mixed_setup(eng, n_ch, wbfm_every)
+    iq_d, pcm_d = eng.dev_alloc(u8.nbytes), eng.dev_alloc(n_ch * (n // 32) * 2)
+    nblk = 2 * n // 32768
+    cnt_d, mag_d, al_d = eng.dev_alloc(n_ch * 4), eng.dev_alloc(n_ch * nblk * 4), eng.dev_alloc(n_ch * nblk)
+    eng.dev_upload(iq_d, u8)
+    picks = _sample_channels(modes, rots, extra)
+    chains = {}
+    for c in picks:
+        o = oracle.chain()
+        o.set_mode(modes[c])
+        o.set_rotation(rots[c])
+        chains[c] = o
+    for call in range(calls):
+        before = eng.stats()["stream_launches"]
+        eng.accept_device(iq_d, 2 * n, pcm_d, cnt_d, mag_d, al_d)
+        eng.synchronize()
+        assert eng.stats()["stream_launches"] - before == expect_streams, (call, eng.stats())
+        pcm = eng.dev_download(pcm_d, n_ch * (n // 32) * 2, np.int16).reshape(n_ch, -1)
+        cnt = eng.dev_download(cnt_d, n_ch * 4, np.uint32)
+        mag = eng.dev_download(mag_d, n_ch * nblk * 4, np.uint32).reshape(n_ch, nblk)
+        assert (cnt == n // 32).all()
+        assert eng.dev_download(al_d, n_ch * nblk, np.uint8).all()
+        for c in picks:
+            ref, rmag, _ = chains[c].accept_stream(u8[c])
+            assert np.array_equal(pcm[c], ref), (call, c, modes[c], rots[c])
+            assert np.array_equal(mag[c], rmag), (call, c)
+    assert eng.stats()["state_repairs"] == 0
+    for p_ in (iq_d, pcm_d, cnt_d, mag_d, al_d):
+        eng.dev_free(p_)
+    return len(picks)
+
+
+def test_config4_mixed_4096_channels_on_cu_shares(capi, oracle):
+    """BASELINE configs[3] exactly as `bench.py --config 3` runs it on one GPU: 4096 channels x 2^16 samples,
+    channel % 5 -> {AM, FM, WBFM, LSB, USB}, every channel its own data, the rotation selector varying inside the
+    AM / FM / SSB families.  Four streaming kernels run side by side on planned shares of the CUs (stream_launches
+    == 4 per call proves it); two consecutive calls; the first and last channel of every family and rotation group and
+    two dozen more against the oracle, every PCM sample and magnitude."""
+    checked = _run_mixed_on_device(capi, oracle, 4096, 16, expect_streams=4, extra=40)
+    assert checked >= 64
+
+
+def test_mixed_1400_channels_at_the_share_threshold(capi, oracle):
+    """The smallest mixed call that still plans CU shares (every family brings just enough samples for its share)."""
+    _run_mixed_on_device(capi, oracle, 1400, 16, expect_streams=4)
+
+
+def test_mixed_call_with_a_family_too_small_to_stream(capi, oracle):
+    """A WBFM family of 82 channels beside thousands of others cannot fill its share: no shares are planned, the big
+    families stream on the whole chip in turn and WBFM takes its tile kernel - same results."""
+    _run_mixed_on_device(capi, oracle, 4096, 16, expect_streams=3, wbfm_every=10)

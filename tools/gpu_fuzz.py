@@ -197,6 +197,119 @@ def one_case(rng, O):
     return True
 
 
+def wide_case(rng, O):
+    """Many channels in one launch (hundreds to thousands): the launch geometry the small cases never reach - channel
+    lists sorted by rotation group and padded, several rounds of the persistent workgroups, CU shares between families,
+    gated calls of many rows.  Channels are drawn from a handful of templates (configuration + signal), scattered over
+    the batch, so that a few oracle runs check EVERY row; device-pointer calls, so that a big batch is one launch and
+    not slices; one operator command on one template between the two calls."""
+    k_tpl = int(rng.integers(3, 9))
+    n_ch = int(rng.integers(600, 4001))
+    nblk = int(rng.integers(1, 5))
+    bb = 32768
+    while n_ch * nblk * bb > (256 << 20):
+        nblk -= 1
+    n = nblk * bb // 2
+    flags = int(rng.choice([0, 0, 0, 4]))
+    tpl = []
+    for t in range(k_tpl):
+        mode = MODES[int(rng.integers(1, 6))] if rng.random() < 0.95 else "none"
+        gain = float(np.float32(10.0 ** rng.uniform(0, 5))) if (mode != "none" and rng.random() < 0.4) else None
+        rot = int(rng.choice([1, 1, 0, -1]))
+        thr = int(rng.choice([-200, -200, -200, -45]))
+        agc = rng.random() < 0.25
+        sig = [signal(rng, n, bb // 2) for _ in range(2)]
+        tpl.append(dict(mode=mode, gain=gain, rot=rot, thr=thr, agc=agc, sig=sig))
+    which = rng.integers(0, k_tpl, n_ch)
+    if rng.random() < 0.5:      # WBFM streams only with one rotation selector per launch: half the cases keep it that way
+        r0 = [t["rot"] for t in tpl if t["mode"] == "wbfm"]
+        for t in tpl:
+            if t["mode"] == "wbfm":
+                t["rot"] = r0[0]
+    eng = capi.Engine(n_ch, block_bytes=bb, flags=flags)
+    chains = []
+    for t in tpl:
+        o = O.chain()
+        o.set_mode(t["mode"]); o.set_rotation(t["rot"]); o.set_squelch(t["thr"])
+        if t["gain"] is not None:
+            o.set_gain(DEMOD[t["mode"]], t["gain"])
+        if t["agc"]:
+            o.agc_enable(True)
+        chains.append(o)
+    for c in range(n_ch):
+        t = tpl[which[c]]
+        eng.set_mode(t["mode"], first=c, n=1)
+        if t["rot"] != 1:
+            eng.set_rotation(t["rot"], first=c, n=1)
+        if t["thr"] != -200:
+            eng.set_squelch(t["thr"], first=c, n=1)
+        if t["gain"] is not None:
+            eng.set_gain(DEMOD[t["mode"]], t["gain"], first=c, n=1)
+        if t["agc"]:
+            eng.agc_enable(True, first=c, n=1)
+    iq_d, pcm_d = eng.dev_alloc(n_ch * 2 * n), eng.dev_alloc(n_ch * (n // 32) * 2)
+    cnt_d, mag_d, al_d = eng.dev_alloc(n_ch * 4), eng.dev_alloc(n_ch * nblk * 4), eng.dev_alloc(n_ch * nblk)
+    ok = True
+    desc = "wide case: %d channels, %d blocks, flags %d, templates %s" % (
+        n_ch, nblk, flags, [(t["mode"], t["gain"], t["rot"], t["thr"], t["agc"]) for t in tpl])
+    for call in range(2):
+        if call == 1 and rng.random() < 0.7:
+            t_i = int(rng.integers(0, k_tpl))
+            what = int(rng.integers(0, 4))
+            members = np.flatnonzero(which == t_i)
+            if what == 0:
+                m = MODES[int(rng.integers(1, 6))]
+                chains[t_i].set_mode(m)
+                for c in members: eng.set_mode(m, first=int(c), n=1)
+            elif what == 1:
+                chains[t_i].reset()
+                for c in members: eng.reset(first=int(c), n=1)
+            elif what == 2:
+                d, g = int(rng.integers(1, 5)), float(np.float32(10.0 ** rng.uniform(0, 5)))
+                chains[t_i].set_gain(d, g)
+                for c in members: eng.set_gain(d, g, first=int(c), n=1)
+            else:
+                r = int(rng.integers(-1, 2))
+                chains[t_i].set_rotation(r)
+                for c in members: eng.set_rotation(r, first=int(c), n=1)
+            desc += "; before call 1: op %d on template %d" % (what, t_i)
+        iq = np.stack([t["sig"][call] for t in tpl])[which]
+        eng.dev_upload(iq_d, iq)
+        eng.accept_device(iq_d, 2 * n, pcm_d, cnt_d, mag_d, al_d)
+        eng.synchronize()
+        pcm = eng.dev_download(pcm_d, n_ch * (n // 32) * 2, np.int16).reshape(n_ch, -1)
+        cnt = eng.dev_download(cnt_d, n_ch * 4, np.uint32)
+        mag = eng.dev_download(mag_d, n_ch * nblk * 4, np.uint32).reshape(n_ch, nblk)
+        al = eng.dev_download(al_d, n_ch * nblk, np.uint8).reshape(n_ch, nblk)
+        for t_i in range(k_tpl):
+            ref, rmag, rallowed = chains[t_i].accept_stream(tpl[t_i]["sig"][call], bb)
+            rows = np.flatnonzero(which == t_i)
+            if not len(rows):
+                continue
+            bad = None
+            if not (al[rows] == rallowed).all():
+                bad = "allowed"
+            elif not (mag[rows] == rmag).all():
+                bad = "magnitude"
+            elif not (cnt[rows] == len(ref)).all():
+                bad = "pcm count"
+            elif not (pcm[rows, :len(ref)] == ref).all():
+                bad = "pcm"
+            if bad:
+                wrong = [int(c) for c in rows if not (np.array_equal(pcm[c, :len(ref)], ref) and np.array_equal(mag[c], rmag)
+                                                      and np.array_equal(al[c], rallowed) and cnt[c] == len(ref))]
+                print("MISMATCH in %s: call %d, template %d, %d of its %d channels (first %s); %s; stats %s"
+                      % (bad, call, t_i, len(wrong), len(rows), wrong[:8], desc, eng.stats()))
+                ok = False
+                break
+        if not ok:
+            break
+    for p_ in (iq_d, pcm_d, cnt_d, mag_d, al_d):
+        eng.dev_free(p_)
+    eng.close()
+    return ok
+
+
 def main():
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -204,7 +317,8 @@ def main():
     O = B.Oracle()
     t0, cases = time.time(), 0
     while time.time() - t0 < seconds:
-        if not one_case(rng, O):
+        wide = os.environ.get("FUZZ_WIDE") == "1" or (os.environ.get("FUZZ_WIDE") is None and rng.random() < 0.03)
+        if not (wide_case(rng, O) if wide else one_case(rng, O)):
             sys.exit(1)
         cases += 1
     print("gpu_fuzz: %d cases identical to the oracle in %.0f s (seed %d)" % (cases, time.time() - t0, seed))
