@@ -306,7 +306,13 @@ def test_mixed_1400_channels_at_the_share_threshold(capi, oracle):
     _run_mixed_on_device(capi, oracle, 1400, 16, expect_streams=4)
 
 
-def test_mixed_call_with_a_family_too_small_to_stream(capi, oracle):
-    """A WBFM family of 82 channels beside thousands of others cannot fill its share: no shares are planned, the big
-    families stream on the whole chip in turn and WBFM takes its tile kernel - same results."""
-    _run_mixed_on_device(capi, oracle, 4096, 16, expect_streams=3, wbfm_every=10)
+def test_mixed_call_with_a_tiny_family(capi, oracle):
+    """A WBFM family of 82 channels beside thousands of others: its share is the minimum of 8 CUs, on which it runs
+    segments of the minimum length - still a streaming kernel beside the others."""
+    _run_mixed_on_device(capi, oracle, 4096, 16, expect_streams=4, wbfm_every=10)
+
+
+def test_mixed_call_where_only_some_families_stream(capi, oracle):
+    """16384 channels x 2^14 samples: rows of 512 PCM samples keep AM and SSB on their tile kernels (batched DC pass),
+    so no CU shares are planned; FM and WBFM bring enough samples to stream on the whole chip in turn."""
+    _run_mixed_on_device(capi, oracle, 16384, 14, expect_streams=2)
