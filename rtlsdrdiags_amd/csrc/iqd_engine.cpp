@@ -100,6 +100,12 @@ struct iqd_engine {
     AgcState *d_agc = nullptr;
     GainEpoch *d_epochs = nullptr;
     std::vector<float> k_applied;           // [n_ch][2]: the WBFM / FM K the device last ran with
+    // [n_ch]: WBFM samples a channel still has to consume before its latest gain change is out of every lead-in's reach
+    // (GainEpochList on the device; this mirror only decides which instantiation of the streaming kernel runs: the one
+    // with the piecewise-gain lookup while any channel of the launch is non-zero here).  Never cleared early: it goes
+    // down only by samples the channel's WBFM chain really consumed.
+    std::vector<uint32_t> wbfm_epoch_left;
+    uint32_t wbfm_epochs_live = 0;          // channels with wbfm_epoch_left != 0
     std::vector<int32_t> rot_applied;       // [n_ch]: the rotation the device last ran with
     bool rot_changed = false;               // some channel's tails need rewriting (retail_kernel)
     ScanConfig *d_scan_cfg = nullptr;
@@ -242,6 +248,7 @@ int iqd_create(const iqd_config *cfg, iqd_t **out)
     st0.rx_gain = 24; st0.if_gain = 24; st0.filtered = 24.f; st0.normalized = -24; st0.signal_magnitude = 64;
     std::vector<AgcState> agc_states(e->n_ch, st0);
     e->k_applied.resize(2 * (size_t)e->n_ch);
+    e->wbfm_epoch_left.assign(e->n_ch, 0u);
     for (uint32_t c = 0; c < e->n_ch; c++) {
         e->k_applied[2 * c] = e->h_params[c].wbfm_k;
         e->k_applied[2 * c + 1] = e->h_params[c].fm_k;
@@ -509,6 +516,8 @@ static int upload_params(iqd_t *e)
             if (!(p.k_changed & 1u)) p.wbfm_k_prev = e->k_applied[2 * c];
             p.k_changed |= 1u;
             e->k_applied[2 * c] = p.wbfm_k;
+            if (!e->wbfm_epoch_left[c]) e->wbfm_epochs_live++;
+            e->wbfm_epoch_left[c] = (uint32_t)TAIL;
         }
         if (f2u(p.fm_k) != f2u(e->k_applied[2 * c + 1])) {
             if (!(p.k_changed & 2u)) p.fm_k_prev = e->k_applied[2 * c + 1];
@@ -1334,7 +1343,10 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
                 HIP_TRY(e, e->stream_hist.ensure((size_t)sa.n_segments * sizeof(StHist)));
                 sa.hist = e->stream_hist.as<StHist>();
                 a.verify_at_end = 1;
-                HIP_LAUNCH(e, launch_wbfm_stream(a, sa, stream_rot, fused_mag, grid, s));
+                bool epochs_live = false;
+                if (e->wbfm_epochs_live)
+                    for (uint32_t c : e->h_lists[FAM_WBFM]) epochs_live = epochs_live || e->wbfm_epoch_left[first_ch + c] != 0;
+                HIP_LAUNCH(e, launch_wbfm_stream(a, sa, stream_rot, fused_mag, epochs_live, grid, s));
                 HIP_LAUNCH(e, launch_wbfm_stream_fixup(a, sa, s));
                 e->stream_handoffs += (uint64_t)n_list * ((vlen + a.tile_len - 1) / a.tile_len - 1);
                 e->stats.stream_launches++;
@@ -1401,6 +1413,13 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
             timed = true;
         }
         e->stats.kernel_launches++;
+        if (f == FAM_WBFM && !chain_gated && e->wbfm_epochs_live)   // every channel of the family has consumed vlen samples
+            for (uint32_t c : e->h_lists[FAM_WBFM]) {
+                uint32_t &left = e->wbfm_epoch_left[first_ch + c];
+                if (!left) continue;
+                left = left > vlen ? left - vlen : 0u;
+                if (!left) e->wbfm_epochs_live--;
+            }
         if (f == FAM_WBFM) {
             // hand-off verification (streaming launches: done by their fix-up kernel), repair of what it flags
             // (normally an immediate exit), then state commit + tail

@@ -81,7 +81,7 @@ hipError_t launch_wbfm_verify(const ChainLaunch &a, hipStream_t s);
 struct StreamArgs;
 hipError_t init_wbfm_stream_kernels();   // LDS attribute of the streaming kernels on the current device (iqd_create)
 hipError_t init_d4_stream_kernels();
-hipError_t launch_wbfm_stream(const ChainLaunch &a, const StreamArgs &sa, int rotation, bool mag, uint32_t grid, hipStream_t s);
+hipError_t launch_wbfm_stream(const ChainLaunch &a, const StreamArgs &sa, int rotation, bool mag, bool epochs, uint32_t grid, hipStream_t s);
 struct D4Args;
 hipError_t launch_d4_stream(const ChainLaunch &a, const D4Args &da, int mode, bool mag, uint32_t grid, hipStream_t s);
 hipError_t launch_am_dc(const ChainLaunch &a, int family, hipStream_t s);   // the DC-removal passes behind an AM/SSB chain launch

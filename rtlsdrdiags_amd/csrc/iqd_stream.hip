@@ -9,6 +9,12 @@
 
 namespace iqd {
 
+// The angle table starts at LDS address 0 (the kernel has no static LDS; checked when the kernel starts), so a table
+// cell's byte offset IS its LDS address: through the generic `lds + offset` form the compiler adds the base - a
+// relocated zero - to every one of the eight addresses of a piece.
+typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
+__device__ __forceinline__ uint32_t st_table_read(uint32_t byte_offset) { return *(lds_cu32 *)(uintptr_t)byte_offset; }
+
 struct StSeg {           // what a lane knows about its segment
     uint32_t valid, li, tile, ch, ech;
     int32_t v0, tlen;
@@ -33,7 +39,10 @@ __device__ __forceinline__ StSeg st_segment(const ChainLaunch &a, uint32_t sid, 
 }
 
 // ---- P wave: 16 segments, raw bytes -> u[n] -------------------------------------------------------
-template <int ROT, bool MAG>
+// EPOCHS: some channel of the launch has a gain change whose samples a lead-in can still reach (GainEpochList; the host
+// knows: iqd_set_gain).  The piecewise-gain lookup lives only in that instantiation - in the common one it would sit
+// in the piece loop as a 16-deep ladder twice over, costing registers (it spilled) and instruction cache for nothing.
+template <int ROT, bool MAG, bool EPOCHS>
 __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs &sa, uint8_t *lds, uint32_t *sync,
                                           int pw, int lane)
 {
@@ -48,8 +57,8 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
     const int g = lane >> 4, c = lane & 15;
     const uint32_t row = (uint32_t)(16 * cg + c);                // ring row of this lane's segment
     uint8_t *ring_base = lds + ST_TABLE_BYTES + ring * (ST_RING_SLOTS * ST_SLOT_BYTES);
-    const uint32_t *full = sync + ring * 2;
-    const uint32_t *consumed = sync + 8 + ring;
+    const uint32_t *full = sync + ring;            // pieces written, x 4 P waves
+    const uint32_t *consumed = sync + 8 + ring;    // pieces the IIR wave has read
     const uint32_t wr_off = st_slot_off(row, (uint32_t)g);
     const int src_lane4 = ((lane - 16) & 63) << 2;               // whose theta[3] precedes this lane's theta[0]
 
@@ -61,7 +70,7 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
     asm volatile("" : "+v"(zero));   // a VGPR holding 0 for the SDWA negations
 
     const int n_pieces = (ST_HALO + (int)a.tile_len) >> 5;
-    uint32_t wg = 0;                                             // windows this ring has seen (all rounds)
+    uint32_t pc = 0;                                             // pieces this ring has seen (all rounds)
     for (uint32_t round = 0; round < sa.rounds; round++) {
         if ((round * gridDim.x + blockIdx.x) * ST_SEGS >= sa.n_segments) break;   // nothing left for this workgroup
         const uint32_t sid = (round * gridDim.x + blockIdx.x) * ST_SEGS + ring * 64 + row;
@@ -73,8 +82,8 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
         const float kneg = -p.wbfm_k;
         // segments whose lead-in reaches back before the call's start may meet earlier gains (GainEpochList)
         const GainEpochList *ep = &a.epochs[sg.ech].wbfm;
-        const bool ep_reach = ep->since[0] < (uint32_t)TAIL && (int64_t)sg.v0 - ST_HALO - 32 < -(int64_t)ep->since[0];
-        const bool ep_any = __any(ep_reach);
+        const bool ep_reach = EPOCHS && ep->since[0] < (uint32_t)TAIL && (int64_t)sg.v0 - ST_HALO - 32 < -(int64_t)ep->since[0];
+        const bool ep_any = EPOCHS && __any(ep_reach);
         uint32_t *mag_row = MAG ? a.mag_sums + (size_t)sg.ch * a.n_blocks : nullptr;
         // squelch magnitude bookkeeping: this lane's chunks are 32 samples apart
         const bool mcount = MAG && sg.valid;
@@ -107,7 +116,7 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
             const uint32_t ti = (uint32_t)ilo[3] + ((uint32_t)ihi[3] << 8), tq = (uint32_t)qlo[3] + ((uint32_t)qhi[3] << 8);
             uint32_t rr;
             asm("v_msad_u8 %0, %1, %2, 0" : "=v"(rr) : "v"(tq), "s"(0x00800000u));
-            const uint32_t t = *(const uint32_t *)(lds + rr * (uint32_t)(ST_ROW_FLOATS * 4) + (bfe(ti, 16, 8) << 2));
+            const uint32_t t = st_table_read(rr * (uint32_t)(ST_ROW_FLOATS * 4) + (bfe(ti, 16, 8) << 2));
             last_prev = u2f((t & 0x7fffffffu) | ((tq << 8) & 0x80000000u));
         }
         for (int q = 0; q < n_pieces; q++) {
@@ -143,7 +152,7 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
                     const uint32_t x4 = bfe(ti, 16, 8) << 2;
                     uint32_t addr;                               // row |y|, column x of the half table
                     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(addr) : "v"(rr), "s"((uint32_t)(ST_ROW_FLOATS * 4)), "v"(x4));
-                    traw[half][r] = *(const uint32_t *)(lds + addr);
+                    traw[half][r] = st_table_read(addr);
                     tqs[half][r] = tq;
                 }
             }
@@ -180,7 +189,7 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
                 const float before = u2f((uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)f2u(give)));
                 last_prev = th[3];
                 float kk = kneg;
-                if (ep_any && ep_reach) kk = -epoch_gain(ep, p.wbfm_k, sg.v0 + wpos);   // (rare: right after a gain change)
+                if (EPOCHS && ep_any && ep_reach) kk = -epoch_gain(ep, p.wbfm_k, sg.v0 + wpos);   // (rare: right after a gain change)
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const float d = wrap_delta(th[r] - (r == 0 ? before : th[r - 1]));   // = -(delta theta)
@@ -188,20 +197,18 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
                     u[half][r] = sa.b0 * v;
                 }
             }
-            // hand the 2 x 4 samples to the IIR wave: slots wg & 1 and (wg + 1) & 1, free once the previous piece's
-            // windows wg - 2 and wg - 1 have been consumed
-            if (wg >= 2)
-                while ((int32_t)(seen - wg) < 0) {
-                    __builtin_amdgcn_s_sleep(1);
-                    seen = lds_load_relaxed(consumed);
-                }
+            // hand the 2 x 4 samples to the IIR wave: the ring's two slots hold one piece (window 0, window 1), free once
+            // the IIR wave has read the previous piece.  One signal per piece in each direction.
+            while ((int32_t)(seen - pc) < 0) {
+                __builtin_amdgcn_s_sleep(1);
+                seen = lds_load_relaxed(consumed);
+            }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            *(u32x4 *)(ring_base + (wg & 1u) * ST_SLOT_BYTES + wr_off) = u32x4{f2u(u[0][0]), f2u(u[0][1]), f2u(u[0][2]), f2u(u[0][3])};
-            *(u32x4 *)(ring_base + ((wg + 1u) & 1u) * ST_SLOT_BYTES + wr_off) = u32x4{f2u(u[1][0]), f2u(u[1][1]), f2u(u[1][2]), f2u(u[1][3])};
+            *(u32x4 *)(ring_base + wr_off) = u32x4{f2u(u[0][0]), f2u(u[0][1]), f2u(u[0][2]), f2u(u[0][3])};
+            *(u32x4 *)(ring_base + ST_SLOT_BYTES + wr_off) = u32x4{f2u(u[1][0]), f2u(u[1][1]), f2u(u[1][2]), f2u(u[1][3])};
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            lds_signal(&full[wg & 1u]);
-            lds_signal(&full[(wg + 1u) & 1u]);
-            wg += 2;
+            lds_signal(full);
+            pc++;
             prev = cur;
         }
         if (MAG && macc) atomicAdd(&mag_row[mblk], macc);
@@ -321,19 +328,23 @@ __device__ __forceinline__ int st_iir_piece(const StreamArgs &sa, uint8_t *ring_
 #pragma unroll
     for (int half = 0; half < 2; half++) {
         const int wpos = pos + 16 * half;
-        const uint32_t target = 4u * ((wg >> 1) + 1u);
-        while ((int32_t)(lds_load_relaxed(&full[wg & 1u]) - target) < 0) __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        const uint8_t *slot = ring_base + (wg & 1u) * ST_SLOT_BYTES + rd_off0;
+        if (half == 0) {   // the four P waves of the ring have written piece `wg` (both windows) when `full` reaches 4 (wg + 1)
+            const uint32_t target = 4u * (wg + 1u);
+            while ((int32_t)(lds_load_relaxed(full) - target) < 0) __builtin_amdgcn_s_sleep(1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        const uint8_t *slot = ring_base + half * ST_SLOT_BYTES + rd_off0;
         float u[16];
 #pragma unroll
         for (int gq = 0; gq < 4; gq++) {
             const u32x4 v = *(const u32x4 *)(slot + (((uint32_t)gq ^ rd_swz) << 4));
             u[4 * gq] = u2f(v.x); u[4 * gq + 1] = u2f(v.y); u[4 * gq + 2] = u2f(v.z); u[4 * gq + 3] = u2f(v.w);
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the reads have returned
-        lds_signal(consumed);
-        wg++;
+        if (half == 1) {   // both windows read: the ring is free for the next piece
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the reads have returned
+            lds_signal(consumed);
+            wg++;
+        }
         st_iir_marks(q, s, wpos);
         const int y2 = st_iir_window(sa, s, u);
         if (wpos >= 0 && wpos < 48 && q.sg.valid) {    // (uniform) the segment's first values, for the boundary fix-up
@@ -357,11 +368,11 @@ __device__ __forceinline__ void st_iir_wave(const ChainLaunch &a, const StreamAr
                                             int ring, int lane)
 {
     uint8_t *ring_base = lds + ST_TABLE_BYTES + ring * (ST_RING_SLOTS * ST_SLOT_BYTES);
-    const uint32_t *full = sync + ring * 2;
+    const uint32_t *full = sync + ring;
     uint32_t *consumed = sync + 8 + ring;
     const uint32_t rd_off0 = (uint32_t)lane * 64u, rd_swz = ((uint32_t)lane >> 2) & 3u;
     const int n_pieces = (ST_HALO + (int)a.tile_len) >> 5;       // a multiple of 4
-    uint32_t wg = 0;
+    uint32_t wg = 0;                                             // pieces read so far (all rounds)
     for (uint32_t round = 0; round < sa.rounds; round++) {
         if ((round * gridDim.x + blockIdx.x) * ST_SEGS >= sa.n_segments) break;
         const uint32_t sid = (round * gridDim.x + blockIdx.x) * ST_SEGS + ring * 64 + lane;
@@ -440,10 +451,11 @@ __device__ __forceinline__ void st_iir_wave(const ChainLaunch &a, const StreamAr
     }
 }
 
-template <int ROT, bool MAG>
+template <int ROT, bool MAG, bool EPOCHS>
 __global__ __launch_bounds__(ST_THREADS, 4) void wbfm_stream_kernel(const ChainLaunch a, const StreamArgs sa)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t st_lds[];
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)st_lds != 0u) __builtin_trap();   // st_table_read()
     uint32_t *sync = (uint32_t *)(st_lds + ST_TABLE_BYTES + ST_RINGS * ST_RING_SLOTS * ST_SLOT_BYTES);
     const int tid = (int)threadIdx.x;
     for (int i = tid; i < ST_TABLE_BYTES / 16; i += ST_THREADS) ((uint4 *)st_lds)[i] = ((const uint4 *)sa.half_lut)[i];
@@ -451,7 +463,7 @@ __global__ __launch_bounds__(ST_THREADS, 4) void wbfm_stream_kernel(const ChainL
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     if (wave < ST_RINGS) st_iir_wave(a, sa, st_lds, sync, wave, lane);
-    else st_p_wave<ROT, MAG>(a, sa, st_lds, sync, wave - ST_RINGS, lane);
+    else st_p_wave<ROT, MAG, EPOCHS>(a, sa, st_lds, sync, wave - ST_RINGS, lane);
 }
 
 // The first ST_FIX_PCM PCM samples of every cold segment, recomputed with the exact histories its predecessor left
@@ -534,26 +546,27 @@ hipError_t launch_wbfm_stream_fixup(const ChainLaunch &a, const StreamArgs &sa, 
 }
 
 typedef void (*StKernel)(const ChainLaunch, const StreamArgs);
-// [rotation selector -1, 0, +1][squelch magnitudes in the kernel]
-static const StKernel st_kernels[3][2] = {{wbfm_stream_kernel<-1, false>, wbfm_stream_kernel<-1, true>},
-                                          {wbfm_stream_kernel<0, false>, wbfm_stream_kernel<0, true>},
-                                          {wbfm_stream_kernel<1, false>, wbfm_stream_kernel<1, true>}};
+// [rotation selector -1, 0, +1][squelch magnitudes in the kernel][gain epochs within reach of a lead-in]
+#define ST_K(R) {{wbfm_stream_kernel<R, false, false>, wbfm_stream_kernel<R, false, true>}, \
+                 {wbfm_stream_kernel<R, true, false>, wbfm_stream_kernel<R, true, true>}}
+static const StKernel st_kernels[3][2][2] = {ST_K(-1), ST_K(0), ST_K(1)};
+#undef ST_K
 
 // One workgroup takes nearly all of a CU's LDS; the attribute belongs to the current device's code object and is set
 // once per engine by iqd_create (serialised there).
 hipError_t init_wbfm_stream_kernels()
 {
     for (int r = 0; r < 3; r++)
-        for (int g = 0; g < 2; g++) {
-            const hipError_t e = hipFuncSetAttribute((const void *)st_kernels[r][g], hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS_BYTES);
+        for (int g = 0; g < 4; g++) {
+            const hipError_t e = hipFuncSetAttribute((const void *)st_kernels[r][g >> 1][g & 1], hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS_BYTES);
             if (e != hipSuccess) return e;
         }
     return hipSuccess;
 }
 
-hipError_t launch_wbfm_stream(const ChainLaunch &a, const StreamArgs &sa, int rotation, bool mag, uint32_t grid, hipStream_t s)
+hipError_t launch_wbfm_stream(const ChainLaunch &a, const StreamArgs &sa, int rotation, bool mag, bool epochs, uint32_t grid, hipStream_t s)
 {
-    hipLaunchKernelGGL(st_kernels[rotation < 0 ? 0 : rotation > 0 ? 2 : 1][mag ? 1 : 0], dim3(grid), dim3(ST_THREADS), ST_LDS_BYTES, s, a, sa);
+    hipLaunchKernelGGL(st_kernels[rotation < 0 ? 0 : rotation > 0 ? 2 : 1][mag ? 1 : 0][epochs ? 1 : 0], dim3(grid), dim3(ST_THREADS), ST_LDS_BYTES, s, a, sa);
     return hipGetLastError();
 }
 
