@@ -11,6 +11,16 @@ namespace iqd {
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 
+typedef float v2f __attribute__((ext_vector_type(2)));
+// x * (s, s) as ONE v_pk_mul_f32 with the constant pair in scalar registers (left to itself the compiler multiplies the
+// halves one by one: a literal does not fit a packed instruction)
+__device__ __forceinline__ v2f pk_mul_s(v2f x, uint64_t s_pair)
+{
+    v2f r;
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(x), "s"(s_pair));
+    return r;
+}
+
 // ---- small device helpers -----------------------------------------------------------------------
 // byte B of x replaced by its two's-complement negation, the other bytes kept (v_sub_u32_sdwa): int8
 // wrap, so -(-128) stays -128 like the reference's rotation (IqDataProcessor.cc:594-607)

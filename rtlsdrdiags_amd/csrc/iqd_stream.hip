@@ -65,11 +65,15 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
     v4i A[8];
 #pragma unroll
     for (int m = 0; m < 8; m++) A[m] = ((const v4i *)sa.amat)[m * 64 + lane];
-    const v4i cbias = {WB_BIAS, WB_BIAS, WB_BIAS, WB_BIAS}, czero = {0, 0, 0, 0};
+    v4i cbias = {WB_BIAS, WB_BIAS, WB_BIAS, WB_BIAS};
+    const v4i czero = {0, 0, 0, 0};
+    asm volatile("" : "+v"(cbias));  // four VGPRs for the whole kernel: else the compiler rebuilds the quad from scalars for every piece
     uint32_t zero = 0;
     asm volatile("" : "+v"(zero));   // a VGPR holding 0 for the SDWA negations
 
     const int n_pieces = (ST_HALO + (int)a.tile_len) >> 5;
+    uint64_t inv_2pi = 0x3e22f9843e22f984ull;                    // (float)(1 / (2 pi)) twice: the scalar operand of v_pk_mul_f32
+    asm volatile("" : "+s"(inv_2pi));
     uint32_t pc = 0;                                             // pieces this ring has seen (all rounds)
     for (uint32_t round = 0; round < sa.rounds; round++) {
         if ((round * gridDim.x + blockIdx.x) * ST_SEGS >= sa.n_segments) break;   // nothing left for this workgroup
@@ -119,9 +123,11 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
             const uint32_t t = st_table_read(rr * (uint32_t)(ST_ROW_FLOATS * 4) + (bfe(ti, 16, 8) << 2));
             last_prev = u2f((t & 0x7fffffffu) | ((tq << 8) & 0x80000000u));
         }
-        for (int q = 0; q < n_pieces; q++) {
+        // one piece: `prev` = the signed bytes of the piece before, `cur` = this piece's (output).  The loop below runs two
+        // copies of the body with the two buffers swapped, so that neither is ever copied.
+        auto do_piece = [&](const int q, const uint4 &prev, uint4 &cur) __attribute__((always_inline)) {
             const int pos = -ST_HALO + 32 * q;
-            const uint4 cur = st_front<ROT>(raw_next, zero);
+            cur = st_front<ROT>(raw_next, zero);
             raw_next = load_piece(pos + 32);                     // in flight during this piece's arithmetic
             // both windows' MFMAs go out first: the second window's run under the first window's index arithmetic.
             // "S" window (the piece's first 16 outputs): lanes 0-31 this piece's first 32 bytes, lanes 32-63 the
@@ -191,10 +197,17 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
                 float kk = kneg;
                 if (EPOCHS && ep_any && ep_reach) kk = -epoch_gain(ep, p.wbfm_k, sg.v0 + wpos);   // (rare: right after a gain change)
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const float d = wrap_delta(th[r] - (r == 0 ? before : th[r - 1]));   // = -(delta theta)
-                    const float v = kk * d;
-                    u[half][r] = sa.b0 * v;
+                for (int r = 0; r < 4; r += 2) {   // two samples per packed operation; wrap_delta() of iqd_prims.h operation by operation
+                    v2f d = {th[r] - (r == 0 ? before : th[r - 1]), th[r + 1] - th[r]};   // = -(delta theta)
+                    v2f m = pk_mul_s(d, inv_2pi);
+                    m.x = __builtin_rintf(m.x);
+                    m.y = __builtin_rintf(m.y);
+                    d = __builtin_elementwise_fma(-m, v2f{6.28318548202514648f, 6.28318548202514648f}, d);
+                    d = __builtin_elementwise_fma(-m, v2f{-1.74845553146951715e-7f, -1.74845553146951715e-7f}, d);
+                    const v2f v = d * v2f{kk, kk};
+                    const v2f w = v2f{sa.b0, sa.b0} * v;
+                    u[half][r] = w.x;
+                    u[half][r + 1] = w.y;
                 }
             }
             // hand the 2 x 4 samples to the IIR wave: the ring's two slots hold one piece (window 0, window 1), free once
@@ -209,7 +222,11 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             lds_signal(full);
             pc++;
-            prev = cur;
+        };
+        uint4 other;
+        for (int q = 0; q < n_pieces; q += 2) {   // (n_pieces is a multiple of 4)
+            do_piece(q, prev, other);
+            do_piece(q + 1, other, prev);
         }
         if (MAG && macc) atomicAdd(&mag_row[mblk], macc);
     }
@@ -321,9 +338,13 @@ __device__ __forceinline__ void st_iir_marks(StIirSeg &q, StIir &s, int pos)
     }
 }
 
-template <int V>
+// FAST: every segment of the wave is cold and of full length (or not there at all), so the few things that happen at
+// particular positions happen at the SAME position in every lane - one scalar compare per window instead of a dozen
+// per-lane compare-and-select operations - and the lead-in has already been run by st_iir_lead_in().
+template <int V, bool FAST>
 __device__ __forceinline__ int st_iir_piece(const StreamArgs &sa, uint8_t *ring_base, const uint32_t *full, uint32_t *consumed,
-                                             uint32_t &wg, StIirSeg &q, StIir &s, int pos, uint32_t rd_off0, uint32_t rd_swz, int lane)
+                                             uint32_t &wg, StIirSeg &q, StIir &s, int pos, uint32_t rd_off0, uint32_t rd_swz, int lane,
+                                             int rec_pos_uniform)
 {
 #pragma unroll
     for (int half = 0; half < 2; half++) {
@@ -345,7 +366,8 @@ __device__ __forceinline__ int st_iir_piece(const StreamArgs &sa, uint8_t *ring_
             lds_signal(consumed);
             wg++;
         }
-        st_iir_marks(q, s, wpos);
+        if (!FAST) st_iir_marks(q, s, wpos);
+        else if (wpos == rec_pos_uniform) { q.rec.y_out = s.y; q.rec.u_out = s.up; }
         const int y2 = st_iir_window(sa, s, u);
         if (wpos >= 0 && wpos < 48 && q.sg.valid) {    // (uniform) the segment's first values, for the boundary fix-up
             if (wpos == 0) *(u32x4 *)q.hist->w_first = u32x4{s.wq0[0], s.wq0[1], s.y1h[2], s.y1h[3]};   // (w_first, y1_first[0..1])
@@ -362,6 +384,35 @@ __device__ __forceinline__ int st_iir_piece(const StreamArgs &sa, uint8_t *ring_
     const int pcm = quiet ? st_audio<V>(sa, s, true) : st_audio<V>(sa, s, false);
     if (s.loud > 0) s.loud--;
     return pcm;
+}
+
+// The lead-in of a wave whose segments are all cold: only the de-emphasis recurrence (its state is what the lead-in is
+// for; a cold segment's decimators start with histories that the boundary fix-up replaces anyway).
+__device__ __forceinline__ void st_iir_lead_in(const StreamArgs &sa, uint8_t *ring_base, const uint32_t *full, uint32_t *consumed,
+                                               uint32_t &wg, StIir &s, uint32_t rd_off0, uint32_t rd_swz)
+{
+    float y = s.y, up = s.up;
+    const float a1 = sa.a1;
+    for (int piece = 0; piece < ST_HALO / 32; piece++) {
+        const uint32_t target = 4u * (wg + 1u);
+        while ((int32_t)(lds_load_relaxed(full) - target) < 0) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        u32x4 v[8];
+#pragma unroll
+        for (int half = 0; half < 2; half++)
+#pragma unroll
+            for (int gq = 0; gq < 4; gq++)
+                v[4 * half + gq] = *(const u32x4 *)(ring_base + half * ST_SLOT_BYTES + rd_off0 + (((uint32_t)gq ^ rd_swz) << 4));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the reads have returned
+        lds_signal(consumed);
+        wg++;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            IQD_IIR_STEP(u2f(v[k].x)) IQD_IIR_STEP(u2f(v[k].y)) IQD_IIR_STEP(u2f(v[k].z)) IQD_IIR_STEP(u2f(v[k].w))
+        }
+    }
+    s.y = y;
+    s.up = up;
 }
 
 __device__ __forceinline__ void st_iir_wave(const ChainLaunch &a, const StreamArgs &sa, uint8_t *lds, uint32_t *sync,
@@ -412,12 +463,29 @@ __device__ __forceinline__ void st_iir_wave(const ChainLaunch &a, const StreamAr
         uint32_t pbuf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         // wide stores need whole 512-sample groups per lane (tile_len a multiple of 512) and 32-byte aligned rows
         const bool wide = (a.tile_len & 511u) == 0 && (((uintptr_t)a.pcm | (a.pcm_stride * 2)) & 31u) == 0;
-        for (int pq = 0; pq < n_pieces; pq += 4) {
+        // (a segment that is not there has tlen 0 and stores nothing: it may run along with any kind of wave)
+        const bool fast = __all(!q.sg.valid || (q.back < 0 && q.sg.tlen == (int32_t)a.tile_len)) != 0;
+        const int rec_pos_uniform = (int)a.tile_len - FORCED_BACK;
+        int pq0 = 0;
+        if (fast) {
+            st_iir_lead_in(sa, ring_base, full, consumed, wg, s, rd_off0, rd_swz);
+            q.rec.y_in = s.y;                                    // the warmed-up state, checked against the predecessor's end
+            pq0 = ST_HALO / 32;
+        }
+        for (int pq = pq0; pq < n_pieces; pq += 4) {
             const int pos = -ST_HALO + 32 * pq;
-            const int p0 = st_iir_piece<0>(sa, ring_base, full, consumed, wg, q, s, pos, rd_off0, rd_swz, lane);
-            const int p1 = st_iir_piece<1>(sa, ring_base, full, consumed, wg, q, s, pos + 32, rd_off0, rd_swz, lane);
-            const int p2 = st_iir_piece<2>(sa, ring_base, full, consumed, wg, q, s, pos + 64, rd_off0, rd_swz, lane);
-            const int p3 = st_iir_piece<3>(sa, ring_base, full, consumed, wg, q, s, pos + 96, rd_off0, rd_swz, lane);
+            int p0, p1, p2, p3;
+            if (fast) {
+                p0 = st_iir_piece<0, true>(sa, ring_base, full, consumed, wg, q, s, pos, rd_off0, rd_swz, lane, rec_pos_uniform);
+                p1 = st_iir_piece<1, true>(sa, ring_base, full, consumed, wg, q, s, pos + 32, rd_off0, rd_swz, lane, rec_pos_uniform);
+                p2 = st_iir_piece<2, true>(sa, ring_base, full, consumed, wg, q, s, pos + 64, rd_off0, rd_swz, lane, rec_pos_uniform);
+                p3 = st_iir_piece<3, true>(sa, ring_base, full, consumed, wg, q, s, pos + 96, rd_off0, rd_swz, lane, rec_pos_uniform);
+            } else {
+                p0 = st_iir_piece<0, false>(sa, ring_base, full, consumed, wg, q, s, pos, rd_off0, rd_swz, lane, 0);
+                p1 = st_iir_piece<1, false>(sa, ring_base, full, consumed, wg, q, s, pos + 32, rd_off0, rd_swz, lane, 0);
+                p2 = st_iir_piece<2, false>(sa, ring_base, full, consumed, wg, q, s, pos + 64, rd_off0, rd_swz, lane, 0);
+                p3 = st_iir_piece<3, false>(sa, ring_base, full, consumed, wg, q, s, pos + 96, rd_off0, rd_swz, lane, 0);
+            }
             // 128 samples = 4 PCM samples = 8 bytes.  Where the row allows it they are collected over 512 samples and
             // leave as one aligned 32-byte sector (segments start on multiples of 512 samples of their channel's
             // stream, so the phase below is the same for every lane); else 8 bytes at a time.
