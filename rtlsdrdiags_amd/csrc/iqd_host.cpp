@@ -284,6 +284,7 @@ void build_stream_taps(const int16_t *d1, const int16_t *post12, const int16_t *
     auto pair = [](int16_t lo, int16_t hi) { return (uint32_t)(uint16_t)lo | ((uint32_t)(uint16_t)hi << 16); };
     // stage 1: window x[4m-4 .. 4m+3] ascending <-> taps h[7 .. 0]
     for (int q = 0; q < 4; q++) sa.d1p[q] = pair(d1[7 - 2 * q], d1[6 - 2 * q]);
+    for (int q = 0; q < 4; q++) sa.d1p2[q] = pair((int16_t)(2 * d1[7 - 2 * q]), (int16_t)(2 * d1[6 - 2 * q]));   // |2 h| <= 12892
     // stages 2 and 3: pair q counts back from the newest dword (older sample low: h[2q+1], newer high: h[2q])
     for (int q = 0; q < 6; q++) sa.p12p[q] = pair(post12[2 * q + 1], post12[2 * q]);
     for (int q = 0; q < 20; q++) sa.a40p[q] = pair(audio40[2 * q + 1], audio40[2 * q]);

@@ -76,6 +76,21 @@ __device__ __forceinline__ uint32_t st_mag_dword(uint32_t sx, uint32_t acc)
 }
 
 
+// The same from the RAW bytes (offset binary I0 Q0 I1 Q1): |u - 128| of one byte is one masked v_msad_u8 (bytes whose
+// reference byte is 0 do not count), two of them join into a 16-bit pair with one v_lshl_or_b32: ten operations per
+// dword against twelve for the byte-parallel arithmetic above.
+__device__ __forceinline__ uint32_t st_mag_raw_dword(uint32_t raw, uint32_t acc)
+{
+    uint32_t a0, b0, a1, b1;
+    asm("v_msad_u8 %0, %1, %2, 0" : "=v"(a0) : "v"(raw), "s"(0x00000080u));
+    asm("v_msad_u8 %0, %1, %2, 0" : "=v"(b0) : "v"(raw), "s"(0x00008000u));
+    asm("v_msad_u8 %0, %1, %2, 0" : "=v"(a1) : "v"(raw), "s"(0x00800000u));
+    asm("v_msad_u8 %0, %1, %2, 0" : "=v"(b1) : "v"(raw), "s"(0x80000000u));
+    const us2 a = __builtin_bit_cast(us2, a0 | (a1 << 16)), b = __builtin_bit_cast(us2, b0 | (b1 << 16));
+    const us2 mx = __builtin_elementwise_max(a, b), mn = __builtin_elementwise_min(a, b);
+    return acc + __builtin_bit_cast(uint32_t, mx) + __builtin_bit_cast(uint32_t, (us2)(mn >> 1));
+}
+
 __device__ __forceinline__ uint32_t st_mag_chunk(const uint4 &s)   // 8 samples of signed bytes
 {
     uint32_t m16 = st_mag_dword(s.x, 0u);

@@ -183,5 +183,7 @@ IQD_DEV uint32_t cast_i16_bounded(float f) { return (uint32_t)(int32_t)f; }
 
 // low halves of two dwords -> one dword (a.lo | b.lo << 16), v_perm_b32
 IQD_DEV uint32_t pack_lo16(uint32_t a, uint32_t b) { return perm(b, a, 0x05040100u); }
+// high halves of two dwords -> one dword (a.hi | b.hi << 16)
+IQD_DEV uint32_t pack_hi16(uint32_t a, uint32_t b) { return perm(b, a, 0x07060302u); }
 
 }  // namespace iqd

@@ -62,6 +62,7 @@ struct StreamArgs {
     uint32_t n_segments;      // n_list * tiles_per_ch
     uint32_t rounds;          // rounds per workgroup
     uint32_t d1p[4];          // decimator taps as v_dot2 pairs (see build_stream_taps)
+    uint32_t d1p2[4];         // stage 1 again with doubled taps (the IIR lanes: result in the accumulator's high half)
     uint32_t p12p[6];
     uint32_t a40p[20];
     float b0, a1;

@@ -59,6 +59,7 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
     uint8_t *ring_base = lds + ST_TABLE_BYTES + ring * (ST_RING_SLOTS * ST_SLOT_BYTES);
     const uint32_t *full = sync + ring;            // pieces written, x 4 P waves
     const uint32_t *consumed = sync + 8 + ring;    // pieces the IIR wave has read
+    asm volatile("" : "+v"(full), "+v"(consumed));   // (their LDS addresses stay in registers: else a move per use)
     const uint32_t wr_off = st_slot_off(row, (uint32_t)g);
     const int src_lane4 = ((lane - 16) & 63) << 2;               // whose theta[3] precedes this lane's theta[0]
 
@@ -127,6 +128,7 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
         // copies of the body with the two buffers swapped, so that neither is ever copied.
         auto do_piece = [&](const int q, const uint4 &prev, uint4 &cur) __attribute__((always_inline)) {
             const int pos = -ST_HALO + 32 * q;
+            const uint4 raw_cur = raw_next;                      // (offset binary, as loaded: the squelch magnitudes below)
             cur = st_front<ROT>(raw_next, zero);
             raw_next = load_piece(pos + 32);                     // in flight during this piece's arithmetic
             // both windows' MFMAs go out first: the second window's run under the first window's index arithmetic.
@@ -165,10 +167,10 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
             uint32_t seen = lds_load_relaxed(consumed);          // asked early, needed only before the ring stores
             // phase B: squelch magnitudes of this lane's 8 samples, while the gathers are in flight
             if (MAG && pos >= 0) {
-                uint32_t m16 = st_mag_dword(cur.x, 0u);
-                m16 = st_mag_dword(cur.y, m16);
-                m16 = st_mag_dword(cur.z, m16);
-                m16 = st_mag_dword(cur.w, m16);
+                uint32_t m16 = st_mag_raw_dword(raw_cur.x, 0u);
+                m16 = st_mag_raw_dword(raw_cur.y, m16);
+                m16 = st_mag_raw_dword(raw_cur.z, m16);
+                m16 = st_mag_raw_dword(raw_cur.w, m16);
                 const uint32_t m = (m16 & 0xffffu) + (m16 >> 16);
                 macc += mcount && pos < mlimit ? m : 0u;
                 minblk += 32;
@@ -245,7 +247,7 @@ struct StIir {
 
 // 16 samples of one segment: de-emphasis (IirFilter.cc:161-176 op by op), (int16), /4 with 8 taps, then one
 // /4 output with 12 taps.  Returns that stage-2 output.
-__device__ __forceinline__ int st_iir_window(const StreamArgs &sa, StIir &s, const float (&u)[16])
+__device__ __forceinline__ int st_iir_window(const StreamArgs &sa, StIir &s, const float (&u)[16], int c14, int c15)
 {
     uint32_t wv[16];
     float y = s.y, up = s.up;
@@ -266,19 +268,23 @@ __device__ __forceinline__ int st_iir_window(const StreamArgs &sa, StIir &s, con
     s.wlast[1] = wq[9];
     s.wq0[0] = wq[2];
     s.wq0[1] = wq[3];
+    // stage 1 with DOUBLED taps (|2 h| <= 12892 fits int16; the sums stay below 2^31: 2 (16384 + 29126 * 32768)): the
+    // output (acc >> 15) then sits in the high half of the accumulator and two of them pack with one v_perm_b32, no shifts.
+    // The accumulators start from a register holding the rounding term (c15 = 1 << 15, c14 = 1 << 14): as constants the
+    // compiler re-materialises them with a move in front of every chain.
     uint32_t y1[4];
 #pragma unroll
     for (int o = 0; o < 4; o++) {                      // window x[4m-4 .. 4m+3] <-> taps h[7 .. 0]
-        int acc = 1 << 14;
-        acc = dot2(wq[2 * o], sa.d1p[0], acc);
-        acc = dot2(wq[2 * o + 1], sa.d1p[1], acc);
-        acc = dot2(wq[2 * o + 2], sa.d1p[2], acc);
-        acc = dot2(wq[2 * o + 3], sa.d1p[3], acc);
-        y1[o] = (uint32_t)(acc >> 15);
+        int acc = c15;
+        acc = dot2(wq[2 * o], sa.d1p2[0], acc);
+        acc = dot2(wq[2 * o + 1], sa.d1p2[1], acc);
+        acc = dot2(wq[2 * o + 2], sa.d1p2[2], acc);
+        acc = dot2(wq[2 * o + 3], sa.d1p2[3], acc);
+        y1[o] = (uint32_t)acc;
     }
     // stage 2: output k from y1[4k-8 .. 4k+3], 12 taps, newest pair first
-    const uint32_t d[6] = {s.y1h[0], s.y1h[1], s.y1h[2], s.y1h[3], pack_lo16(y1[0], y1[1]), pack_lo16(y1[2], y1[3])};
-    int acc = 1 << 14;
+    const uint32_t d[6] = {s.y1h[0], s.y1h[1], s.y1h[2], s.y1h[3], pack_hi16(y1[0], y1[1]), pack_hi16(y1[2], y1[3])};
+    int acc = c14;
 #pragma unroll
     for (int q = 0; q < 6; q++) acc = dot2(d[5 - q], sa.p12p[q], acc);
     s.y1h[0] = d[2];
@@ -291,9 +297,9 @@ __device__ __forceinline__ int st_iir_window(const StreamArgs &sa, StIir &s, con
 // /2, 40 taps over the pairs p[1..20] (p[20] newest): without clamps when no loud value is in reach, else in
 // the reference's order with the clamp after every MAC (Decimator_int16.cc:176-238)
 template <int V>
-__device__ __forceinline__ int st_audio(const StreamArgs &sa, const StIir &s, bool quiet)
+__device__ __forceinline__ int st_audio(const StreamArgs &sa, const StIir &s, bool quiet, int c14)
 {
-    int acc = 1 << 14;
+    int acc = c14;
     if (quiet) {
 #pragma unroll
         for (int q = 0; q < 20; q++) acc = dot2(s.y2p[V + 20 - q], sa.a40p[q], acc);
@@ -315,6 +321,7 @@ struct StIirSeg {
     WbfmRecord rec;
     int16_t *pcm_row;
     StHist *hist;          // this segment's boundary record
+    int c14, c15;          // 1 << 14, 1 << 15 in registers (the decimators' rounding terms)
 };
 
 __device__ __forceinline__ void st_iir_marks(StIirSeg &q, StIir &s, int pos)
@@ -368,7 +375,7 @@ __device__ __forceinline__ int st_iir_piece(const StreamArgs &sa, uint8_t *ring_
         }
         if (!FAST) st_iir_marks(q, s, wpos);
         else if (wpos == rec_pos_uniform) { q.rec.y_out = s.y; q.rec.u_out = s.up; }
-        const int y2 = st_iir_window(sa, s, u);
+        const int y2 = st_iir_window(sa, s, u, q.c14, q.c15);
         if (wpos >= 0 && wpos < 48 && q.sg.valid) {    // (uniform) the segment's first values, for the boundary fix-up
             if (wpos == 0) *(u32x4 *)q.hist->w_first = u32x4{s.wq0[0], s.wq0[1], s.y1h[2], s.y1h[3]};   // (w_first, y1_first[0..1])
             else *(u32x2 *)&q.hist->y1_first[wpos >> 3] = u32x2{s.y1h[2], s.y1h[3]};
@@ -381,7 +388,7 @@ __device__ __forceinline__ int st_iir_piece(const StreamArgs &sa, uint8_t *ring_
     if (V == 3 && pos >= 96 && pos < 768 && q.sg.valid)   // the four pairs of this run of 128 samples (pos = its last piece)
         *(u32x4 *)&q.hist->y2_first[(pos - 96) >> 5] = u32x4{s.y2p[20], s.y2p[21], s.y2p[22], s.y2p[23]};
     const bool quiet = !__any(s.loud > 0);
-    const int pcm = quiet ? st_audio<V>(sa, s, true) : st_audio<V>(sa, s, false);
+    const int pcm = quiet ? st_audio<V>(sa, s, true, q.c14) : st_audio<V>(sa, s, false, q.c14);
     if (s.loud > 0) s.loud--;
     return pcm;
 }
@@ -433,6 +440,9 @@ __device__ __forceinline__ void st_iir_wave(const ChainLaunch &a, const StreamAr
         q.hist = sa.hist + (q.sg.valid ? (size_t)q.sg.li * a.tiles_per_ch + q.sg.tile : 0);
         q.back = -1;
         q.cy_y = q.cy_u = 0.f;
+        q.c14 = 1 << 14;
+        q.c15 = 1 << 15;
+        asm volatile("" : "+v"(q.c14), "+v"(q.c15));
         int32_t halo = ST_HALO;
         if (q.sg.tile == 0) {
             const WbfmCarry cy = a.wbfm_carry[q.sg.ech];
