@@ -271,6 +271,7 @@ int iqd_dev_tile(iqd_t *e, void *dst_dev, size_t period, size_t total);
 void *iqd_stream(iqd_t *e); /* the engine's hipStream_t */
 /* Diagnostic builds (-DIQD_STAMPS) only: cycle sums per kernel phase; zeros otherwise. */
 int iqd_debug_stamps(iqd_t *e, unsigned long long *out16);
+int iqd_debug_stamps_ext(iqd_t *e, unsigned long long *out, uint32_t n);   /* the first n <= 32768 of them (IQD_ST_TIMING / IQD_ST_WAITSTAT / IQD_ST_TRACE builds) */
 
 #ifdef __cplusplus
 }

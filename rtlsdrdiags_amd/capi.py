@@ -49,7 +49,7 @@ EXPORTS = [
     "iqd_set_gain", "iqd_set_squelch", "iqd_set_rx_gain_db", "iqd_set_rotation", "iqd_reset", "iqd_reset_demod",
     "iqd_accept_iq", "iqd_accept_iq_device", "iqd_synchronize", "iqd_get_stats", "iqd_set_profiling",
     "iqd_get_channel_mode", "iqd_get_channel_gain", "iqd_dev_alloc", "iqd_dev_free", "iqd_dev_upload",
-    "iqd_dev_download", "iqd_dev_tile", "iqd_stream", "iqd_debug_stamps", "iqd_host_alloc", "iqd_host_free",
+    "iqd_dev_download", "iqd_dev_tile", "iqd_stream", "iqd_debug_stamps", "iqd_debug_stamps_ext", "iqd_host_alloc", "iqd_host_free",
     "iqd_get_rx_gain_db", "iqd_agc_set_type", "iqd_agc_set_deadband", "iqd_agc_set_blanking_limit",
     "iqd_agc_set_operating_point", "iqd_agc_set_filter_coefficient", "iqd_agc_enable", "iqd_agc_get_state",
     "iqd_set_gain_trace", "iqd_get_gain_trace", "iqd_scanner_set_parameters", "iqd_scanner_start",
@@ -327,6 +327,12 @@ class Engine:
         g = C.c_float()
         self._check(self._L.iqd_get_channel_gain(self._h, ch, int(DEMOD.get(demod, demod)), C.byref(g)))
         return g.value
+
+    def debug_stamps_ext(self, n=64):
+        out = (C.c_ulonglong * n)()
+        self._L.iqd_debug_stamps_ext.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        self._check(self._L.iqd_debug_stamps_ext(self._h, out, n))
+        return list(out)
 
     def debug_stamps(self):
         out = (C.c_ulonglong * 16)()

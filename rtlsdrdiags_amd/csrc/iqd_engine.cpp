@@ -319,8 +319,8 @@ int iqd_create(const iqd_config *cfg, iqd_t **out)
     ok = ok && hipMalloc((void **)&e->d_amat4, amat4.size() * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMalloc((void **)&e->d_counters, CNT_COUNT * sizeof(uint32_t)) == hipSuccess;
     ok = ok && hipMemset(e->d_counters, 0, CNT_COUNT * sizeof(uint32_t)) == hipSuccess;
-    ok = ok && hipMalloc((void **)&e->d_stamps, 16 * sizeof(unsigned long long)) == hipSuccess;
-    ok = ok && hipMemset(e->d_stamps, 0, 16 * sizeof(unsigned long long)) == hipSuccess;
+    ok = ok && hipMalloc((void **)&e->d_stamps, 32768 * sizeof(unsigned long long)) == hipSuccess;
+    ok = ok && hipMemset(e->d_stamps, 0, 32768 * sizeof(unsigned long long)) == hipSuccess;
     ok = ok && hipHostMalloc((void **)&e->h_counters, CNT_COUNT * sizeof(uint32_t)) == hipSuccess;
     if (ok) {
         ok = hipMemsetAsync(e->d_tails, 0x80, n * FAM_COUNT * TAIL_BYTES, e->stream) == hipSuccess;
@@ -774,6 +774,15 @@ int iqd_debug_stamps(iqd_t *e, unsigned long long *out16)
     (void)hipSetDevice(e->device);
     HIP_TRY(e, hipStreamSynchronize(e->stream));
     HIP_TRY(e, hipMemcpy(out16, e->d_stamps, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return IQD_OK;
+}
+
+int iqd_debug_stamps_ext(iqd_t *e, unsigned long long *out, uint32_t n)
+{
+    if (!e || !out || n > 32768) return IQD_EINVAL;
+    (void)hipSetDevice(e->device);
+    HIP_TRY(e, hipStreamSynchronize(e->stream));
+    HIP_TRY(e, hipMemcpy(out, e->d_stamps, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return IQD_OK;
 }
 
@@ -1420,11 +1429,19 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
                 left = left > vlen ? left - vlen : 0u;
                 if (!left) e->wbfm_epochs_live--;
             }
+        const bool rides_with_squelch = !forked && !gated && (want_mag || pcm_count_dev || signal_present_dev || e->trace_on);
         if (f == FAM_WBFM) {
             // hand-off verification (streaming launches: done by their fix-up kernel), repair of what it flags
-            // (normally an immediate exit), then state commit + tail
+            // (normally an immediate exit), then state commit + tail - in the squelch launch below when the call has
+            // no other family
             if (!use_stream) HIP_LAUNCH(e, launch_wbfm_verify(a, s));
-            HIP_LAUNCH(e, launch_wbfm_repair(a, chain_gated, s));   // (ends with the channels' state commit and tail update)
+            if (rides_with_squelch) {
+                tail_a = a;
+                tail_f = f;
+                tail_pending = true;
+            } else {
+                HIP_LAUNCH(e, launch_wbfm_repair(a, chain_gated, s));   // (ends with the channels' state commit and tail update)
+            }
         } else if (!forked && !gated && (want_mag || pcm_count_dev || signal_present_dev || e->trace_on)) {
             tail_a = a;        // the only family of the call: its tail update rides in the squelch launch below
             tail_f = f;
@@ -1451,7 +1468,10 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         tail_pending = false;
         if (q.zero_sums_after) e->mag_sums_zero = (size_t)n_ch * n_blocks;
     }
-    if (tail_pending) HIP_LAUNCH(e, launch_tail_update(tail_a, tail_f, s));   // (no squelch launch to ride in)
+    if (tail_pending) {   // (no squelch launch to ride in)
+        if (tail_f == FAM_WBFM) HIP_LAUNCH(e, launch_wbfm_repair(tail_a, chain_gated, s));
+        else HIP_LAUNCH(e, launch_tail_update(tail_a, tail_f, s));
+    }
 
     e->stats.accepts++;
     e->stats.samples += (uint64_t)vlen * n_ch;

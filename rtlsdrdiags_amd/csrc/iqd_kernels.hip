@@ -153,10 +153,8 @@ static_assert(WB_THREADS == 256, "the repair kernel ends with the tail update, w
 // (The channel's state commit and new tail follow in the same launch: they need the repaired records, and a launch of
 // their own cost more than both together.)
 template <bool GATED>
-__global__ __launch_bounds__(WB_THREADS, IQD_WBFM_MIN_WAVES) void wbfm_repair_kernel(const ChainLaunch a)
+__device__ __forceinline__ void wbfm_repair_body(const ChainLaunch &a, WbfmLds &lds, const uint32_t li)
 {
-    __shared__ WbfmLds lds;
-    const uint32_t li = blockIdx.x;
     if (!a.repair_flags[li]) {
         tail_update_body(a, FAM_WBFM, li);
         return;
@@ -165,22 +163,52 @@ __global__ __launch_bounds__(WB_THREADS, IQD_WBFM_MIN_WAVES) void wbfm_repair_ke
     const uint32_t vlen = GATED ? a.vlen_gated[ch] : a.vlen;
     const uint32_t ntiles = (vlen + a.tile_len - 1) / a.tile_len;
     WbfmRecord *r = a.records + (size_t)li * a.tiles_per_ch;
-    bool redo_next = false;   // streaming launches: the tile after a re-run one took its first PCM samples from histories
-                              // that the failed run may have left inexact - it is re-run too
-    for (uint32_t tile = 1; tile < ntiles; tile++) {
-        const WbfmRecord prev = r[tile - 1];
-        const bool ok = iir_states_agree(r[tile].y_in, a.verify_at_end ? prev.y_end : prev.y_out, a.params[a.first_ch + ch].wbfm_k >= 1.0f);
-        if (ok && !redo_next) continue;
-        redo_next = a.verify_at_end && !ok;
-        WbfmStart start;
-        start.y = prev.y_out; start.u = prev.u_out; start.back = prev.back_out; start.cold = 0;
-        wbfm_run_tile<GATED, false>(a, lds, li, tile, ch, vlen, start);
-        __threadfence();
-        __syncthreads();     // the new record is written by one lane; everybody reads it next
-        if (threadIdx.x == 0) atomicAdd(&a.counters[CNT_TILE_REPAIRS], 1u);
+    const bool strong = a.params[a.first_ch + ch].wbfm_k >= 1.0f;
+    // Which hand-offs do not chain up?  All of them are looked at in parallel first (a long row has tens of thousands
+    // of tiles; walking their records one dependent load after the other cost tens of milliseconds for one bad tile);
+    // then the bad ones are re-run in order - a re-run makes that tile's own record exact, so the hand-off behind it is
+    // looked at again when its turn comes.
+    __shared__ uint32_t first_bad;
+    uint32_t from = 1;
+    for (;;) {
+        if (threadIdx.x == 0) first_bad = ntiles;
+        __syncthreads();
+        for (uint32_t tile = from + threadIdx.x; tile < ntiles; tile += blockDim.x)
+            if (!iir_states_agree(r[tile].y_in, a.verify_at_end ? r[tile - 1].y_end : r[tile - 1].y_out, strong)) {
+                atomicMin(&first_bad, tile);
+                break;                                 // (this thread's later tiles lie behind a bad one anyway)
+            }
+        __syncthreads();
+        uint32_t tile = first_bad;
+        __syncthreads();
+        if (tile >= ntiles) break;
+        // re-run `tile` from its predecessor's recorded exact state; streaming launches: the tile after a re-run one took
+        // its first PCM samples from histories that the failed run may have left inexact - it is re-run too
+        bool redo_next = false;
+        for (; tile < ntiles; tile++) {
+            const WbfmRecord prev = r[tile - 1];
+            const bool ok = iir_states_agree(r[tile].y_in, a.verify_at_end ? prev.y_end : prev.y_out, strong);
+            if (ok && !redo_next) break;
+            redo_next = a.verify_at_end && !ok;
+            WbfmStart start;
+            start.y = prev.y_out; start.u = prev.u_out; start.back = prev.back_out; start.cold = 0;
+            wbfm_run_tile<GATED, false>(a, lds, li, tile, ch, vlen, start);
+            __threadfence();
+            __syncthreads();     // the new record is written by one lane; everybody reads it next
+            if (threadIdx.x == 0) atomicAdd(&a.counters[CNT_TILE_REPAIRS], 1u);
+        }
+        from = tile;                                   // everything before `tile` chains up now
+        if (from >= ntiles) break;
     }
     if (threadIdx.x == 0) a.repair_flags[li] = 0;
     tail_update_body(a, FAM_WBFM, li);
+}
+
+template <bool GATED>
+__global__ __launch_bounds__(WB_THREADS, IQD_WBFM_MIN_WAVES) void wbfm_repair_kernel(const ChainLaunch a)
+{
+    __shared__ WbfmLds lds;
+    wbfm_repair_body<GATED>(a, lds, blockIdx.x);
 }
 
 // Common tile set-up of the FM / AM / SSB kernels (no carried float state: FIR chains only).
@@ -483,6 +511,15 @@ __global__ void squelch_block_kernel(const SquelchLaunch q, int always_open)
 __global__ __launch_bounds__(256) void tail_squelch_kernel(const ChainLaunch a, int family, const SquelchLaunch q, int always_open)
 {
     if (blockIdx.x < a.n_list) tail_update_body(a, family, blockIdx.x);
+    else squelch_block_body(q, always_open, (blockIdx.x - a.n_list) * 256u + threadIdx.x);
+}
+
+// The same for a call whose one family is WBFM: hand-off repair check, state commit and tail (workgroups 0 .. n_list-1)
+// beside the squelch pass's first part.
+__global__ __launch_bounds__(WB_THREADS, IQD_WBFM_MIN_WAVES) void wbfm_repair_squelch_kernel(const ChainLaunch a, const SquelchLaunch q, int always_open)
+{
+    __shared__ WbfmLds lds;
+    if (blockIdx.x < a.n_list) wbfm_repair_body<false>(a, lds, blockIdx.x);
     else squelch_block_body(q, always_open, (blockIdx.x - a.n_list) * 256u + threadIdx.x);
 }
 
@@ -922,7 +959,9 @@ hipError_t launch_magnitude(const uint8_t *iq, size_t ch_stride_bytes, const uin
 hipError_t launch_squelch(const SquelchLaunch &q, bool always_open, hipStream_t s, const ChainLaunch *tail_of, int tail_family)
 {
     const uint32_t n = q.n_ch * q.n_blocks;
-    if (tail_of)
+    if (tail_of && tail_family == FAM_WBFM)
+        hipLaunchKernelGGL(wbfm_repair_squelch_kernel, dim3(tail_of->n_list + (n + 255) / 256), dim3(WB_THREADS), 0, s, *tail_of, q, always_open ? 1 : 0);
+    else if (tail_of)
         hipLaunchKernelGGL(tail_squelch_kernel, dim3(tail_of->n_list + (n + 255) / 256), dim3(256), 0, s, *tail_of, tail_family, q, always_open ? 1 : 0);
     else
         hipLaunchKernelGGL(squelch_block_kernel, dim3((n + 255) / 256), dim3(256), 0, s, q, always_open ? 1 : 0);

@@ -32,6 +32,10 @@ constexpr int ST_HALO = FORCED_BACK;         // lead-in of every segment, 768 sa
                                             // (checked against its predecessor's end state) and starts its decimators
                                             // with unknown histories: the 21 PCM samples those reach into are recomputed
                                             // from the boundary records (StHist) by wbfm_stream_fixup_kernel.
+#ifndef IQD_ST_AHEAD
+#define IQD_ST_AHEAD 4
+#endif
+constexpr int ST_AHEAD = IQD_ST_AHEAD;      // pieces of input a P wave keeps in flight (2 or 4: the piece loop is unrolled by it)
 constexpr int ST_MIN_TILE = 768;            // a segment's own end histories must not reach back before its start
 constexpr int ST_FIX_PCM = 21;              // PCM samples of a cold segment that depend on its predecessor's histories
 constexpr int ST_ROW_FLOATS = 260;          // half-table row stride (1040 B: bank = x + 4 r)

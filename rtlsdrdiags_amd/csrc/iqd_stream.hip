@@ -15,6 +15,36 @@ namespace iqd {
 typedef __attribute__((address_space(3))) const uint32_t lds_cu32;
 __device__ __forceinline__ uint32_t st_table_read(uint32_t byte_offset) { return *(lds_cu32 *)(uintptr_t)byte_offset; }
 
+#ifndef IQD_ST_WAITSTAT   // diagnostic build: how often each side of a ring sleeps on the other (per-wave counts, added once
+#define IQD_ST_WAITSTAT 0 // per wave to ChainLaunch::stamps[0..3] = P sleeps, IIR sleeps, P pieces, IIR pieces; iqd_debug_stamps)
+#endif
+
+// How long a wave sleeps between two looks at its ring counter (units of 64 cycles).  A waiting wave's polls are
+// instructions like any others, on a SIMD whose other waves are not waiting.
+#ifndef IQD_ST_SLEEP_P
+#define IQD_ST_SLEEP_P 1
+#endif
+#ifndef IQD_ST_SLEEP_I
+#define IQD_ST_SLEEP_I 1
+#endif
+#ifndef IQD_ST_TRACE      // diagnostic build: workgroup 5 writes clock64() of (hardware wave, piece, event k) to stamps[64 + ((wave * 256 + piece) * 4 + k)]
+#define IQD_ST_TRACE 0
+#endif
+#if IQD_ST_TRACE
+#define ST_TRACE(st, wave, piece, k) do { if (blockIdx.x == 5 && lane == 0 && (piece) < 256) (st)[64 + (((wave) * 256 + (int)(piece)) * 4 + (k))] = (unsigned long long)clock64(); } while (0)
+#else
+#define ST_TRACE(st, wave, piece, k) do { } while (0)
+#endif
+#ifndef IQD_ST_TIMING     // diagnostic build: where a P wave's and an IIR wave's cycles go, per SIMD (stamps[16 + 8 simd + k])
+#define IQD_ST_TIMING 0
+#endif
+#if IQD_ST_TIMING
+#define ST_T(var) const long long var = clock64()
+__device__ __forceinline__ int st_simd_id() { return (__builtin_amdgcn_s_getreg((4 << 0) | (4 << 6) | (1 << 11)) ) & 3; }   // HW_ID[5:4]
+#else
+#define ST_T(var) do { } while (0)
+#endif
+
 struct StSeg {           // what a lane knows about its segment
     uint32_t valid, li, tile, ch, ech;
     int32_t v0, tlen;
@@ -101,14 +131,20 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
         const int32_t vlane = sg.v0 + 8 * g;
         const uint8_t *base_iq = iq_ch + 2 * (int64_t)vlane, *base_tail = tail + 2 * (int64_t)vlane;
         const int32_t pos_max = vmax - vlane;
-        auto load_piece = [&](int pos) -> uint4 {
+        auto piece_address = [&](int pos) -> const uint8_t * {
             const int32_t pc = pos < pos_max ? pos : pos_max;
             const uint8_t *base = pc < -vlane ? base_tail : base_iq;
-            return *(const uint4 *)(base + 2 * (int64_t)pc);
+            return base + 2 * (int64_t)pc;
         };
-
-        uint4 prev = st_front<ROT>(load_piece(-ST_HALO - 32), zero);
-        uint4 raw_next = load_piece(-ST_HALO);
+        // ST_AHEAD pieces of input in flight per wave (a piece's arithmetic is about as long as a trip to HBM under load:
+        // with one piece asked for in advance the wave stood at the loop's head waiting - and 12 waves x 1 KB in flight per
+        // CU cap the chip near 1.5 TB/s whatever the arithmetic costs).  The loads are the untracked ones of iqd_mfma.h:
+        // the compiler's own wait placement would join the loop's back edge to vmcnt(0).  A buffer is re-asked right after
+        // the last use of its old contents, in ST_AHEAD copies of the loop body with named buffers.
+        uint4 prev = st_front<ROT>(*(const uint4 *)piece_address(-ST_HALO - 32), zero);
+        v4u raw[ST_AHEAD];
+#pragma unroll
+        for (int j = 0; j < ST_AHEAD; j++) raw[j] = gload16_untracked(piece_address(-ST_HALO + 32 * j));
         // theta' of the sample before the lead-in (a warm segment's carried state applies from the lead-in's very first
         // sample, whose delta theta needs it): the last output of the piece before, from that piece's "N" window
         float last_prev;                                         // theta'[3] of this lane's previous window
@@ -126,11 +162,18 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
         }
         // one piece: `prev` = the signed bytes of the piece before, `cur` = this piece's (output).  The loop below runs two
         // copies of the body with the two buffers swapped, so that neither is ever copied.
-        auto do_piece = [&](const int q, const uint4 &prev, uint4 &cur) __attribute__((always_inline)) {
+        uint32_t n_sleeps = 0;                                   // (IQD_ST_WAITSTAT)
+#if IQD_ST_TIMING
+        long long tt[4] = {0, 0, 0, 0};
+#endif
+        auto do_piece = [&](const int q, const int j, const uint4 &prev, uint4 &cur) __attribute__((always_inline)) {
             const int pos = -ST_HALO + 32 * q;
-            const uint4 raw_cur = raw_next;                      // (offset binary, as loaded: the squelch magnitudes below)
-            cur = st_front<ROT>(raw_next, zero);
-            raw_next = load_piece(pos + 32);                     // in flight during this piece's arithmetic
+            ST_TRACE(a.stamps, pw + 3, q, 0);
+            ST_T(t0);
+            gload_wait<ST_AHEAD - 1>(raw[j]);                    // younger than this buffer's load: the other buffers' loads
+            ST_T(t1);
+            const uint4 raw_cur = as_uint4(raw[j]);              // (offset binary, as loaded: the squelch magnitudes below)
+            cur = st_front<ROT>(raw_cur, zero);
             // both windows' MFMAs go out first: the second window's run under the first window's index arithmetic.
             // "S" window (the piece's first 16 outputs): lanes 0-31 this piece's first 32 bytes, lanes 32-63 the
             // previous piece's last 32; "N" window: the piece itself.
@@ -181,6 +224,7 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
                     minblk -= a.block_samples;
                 }
             }
+            raw[j] = gload16_untracked(piece_address(pos + 32 * ST_AHEAD));   // (after the last use of its old contents)
             // phase C, both windows: sign, delta theta, branch cut, K, b0
             float u[2][4];
 #pragma unroll
@@ -214,23 +258,48 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
             }
             // hand the 2 x 4 samples to the IIR wave: the ring's two slots hold one piece (window 0, window 1), free once
             // the IIR wave has read the previous piece.  One signal per piece in each direction.
+            ST_T(t2);
+            ST_TRACE(a.stamps, pw + 3, q, 1);
             while ((int32_t)(seen - pc) < 0) {
-                __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_s_sleep(IQD_ST_SLEEP_P);
                 seen = lds_load_relaxed(consumed);
+                if (IQD_ST_WAITSTAT) n_sleeps++;
             }
+            ST_T(t3);
+            ST_TRACE(a.stamps, pw + 3, q, 2);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             *(u32x4 *)(ring_base + wr_off) = u32x4{f2u(u[0][0]), f2u(u[0][1]), f2u(u[0][2]), f2u(u[0][3])};
             *(u32x4 *)(ring_base + ST_SLOT_BYTES + wr_off) = u32x4{f2u(u[1][0]), f2u(u[1][1]), f2u(u[1][2]), f2u(u[1][3])};
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             lds_signal(full);
+            ST_TRACE(a.stamps, pw + 3, q, 3);
             pc++;
+#if IQD_ST_TIMING
+            { ST_T(t4); tt[0] += t1 - t0; tt[1] += t2 - t1; tt[2] += t3 - t2; tt[3] += t4 - t3; }
+#endif
         };
         uint4 other;
-        for (int q = 0; q < n_pieces; q += 2) {   // (n_pieces is a multiple of 4)
-            do_piece(q, prev, other);
-            do_piece(q + 1, other, prev);
+        for (int q = 0; q < n_pieces; q += ST_AHEAD) {   // (n_pieces is a multiple of 4)
+#pragma unroll
+            for (int j = 0; j < ST_AHEAD; j += 2) {
+                do_piece(q + j, j, prev, other);
+                do_piece(q + j + 1, j + 1, other, prev);
+            }
         }
+#pragma unroll
+        for (int j = 0; j < ST_AHEAD; j++) gload_wait<0>(raw[j]);   // the loads asked for beyond the last piece: drained before their registers move on
         if (MAG && macc) atomicAdd(&mag_row[mblk], macc);
+        if (IQD_ST_WAITSTAT && lane == 0) {
+            atomicAdd(&a.stamps[0], (unsigned long long)n_sleeps);
+            atomicAdd(&a.stamps[2], (unsigned long long)n_pieces);
+        }
+#if IQD_ST_TIMING
+        if (lane == 0) {   // per P wave of the workgroup: [16 + pw] compute, [32 + pw] ring wait, [48 + pw] raw wait + hand-over
+            atomicAdd(&a.stamps[16 + pw], (unsigned long long)tt[1]);
+            atomicAdd(&a.stamps[32 + pw], (unsigned long long)tt[2]);
+            atomicAdd(&a.stamps[48 + pw], (unsigned long long)(tt[0] + tt[3]));
+        }
+#endif
     }
 }
 
@@ -243,6 +312,12 @@ struct StIir {
     uint32_t y2p[24];      // stage-2 outputs as pairs; variant V of a piece uses [V+1 .. V+20]
     uint32_t y2lo;         // first stage-2 output of the current piece
     int loud;              // pieces for which a |y2| > AUDIO40_SAFE stays in reach of the 40-tap window
+    uint32_t n_sleeps;     // (IQD_ST_WAITSTAT)
+    int ring;              // (IQD_ST_TRACE)
+    unsigned long long *stamps;
+#if IQD_ST_TIMING
+    long long t_wait, t_seen, t_to_consumed;
+#endif
 };
 
 // 16 samples of one segment: de-emphasis (IirFilter.cc:161-176 op by op), (int16), /4 with 8 taps, then one
@@ -358,7 +433,15 @@ __device__ __forceinline__ int st_iir_piece(const StreamArgs &sa, uint8_t *ring_
         const int wpos = pos + 16 * half;
         if (half == 0) {   // the four P waves of the ring have written piece `wg` (both windows) when `full` reaches 4 (wg + 1)
             const uint32_t target = 4u * (wg + 1u);
-            while ((int32_t)(lds_load_relaxed(full) - target) < 0) __builtin_amdgcn_s_sleep(1);
+            ST_T(tw0);
+            while ((int32_t)(lds_load_relaxed(full) - target) < 0) {
+                __builtin_amdgcn_s_sleep(IQD_ST_SLEEP_I);
+                if (IQD_ST_WAITSTAT) s.n_sleeps++;
+            }
+#if IQD_ST_TIMING
+            { ST_T(tw1); s.t_wait += tw1 - tw0; s.t_seen = tw1; }
+#endif
+            ST_TRACE(s.stamps, s.ring, wg, 0);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
         const uint8_t *slot = ring_base + half * ST_SLOT_BYTES + rd_off0;
@@ -371,7 +454,11 @@ __device__ __forceinline__ int st_iir_piece(const StreamArgs &sa, uint8_t *ring_
         if (half == 1) {   // both windows read: the ring is free for the next piece
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the reads have returned
             lds_signal(consumed);
+            ST_TRACE(s.stamps, s.ring, wg, 1);
             wg++;
+#if IQD_ST_TIMING
+            { ST_T(tc); s.t_to_consumed += tc - s.t_seen; }
+#endif
         }
         if (!FAST) st_iir_marks(q, s, wpos);
         else if (wpos == rec_pos_uniform) { q.rec.y_out = s.y; q.rec.u_out = s.up; }
@@ -387,6 +474,7 @@ __device__ __forceinline__ int st_iir_piece(const StreamArgs &sa, uint8_t *ring_
     }
     if (V == 3 && pos >= 96 && pos < 768 && q.sg.valid)   // the four pairs of this run of 128 samples (pos = its last piece)
         *(u32x4 *)&q.hist->y2_first[(pos - 96) >> 5] = u32x4{s.y2p[20], s.y2p[21], s.y2p[22], s.y2p[23]};
+    ST_TRACE(s.stamps, s.ring, wg - 1, 2);
     const bool quiet = !__any(s.loud > 0);
     const int pcm = quiet ? st_audio<V>(sa, s, true, q.c14) : st_audio<V>(sa, s, false, q.c14);
     if (s.loud > 0) s.loud--;
@@ -470,6 +558,15 @@ __device__ __forceinline__ void st_iir_wave(const ChainLaunch &a, const StreamAr
         for (int k = 0; k < 24; k++) s.y2p[k] = 0;
         s.y2lo = 0;
         s.loud = 0;
+        s.n_sleeps = 0;
+        s.ring = ring;
+        s.stamps = a.stamps;
+#if IQD_ST_TIMING
+        s.t_wait = 0;
+        s.t_seen = 0;
+        s.t_to_consumed = 0;
+        const long long t_iir0 = clock64();
+#endif
         uint32_t pbuf[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         // wide stores need whole 512-sample groups per lane (tile_len a multiple of 512) and 32-byte aligned rows
         const bool wide = (a.tile_len & 511u) == 0 && (((uintptr_t)a.pcm | (a.pcm_stride * 2)) & 31u) == 0;
@@ -526,6 +623,17 @@ __device__ __forceinline__ void st_iir_wave(const ChainLaunch &a, const StreamAr
         }
         st_iir_marks(q, s, (int)a.tile_len);
         if (q.sg.valid) a.records[(size_t)q.sg.li * a.tiles_per_ch + q.sg.tile] = q.rec;
+        if (IQD_ST_WAITSTAT && lane == 0) {
+            atomicAdd(&a.stamps[1], (unsigned long long)s.n_sleeps);
+            atomicAdd(&a.stamps[3], (unsigned long long)n_pieces);
+        }
+#if IQD_ST_TIMING
+        if (lane == 0) {   // per IIR wave: [28 + ring] wait, [44 + ring] total
+            atomicAdd(&a.stamps[28 + ring], (unsigned long long)s.t_wait);
+            atomicAdd(&a.stamps[44 + ring], (unsigned long long)(clock64() - t_iir0));
+            atomicAdd(&a.stamps[60 + ring], (unsigned long long)s.t_to_consumed);
+        }
+#endif
     }
 }
 

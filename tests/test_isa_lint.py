@@ -8,6 +8,16 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def test_untracked_loads_of_the_wbfm_stream_kernel():
+    """Round 3: the WBFM streaming kernel keeps four pieces of input in flight with the same untracked loads."""
+    src = os.path.join(ROOT, "rtlsdrdiags_amd", "csrc", "iqd_stream.hip")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_lint.py"), src], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-4000:]
+    last = r.stdout.strip().splitlines()[-1]
+    assert "0 finding(s)" in last and " 13 kernels" in last, last
+    assert int(last.split(" global loads")[0].split()[-1]) > 100
+
+
 def test_untracked_loads_are_not_touched_before_they_arrive():
     src = os.path.join(ROOT, "rtlsdrdiags_amd", "csrc", "iqd_stream2.hip")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_lint.py"), src], capture_output=True, text=True, timeout=600)
