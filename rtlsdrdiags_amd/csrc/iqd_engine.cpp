@@ -79,7 +79,7 @@ struct iqd_engine {
     // (+1 / -1, 0 = choose), IQD_FULL_GRID, IQD_STREAM_WGS=<n>, IQD_PLAN_CHUNKS=<k>
     int env_path = 0;
     bool env_full_grid = false;
-    uint32_t env_stream_wgs = 0, env_plan_chunks = 0;
+    uint32_t env_stream_wgs = 0, env_plan_chunks = 0, env_stream_gran = 0;
     size_t dcr_layout[2][2] = {{~(size_t)0, 0}, {~(size_t)0, 0}};   // AM / SSB: where the DC redo flags sit in their buffer, and how many
     bool any_gated = false, any_agc = false;
     std::vector<AgcConfig> h_agc;           // per channel; the one-shot fields are cleared once applied
@@ -234,6 +234,7 @@ int iqd_create(const iqd_config *cfg, iqd_t **out)
     if (const char *env = getenv("IQD_WBFM_PATH")) e->env_path = env[0] == 's' ? 1 : env[0] == 't' ? -1 : 0;
     e->env_full_grid = getenv("IQD_FULL_GRID") != nullptr;
     if (const char *env = getenv("IQD_STREAM_WGS")) e->env_stream_wgs = atoi(env) > 0 ? (uint32_t)atoi(env) : 0u;
+    if (const char *env = getenv("IQD_STREAM_GRAN")) e->env_stream_gran = (uint32_t)atoi(env);
     if (const char *env = getenv("IQD_PLAN_CHUNKS")) e->env_plan_chunks = atoi(env) > 0 ? (uint32_t)atoi(env) : 0u;
     build_consts(e->consts);
     e->h_params.resize(e->n_ch);
@@ -1121,7 +1122,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         e->trace_first = first_ch; e->trace_n = n_ch; e->trace_blocks = n_blocks;
     }
 
-    bool chain_gated = gated;   // what the chain kernels are told: false as well when the squelch pass rejected nothing
+    const bool chain_gated = gated;   // the chain kernels walk each channel's open blocks (blk_lists, vlen_gated)
     if (gated) {
         // pass 1: magnitudes of every block, then the squelch decisions and open-block lists
         HIP_TRY(e, e->blk_lists.ensure((size_t)n_ch * n_blocks * sizeof(uint32_t)));
@@ -1130,27 +1131,10 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
                                     n_blocks, e->mag_sums.as<uint32_t>(), s));
         q.blk_lists = e->blk_lists.as<uint32_t>();
         q.vlen_out = e->vlen.as<uint32_t>();
-        // A call big enough for the streaming kernels asks whether anything was rejected at all: if every block of every
-        // channel is open the chain kernels run exactly as in an ungated call (the squelch work is done either way),
-        // streaming kernels included.  One word comes back; the wait is a few microseconds against a third of the
-        // chain's time.
-        const bool probe = !(e->flags & IQD_F_WBFM_TILES) && e->env_path >= 0 && vlen % 128 == 0 &&
-                           ((e->flags & IQD_F_WBFM_STREAM) || (uint64_t)vlen * n_ch >= (uint64_t)e->n_cus * ST_SEGS * STREAM_MIN_PER_SEGMENT);
-        if (probe) {
-            if (!e->d_closed) {
-                HIP_TRY(e, hipMalloc((void **)&e->d_closed, sizeof(uint32_t)));
-                HIP_TRY(e, hipHostMalloc((void **)&e->h_closed, sizeof(uint32_t), hipHostMallocDefault));
-            }
-            HIP_COPY(e, hipMemsetAsync(e->d_closed, 0, sizeof(uint32_t), s));
-            q.closed_any = e->d_closed;
-        }
+        // (Round 2 read one word back here - did any channel lose a block? - to let an all-open call take the streaming
+        // kernels, which could not gate.  They can now (a virtual sample axis over each channel's open blocks), so the
+        // call stays asynchronous whatever the squelch decides.)
         HIP_LAUNCH(e, launch_squelch(q, false, s));
-        if (probe) {
-            HIP_COPY(e, hipMemcpyAsync(e->h_closed, e->d_closed, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
-            HIP_TRY(e, hipStreamSynchronize(s));
-            chain_gated = *e->h_closed != 0;
-            q.closed_any = nullptr;
-        }
     }
 
     ChainLaunch base{};
@@ -1220,7 +1204,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         // (only when every family of the call will take its streaming kernel - here that means: brings enough samples
         // for ITS share of the CUs; tile kernels know nothing of shares, and a streaming kernel held to its share beside
         // them lost 12-16 % at 2500-3000 mixed channels)
-        bool all_stream = !chain_gated && !(e->flags & IQD_F_WBFM_TILES) && vlen % 128 == 0;
+        bool all_stream = !(e->flags & IQD_F_WBFM_TILES) && vlen % 128 == 0;
         all_stream = all_stream && e->env_path >= 0;
         for (int f = 0; f < FAM_COUNT && all_stream; f++) {
             const uint64_t n_f = e->h_lists[f].size();
@@ -1267,7 +1251,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         // (int16)y can hit the "integer indefinite" value.  Results are identical either way.
         bool use_stream = false;
         int stream_rot = 0;
-        if (f == FAM_WBFM && e->stream_ok && !chain_gated && !(e->flags & IQD_F_WBFM_TILES) && vlen % 128 == 0) {
+        if (f == FAM_WBFM && e->stream_ok && !(e->flags & IQD_F_WBFM_TILES) && vlen % 128 == 0) {
             const auto &l = e->h_lists[FAM_WBFM];
             stream_rot = e->h_params[first_ch + l[0]].rotation;
             bool ok = true;
@@ -1280,7 +1264,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
             if (e->env_path) want = e->env_path;
             const uint64_t work = (uint64_t)vlen * n_list;
             if (ok && want >= 0 && (want > 0 || work >= (uint64_t)(shares_on ? fam_wgs : e->n_cus) * ST_SEGS * STREAM_MIN_PER_SEGMENT || shares_on)) {
-                const TilePlan sp = plan_stream(vlen, n_list, fam_wgs * ST_SEGS);
+                const TilePlan sp = plan_stream(vlen, n_list, fam_wgs * ST_SEGS, e->env_stream_gran);
                 a.tile_len = sp.tile_len;
                 a.tiles_per_ch = sp.tiles_per_ch;
                 use_stream = true;
@@ -1291,7 +1275,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         bool use_d4 = false;
         uint32_t d4_wgs = fam_wgs;
         D4Args d4 = e->d4_args;
-        if (f != FAM_WBFM && !chain_gated && !(e->flags & IQD_F_WBFM_TILES) && vlen % 128 == 0 && (f == FAM_FM || vlen / 32 > 512)) {
+        if (f != FAM_WBFM && !(e->flags & IQD_F_WBFM_TILES) && vlen % 128 == 0 && (f == FAM_FM || vlen / 32 > 512)) {
             bool ok = true;
             if (f == FAM_FM)
                 for (uint32_t c : e->h_lists[f]) ok = ok && e->fm_kmax[first_ch + c] * 6.35f < 2147483648.0f;
@@ -1351,13 +1335,13 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
                 sa.rounds = (wgs_needed + grid - 1) / grid;
                 HIP_TRY(e, e->stream_hist.ensure((size_t)sa.n_segments * sizeof(StHist)));
                 sa.hist = e->stream_hist.as<StHist>();
-                a.verify_at_end = 1;
+                a.verify_at_end = chain_gated ? 2u : 1u;   // (2: the hand-offs are counted on the device - how many tiles a channel has depends on its squelch)
                 bool epochs_live = false;
                 if (e->wbfm_epochs_live)
                     for (uint32_t c : e->h_lists[FAM_WBFM]) epochs_live = epochs_live || e->wbfm_epoch_left[first_ch + c] != 0;
                 HIP_LAUNCH(e, launch_wbfm_stream(a, sa, stream_rot, fused_mag, epochs_live, grid, s));
                 HIP_LAUNCH(e, launch_wbfm_stream_fixup(a, sa, s));
-                e->stream_handoffs += (uint64_t)n_list * ((vlen + a.tile_len - 1) / a.tile_len - 1);
+                if (!chain_gated) e->stream_handoffs += (uint64_t)n_list * ((vlen + a.tile_len - 1) / a.tile_len - 1);
                 e->stats.stream_launches++;
             } else {
                 HIP_LAUNCH(e, launch_wbfm(a, chain_gated, fused_mag, n_list * a.tiles_per_ch, s));

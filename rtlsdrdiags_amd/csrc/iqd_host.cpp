@@ -331,7 +331,7 @@ bool plan_family_shares(const float *cost, int n, uint32_t n_cus, uint32_t *shar
     return true;
 }
 
-TilePlan plan_stream(uint32_t vlen, uint32_t n_channels, uint32_t streams)
+TilePlan plan_stream(uint32_t vlen, uint32_t n_channels, uint32_t streams, uint32_t granule)
 {
     TilePlan p;
     // As many segments as fit ONE round of the persistent workgroups (all segments of a round advance in lock step,
@@ -339,7 +339,8 @@ TilePlan plan_stream(uint32_t vlen, uint32_t n_channels, uint32_t streams)
     uint32_t per_ch = n_channels ? streams / n_channels : 1;
     if (per_ch == 0) per_ch = 1;
     uint64_t len = ((uint64_t)vlen + per_ch - 1) / per_ch;
-    len = (len + 511) / 512 * 512;              // whole 32-byte PCM sectors per segment (16 PCM samples)
+    if (granule != 128 && granule != 256) granule = 512;
+    len = (len + granule - 1) / granule * granule;   // 512: whole 32-byte PCM sectors per segment (16 PCM samples)
     if (len < ST_MIN_TILE) len = ST_MIN_TILE;   // a segment's end histories must be its own
     p.tile_len = (uint32_t)len;
     p.tiles_per_ch = (uint32_t)(((uint64_t)vlen + len - 1) / len);

@@ -31,7 +31,7 @@ struct TilePlan { uint32_t tile_len, tiles_per_ch; };
 TilePlan plan_tiles(uint32_t vlen, uint32_t n_channels, uint32_t chunk, uint32_t halo, uint32_t resident_wgs,
                     uint32_t force_chunks = 0 /* experiments: k chunks per tile */);
 
-TilePlan plan_stream(uint32_t vlen, uint32_t n_channels, uint32_t streams);
+TilePlan plan_stream(uint32_t vlen, uint32_t n_channels, uint32_t streams, uint32_t granule = 512 /* segment lengths are multiples of this: 128, 256 or 512 samples */);
 // Several demodulator families in one call, each with its streaming kernel: the CUs each family's persistent workgroups
 // get, in proportion to cost[f] (0 = family absent: its entry becomes n_cus).  Whole multiples of 8, at least 8, two CUs
 // per XCD left unplanned; false (and every entry n_cus) when that cannot be had.  See iqd_host.cpp.

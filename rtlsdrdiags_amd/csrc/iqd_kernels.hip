@@ -155,13 +155,15 @@ static_assert(WB_THREADS == 256, "the repair kernel ends with the tail update, w
 template <bool GATED>
 __device__ __forceinline__ void wbfm_repair_body(const ChainLaunch &a, WbfmLds &lds, const uint32_t li)
 {
+    const uint32_t ch = a.ch_list[li];
+    const uint32_t vlen = GATED ? a.vlen_gated[ch] : a.vlen;
+    const uint32_t ntiles = (vlen + a.tile_len - 1) / a.tile_len;
+    // (squelch-gated streaming launches: the host cannot know how many hand-offs the fix-up kernel verified)
+    if (a.verify_at_end == 2 && threadIdx.x == 0 && ntiles > 1) atomicAdd(&a.counters[CNT_TILE_CHECKS], ntiles - 1);
     if (!a.repair_flags[li]) {
         tail_update_body(a, FAM_WBFM, li);
         return;
     }
-    const uint32_t ch = a.ch_list[li];
-    const uint32_t vlen = GATED ? a.vlen_gated[ch] : a.vlen;
-    const uint32_t ntiles = (vlen + a.tile_len - 1) / a.tile_len;
     WbfmRecord *r = a.records + (size_t)li * a.tiles_per_ch;
     const bool strong = a.params[a.first_ch + ch].wbfm_k >= 1.0f;
     // Which hand-offs do not chain up?  All of them are looked at in parallel first (a long row has tens of thousands

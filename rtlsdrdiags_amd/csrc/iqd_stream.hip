@@ -48,6 +48,7 @@ __device__ __forceinline__ int st_simd_id() { return (__builtin_amdgcn_s_getreg(
 struct StSeg {           // what a lane knows about its segment
     uint32_t valid, li, tile, ch, ech;
     int32_t v0, tlen;
+    int32_t vlen;        // samples the channel consumes in this call: all of them, or those of its open blocks (squelch-gated call)
 };
 
 __device__ __forceinline__ StSeg st_segment(const ChainLaunch &a, uint32_t sid, uint32_t n_segments)
@@ -59,10 +60,14 @@ __device__ __forceinline__ StSeg st_segment(const ChainLaunch &a, uint32_t sid, 
     s.tile = id - s.li * a.tiles_per_ch;
     s.ch = a.ch_list[s.li];
     s.ech = a.first_ch + s.ch;
+    // a squelch-gated call: the chain sees the concatenation of the channel's open blocks (IqDataProcessor.cc:793), a
+    // virtual stream of vlen_gated[ch] samples, and the segments are cut on that axis
+    const uint32_t vlen = a.vlen_gated ? a.vlen_gated[s.ch] : a.vlen;
+    s.vlen = (int32_t)vlen;
     const int64_t v0 = (int64_t)s.tile * a.tile_len;
-    if (v0 >= (int64_t)a.vlen) { s.valid = 0; s.v0 = 0; s.tlen = 0; return s; }
+    if (v0 >= (int64_t)vlen) { s.valid = 0; s.v0 = 0; s.tlen = 0; return s; }
     s.v0 = (int32_t)v0;
-    const int64_t rest = (int64_t)a.vlen - v0;
+    const int64_t rest = (int64_t)vlen - v0;
     s.tlen = (int32_t)(rest < (int64_t)a.tile_len ? rest : (int64_t)a.tile_len);
     if (!s.valid) s.tlen = 0;
     return s;
@@ -72,7 +77,9 @@ __device__ __forceinline__ StSeg st_segment(const ChainLaunch &a, uint32_t sid, 
 // EPOCHS: some channel of the launch has a gain change whose samples a lead-in can still reach (GainEpochList; the host
 // knows: iqd_set_gain).  The piecewise-gain lookup lives only in that instantiation - in the common one it would sit
 // in the piece loop as a 16-deep ladder twice over, costing registers (it spilled) and instruction cache for nothing.
-template <int ROT, bool MAG, bool EPOCHS>
+// GATED: a squelch-gated launch (some channel lost blocks): virtual sample v of a channel lives in its open block number
+// v / block_samples (ChainLaunch::blk_lists); a lane keeps the block it is in and looks the next one up when it leaves it.
+template <int ROT, bool MAG, bool EPOCHS, bool GATED>
 __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs &sa, uint8_t *lds, uint32_t *sync,
                                           int pw, int lane)
 {
@@ -113,7 +120,7 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
         const ChanParams &p = a.params[sg.ech];
         const uint8_t *iq_ch = a.iq + (size_t)sg.ch * a.ch_stride_bytes;
         const uint8_t *tail = a.tails + ((size_t)sg.ech * FAM_COUNT + FAM_WBFM) * TAIL_BYTES + TAIL_BYTES;
-        const int32_t vmax = (int32_t)a.vlen - 8;
+        const int32_t vmax = sg.vlen - 8;
         const float kneg = -p.wbfm_k;
         // segments whose lead-in reaches back before the call's start may meet earlier gains (GainEpochList)
         const GainEpochList *ep = &a.epochs[sg.ech].wbfm;
@@ -131,10 +138,23 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
         const int32_t vlane = sg.v0 + 8 * g;
         const uint8_t *base_iq = iq_ch + 2 * (int64_t)vlane, *base_tail = tail + 2 * (int64_t)vlane;
         const int32_t pos_max = vmax - vlane;
+        const uint32_t *blk_list = GATED ? a.blk_lists + (size_t)sg.ch * a.n_blocks : nullptr;
+        int32_t gb_v0 = 0, gb_v1 = 0;                            // GATED: virtual range of the open block this lane is in
+        const uint8_t *gb_base = iq_ch;                          // ... and the address its virtual sample 0 would have
         auto piece_address = [&](int pos) -> const uint8_t * {
             const int32_t pc = pos < pos_max ? pos : pos_max;
-            const uint8_t *base = pc < -vlane ? base_tail : base_iq;
-            return base + 2 * (int64_t)pc;
+            if (!GATED) {
+                const uint8_t *base = pc < -vlane ? base_tail : base_iq;
+                return base + 2 * (int64_t)pc;
+            }
+            const int32_t vv = vlane + pc;
+            if (vv >= 0 && (vv >= gb_v1 || vv < gb_v0)) {        // (rare) into another open block
+                const uint32_t blk = (uint32_t)vv / a.block_samples;
+                gb_v0 = (int32_t)(blk * a.block_samples);
+                gb_v1 = gb_v0 + (int32_t)a.block_samples;
+                gb_base = iq_ch + 2 * ((int64_t)blk_list[blk] * a.block_samples - (int64_t)gb_v0);
+            }
+            return vv < 0 ? base_tail + 2 * (int64_t)pc : gb_base + 2 * (int64_t)vv;
         };
         // ST_AHEAD pieces of input in flight per wave (a piece's arithmetic is about as long as a trip to HBM under load:
         // with one piece asked for in advance the wave stood at the loop's head waiting - and 12 waves x 1 KB in flight per
@@ -637,7 +657,7 @@ __device__ __forceinline__ void st_iir_wave(const ChainLaunch &a, const StreamAr
     }
 }
 
-template <int ROT, bool MAG, bool EPOCHS>
+template <int ROT, bool MAG, bool EPOCHS, bool GATED>
 __global__ __launch_bounds__(ST_THREADS, 4) void wbfm_stream_kernel(const ChainLaunch a, const StreamArgs sa)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t st_lds[];
@@ -649,7 +669,7 @@ __global__ __launch_bounds__(ST_THREADS, 4) void wbfm_stream_kernel(const ChainL
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     if (wave < ST_RINGS) st_iir_wave(a, sa, st_lds, sync, wave, lane);
-    else st_p_wave<ROT, MAG, EPOCHS>(a, sa, st_lds, sync, wave - ST_RINGS, lane);
+    else st_p_wave<ROT, MAG, EPOCHS, GATED>(a, sa, st_lds, sync, wave - ST_RINGS, lane);
 }
 
 // The first ST_FIX_PCM PCM samples of every cold segment, recomputed with the exact histories its predecessor left
@@ -732,10 +752,12 @@ hipError_t launch_wbfm_stream_fixup(const ChainLaunch &a, const StreamArgs &sa, 
 }
 
 typedef void (*StKernel)(const ChainLaunch, const StreamArgs);
-// [rotation selector -1, 0, +1][squelch magnitudes in the kernel][gain epochs within reach of a lead-in]
-#define ST_K(R) {{wbfm_stream_kernel<R, false, false>, wbfm_stream_kernel<R, false, true>}, \
-                 {wbfm_stream_kernel<R, true, false>, wbfm_stream_kernel<R, true, true>}}
-static const StKernel st_kernels[3][2][2] = {ST_K(-1), ST_K(0), ST_K(1)};
+// [rotation selector -1, 0, +1][0: no magnitudes, 1: squelch magnitudes in the kernel, 2: squelch-gated launch][gain epochs
+// within reach of a lead-in]
+#define ST_K(R) {{wbfm_stream_kernel<R, false, false, false>, wbfm_stream_kernel<R, false, true, false>}, \
+                 {wbfm_stream_kernel<R, true, false, false>, wbfm_stream_kernel<R, true, true, false>},   \
+                 {wbfm_stream_kernel<R, false, false, true>, wbfm_stream_kernel<R, false, true, true>}}
+static const StKernel st_kernels[3][3][2] = {ST_K(-1), ST_K(0), ST_K(1)};
 #undef ST_K
 
 // One workgroup takes nearly all of a CU's LDS; the attribute belongs to the current device's code object and is set
@@ -743,7 +765,7 @@ static const StKernel st_kernels[3][2][2] = {ST_K(-1), ST_K(0), ST_K(1)};
 hipError_t init_wbfm_stream_kernels()
 {
     for (int r = 0; r < 3; r++)
-        for (int g = 0; g < 4; g++) {
+        for (int g = 0; g < 6; g++) {
             const hipError_t e = hipFuncSetAttribute((const void *)st_kernels[r][g >> 1][g & 1], hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS_BYTES);
             if (e != hipSuccess) return e;
         }
@@ -752,7 +774,8 @@ hipError_t init_wbfm_stream_kernels()
 
 hipError_t launch_wbfm_stream(const ChainLaunch &a, const StreamArgs &sa, int rotation, bool mag, bool epochs, uint32_t grid, hipStream_t s)
 {
-    hipLaunchKernelGGL(st_kernels[rotation < 0 ? 0 : rotation > 0 ? 2 : 1][mag ? 1 : 0][epochs ? 1 : 0], dim3(grid), dim3(ST_THREADS), ST_LDS_BYTES, s, a, sa);
+    const int variant = a.vlen_gated ? 2 : (mag ? 1 : 0);
+    hipLaunchKernelGGL(st_kernels[rotation < 0 ? 0 : rotation > 0 ? 2 : 1][variant][epochs ? 1 : 0], dim3(grid), dim3(ST_THREADS), ST_LDS_BYTES, s, a, sa);
     return hipGetLastError();
 }
 

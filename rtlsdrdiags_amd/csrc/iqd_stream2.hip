@@ -71,6 +71,7 @@ constexpr int D4_LDS_BYTES = D4_MAGLUT_OFF + ST_MAGLUT_BYTES;
 struct D4Seg {
     uint32_t valid, li, tile, ch, ech;
     int32_t v0, tlen;
+    int32_t vlen;          // samples this channel consumes in the call: all of them, or those of its open blocks (squelch)
     int rot;
 };
 
@@ -88,10 +89,14 @@ __device__ __forceinline__ D4Seg d4_segment(const ChainLaunch &a, const D4Args &
     s.tile = id % a.tiles_per_ch;
     s.ch = a.ch_list[s.li];
     s.ech = a.first_ch + s.ch;
+    // a squelch-gated call: the channel's chain sees the concatenation of its open blocks (IqDataProcessor.cc:793), a
+    // virtual stream of vlen_gated[ch] samples; the segments are cut on that axis, those beyond its end are not there
+    const uint32_t vlen = a.vlen_gated ? a.vlen_gated[s.ch] : a.vlen;
+    s.vlen = (int32_t)vlen;
     const int64_t v0 = (int64_t)s.tile * a.tile_len;
-    if (v0 >= (int64_t)a.vlen) { s.valid = 0; s.v0 = 0; s.tlen = 0; return s; }
+    if (v0 >= (int64_t)vlen) { s.valid = 0; s.v0 = 0; s.tlen = 0; return s; }
     s.v0 = (int32_t)v0;
-    const int64_t rest = (int64_t)a.vlen - v0;
+    const int64_t rest = (int64_t)vlen - v0;
     s.tlen = s.valid ? (int32_t)(rest < (int64_t)a.tile_len ? rest : (int64_t)a.tile_len) : 0;
     return s;
 }
@@ -106,7 +111,10 @@ __device__ __forceinline__ uint32_t d4_ring_off(uint32_t row, uint32_t g) { retu
 // when they sit 16 lanes apart, which is how the matrix instruction wants them); squelch magnitudes are taken in this
 // arrangement.  Four ds_bpermute then put the bytes where v_mfma expects them - lane 16 k + c - and everything behind
 // the matrix instruction (sg, g) belongs to that arrangement.
-template <int MODE, bool MAG, int ROT>
+// GATED: the launch follows a squelch pre-pass and some channel lost blocks: virtual sample v of a channel lives in its
+// open block number v / block_samples (ChainLaunch::blk_lists).  A lane keeps the block it is in (virtual range and
+// where its bytes are) and looks the next one up when it leaves it - once per block_samples / 32 pieces.
+template <int MODE, bool MAG, int ROT, bool GATED>
 __device__ __forceinline__ void d4_p_round(const ChainLaunch &a, const D4Args &da, const D4Seg &sg, const D4Seg &sgl, uint8_t *ring_base,
                                            const uint32_t *full, const uint32_t *consumed, uint32_t *sync, uint32_t wr_off,
                                            int g, int lane, uint32_t &pg)
@@ -130,11 +138,25 @@ __device__ __forceinline__ void d4_p_round(const ChainLaunch &a, const D4Args &d
         const uint8_t *tail = a.tails + ((size_t)sgl.ech * FAM_COUNT + fam) * TAIL_BYTES + TAIL_BYTES;
         const int32_t vlane = sgl.v0 + 8 * gl;
         const uint8_t *base_iq = iq_ch + 2 * (int64_t)vlane, *base_tail = tail + 2 * (int64_t)vlane;
-        const int32_t pos_max = (int32_t)a.vlen - 8 - vlane;
+        const int32_t pos_max = sgl.vlen - 8 - vlane;
+        const uint32_t *blk_list = GATED ? a.blk_lists + (size_t)sgl.ch * a.n_blocks : nullptr;
+        int32_t gb_v0 = 0, gb_v1 = 0;                           // GATED: virtual range of the open block this lane is in
+        const uint8_t *gb_base = iq_ch;                          // ... and the address its virtual sample 0 would have
         auto load_piece = [&](int pos) -> v4u {
             const int32_t pc = pos < pos_max ? pos : pos_max;
-            const uint8_t *base = pc < -vlane ? base_tail : base_iq;
-            return gload16_untracked(base + 2 * (int64_t)pc);
+            if (!GATED) {
+                const uint8_t *base = pc < -vlane ? base_tail : base_iq;
+                return gload16_untracked(base + 2 * (int64_t)pc);
+            }
+            const int32_t vv = vlane + pc;                       // virtual sample of this lane's 8
+            if (vv >= 0 && (vv >= gb_v1 || vv < gb_v0)) {        // (rare) into another open block
+                const uint32_t blk = (uint32_t)vv / a.block_samples;
+                gb_v0 = (int32_t)(blk * a.block_samples);
+                gb_v1 = gb_v0 + (int32_t)a.block_samples;
+                gb_base = iq_ch + 2 * ((int64_t)blk_list[blk] * a.block_samples - (int64_t)gb_v0);
+            }
+            const uint8_t *addr = vv < 0 ? base_tail + 2 * (int64_t)pc : gb_base + 2 * (int64_t)vv;
+            return gload16_untracked(addr);
         };
 #if IQD_D4_TRANSPOSE
         auto front = [&](uint4 raw) -> uint4 {                   // signed bytes, rotation signs, then to the matrix arrangement
@@ -319,7 +341,7 @@ __device__ __forceinline__ void d4_p_round(const ChainLaunch &a, const D4Args &d
 #endif
 }
 
-template <int MODE, bool MAG>
+template <int MODE, bool MAG, bool GATED>
 __device__ __forceinline__ void d4_p_wave(const ChainLaunch &a, const D4Args &da, uint8_t *lds, uint32_t *sync, int pw, int lane)
 {
     // a ring's four P waves are every third wave, not four in a row: the hardware issues oldest wave first, and with
@@ -347,9 +369,9 @@ __device__ __forceinline__ void d4_p_wave(const ChainLaunch &a, const D4Args &da
         const D4Seg &sgl = sg;
 #endif
         const int rot = __builtin_amdgcn_readfirstlane(sg.rot);
-        if (rot == 0) d4_p_round<MODE, MAG, 0>(a, da, sg, sgl, ring_base, full, consumed, sync, wr_off, g, lane, pg);
-        else if (rot > 0) d4_p_round<MODE, MAG, 1>(a, da, sg, sgl, ring_base, full, consumed, sync, wr_off, g, lane, pg);
-        else d4_p_round<MODE, MAG, -1>(a, da, sg, sgl, ring_base, full, consumed, sync, wr_off, g, lane, pg);
+        if (rot == 0) d4_p_round<MODE, MAG, 0, GATED>(a, da, sg, sgl, ring_base, full, consumed, sync, wr_off, g, lane, pg);
+        else if (rot > 0) d4_p_round<MODE, MAG, 1, GATED>(a, da, sg, sgl, ring_base, full, consumed, sync, wr_off, g, lane, pg);
+        else d4_p_round<MODE, MAG, -1, GATED>(a, da, sg, sgl, ring_base, full, consumed, sync, wr_off, g, lane, pg);
     }
 }
 
@@ -656,7 +678,7 @@ __device__ __forceinline__ void d4_fm_wave(const ChainLaunch &a, const D4Args &d
 #define IQD_D4_AM_TWO_WGS 0
 #endif
 #define D4_WAVES_PER_SIMD(MODE) ((MODE) == D4_AM && IQD_D4_AM_TWO_WGS ? 8 : 4)
-template <int MODE, bool MAG>
+template <int MODE, bool MAG, bool GATED>
 __global__ __launch_bounds__(ST_THREADS, D4_WAVES_PER_SIMD(MODE)) void d4_stream_kernel(const ChainLaunch a, const D4Args da)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t d4_lds[];
@@ -675,7 +697,7 @@ __global__ __launch_bounds__(ST_THREADS, D4_WAVES_PER_SIMD(MODE)) void d4_stream
         if (MODE == D4_FM) d4_fm_wave(a, da, d4_lds, sync, wave, lane);
         else d4_am_wave<MODE>(a, da, d4_lds, sync, wave, lane);
     } else {
-        d4_p_wave<MODE, MAG>(a, da, d4_lds, sync, wave - ST_RINGS, lane);
+        d4_p_wave<MODE, MAG, GATED>(a, da, d4_lds, sync, wave - ST_RINGS, lane);
     }
 #if IQD_D4_TIMING == 2
     {
@@ -705,9 +727,10 @@ __global__ __launch_bounds__(ST_THREADS, D4_WAVES_PER_SIMD(MODE)) void d4_stream
 }
 
 typedef void (*D4Kernel)(const ChainLaunch, const D4Args);
-static const D4Kernel d4_kernels[3][2] = {{d4_stream_kernel<D4_AM, false>, d4_stream_kernel<D4_AM, true>},
-                                          {d4_stream_kernel<D4_SSB, false>, d4_stream_kernel<D4_SSB, true>},
-                                          {d4_stream_kernel<D4_FM, false>, d4_stream_kernel<D4_FM, true>}};
+// [chain][0: no magnitudes, 1: squelch magnitudes in the kernel, 2: squelch-gated launch (magnitudes taken by the pre-pass)]
+static const D4Kernel d4_kernels[3][3] = {{d4_stream_kernel<D4_AM, false, false>, d4_stream_kernel<D4_AM, true, false>, d4_stream_kernel<D4_AM, false, true>},
+                                          {d4_stream_kernel<D4_SSB, false, false>, d4_stream_kernel<D4_SSB, true, false>, d4_stream_kernel<D4_SSB, false, true>},
+                                          {d4_stream_kernel<D4_FM, false, false>, d4_stream_kernel<D4_FM, true, false>, d4_stream_kernel<D4_FM, false, true>}};
 
 // The streaming kernels want more LDS than the 64 KiB a kernel gets without asking.  The attribute belongs to the
 // current device's code object: iqd_create calls this once per engine, serialised (no unsynchronised statics
@@ -715,7 +738,7 @@ static const D4Kernel d4_kernels[3][2] = {{d4_stream_kernel<D4_AM, false>, d4_st
 hipError_t init_d4_stream_kernels()
 {
     for (int m = 0; m < 3; m++)
-        for (int g = 0; g < 2; g++) {
+        for (int g = 0; g < 3; g++) {
             const hipError_t e = hipFuncSetAttribute((const void *)d4_kernels[m][g], hipFuncAttributeMaxDynamicSharedMemorySize, D4_LDS_BYTES);
             if (e != hipSuccess) return e;
         }
@@ -724,9 +747,10 @@ hipError_t init_d4_stream_kernels()
 
 hipError_t launch_d4_stream(const ChainLaunch &a, const D4Args &da, int mode, bool mag, uint32_t grid, hipStream_t s)
 {
-    const D4Kernel (&ks)[3][2] = d4_kernels;
+    const D4Kernel (&ks)[3][3] = d4_kernels;
+    const bool gated = a.vlen_gated != nullptr;
     const int m = mode == D4_AM ? 0 : (mode == D4_SSB ? 1 : 2);
-    hipLaunchKernelGGL(ks[m][mag ? 1 : 0], dim3(grid), dim3(ST_THREADS), D4_LDS_BYTES, s, a, da);
+    hipLaunchKernelGGL(ks[m][gated ? 2 : (mag ? 1 : 0)], dim3(grid), dim3(ST_THREADS), D4_LDS_BYTES, s, a, da);
     return hipGetLastError();
 }
 

@@ -187,24 +187,74 @@ def test_more_segments_than_one_round_holds(capi, oracle, mode):
         assert np.array_equal(mag[c], ref[1]), (mode, c)
 
 
-@pytest.mark.parametrize("mode", ["wbfm", "fm", "usb"])
-def test_squelch_that_rejects_nothing_leaves_the_streaming_path_open(capi, oracle, mode):
+@pytest.mark.parametrize("mode", ["wbfm", "fm", "usb", "am"])
+def test_squelch_gated_calls_stay_on_the_streaming_kernels(capi, oracle, mode):
     """A threshold that could close the squelch makes the call a gated one (magnitude pass, decisions, open-block lists
-    first).  When the decisions reject nothing - one word read back - the chain runs through the streaming kernel as in
-    an ungated call; when they reject something, through the tile kernels.  Identical to the oracle either way."""
+    first).  Whether the decisions reject nothing or several blocks, the chain runs through the streaming kernel - over
+    the concatenation of the channel's open blocks, like the reference's filters (IqDataProcessor.cc:793) - and the
+    call stays asynchronous (round 2 read a word back and fell to the tile kernels when anything was rejected)."""
     u8 = synth.fm_tone(8 * 16384, seed=33)
     quiet = u8.copy().reshape(-1, 2)
     quiet[3 * 16384:5 * 16384] = 128                         # two silent blocks: rejected at -40 dBFS
-    for data, threshold, streamed in ((u8, -60, True), (quiet.reshape(-1), -40, False)):
+    for data, threshold, all_open in ((u8, -60, True), (quiet.reshape(-1), -40, False)):
         eng = capi.Engine(1, flags=STREAM)
         eng.set_mode(mode)
         eng.set_squelch(threshold)
         o = oracle.chain()
         o.set_mode(mode)
         o.set_squelch(threshold)
-        pcm, cnt, mag, allowed = eng.accept(data)
-        ref = o.accept_stream(data, 32768)
-        assert (eng.stats()["stream_launches"] == 1) == streamed, (mode, threshold)
-        assert np.array_equal(allowed[0], ref[2]) and np.array_equal(mag[0], ref[1]), (mode, threshold)
-        assert bool(np.all(ref[2] == 1)) == streamed          # the case is what it claims to be
-        assert np.array_equal(pcm[0, :cnt[0]], ref[0]), (mode, threshold)
+        outs, refs = [], []
+        for call in range(2):                                 # the second call continues from the gated call's state
+            pcm, cnt, mag, allowed = eng.accept(data)
+            ref = o.accept_stream(data, 32768)
+            assert np.array_equal(allowed[0], ref[2]) and np.array_equal(mag[0], ref[1]), (mode, threshold, call)
+            assert np.array_equal(pcm[0, :cnt[0]], ref[0]), (mode, threshold, call)
+            assert cnt[0] == len(ref[0]) and not pcm[0, cnt[0]:].any()
+        assert eng.stats()["stream_launches"] == 2, (mode, threshold)
+        assert bool(np.all(ref[2] == 1)) == all_open          # the case is what it claims to be
+
+
+def test_gated_streaming_many_channels_like_configs4(capi, oracle):
+    """BASELINE configs[4] as bench.py --config 4 stages it, at 2048 channels: LSB / USB alternating, the rotation selector
+    cycling, Harris AGC running, loud / quiet blocks per channel class, threshold -60 dBFS: a quarter of the blocks is
+    rejected in the steady state and the streaming kernel compacts them away.  Three consecutive calls (the AGC moves
+    the gain from call to call), every checked channel against the oracle: PCM, magnitudes, decisions, final IF gain."""
+    import bench
+    n_ch, n = 2048, 1 << 16
+    rows = bench.gating_rows(synth, n)
+    iq = np.stack([rows[c % 4] for c in range(n_ch)])
+    iq[:, 5000:5016] = np.random.default_rng(3).integers(0, 256, size=(n_ch, 16), dtype=np.uint8)   # every channel a few bytes of its own
+    eng = capi.Engine(n_ch)
+    bench.configure(eng, "ssb_stress", n_ch, 0, None)
+    iq_d, pcm_d = eng.dev_alloc(iq.nbytes), eng.dev_alloc(n_ch * (n // 32) * 2)
+    cnt_d, mag_d, al_d = eng.dev_alloc(n_ch * 4), eng.dev_alloc(n_ch * 4 * 4), eng.dev_alloc(n_ch * 4)
+    eng.dev_upload(iq_d, iq)
+    picks = list(range(0, 24)) + list(range(1000, 1012)) + list(range(n_ch - 12, n_ch))
+    chains = {}
+    for c in picks:
+        o = oracle.chain()
+        o.set_mode("lsb" if c % 2 == 0 else "usb")
+        o.set_rotation((1, 0, -1)[c % 3])
+        o.set_squelch(bench.GATE_THRESHOLD_DBFS)
+        o.agc_set_type(1)
+        o.agc_enable(True)
+        chains[c] = o
+    rejected = 0
+    for call in range(3):
+        before = eng.stats()["stream_launches"]
+        eng.accept_device(iq_d, 2 * n, pcm_d, cnt_d, mag_d, al_d)
+        eng.synchronize()
+        assert eng.stats()["stream_launches"] - before == 1, call
+        pcm = eng.dev_download(pcm_d, n_ch * (n // 32) * 2, np.int16).reshape(n_ch, -1)
+        cnt = eng.dev_download(cnt_d, n_ch * 4, np.uint32)
+        mag = eng.dev_download(mag_d, n_ch * 16, np.uint32).reshape(n_ch, 4)
+        al = eng.dev_download(al_d, n_ch * 4, np.uint8).reshape(n_ch, 4)
+        rejected += int((al == 0).sum())
+        for c in picks:
+            ref, rmag, rallowed = chains[c].accept_stream(iq[c])
+            assert np.array_equal(al[c], rallowed) and np.array_equal(mag[c], rmag), (call, c)
+            assert cnt[c] == len(ref) and np.array_equal(pcm[c, :cnt[c]], ref), (call, c)
+            assert eng.rx_gain_db(c) == chains[c].rx_gain_db(), (call, c)
+    assert rejected > n_ch                                    # the squelch really closed on many blocks
+    for p_ in (iq_d, pcm_d, cnt_d, mag_d, al_d):
+        eng.dev_free(p_)
