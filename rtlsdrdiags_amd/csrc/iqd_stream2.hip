@@ -267,8 +267,14 @@ __device__ __forceinline__ void d4_p_round(const ChainLaunch &a, const D4Args &d
             lo = __builtin_amdgcn_mfma_i32_16x16x64_i8(A2, bp, lo, 0, 0, 0);
             hi = __builtin_amdgcn_mfma_i32_16x16x64_i8(A3, bp, hi, 0, 0, 0);
             if (MAG && pos >= 0) {
-#if IQD_D4_MAGLUT
+#if IQD_D4_MAGLUT == 1
                 const uint32_t m = st_maglut_chunk(maglut, rawj, four);
+#elif IQD_D4_MAGLUT == 2   // masked SADs on the raw bytes (iqd_mfma.h: st_mag_raw_dword), no table
+                uint32_t m16 = st_mag_raw_dword(rawj.x, 0u);
+                m16 = st_mag_raw_dword(rawj.y, m16);
+                m16 = st_mag_raw_dword(rawj.z, m16);
+                m16 = st_mag_raw_dword(rawj.w, m16);
+                const uint32_t m = (m16 & 0xffffu) + (m16 >> 16);
 #else
                 const uint32_t m = st_mag_chunk(cur);
 #endif

@@ -34,7 +34,7 @@ def compile_to_asm(src):
     os.close(fd)
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-strict-aliasing",
            "-w", "-I" + os.path.join(ROOT, "rtlsdrdiags_amd", "csrc"), "-I" + os.path.join(ROOT, "include"),
-           "-S", "--cuda-device-only", "-o", path, src]
+           "-S", "--cuda-device-only", "-o", path, src] + os.environ.get("ISA_LINT_FLAGS", "").split()
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     text = open(path).read()
     os.unlink(path)
