@@ -139,6 +139,8 @@ struct iqd_engine {
     uint32_t *h_slice_counts = nullptr;  // pinned, [2][n_ch of a slice]
     uint32_t *d_closed = nullptr, *h_closed = nullptr;   // squelch-gated calls: did any channel lose a block? (device word, pinned copy)
     size_t h_slice_counts_cap = 0;
+    uint8_t *h_small = nullptr;          // page-locked staging of small host-pointer calls: [input | pcm | counts | magnitudes | flags]
+    size_t h_small_cap = 0;
 
     bool profiling = false;
     // profiling: one event pair per timed launch, read back lazily so that accepts stay asynchronous
@@ -376,6 +378,7 @@ void iqd_destroy(iqd_t *e)
         if (e->ev_free[b]) (void)hipEventDestroy(e->ev_free[b]);
     }
     if (e->h_slice_counts) (void)hipHostFree(e->h_slice_counts);
+    if (e->h_small) (void)hipHostFree(e->h_small);
     if (e->d_closed) (void)hipFree(e->d_closed);
     if (e->h_closed) (void)hipHostFree(e->h_closed);
     if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
@@ -1468,6 +1471,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
 // whole rows (many channels).  Per-channel state is carried from slice to slice exactly as from one accept call
 // to the next, so the result equals the unsliced call; squelch-gated rows are compacted on the host at the end.
 static const size_t SLICE_BYTES = (size_t)32 << 20;
+static const size_t SMALL_CALL_BYTES = (size_t)256 << 10;   // host-pointer calls up to this size run straight out of page-locked host memory
 
 static int accept_sliced(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const uint8_t *iq, size_t bytes_per_ch, uint32_t call_bb,
                          int16_t *pcm, uint32_t *pcm_count, uint32_t *magnitude, uint8_t *signal_present)
@@ -1498,6 +1502,7 @@ static int accept_sliced(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const uint8
     const size_t st_blocks = st / bb;
     if (e->h_slice_counts_cap < 2 * sc) {
         if (e->h_slice_counts) (void)hipHostFree(e->h_slice_counts);
+    if (e->h_small) (void)hipHostFree(e->h_small);
         e->h_slice_counts = nullptr;
         e->h_slice_counts_cap = 0;
         HIP_TRY(e, hipHostMalloc((void **)&e->h_slice_counts, 2 * sc * sizeof(uint32_t), hipHostMallocDefault));
@@ -1594,6 +1599,34 @@ int iqd_accept_iq(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const uint8_t *iq,
     const size_t nb = (size_t)n_ch * (bytes_per_ch / call_bb);
     if (in_bytes >= 2 * SLICE_BYTES)
         return accept_sliced(e, first_ch, n_ch, iq, bytes_per_ch, call_bb, pcm, pcm_count, magnitude, signal_present);
+    if (in_bytes <= SMALL_CALL_BYTES) {
+        // A small call - the reference's own operating point is ONE 32768-byte block per call (DataConsumer.cc:333-346) -
+        // is all latency: through the staging path it was an upload, two fills, two kernels and up to four downloads,
+        // ~90 us per block.  Here the kernels read the block from, and write their results to, page-locked host memory
+        // that the device addresses directly: no copy operation is queued at all, two launches and one wait remain.
+        const size_t off_cnt = (pcm_bytes + 15) & ~(size_t)15, off_mag = off_cnt + (((size_t)n_ch * 4 + 15) & ~(size_t)15);
+        const size_t off_al = off_mag + ((nb * 4 + 15) & ~(size_t)15), out_bytes = off_al + ((nb + 15) & ~(size_t)15);
+        if (e->h_small_cap < in_bytes + out_bytes + 16) {
+            if (e->h_small) (void)hipHostFree(e->h_small);
+            e->h_small = nullptr;
+            e->h_small_cap = 0;
+            const size_t want = 2 * (in_bytes + out_bytes) + 4096;
+            HIP_TRY(e, hipHostMalloc((void **)&e->h_small, want, hipHostMallocDefault));
+            e->h_small_cap = want;
+        }
+        uint8_t *h_in = e->h_small, *h_out = e->h_small + ((in_bytes + 15) & ~(size_t)15);
+        memcpy(h_in, iq, in_bytes);
+        memset(h_out, 0, pcm_bytes);   // (zeros behind the valid samples, as the staging path leaves them)
+        int rc = iqd_accept_iq_device(e, first_ch, n_ch, h_in, bytes_per_ch, h_out, h_out + off_cnt,
+                                      magnitude ? h_out + off_mag : nullptr, signal_present ? h_out + off_al : nullptr);
+        if (rc != IQD_OK) return rc;
+        HIP_TRY(e, hipStreamSynchronize(s));
+        memcpy(pcm, h_out, pcm_bytes);
+        if (pcm_count) memcpy(pcm_count, h_out + off_cnt, (size_t)n_ch * sizeof(uint32_t));
+        if (magnitude) memcpy(magnitude, h_out + off_mag, nb * sizeof(uint32_t));
+        if (signal_present) memcpy(signal_present, h_out + off_al, nb);
+        return IQD_OK;
+    }
     HIP_TRY(e, e->st_iq.ensure(in_bytes));
     HIP_TRY(e, e->st_pcm.ensure(pcm_bytes));
     HIP_TRY(e, e->st_count.ensure(n_ch * sizeof(uint32_t)));
