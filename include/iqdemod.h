@@ -54,7 +54,12 @@ typedef struct iqd_config {
     uint32_t n_channels;    /* >= 1 */
     uint32_t block_bytes;   /* squelch / acceptIqData granularity per channel.  0 -> 32768
                                (Radio.cc:16, 1895).  Multiple of 256, <= 32768 (the cap of
-                               SignalDetector.h:49). */
+                               SignalDetector.h:49).  A call SHORTER than this is one short block
+                               (a short USB read, Radio.cc:1895-1906): a multiple of 64 bytes - 32
+                               samples, one PCM sample, the period of the chains' /32 commutators
+                               (the reference itself strides 8 bytes, IqDataProcessor.cc:567-611) -
+                               and of 256 bytes while a channel of the call is in WBFM mode (that
+                               chain's de-emphasis runs in 128-sample segments, one per lane). */
     int32_t device;         /* HIP device ordinal, -1 -> current device */
     uint32_t flags;         /* IQD_F_* */
     uint32_t reserved[3];
@@ -170,7 +175,7 @@ int iqd_reset_demod(iqd_t *e, uint32_t first_ch, uint32_t n_ch, int demod);
  *
  *   iq             [n_ch][bytes_per_ch] uint8, channel-major; NOT modified (the reference
  *                  mutates its buffer in place; callers that relied on that must not).
- *   bytes_per_ch   multiple of block_bytes.
+ *   bytes_per_ch   multiple of block_bytes, or one short block (see iqd_config::block_bytes).
  *   pcm            [n_ch][bytes_per_ch/64] int16; channel c's samples are packed at the front
  *                  of its row (squelched blocks contribute nothing, like the reference's
  *                  callback, IqDataProcessor.cc:793).

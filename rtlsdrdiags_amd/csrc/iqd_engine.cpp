@@ -827,17 +827,25 @@ int iqd_dev_download(iqd_t *e, void *dst, const void *src, size_t bytes)
 
 // A call is k whole blocks of block_bytes (k consecutive acceptIqData calls) - or ONE short block: the reference
 // forwards whatever rtlsdr_read_sync returned (Radio.cc:1895-1906; DataConsumer.cc:238-242 only counts short
-// reads) and acceptIqData averages the squelch over that call's samples (IqDataProcessor.cc:722-749).  Short
-// blocks come in whole 256-byte units (the chains' state is kept in 128-sample units; USB reads are multiples of
-// 512 bytes).  Returns the block size in force for the call, 0 if the length is not acceptable.
-static uint32_t call_block_bytes(const iqd_t *e, size_t bytes_per_ch)
+// reads) and acceptIqData averages the squelch over that call's samples (IqDataProcessor.cc:722-749).  A short
+// block is a whole number of 64-byte units (32 samples: the period of the chains' /32 commutators; USB reads are
+// multiples of 512 bytes) - of 256-byte units while a channel of the call is in WBFM mode: that chain's de-emphasis
+// is run in 128-sample segments, each lane of a wave one segment, and a call that ends inside a segment would leave
+// the carried state where the next call cannot pick it up.  Returns the block size in force for the call, 0 if the
+// length is not acceptable.
+static uint32_t call_block_bytes(iqd_t *e, uint32_t first_ch, uint32_t n_ch, size_t bytes_per_ch)
 {
     if (bytes_per_ch == 0) return 0;
     if (bytes_per_ch % e->block_bytes == 0) return e->block_bytes;
-    if (bytes_per_ch < e->block_bytes && bytes_per_ch % 256 == 0) return (uint32_t)bytes_per_ch;
-    return 0;
+    if (bytes_per_ch >= e->block_bytes || bytes_per_ch % 64 != 0) return 0;
+    if (bytes_per_ch % 256 != 0) {
+        std::lock_guard<std::mutex> lk(e->mu);
+        for (uint32_t c = first_ch; c < first_ch + n_ch; c++)
+            if (e->h_params[c].mode == IQD_MODE_WBFM) return 0;
+    }
+    return (uint32_t)bytes_per_ch;
 }
-#define IQD_LEN_MSG "bytes_per_ch (%zu) must be a positive multiple of block_bytes (%u), or one short block: a multiple of 256 below it"
+#define IQD_LEN_MSG "bytes_per_ch (%zu) must be a positive multiple of block_bytes (%u), or one short block: a multiple of 64 below it (of 256 while a channel of the call is in WBFM mode)"
 
 // The front end alone: what the reference leaves in the caller's buffer / sends from its IQ dump tap.
 int iqd_front_end_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void *iq_dev, size_t bytes_per_ch,
@@ -1060,7 +1068,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
                          void *pcm_dev, void *pcm_count_dev, void *magnitude_dev, void *signal_present_dev)
 {
     if (!range_ok(e, first_ch, n_ch) || !iq_dev || !pcm_dev) return e ? e->fail(IQD_EINVAL, "bad channel range or NULL buffer") : IQD_EINVAL;
-    const uint32_t call_bb = call_block_bytes(e, bytes_per_ch);
+    const uint32_t call_bb = call_block_bytes(e, first_ch, n_ch, bytes_per_ch);
     if (!call_bb) return e->fail(IQD_EINVAL, IQD_LEN_MSG, bytes_per_ch, e->block_bytes);
     const uint32_t call_bs = call_bb / 2;
     if (bytes_per_ch / 2 > 0x7fff0000ull) return e->fail(IQD_EINVAL, "bytes_per_ch too large");
@@ -1590,7 +1598,7 @@ int iqd_accept_iq(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const uint8_t *iq,
                   int16_t *pcm, uint32_t *pcm_count, uint32_t *magnitude, uint8_t *signal_present)
 {
     if (!range_ok(e, first_ch, n_ch) || !iq || !pcm) return e ? e->fail(IQD_EINVAL, "bad channel range or NULL buffer") : IQD_EINVAL;
-    const uint32_t call_bb = call_block_bytes(e, bytes_per_ch);
+    const uint32_t call_bb = call_block_bytes(e, first_ch, n_ch, bytes_per_ch);
     if (!call_bb) return e->fail(IQD_EINVAL, IQD_LEN_MSG, bytes_per_ch, e->block_bytes);
     (void)hipSetDevice(e->device);
     hipStream_t s = e->stream;

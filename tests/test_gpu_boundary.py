@@ -94,7 +94,12 @@ def test_unacceptable_lengths_are_reported_not_dropped(capi):
     eng.set_mode("fm")
     with pytest.raises(capi.IqdError) as e:
         eng.accept(np.zeros(1000, np.uint8))
-    assert "256" in str(e.value)
+    assert "multiple of 64" in str(e.value)
+    eng.set_mode("wbfm")                               # the WBFM chain works in 128-sample segments: 256-byte units there
+    with pytest.raises(capi.IqdError) as e:
+        eng.accept(np.full(320, 128, np.uint8))
+    assert "256 while a channel of the call is in WBFM mode" in str(e.value)
+    eng.set_mode("fm")
     u8 = synth.fm_tone(16384 + 500, seed=1)          # a trailing 1000-byte read
     r = subprocess.run([TOOL, "2"], input=u8.tobytes(), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 3
@@ -116,3 +121,26 @@ def test_public_fs_over_4_conversions(capi, oracle, direction):
     assert np.array_equal(back, s8)                   # exact inverse: negation is an involution with -128 fixed
     with pytest.raises(capi.IqdError):
         eng.convert_fs_over_4(direction, s8[:12])
+
+
+@pytest.mark.parametrize("mode", ["fm", "am", "lsb", "usb"])
+def test_short_reads_in_64_byte_units(capi, oracle, mode):
+    """The reference's rotation strides 8 bytes and its chains take any length (PCM invariant under the
+    block size from 8 to 32768 bytes).  Here a short block is a whole number of 64-byte units = 32 samples = one PCM
+    sample (the /32 commutators' period); each call is one acceptIqData call: its own squelch average, PCM continuing
+    sample for sample across calls of 64, 192, 8256 ... bytes."""
+    sizes = [64, 192, 8256, 320, 64, 64, 4096 - 64, 32768, 16384 + 64, 128, 2048 + 192]
+    u8 = synth.fm_tone(sum(sizes) // 2, seed=21)
+    eng = capi.Engine(1)
+    eng.set_mode(mode)
+    o = oracle.chain()
+    o.set_mode(mode)
+    off = 0
+    for k, nb in enumerate(sizes):
+        blk = u8[off:off + nb]
+        off += nb
+        pcm, cnt, mag, ok = eng.accept(blk)
+        ref, rmag, rok = o.accept_stream(blk, nb)
+        assert cnt[0] == len(ref) == nb // 64, (mode, k)
+        assert np.array_equal(pcm[0, :cnt[0]], ref), (mode, k, nb)
+        assert int(mag[0, 0]) == int(rmag[0]) and int(ok[0, 0]) == int(rok[0]), (mode, k)
