@@ -145,13 +145,51 @@ def host_path(eng, iq_dev, n, n_ch, reps=3):
 
 def profile_summary(tag):
     """Counter-derived figures of the same workload from the committed rocprofv3 summary (profiles/, written by
-    tools/profile.sh + tools/pmc_summary.py): bench.py itself cannot collect PMC counters."""
-    for rnd in (2, 1):
+    tools/profile.sh + tools/pmc_summary.py) - accepted only if it was taken from THESE kernel sources (the summary
+    records a hash of rtlsdrdiags_amd/csrc): a kernel change without a new profile must not keep stale counters."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_summary
+    now = pmc_summary.source_hash()
+    for rnd in (3, 2, 1):
         path = os.path.join(ROOT, "profiles", "r%d_%s_pmc.json" % (rnd, tag))
         if os.path.exists(path):
             with open(path) as f:
-                return json.load(f), os.path.relpath(path, ROOT)
+                prof = json.load(f)
+            if prof.get("sources_sha16") == now:
+                return prof, os.path.relpath(path, ROOT)
+            return None, "%s is stale (taken from sources %s, running %s)" % (os.path.relpath(path, ROOT), prof.get("sources_sha16"), now)
     return None, None
+
+
+def live_pmc(argv, needle, samples_per_launch):
+    """HBM traffic and vector-ALU counters of the SAME command, collected now: three short rocprofv3 passes of this
+    script as child processes (--pmc on its own, no trace domain beside it, the program itself after `--`, from /tmp:
+    MI355X_MICROARCH.md), condensed by tools/pmc_summary.py.  None if rocprofv3 is not there or a pass fails."""
+    import shutil
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not rocprof or not needle:
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pmc_summary
+    tmp = tempfile.mkdtemp(prefix="iqd_pmc_", dir="/tmp")
+    child = [sys.executable, os.path.abspath(__file__)] + [a for a in argv if a not in ("--gather",)] + \
+            ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-host-path", "--no-live-pmc"]
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for sub, counters in (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]),
+                              ("sq1", ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE"])):
+            r = subprocess.run([rocprof, "--pmc"] + counters + ["--output-format", "csv", "-d", os.path.join(tmp, sub), "--"] + child,
+                               cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+            if r.returncode != 0:
+                return None
+        res = pmc_summary.summarize(tmp, needle, float(samples_per_launch), passes=("fetch", "write", "sq1"), notes=False)
+        return res if res.get("counters_per_launch", {}).get("FETCH_SIZE") else None
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 # ---- the workload --------------------------------------------------------------------------------------------
@@ -300,6 +338,11 @@ def rank_body(args, rank, world, dev, make_engine, dist, torch, order_streams=No
         else:
             timed, timed_samples = ("wbfm_stream_kernel + wbfm_stream_fixup_kernel" if streamed else "wbfm_chain_kernel"), n * n_ch
         prof, prof_path = profile_summary(args.tag) if args.tag else (None, None)
+        needle = {"wbfm": "wbfm_stream_kernel" if streamed else "wbfm_chain_kernel", "fm": "d4_stream_kernel" if streamed else "fm_chain_kernel",
+                  "am": "d4_stream_kernel" if streamed else "am_chain_kernel"}.get("am" if args.mode in ("am", "lsb", "usb", "ssb_stress") else args.mode)
+        live = None
+        if world == 1 and dev.type == "cuda" and not args.no_live_pmc and timed_samples is not None:
+            live = live_pmc(args.argv, needle, timed_samples)
         roof = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": timed, "kernel_ms": round(kern_ms, 4)}
         if timed_samples is not None and kern_ms > 0:
             achieved = ALGO_BYTES_PER_SAMPLE * timed_samples / (kern_ms * 1e-3) / 1e9
@@ -310,14 +353,20 @@ def rank_body(args, rank, world, dev, make_engine, dist, torch, order_streams=No
             roof.update({"achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_SAMPLE * n * n_ch,
                          "note": "achieved = algorithmic bytes of the step / step time (all families' kernels)"})
-        roof["traffic"] = (prof.get("derived", {}).get("hbm_bytes_per_launch") or prof.get("traffic_bytes_per_launch")) if prof else None
-        if prof:   # the second ceiling: vector-ALU issue (SQ_ACTIVE_INST_VALU, 4 cycles per wave-instruction, 1024 SIMDs)
-            c = prof.get("counters_per_launch", {})
-            if c.get("SQ_ACTIVE_INST_VALU") and prof.get("kernel_ms_avg"):
-                busy_ms = c["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (prof.get("clock_ghz", 2.3) * 1e9) * 1e3
-                roof["valu_issue_frac"] = round(busy_ms / prof["kernel_ms_avg"], 3)
-                roof["valu_lane_ops_per_sample"] = round(prof.get("derived", {}).get("valu_lane_ops_per_sample", 0.0), 1)
-            roof["profile"] = prof_path
+        src = live or prof
+        roof["traffic"] = src.get("derived", {}).get("hbm_bytes_per_launch") if src else None
+        if src:   # the second ceiling: vector-ALU issue (SQ_ACTIVE_INST_VALU, 4 cycles per wave-instruction, 1024 SIMDs)
+            c = src.get("counters_per_launch", {})
+            ms = kern_ms if live else src.get("kernel_ms_avg")
+            ghz = min(c["GRBM_GUI_ACTIVE"] / 8 / (ms * 1e-3) / 1e9, 2.4) if (live and c.get("GRBM_GUI_ACTIVE") and ms) else src.get("clock_ghz", 2.3)
+            if c.get("SQ_ACTIVE_INST_VALU") and ms:
+                roof["valu_issue_frac"] = round(c["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (ghz * 1e9) * 1e3 / ms, 3)
+                roof["valu_lane_ops_per_sample"] = round(src.get("derived", {}).get("valu_lane_ops_per_sample", 0.0), 1)
+            roof["traffic_over_algorithmic"] = round(roof["traffic"] / (ALGO_BYTES_PER_SAMPLE * (timed_samples or n * n_ch)), 3) if roof["traffic"] else None
+            roof["counters"] = ("collected in this run: rocprofv3 --pmc passes of the same command (FETCH_SIZE x 2 + WRITE_SIZE per the "
+                                "guide's gfx950 correction; per launch of %s)" % needle) if live else prof_path
+        elif prof_path:
+            roof["counters"] = prof_path   # (says why the committed summary was not used)
         out = {
             "metric": METRIC if args.mode == "wbfm" else METRIC.replace("WBFM chain", "%s chains" % args.mode.upper()),
             "value": round(total_samples / elapsed / 1e6, 1), "unit": "MSamples/s", "n_gpus": world, "steps": args.steps,
@@ -366,8 +415,10 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-one-core-only", action="store_true", help="skip the all-host-cores CPU baseline")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive iqd_accept_iq measurement")
     ap.add_argument("--gather", action="store_true", help="also gather the PCM to rank 0 over RCCL each step")
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not collect HBM / VALU counters with rocprofv3 child runs")
     ap.add_argument("--standin", default=None, help=argparse.SUPPRESS)   # module:Class of a host-memory engine (CPU tests of the launcher)
     args = ap.parse_args(argv)
+    args.argv = list(sys.argv[1:] if argv is None else argv)
     preset = CONFIGS[1 if args.config is None else args.config]
     if args.config == 0 and args.steps == 20 and args.warmup == 3:
         args.steps, args.warmup = 61, 3          # 64 blocks = 2^20 samples, SURVEY 8(d) Config 1
