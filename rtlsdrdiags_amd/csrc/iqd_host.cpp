@@ -252,7 +252,9 @@ void build_decim4_amat(int rotation, const int16_t *taps_q15, int ntaps, uint32_
 void build_d4_taps(const Consts &c, D4Args &da)
 {
     auto pair = [](int16_t lo, int16_t hi) { return (uint32_t)(uint16_t)lo | ((uint32_t)(uint16_t)hi << 16); };
-    for (int q = 0; q < 6; q++) da.s2p[q] = pair(c.am_s2[2 * q + 1], c.am_s2[2 * q]);
+    // stage 2 with DOUBLED taps (|2 h| <= 11828): the output (acc >> 15) then is the accumulator's high half and two
+    // of them pack with one v_perm_b32; its input is a stage-1 output of int8 data (|y1| <= 114): nowhere near 2^31
+    for (int q = 0; q < 6; q++) da.s2p[q] = pair((int16_t)(2 * c.am_s2[2 * q + 1]), (int16_t)(2 * c.am_s2[2 * q]));
     for (int q = 0; q < 8; q++) da.s3p[q] = pair(c.am_s3[2 * q + 1], c.am_s3[2 * q]);
     for (int j = 0; j < 16; j++) da.hilb[j] = (uint32_t)(uint16_t)c.ssb_hilbert[2 * j];
     for (int q = 0; q < 6; q++) da.p12p[q] = pair(c.post12[2 * q + 1], c.post12[2 * q]);

@@ -84,7 +84,7 @@ struct D4Args {
     uint32_t group_nseg[3];      // real segments in each group
     uint32_t rounds;
     int32_t halo;
-    uint32_t s2p[6], s3p[8];     // AM/SSB stage 2 (12 taps) and stage 3 (16 taps) as v_dot2 pairs, newest pair first
+    uint32_t s2p[6], s3p[8];     // AM/SSB stage 2 (12 taps, DOUBLED: the result is the accumulator's high half) and stage 3 (16 taps) as v_dot2 pairs, newest pair first
     uint32_t hilb[16];           // SSB: the nonzero Hilbert taps h[0], h[2], ..., h[30] (int16 in the low half)
     uint32_t p12p[6], a40p[20];  // FM post-discriminator decimators
 };

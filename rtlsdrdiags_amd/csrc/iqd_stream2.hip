@@ -445,11 +445,13 @@ struct D4Rail {
 };
 
 // one piece of one rail: 8 stage-1 outputs in, 2 stage-2 outputs (a pair) kept, 1 stage-3 output returned
+// (c14, c15: the rounding terms 1 << 14 and 1 << 15 in registers - as constants the compiler moves them into the
+// accumulator in front of every chain; stage 2 runs with doubled taps, D4Args::s2p, and rounds with 1 << 15)
 template <int V>
-__device__ __forceinline__ int d4_am_rail(const D4Args &da, D4Rail &r, const uint32_t (&n1)[4])
+__device__ __forceinline__ int d4_am_rail(const D4Args &da, D4Rail &r, const uint32_t (&n1)[4], int c14, int c15)
 {
     const uint32_t w[8] = {r.y1h[0], r.y1h[1], r.y1h[2], r.y1h[3], n1[0], n1[1], n1[2], n1[3]};
-    int a0 = 1 << 14, a1 = 1 << 14;                    // /4, 12 taps: output k from y1[4k-8 .. 4k+3]
+    int a0 = c15, a1 = c15;                            // /4, 12 taps: output k from y1[4k-8 .. 4k+3]
 #pragma unroll
     for (int q = 0; q < 6; q++) {
         a0 = dot2(w[5 - q], da.s2p[q], a0);
@@ -457,8 +459,8 @@ __device__ __forceinline__ int d4_am_rail(const D4Args &da, D4Rail &r, const uin
     }
 #pragma unroll
     for (int k = 0; k < 4; k++) r.y1h[k] = n1[k];
-    r.y2[V + 7] = pack_lo16((uint32_t)(a0 >> 15), (uint32_t)(a1 >> 15));
-    int s3 = 1 << 14;                                  // /2, 16 taps: from y2[2i-14 .. 2i+1]
+    r.y2[V + 7] = pack_hi16((uint32_t)a0, (uint32_t)a1);
+    int s3 = c14;                                      // /2, 16 taps: from y2[2i-14 .. 2i+1]
 #if IQD_D4_SPLIT
     int s3b = 0;                                       // (two half-length chains: int32 sums wrap, so any order is exact)
 #pragma unroll
@@ -497,13 +499,13 @@ __device__ __forceinline__ int d4_hilbert(const D4Args &da, const uint32_t (&p)[
 
 template <int MODE, int V>
 __device__ __forceinline__ int d4_am_piece(const D4Args &da, const uint8_t *ring_base, const uint32_t *full, uint32_t *consumed,
-                                           uint32_t &pg, uint32_t row, int lane, D4Rail &ri, D4Rail &rq, D4Ssb &sb, int lsb)
+                                           uint32_t &pg, uint32_t row, int lane, D4Rail &ri, D4Rail &rq, D4Ssb &sb, int lsb, int c14, int c15)
 {
     u32x2 p[4];
     d4_read_row(d4_take_piece<V>(ring_base, full, pg), row, p);
     d4_piece_taken<V>(consumed, pg);
     const uint32_t ni[4] = {p[0].x, p[1].x, p[2].x, p[3].x}, nq[4] = {p[0].y, p[1].y, p[2].y, p[3].y};
-    const int iv = d4_am_rail<V>(da, ri, ni), qv = d4_am_rail<V>(da, rq, nq);
+    const int iv = d4_am_rail<V>(da, ri, ni, c14, c15), qv = d4_am_rail<V>(da, rq, nq, c14, c15);
     if (MODE == D4_AM) {   // AmDemodulator.cc:446-459: max(|i|,|q|) + min(|i|,|q|)/2 in int16 arithmetic
         const int im = (int)(int16_t)(iv < 0 ? -iv : iv), qm = (int)(int16_t)(qv < 0 ? -qv : qv);
         return (int)(int16_t)((im > qm) ? im + (qm >> 1) : qm + (im >> 1));
@@ -545,6 +547,8 @@ __device__ __forceinline__ void d4_am_wave(const ChainLaunch &a, const D4Args &d
         int32_t *base_row = a.base8k + (size_t)sg.ch * a.base_stride_ch;
         D4Rail ri, rq;
         D4Ssb sb;
+        int c14 = 1 << 14, c15 = 1 << 15;
+        asm volatile("" : "+v"(c14), "+v"(c15));
 #pragma unroll
         for (int k = 0; k < 4; k++) ri.y1h[k] = rq.y1h[k] = 0;
 #pragma unroll
@@ -555,10 +559,10 @@ __device__ __forceinline__ void d4_am_wave(const ChainLaunch &a, const D4Args &d
         for (int k = 0; k < 5; k++) sb.ie[k] = sb.io[k] = 0;
         for (int pq = 0; pq < n_pieces; pq += 4) {
             const int pos = -da.halo + 32 * pq;
-            const int x0 = d4_am_piece<MODE, 0>(da, ring_base, full, consumed, pg, (uint32_t)lane, lane, ri, rq, sb, lsb);
-            const int x1 = d4_am_piece<MODE, 1>(da, ring_base, full, consumed, pg, (uint32_t)lane, lane, ri, rq, sb, lsb);
-            const int x2 = d4_am_piece<MODE, 2>(da, ring_base, full, consumed, pg, (uint32_t)lane, lane, ri, rq, sb, lsb);
-            const int x3 = d4_am_piece<MODE, 3>(da, ring_base, full, consumed, pg, (uint32_t)lane, lane, ri, rq, sb, lsb);
+            const int x0 = d4_am_piece<MODE, 0>(da, ring_base, full, consumed, pg, (uint32_t)lane, lane, ri, rq, sb, lsb, c14, c15);
+            const int x1 = d4_am_piece<MODE, 1>(da, ring_base, full, consumed, pg, (uint32_t)lane, lane, ri, rq, sb, lsb, c14, c15);
+            const int x2 = d4_am_piece<MODE, 2>(da, ring_base, full, consumed, pg, (uint32_t)lane, lane, ri, rq, sb, lsb, c14, c15);
+            const int x3 = d4_am_piece<MODE, 3>(da, ring_base, full, consumed, pg, (uint32_t)lane, lane, ri, rq, sb, lsb, c14, c15);
             // 128 samples = 4 detector inputs = one 16-byte store (segments start and end on multiples of 128)
             if (sg.valid && pos >= 0 && pos < sg.tlen)
                 *(u32x4 *)(base_row + ((sg.v0 + pos) >> 5)) = u32x4{(uint32_t)x0, (uint32_t)x1, (uint32_t)x2, (uint32_t)x3};
