@@ -281,14 +281,21 @@ def rank_body(args, rank, world, dev, make_engine, dist, torch, order_streams=No
     flags = (1 if args.no_magnitude else 0) | {"tiles": 2, "stream": 4}.get(args.wbfm_path, 0)
     eng = make_engine(n_channels=n_ch, flags=flags)
     configure(eng, args.mode, n_ch, first_global, args.squelch)
-    gatherer = shard.PcmGatherer(n_ch, n // 32, dev) if (args.gather and dist is not None) else None
+    gatherer, native_gather = None, False
+    if args.gather and dist is not None:
+        if dev.type == "cuda" and not args.torch_gather:   # the engine's own RCCL gather (iqd_gather_*), on its stream
+            gatherer, native_gather = shard.NativeGatherer(eng, n_ch, n // 32, dev), True
+        else:                                              # torch.distributed tensors (the CPU tests run this one over gloo)
+            gatherer = shard.PcmGatherer(n_ch, n // 32, dev)
 
     def step():
         if args.no_magnitude:
             eng.accept_device(iq.data_ptr(), 2 * n, pcm.data_ptr())
         else:
             eng.accept_device(iq.data_ptr(), 2 * n, pcm.data_ptr(), cnt.data_ptr(), mag.data_ptr(), allowed.data_ptr())
-        if gatherer is not None:
+        if gatherer is not None and native_gather:
+            gatherer.gather(pcm.view(n_ch, -1), cnt)   # queued on the engine's stream: ordered by construction
+        elif gatherer is not None:
             if order_streams is not None:
                 order_streams(eng, True)    # the collective's stream waits for the engine's kernels (no host sync)
             else:
@@ -378,7 +385,8 @@ def rank_body(args, rank, world, dev, make_engine, dist, torch, order_streams=No
                                                 % (args.mode.upper(), n_ch, args.log2_samples),
                        "channels_per_gpu": n_ch, "log2_samples_per_channel": args.log2_samples, "kernels": kernels_ran,
                        "sharding": "independent channels, contiguous range per rank, no data-path collective"
-                                   + ("; PCM gathered to rank 0 over RCCL" if args.gather else "")},
+                                   + ("; PCM gathered to rank 0 over RCCL (%s)" % ("iqd_gather_pcm, C ABI" if native_gather else "torch.distributed")
+                                      if args.gather else "")},
             "roofline": roof,
             "state_checks": k1["state_checks"] - k0["state_checks"],
             "state_repairs": k1["state_repairs"] - k0["state_repairs"],
@@ -415,6 +423,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-one-core-only", action="store_true", help="skip the all-host-cores CPU baseline")
     ap.add_argument("--no-host-path", action="store_true", help="skip the PCIe-inclusive iqd_accept_iq measurement")
     ap.add_argument("--gather", action="store_true", help="also gather the PCM to rank 0 over RCCL each step")
+    ap.add_argument("--torch-gather", action="store_true", help="with --gather: torch.distributed tensors instead of the engine's own iqd_gather_pcm")
     ap.add_argument("--no-live-pmc", action="store_true", help="do not collect HBM / VALU counters with rocprofv3 child runs")
     ap.add_argument("--standin", default=None, help=argparse.SUPPRESS)   # module:Class of a host-memory engine (CPU tests of the launcher)
     args = ap.parse_args(argv)

@@ -260,6 +260,23 @@ size_t iqd_resampler_out_count(const iqd_resampler_t *r, size_t n_in);
 int iqd_resampler_run(iqd_resampler_t *r, const void *in, size_t n_in, void *out);                 /* host pointers */
 int iqd_resampler_run_device(iqd_resampler_t *r, const void *in_dev, size_t n_in, void *out_dev);  /* queued on the engine's stream */
 
+/* PCM of several engines (one per GPU, one host process each or all in one) into one place over RCCL / xGMI.  The data
+ * path itself has no collective - channels are independent, every GPU demodulates its own - this only
+ * delivers the audio, 1/32 of the input volume, to one rank.  The reference has no counterpart (one dongle, one
+ * process); the sink it stands in front of is radioApp.cc:103-111.
+ *   iqd_gather_unique_id   the root makes an id; the host passes it to the other ranks by any means of its own
+ *   iqd_gather_create      every rank, with its own engine (its GPU current), the id, its rank, the world size
+ *   iqd_gather_pcm         every rank: its bytes_per_rank[rank] bytes at send_dev go to row `rank` of recv_dev on the
+ *                          root (rows row_stride bytes apart; recv_dev is ignored elsewhere).  Queued on the engine's
+ *                          stream behind the accept that produced the PCM; the next accept queues behind it.
+ * librccl.so is loaded when the first of these is called.  IQD_ENODEV: no RCCL on this host. */
+#define IQD_GATHER_ID_BYTES 128
+typedef struct iqd_gather iqd_gather_t;
+int iqd_gather_unique_id(uint8_t *id128);
+int iqd_gather_create(iqd_t *e, const uint8_t *id128, uint32_t rank, uint32_t world, uint32_t root, iqd_gather_t **out);
+int iqd_gather_pcm(iqd_gather_t *g, const void *send_dev, const size_t *bytes_per_rank, void *recv_dev, size_t row_stride);
+void iqd_gather_destroy(iqd_gather_t *g);
+
 /* Small device-memory helpers so that non-HIP hosts (ctypes, cgo, JNI) can stage
  * device-resident buffers for iqd_accept_iq_device without linking the HIP runtime. */
 int iqd_dev_alloc(iqd_t *e, size_t bytes, void **out);

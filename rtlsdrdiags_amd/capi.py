@@ -55,7 +55,7 @@ EXPORTS = [
     "iqd_set_gain_trace", "iqd_get_gain_trace", "iqd_scanner_set_parameters", "iqd_scanner_start",
     "iqd_scanner_get", "iqd_get_frequency_trace", "iqd_front_end", "iqd_front_end_device", "iqd_convert_fs_over_4",
     "iqd_resampler_create", "iqd_resampler_destroy", "iqd_resampler_reset", "iqd_resampler_out_count",
-    "iqd_resampler_run", "iqd_resampler_run_device",
+    "iqd_resampler_run", "iqd_resampler_run_device", "iqd_gather_unique_id", "iqd_gather_create", "iqd_gather_pcm", "iqd_gather_destroy",
 ]
 
 _LIB = None
@@ -382,6 +382,44 @@ class Engine:
 
     def dev_tile(self, dst, period, total):
         self._check(self._L.iqd_dev_tile(self._h, C.c_void_p(dst), period, total))
+
+
+class Gatherer:
+    """iqd_gather_*: this rank's PCM to row `rank` of a buffer on the root, over RCCL, on the engine's stream."""
+
+    def __init__(self, engine, unique_id, rank, world, root=0):
+        self._e, self._L = engine, engine._L
+        self.rank, self.world, self.root = rank, world, root
+        self._L.iqd_gather_create.argtypes = [C.c_void_p, C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_void_p)]
+        self._L.iqd_gather_pcm.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_size_t), C.c_void_p, C.c_size_t]
+        self._L.iqd_gather_destroy.argtypes = [C.c_void_p]
+        self._L.iqd_gather_destroy.restype = None
+        h = C.c_void_p()
+        rc = self._L.iqd_gather_create(engine._h, bytes(unique_id), rank, world, root, C.byref(h))
+        if rc != 0:
+            raise IqdError(rc, "iqd_gather_create failed (is librccl.so there?)")
+        self._h = h
+
+    @staticmethod
+    def unique_id():
+        L = _lib()
+        buf = (C.c_uint8 * 128)()
+        L.iqd_gather_unique_id.argtypes = [C.c_void_p]
+        rc = L.iqd_gather_unique_id(buf)
+        if rc != 0:
+            raise IqdError(rc, "iqd_gather_unique_id failed (is librccl.so there?)")
+        return bytes(buf)
+
+    def gather(self, send_dev, bytes_per_rank, recv_dev, row_stride):
+        arr = (C.c_size_t * self.world)(*[int(b) for b in bytes_per_rank])
+        rc = self._L.iqd_gather_pcm(self._h, C.c_void_p(send_dev), arr, C.c_void_p(recv_dev or None), int(row_stride))
+        if rc != 0:
+            raise IqdError(rc, "iqd_gather_pcm failed")
+
+    def close(self):
+        if self._h:
+            self._L.iqd_gather_destroy(self._h)
+            self._h = None
 
 
 class Resampler:

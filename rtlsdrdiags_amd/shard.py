@@ -56,6 +56,43 @@ class PcmGatherer:
                 [c[:n] for c, n in zip(self.recv_cnt, self.sizes)])
 
 
+class NativeGatherer:
+    """The same gather through the engine's own C ABI (iqd_gather_*: RCCL point-to-point transfers on the ENGINE's
+    stream, csrc/iqd_gather.cpp) - what a C++ host would call.  Nothing of torch is on the data path: the transfers
+    read the engine's output buffers where they lie (the accept that filled them and the next accept that will overwrite
+    them are on the same stream).  torch.distributed is used once, to hand the communicator id to the other ranks."""
+
+    def __init__(self, engine, n_local, row, device, dst=0):
+        from . import capi
+        self.world, self.rank, self.dst = dist.get_world_size(), dist.get_rank(), dst
+        n = torch.tensor([n_local], dtype=torch.int64, device=device)
+        sizes = [torch.zeros_like(n) for _ in range(self.world)]
+        dist.all_gather(sizes, n)
+        self.sizes = [int(s.item()) for s in sizes]
+        self.n_local, self.row, self.n_max = n_local, row, max(self.sizes)
+        box = [capi.Gatherer.unique_id() if self.rank == dst else None]
+        dist.broadcast_object_list(box, src=dst)
+        self._g = capi.Gatherer(engine, box[0], self.rank, self.world, dst)
+        is_dst = self.rank == dst
+        self.recv_pcm = torch.zeros((self.world, self.n_max, row), dtype=torch.int16, device=device) if is_dst else None
+        self.recv_cnt = torch.zeros((self.world, self.n_max), dtype=torch.int32, device=device) if is_dst else None
+
+    def gather(self, pcm_rows, counts):
+        """pcm_rows [n_local, row] int16 and counts [n_local] (4-byte) as the engine wrote them, contiguous."""
+        self._g.gather(pcm_rows.data_ptr(), [s * self.row * 2 for s in self.sizes],
+                       self.recv_pcm.data_ptr() if self.recv_pcm is not None else 0, self.n_max * self.row * 2)
+        self._g.gather(counts.data_ptr(), [s * 4 for s in self.sizes],
+                       self.recv_cnt.data_ptr() if self.recv_cnt is not None else 0, self.n_max * 4)
+
+    def result(self):
+        if self.rank != self.dst:
+            return None, None
+        return ([self.recv_pcm[r, :n] for r, n in enumerate(self.sizes)], [self.recv_cnt[r, :n] for r, n in enumerate(self.sizes)])
+
+    def close(self):
+        self._g.close()
+
+
 def gather_pcm(pcm_rows, counts, dst=0):
     """One-off gather (set-up and step in one call); a timed loop keeps a PcmGatherer instead."""
     g = PcmGatherer(pcm_rows.shape[0], pcm_rows.shape[1], pcm_rows.device, dst=dst, count_dtype=counts.dtype)

@@ -9,7 +9,7 @@ ROOT=$(pwd)
 cd /tmp && export TMPDIR=/tmp && cd "$ROOT"
 OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
-B="python3 bench.py --no-cpu-baseline --no-host-path $*"
+B="python3 bench.py --no-cpu-baseline --no-host-path --no-live-pmc $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $B --steps 20 --warmup 3 > $OUT/kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $B --steps 3 --warmup 1 > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $B --steps 3 --warmup 1 > $OUT/write.log 2>&1

@@ -1,23 +1,41 @@
 #!/bin/bash
-# Round profiles of the bench configurations (run on the GPU box from the repo root); summaries land in
-# gpurun_out/<tag>/summary.json and the kernel stats in gpurun_out/<tag>/kt/**/_kernel_stats.csv.
+# Round profiles of the bench configurations (run on the GPU box from the repo root).  For each: the rocprofv3 kernel
+# trace + the PMC passes of tools/profile.sh, condensed by tools/pmc_summary.py; the summary and the kernel stats are
+# copied to profiles/<tag>_pmc.json and profiles/<tag>_kernel_stats.csv (copy them back from gpurun_out/profiles_out/).
 set -u
-# (copy what is to be judged into profiles/: <tag>/summary.json -> profiles/<tag>_pmc.json, the newest kt/**/_kernel_stats.csv beside it)
+R=${ROUND:-r3}
+OUT=gpurun_out/profiles_out
+mkdir -p $OUT
 run() { # tag needle samples args...
   local tag=$1 needle=$2 samples=$3; shift 3
-  tools/profile.sh $tag "$@" > /dev/null
-  python3 tools/pmc_summary.py gpurun_out/$tag "$needle" $samples gpurun_out/$tag/summary.json > /dev/null
+  tools/profile.sh $tag --no-live-pmc "$@" > /dev/null
+  python3 tools/pmc_summary.py gpurun_out/$tag "$needle" $samples $OUT/${tag}_pmc.json > /dev/null
+  cp "$(ls -t gpurun_out/$tag/kt/*/*kernel_stats.csv | head -1)" $OUT/${tag}_kernel_stats.csv
   python3 - <<PY
-import json; o=json.load(open("gpurun_out/$tag/summary.json"))
-print("$tag", o.get("kernel","?")[:50], "ms", round(o.get("kernel_ms_avg",0),4), "ops/sample", round(o["derived"].get("valu_lane_ops_per_sample",0),1),
-      "valu_frac", round(o["derived"].get("valu_issue_frac",0),3), "traffic/algo", round(o["derived"].get("traffic_over_algorithmic",0),3), "clk", o.get("clock_ghz"))
+import json; o=json.load(open("$OUT/${tag}_pmc.json"))
+print("$tag", o.get("kernel","?")[:60], "ms", round(o.get("kernel_ms_avg",0),4), "ops/sample", round(o["derived"].get("valu_lane_ops_per_sample",0),1),
+      "valu_frac", round(o["derived"].get("valu_issue_frac",0),3), "traffic/algo", round(o["derived"].get("traffic_over_algorithmic",0),3), "clk", o.get("clock_ghz"), o.get("code_object",{}).get("vgpr_count"))
 PY
 }
-run r2_wbfm_2p28 wbfm_stream_kernel 268435456
-run r2_wbfm_2p28_tiles wbfm_chain_kernel 268435456 --wbfm-path tiles
-run r2_wbfm_2p28_white wbfm_stream_kernel 268435456 --signal white
-run r2_fm_4096 d4_stream_kernel 268435456 --config 2
-run r2_am_4096 d4_stream_kernel 268435456 --mode am --channels 4096 --log2-samples 16
-run r2_usb_4096 d4_stream_kernel 268435456 --mode usb --channels 4096 --log2-samples 16
-run r2_ssb_8192 d4_stream_kernel 536870912 --config 4
-run r2_mixed_4096 wbfm_stream_kernel 53673984 --config 3
+run ${R}_wbfm_2p28 wbfm_stream_kernel 268435456
+run ${R}_wbfm_2p28_white wbfm_stream_kernel 268435456 --signal white
+run ${R}_fm_4096 d4_stream_kernel 268435456 --config 2
+run ${R}_am_4096 d4_stream_kernel 268435456 --mode am --channels 4096 --log2-samples 16
+run ${R}_usb_4096 d4_stream_kernel 268435456 --mode usb --channels 4096 --log2-samples 16
+run ${R}_ssb_8192 d4_stream_kernel 536870912 --config 4
+# the mixed configuration: four streaming kernels side by side; one summary per kernel from the same passes
+tools/profile.sh ${R}_mixed_4096 --no-live-pmc --config 3 > /dev/null
+cp "$(ls -t gpurun_out/${R}_mixed_4096/kt/*/*kernel_stats.csv | head -1)" $OUT/${R}_mixed_4096_kernel_stats.csv
+python3 - <<PY
+import json, sys
+sys.path.insert(0, "tools")
+import pmc_summary
+n = 4096 * 65536
+parts = {"wbfm": ("wbfm_stream_kernel", n // 5), "am": ("d4_stream_kernel<0", n // 5), "ssb": ("d4_stream_kernel<1", 2 * n // 5), "fm": ("d4_stream_kernel<2", n // 5)}
+out = {"workload": "BASELINE configs[3]: 4096 channels x 2^16 samples, channel % 5 -> AM, FM, WBFM, LSB, USB; four streaming kernels on planned CU shares"}
+for k, (needle, samples) in parts.items():
+    out[k] = pmc_summary.summarize("gpurun_out/${R}_mixed_4096", needle, float(samples))
+    d = out[k]
+    print("${R}_mixed_4096", k, d.get("kernel", "?")[:50], "ms", round(d.get("kernel_ms_avg", 0), 4), "grid", d.get("grid_workgroups"), "traffic/algo", round(d["derived"].get("traffic_over_algorithmic", 0), 3))
+json.dump(out, open("$OUT/${R}_mixed_4096_pmc.json", "w"), indent=1)
+PY
