@@ -310,7 +310,7 @@ def rank_body(args, rank, world, dev, make_engine, dist, torch, order_streams=No
     sync()
     if dist is not None:
         dist.barrier()
-    eng.set_profiling(True)
+    eng.set_profiling(not getattr(args, "no_kernel_events", False))
     k0 = eng.stats()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -425,6 +425,8 @@ def parse_args(argv=None):
     ap.add_argument("--gather", action="store_true", help="also gather the PCM to rank 0 over RCCL each step")
     ap.add_argument("--torch-gather", action="store_true", help="with --gather: torch.distributed tensors instead of the engine's own iqd_gather_pcm")
     ap.add_argument("--no-live-pmc", action="store_true", help="do not collect HBM / VALU counters with rocprofv3 child runs")
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="diagnostic: time the steps without the engine's per-kernel HIP events (no roofline.kernel_ms then)")
     ap.add_argument("--standin", default=None, help=argparse.SUPPRESS)   # module:Class of a host-memory engine (CPU tests of the launcher)
     args = ap.parse_args(argv)
     args.argv = list(sys.argv[1:] if argv is None else argv)

@@ -134,6 +134,25 @@ __device__ __forceinline__ void st_maglut_pair(const uint8_t *lut, uint32_t w, u
     m0 = lut[a0];                                                // 256 Q + I + 16 Q
     m1 = lut[a1];
 }
+// The same with the table at a known LDS ADDRESS (the kernel's dynamic LDS starts at address 0, checked at kernel start):
+// through a generic pointer the compiler adds the LDS base - a relocated zero - to every one of the eight addresses.
+typedef __attribute__((address_space(3))) const uint8_t lds_cu8;
+__device__ __forceinline__ uint32_t st_maglut_chunk_at(uint32_t lut_lds_address, const uint4 &raw, uint32_t four)   // 8 raw samples
+{
+    const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+    uint32_t m[8];
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+        uint32_t t0, a0, t1, a1;
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(t0) : "v"(four), "v"(w[d]));
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(a0) : "v"(t0), "v"(w[d]));
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(t1) : "v"(four), "v"(w[d]));
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(a1) : "v"(t1), "v"(w[d]));
+        m[2 * d] = *(lds_cu8 *)(uintptr_t)(lut_lds_address + a0);
+        m[2 * d + 1] = *(lds_cu8 *)(uintptr_t)(lut_lds_address + a1);
+    }
+    return (m[0] + m[1] + m[2]) + (m[3] + m[4] + m[5]) + (m[6] + m[7]);
+}
 __device__ __forceinline__ uint32_t st_maglut_chunk(const uint8_t *lut, const uint4 &raw, uint32_t four)   // 8 raw samples
 {
     uint32_t m[8];
@@ -203,9 +222,12 @@ __device__ __forceinline__ void gload_wait(uint32_t &r)
 #endif
 
 // ---- producer / consumer plumbing of the streaming kernels (waves of one workgroup talking through LDS rings) ----
+// (through the LDS address space: on the generic pointer this is a flat_load, which travels the vector-memory path
+// as well and is waited for with vmcnt(0) - i.e. together with every input load the wave has in flight)
 __device__ __forceinline__ uint32_t lds_load_relaxed(const uint32_t *p)
 {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const __attribute__((address_space(3))) uint32_t *q = (const __attribute__((address_space(3))) uint32_t *)(uintptr_t)(uint32_t)(uintptr_t)p;
+    return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
 // lane 0 adds 1 to an LDS word (exec is all ones wherever this is used); the plain HIP form costs a dozen

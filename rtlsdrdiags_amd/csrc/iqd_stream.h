@@ -39,9 +39,17 @@ constexpr int ST_AHEAD = IQD_ST_AHEAD;      // pieces of input a P wave keeps in
 constexpr int ST_MIN_TILE = 768;            // a segment's own end histories must not reach back before its start
 constexpr int ST_FIX_PCM = 21;              // PCM samples of a cold segment that depend on its predecessor's histories
 constexpr int ST_ROW_FLOATS = 260;          // half-table row stride (1040 B: bank = x + 4 r)
-constexpr int ST_TABLE_BYTES = 129 * ST_ROW_FLOATS * 4;
+#ifndef IQD_ST_FAKE_SHIFT
+#define IQD_ST_FAKE_SHIFT 0                 // TIMING PROBES ONLY (wrong PCM): the LDS copy of the table with its columns 2^shift apart dropped
+#endif
+constexpr int ST_LDS_ROW_FLOATS = IQD_ST_FAKE_SHIFT ? (256 >> IQD_ST_FAKE_SHIFT) + 4 : ST_ROW_FLOATS;
+constexpr int ST_TABLE_BYTES = 129 * ST_LDS_ROW_FLOATS * 4;
 constexpr int ST_SLOT_BYTES = 64 * 16 * 4;  // one window of one ring: 64 segments x 16 samples, f32
-constexpr int ST_RING_SLOTS = 2;
+#ifndef IQD_ST_DEPTH
+#define IQD_ST_DEPTH 1
+#endif
+constexpr int ST_DEPTH = IQD_ST_DEPTH;      // pieces a ring holds (a power of two)
+constexpr int ST_RING_SLOTS = 2 * ST_DEPTH;
 constexpr int ST_SYNC_WORDS = 16;
 constexpr int ST_LDS_BYTES = ST_TABLE_BYTES + ST_RINGS * ST_RING_SLOTS * ST_SLOT_BYTES + ST_SYNC_WORDS * 4;
 static_assert(ST_LDS_BYTES <= 160 * 1024, "table + rings must fit the CU's LDS");

@@ -94,8 +94,8 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
     const int g = lane >> 4, c = lane & 15;
     const uint32_t row = (uint32_t)(16 * cg + c);                // ring row of this lane's segment
     uint8_t *ring_base = lds + ST_TABLE_BYTES + ring * (ST_RING_SLOTS * ST_SLOT_BYTES);
-    const uint32_t *full = sync + ring;            // pieces written, x 4 P waves
-    const uint32_t *consumed = sync + 8 + ring;    // pieces the IIR wave has read
+    const uint32_t *full = sync + ring * 4;        // [slot of the ring]: pieces written into it, x 4 P waves
+    const uint32_t *consumed = sync + 12 + ring;   // pieces the IIR wave has read
     asm volatile("" : "+v"(full), "+v"(consumed));   // (their LDS addresses stay in registers: else a move per use)
     const uint32_t wr_off = st_slot_off(row, (uint32_t)g);
     const int src_lane4 = ((lane - 16) & 63) << 2;               // whose theta[3] precedes this lane's theta[0]
@@ -220,9 +220,9 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
                     const uint32_t tq = (uint32_t)acc[half][2][r] + ((uint32_t)acc[half][3][r] << 8);
                     uint32_t rr;                                 // |y| = |byte 2 of tq - 128|
                     asm("v_msad_u8 %0, %1, %2, 0" : "=v"(rr) : "v"(tq), "s"(0x00800000u));
-                    const uint32_t x4 = bfe(ti, 16, 8) << 2;
+                    const uint32_t x4 = bfe(ti, 16 + IQD_ST_FAKE_SHIFT, 8 - IQD_ST_FAKE_SHIFT) << 2;
                     uint32_t addr;                               // row |y|, column x of the half table
-                    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(addr) : "v"(rr), "s"((uint32_t)(ST_ROW_FLOATS * 4)), "v"(x4));
+                    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(addr) : "v"(rr), "s"((uint32_t)(ST_LDS_ROW_FLOATS * 4)), "v"(x4));
                     traw[half][r] = st_table_read(addr);
                     tqs[half][r] = tq;
                 }
@@ -280,7 +280,7 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
             // the IIR wave has read the previous piece.  One signal per piece in each direction.
             ST_T(t2);
             ST_TRACE(a.stamps, pw + 3, q, 1);
-            while ((int32_t)(seen - pc) < 0) {
+            while ((int32_t)(seen + (uint32_t)(ST_DEPTH - 1) - pc) < 0) {   // piece pc - ST_DEPTH has been read: its slots are free
                 __builtin_amdgcn_s_sleep(IQD_ST_SLEEP_P);
                 seen = lds_load_relaxed(consumed);
                 if (IQD_ST_WAITSTAT) n_sleeps++;
@@ -288,10 +288,11 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
             ST_T(t3);
             ST_TRACE(a.stamps, pw + 3, q, 2);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            *(u32x4 *)(ring_base + wr_off) = u32x4{f2u(u[0][0]), f2u(u[0][1]), f2u(u[0][2]), f2u(u[0][3])};
-            *(u32x4 *)(ring_base + ST_SLOT_BYTES + wr_off) = u32x4{f2u(u[1][0]), f2u(u[1][1]), f2u(u[1][2]), f2u(u[1][3])};
+            uint8_t *const slot = ring_base + (ST_DEPTH > 1 ? (pc & (uint32_t)(ST_DEPTH - 1)) * (2 * ST_SLOT_BYTES) : 0u) + wr_off;
+            *(u32x4 *)slot = u32x4{f2u(u[0][0]), f2u(u[0][1]), f2u(u[0][2]), f2u(u[0][3])};
+            *(u32x4 *)(slot + ST_SLOT_BYTES) = u32x4{f2u(u[1][0]), f2u(u[1][1]), f2u(u[1][2]), f2u(u[1][3])};
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            lds_signal(full);
+            lds_signal(ST_DEPTH > 1 ? full + (pc & (uint32_t)(ST_DEPTH - 1)) : full);
             ST_TRACE(a.stamps, pw + 3, q, 3);
             pc++;
 #if IQD_ST_TIMING
@@ -452,9 +453,10 @@ __device__ __forceinline__ int st_iir_piece(const StreamArgs &sa, uint8_t *ring_
     for (int half = 0; half < 2; half++) {
         const int wpos = pos + 16 * half;
         if (half == 0) {   // the four P waves of the ring have written piece `wg` (both windows) when `full` reaches 4 (wg + 1)
-            const uint32_t target = 4u * (wg + 1u);
+            const uint32_t target = 4u * (wg / (uint32_t)ST_DEPTH + 1u);
+            const uint32_t *const fullp = ST_DEPTH > 1 ? full + (wg & (uint32_t)(ST_DEPTH - 1)) : full;
             ST_T(tw0);
-            while ((int32_t)(lds_load_relaxed(full) - target) < 0) {
+            while ((int32_t)(lds_load_relaxed(fullp) - target) < 0) {
                 __builtin_amdgcn_s_sleep(IQD_ST_SLEEP_I);
                 if (IQD_ST_WAITSTAT) s.n_sleeps++;
             }
@@ -464,7 +466,7 @@ __device__ __forceinline__ int st_iir_piece(const StreamArgs &sa, uint8_t *ring_
             ST_TRACE(s.stamps, s.ring, wg, 0);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
-        const uint8_t *slot = ring_base + half * ST_SLOT_BYTES + rd_off0;
+        const uint8_t *slot = ring_base + (ST_DEPTH > 1 ? (wg & (uint32_t)(ST_DEPTH - 1)) * (2 * ST_SLOT_BYTES) : 0u) + half * ST_SLOT_BYTES + rd_off0;
         float u[16];
 #pragma unroll
         for (int gq = 0; gq < 4; gq++) {
@@ -509,15 +511,16 @@ __device__ __forceinline__ void st_iir_lead_in(const StreamArgs &sa, uint8_t *ri
     float y = s.y, up = s.up;
     const float a1 = sa.a1;
     for (int piece = 0; piece < ST_HALO / 32; piece++) {
-        const uint32_t target = 4u * (wg + 1u);
-        while ((int32_t)(lds_load_relaxed(full) - target) < 0) __builtin_amdgcn_s_sleep(1);
+        const uint32_t target = 4u * (wg / (uint32_t)ST_DEPTH + 1u);
+        while ((int32_t)(lds_load_relaxed(ST_DEPTH > 1 ? full + (wg & (uint32_t)(ST_DEPTH - 1)) : full) - target) < 0) __builtin_amdgcn_s_sleep(1);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         u32x4 v[8];
 #pragma unroll
         for (int half = 0; half < 2; half++)
 #pragma unroll
             for (int gq = 0; gq < 4; gq++)
-                v[4 * half + gq] = *(const u32x4 *)(ring_base + half * ST_SLOT_BYTES + rd_off0 + (((uint32_t)gq ^ rd_swz) << 4));
+                v[4 * half + gq] = *(const u32x4 *)(ring_base + (ST_DEPTH > 1 ? (wg & (uint32_t)(ST_DEPTH - 1)) * (2 * ST_SLOT_BYTES) : 0u) +
+                                                    half * ST_SLOT_BYTES + rd_off0 + (((uint32_t)gq ^ rd_swz) << 4));
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the reads have returned
         lds_signal(consumed);
         wg++;
@@ -534,8 +537,8 @@ __device__ __forceinline__ void st_iir_wave(const ChainLaunch &a, const StreamAr
                                             int ring, int lane)
 {
     uint8_t *ring_base = lds + ST_TABLE_BYTES + ring * (ST_RING_SLOTS * ST_SLOT_BYTES);
-    const uint32_t *full = sync + ring;
-    uint32_t *consumed = sync + 8 + ring;
+    const uint32_t *full = sync + ring * 4;
+    uint32_t *consumed = sync + 12 + ring;
     const uint32_t rd_off0 = (uint32_t)lane * 64u, rd_swz = ((uint32_t)lane >> 2) & 3u;
     const int n_pieces = (ST_HALO + (int)a.tile_len) >> 5;       // a multiple of 4
     uint32_t wg = 0;                                             // pieces read so far (all rounds)
@@ -684,15 +687,24 @@ __global__ __launch_bounds__(32 * FIX_SEGS) void wbfm_stream_fixup_kernel(const 
     __shared__ uint32_t y2x[FIX_SEGS][41];             // per segment: stage-2 pairs -40 .. 41 with the boundary ones exact
     const uint32_t sid0 = blockIdx.x * FIX_SEGS;
     const int tid = (int)threadIdx.x, sl = tid >> 5, i = tid & 31;
+    // Everything this workgroup needs from memory is asked for at once - the segment's channel, the two states of the
+    // hand-off, the nine records - instead of one dependent trip after the other (round 2: 17.6 us of latency for
+    // 47 662 boundaries).
+    const uint32_t sid = sid0 + (uint32_t)sl;
+    const StSeg sg = st_segment(a, sid < sa.n_segments ? sid : 0u, sa.n_segments);
+    const bool live = sid < sa.n_segments && sg.valid && sg.tile != 0;
+    float y_in = 0.f, y_end = 0.f;
+    if (live && i == 31) {
+        const WbfmRecord *r = a.records + (size_t)sg.li * a.tiles_per_ch;
+        y_in = r[sg.tile].y_in;
+        y_end = r[sg.tile - 1].y_end;
+    }
     {
         const uint32_t *src = (const uint32_t *)sa.hist + ((size_t)sid0 - (sid0 ? 1 : 0)) * 64;
         const uint32_t n_avail = (sa.n_segments - sid0 < (uint32_t)FIX_SEGS ? sa.n_segments - sid0 : (uint32_t)FIX_SEGS) + (sid0 ? 1u : 0u);
         for (uint32_t k = (uint32_t)tid; k < n_avail * 64; k += 32 * FIX_SEGS) rec[k + (sid0 ? 0 : 64)] = src[k];
     }
     __syncthreads();
-    const uint32_t sid = sid0 + (uint32_t)sl;
-    const StSeg sg = st_segment(a, sid < sa.n_segments ? sid : 0u, sa.n_segments);
-    const bool live = sid < sa.n_segments && sg.valid && sg.tile != 0;
     const StHist &prev = *(const StHist *)&rec[sl * 64], &own = *(const StHist *)&rec[(sl + 1) * 64];
     if (live && i < 3) {                               // stage-2 output i (0..2) of the segment, from y1[4i-8 .. 4i+3]
         int acc = 1 << 14;                             // stage-1 output 0: w[-4 .. 3]
@@ -724,9 +736,8 @@ __global__ __launch_bounds__(32 * FIX_SEGS) void wbfm_stream_fixup_kernel(const 
     // warmed-up state at its start must be its predecessor's end state, bit for bit.  Only mismatches touch the
     // device counters (thousands of workgroups adding to one word would cost more than the whole kernel); the host
     // knows how many hand-offs a launch has.
-    if (live && i == 31) {
-        const WbfmRecord *r = a.records + (size_t)sg.li * a.tiles_per_ch;
-        if (!iir_states_agree(r[sg.tile].y_in, r[sg.tile - 1].y_end, a.params[sg.ech].wbfm_k >= 1.0f)) {
+    if (live && i == 31 && f2u(y_in) != f2u(y_end)) {   // (bit-equal is the rule; the sub-2^-100 exception needs the channel's K: rare)
+        if (!iir_states_agree(y_in, y_end, a.params[sg.ech].wbfm_k >= 1.0f)) {
             atomicAdd(&a.counters[CNT_TILE_MISMATCH], 1u);
             atomicAdd(&a.counters[CNT_STREAM_MISMATCH], 1u);
             a.repair_flags[sg.li] = 1;

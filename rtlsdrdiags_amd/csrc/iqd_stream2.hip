@@ -129,7 +129,6 @@ __device__ __forceinline__ void d4_p_round(const ChainLaunch &a, const D4Args &d
         const v4i cround = {1 << 14, 1 << 14, 1 << 14, 1 << 14}, czero = {0, 0, 0, 0};
         uint32_t zero = 0, four = 4;
         asm volatile("" : "+v"(zero), "+v"(four));
-        const uint8_t *maglut = (const uint8_t *)sync + (D4_MAGLUT_OFF - ST_RINGS * D4_SLOTS * D4_SLOT_BYTES);
         const int n_pieces = (da.halo + (int)a.tile_len) >> 5;
         const v4i *am = (const v4i *)da.amat + (size_t)(rot + 1) * 4 * 64;
         const v4i A0 = am[0 * 64 + lane], A1 = am[1 * 64 + lane], A2 = am[2 * 64 + lane], A3 = am[3 * 64 + lane];
@@ -268,7 +267,7 @@ __device__ __forceinline__ void d4_p_round(const ChainLaunch &a, const D4Args &d
             hi = __builtin_amdgcn_mfma_i32_16x16x64_i8(A3, bp, hi, 0, 0, 0);
             if (MAG && pos >= 0) {
 #if IQD_D4_MAGLUT == 1
-                const uint32_t m = st_maglut_chunk(maglut, rawj, four);
+                const uint32_t m = st_maglut_chunk_at((uint32_t)D4_MAGLUT_OFF, rawj, four);
 #elif IQD_D4_MAGLUT == 2   // masked SADs on the raw bytes (iqd_mfma.h: st_mag_raw_dword), no table
                 uint32_t m16 = st_mag_raw_dword(rawj.x, 0u);
                 m16 = st_mag_raw_dword(rawj.y, m16);
@@ -692,6 +691,7 @@ template <int MODE, bool MAG, bool GATED>
 __global__ __launch_bounds__(ST_THREADS, D4_WAVES_PER_SIMD(MODE)) void d4_stream_kernel(const ChainLaunch a, const D4Args da)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t d4_lds[];
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)d4_lds != 0u) __builtin_trap();   // st_maglut_chunk_at()
     uint32_t *sync = (uint32_t *)(d4_lds + ST_RINGS * D4_SLOTS * D4_SLOT_BYTES);
     const int tid = (int)threadIdx.x;
     if (tid < D4_SYNC_WORDS) sync[tid] = 0;
