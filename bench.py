@@ -336,8 +336,12 @@ def rank_body(args, rank, world, dev, make_engine, dist, torch, order_streams=No
         kernels_ran = ("streaming pipelines" if st_launches == ch_launches and ch_launches else
                        "tile kernels" if st_launches == 0 else
                        "%d of %d chain launches as streaming pipelines, the rest as tile kernels" % (st_launches, ch_launches))
+        mixed_one = k1.get("mixed_launches", 0) - k0.get("mixed_launches", 0) > 0
+        if mixed_one:
+            kernels_ran = "every family's streaming pipeline as a range of one launch's workgroups (mixed_stream_kernel)"
         if args.mode == "mixed":
-            timed, timed_samples = "the first demodulator family launched (WBFM's stream / chain kernel)", None
+            timed, timed_samples = ("mixed_stream_kernel: all families' streaming pipelines in one launch" if mixed_one else
+                                    "the first demodulator family launched (WBFM's stream / chain kernel)"), None
         elif args.mode in ("am", "lsb", "usb", "ssb_stress"):
             timed, timed_samples = ("d4_stream_kernel" if streamed else "am_chain_kernel") + " + its DC-removal kernels", n * n_ch
         elif args.mode == "fm":

@@ -71,8 +71,12 @@ typedef struct iqd_config {
  * samples) and a streaming pipeline (one persistent workgroup per CU, used for launches big enough to fill the chip
  * that are not squelch-gated).  These two flags pin the choice for all chains (tests, A/B measurements; the names
  * are from the round in which only WBFM had both); the environment variable IQD_WBFM_PATH=tiles|stream does the same.
- * Two more environment variables exist for measurements only: IQD_FULL_GRID=1 gives every family of a multi-family call all
- * CUs in turn instead of a share of them side by side, IQD_STREAM_WGS=<n> fixes the streaming kernels' workgroup count. */
+ * A call with several families whose streaming pipelines all apply runs them as ranges of ONE launch's workgroups
+ * (stats.mixed_launches), each family on a share of the CUs in proportion to its estimated cost.
+ * More environment variables exist for measurements only, read once by iqd_create: IQD_MIXED=forked runs such a call's
+ * families as kernels of their own on side streams instead (the round-2 arrangement), IQD_FULL_GRID=1 then gives every
+ * family all CUs in turn instead of a share of them side by side, IQD_FAMILY_WEIGHTS=am,fm,wbfm,ssb replaces the
+ * relative cost estimates, IQD_STREAM_WGS=<n> fixes the streaming kernels' workgroup count. */
 #define IQD_F_WBFM_TILES  0x2u
 #define IQD_F_WBFM_STREAM 0x4u
 
@@ -230,6 +234,7 @@ typedef struct iqd_stats {
     uint64_t stream_launches;    /* chain launches (any family) that ran as a streaming pipeline */
     uint64_t device_launches;    /* kernel-launch calls queued by iqd_accept_* (all kinds) */
     uint64_t device_copies;      /* memcpy / memset operations queued by iqd_accept_* */
+    uint64_t mixed_launches;     /* calls whose families' streaming pipelines ran as ranges of one launch */
 } iqd_stats;
 
 int iqd_get_stats(iqd_t *e, iqd_stats *out);

@@ -27,7 +27,8 @@ class Stats(C.Structure):
     _fields_ = [("accepts", C.c_uint64), ("samples", C.c_uint64), ("kernel_launches", C.c_uint64),
                 ("state_checks", C.c_uint64), ("state_repairs", C.c_uint64),
                 ("chain_kernel_ms", C.c_double), ("chain_kernel_count", C.c_uint64), ("segment_repairs", C.c_uint64),
-                ("stream_launches", C.c_uint64), ("device_launches", C.c_uint64), ("device_copies", C.c_uint64)]
+                ("stream_launches", C.c_uint64), ("device_launches", C.c_uint64), ("device_copies", C.c_uint64),
+                ("mixed_launches", C.c_uint64)]
 
 
 class AgcState(C.Structure):

@@ -21,6 +21,7 @@
 #include "iqd_host.h"
 #include "iqd_kernels.h"
 #include "iqd_stream.h"
+#include "iqd_stream_mixed.h"
 #include "iqd_taps.h"
 #include "iqd_wbfm.h"
 #include "iqd_chains.h"
@@ -79,6 +80,8 @@ struct iqd_engine {
     // (+1 / -1, 0 = choose), IQD_FULL_GRID, IQD_STREAM_WGS=<n>, IQD_PLAN_CHUNKS=<k>
     int env_path = 0;
     bool env_full_grid = false;
+    bool env_mixed_forked = false;         // IQD_MIXED=forked: several families as kernels of their own side by side (A/B runs)
+    float fam_weight[FAM_COUNT] = {3.4f, 6.3f, 10.8f, 3.6f};   // relative cost per channel-sample of the streaming pipelines: AM, FM, WBFM, SSB
     uint32_t env_stream_wgs = 0, env_plan_chunks = 0, env_stream_gran = 0;
     size_t dcr_layout[2][2] = {{~(size_t)0, 0}, {~(size_t)0, 0}};   // AM / SSB: where the DC redo flags sit in their buffer, and how many
     bool any_gated = false, any_agc = false;
@@ -235,6 +238,12 @@ int iqd_create(const iqd_config *cfg, iqd_t **out)
     e->flags = cfg->flags;
     if (const char *env = getenv("IQD_WBFM_PATH")) e->env_path = env[0] == 's' ? 1 : env[0] == 't' ? -1 : 0;
     e->env_full_grid = getenv("IQD_FULL_GRID") != nullptr;
+    if (const char *env = getenv("IQD_MIXED")) e->env_mixed_forked = env[0] == 'f' && env[1] == 'o';
+    if (const char *env = getenv("IQD_FAMILY_WEIGHTS")) {   // "am,fm,wbfm,ssb" (measurement runs)
+        float w[FAM_COUNT];
+        if (sscanf(env, "%f,%f,%f,%f", &w[0], &w[1], &w[2], &w[3]) == 4 && w[0] > 0 && w[1] > 0 && w[2] > 0 && w[3] > 0)
+            for (int f = 0; f < FAM_COUNT; f++) e->fam_weight[f] = w[f];
+    }
     if (const char *env = getenv("IQD_STREAM_WGS")) e->env_stream_wgs = atoi(env) > 0 ? (uint32_t)atoi(env) : 0u;
     if (const char *env = getenv("IQD_STREAM_GRAN")) e->env_stream_gran = (uint32_t)atoi(env);
     if (const char *env = getenv("IQD_PLAN_CHUNKS")) e->env_plan_chunks = atoi(env) > 0 ? (uint32_t)atoi(env) : 0u;
@@ -303,7 +312,7 @@ int iqd_create(const iqd_config *cfg, iqd_t **out)
     {
         static std::mutex attr_mu;   // engines may be created from several threads
         std::lock_guard<std::mutex> lk(attr_mu);
-        ok = ok && init_wbfm_stream_kernels() == hipSuccess && init_d4_stream_kernels() == hipSuccess;
+        ok = ok && init_wbfm_stream_kernels() == hipSuccess && init_d4_stream_kernels() == hipSuccess && init_mixed_stream_kernels() == hipSuccess;
     }
     ok = ok && hipMalloc((void **)&e->d_params, n * sizeof(ChanParams)) == hipSuccess;
     ok = ok && hipMalloc((void **)&e->d_tails, n * FAM_COUNT * TAIL_BYTES) == hipSuccess;
@@ -1195,9 +1204,10 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
             }
         }
         HIP_TRY(e, e->base8k.ensure((size_t)n_ch * base.pcm_stride * sizeof(int32_t)));   // before the fork: shared by AM and SSB
-        HIP_TRY(e, hipEventRecord(e->fam_fork, s_main));
     }
-    static const float weight[FAM_COUNT] = {3.4f, 5.2f, 9.0f, 2.9f};   // relative cost per channel-sample: AM, FM, WBFM, SSB (streaming kernels side by side, 64 CUs each: 138 / 211 / 326 / 117 us per 820 channels x 2^16)
+    // relative cost per channel-sample: AM, FM, WBFM, SSB (the families' workgroups side by side: 214 / 228 / 227 / 259 us on
+    // 32 / 56 / 96 / 56 CUs for 819 / 819 / 820 / 1638 channels x 2^16, profiles/r3_mixed_4096_kernel_stats.csv)
+    const float *weight = e->fam_weight;
     int order[FAM_COUNT] = {0, 1, 2, 3};
     float cost[FAM_COUNT];
     for (int f = 0; f < FAM_COUNT; f++) cost[f] = weight[f] * (float)e->h_lists[f].size();
@@ -1208,6 +1218,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
     // configuration, 4096 channels x 2^16: 0.45 ms per step with every family on all CUs in turn, 0.39 with shares.)
     uint32_t fam_share[FAM_COUNT];
     bool shares_on = false;   // the families of this call run their streaming kernels side by side, each on a share of the CUs
+    bool fused = false;       // ... as ranges of one launch's workgroups
     {
         float total = 0.f;
         for (int f = 0; f < FAM_COUNT; f++) total += cost[f];
@@ -1226,8 +1237,31 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
             if ((f == FAM_AM || f == FAM_SSB) && vlen / 32 <= 512) all_stream = false;
         }
         shares_on = forked && all_stream && total > 0.f && e->n_cus >= 64 && !e->env_full_grid;
-        if (shares_on && !plan_family_shares(cost, FAM_COUNT, e->n_cus, fam_share)) shares_on = false;
+        // ONE launch for all of them (iqd_stream_mixed.hip) when each family can take its streaming pipeline in the plain
+        // instantiation: nothing squelch-gated, the WBFM channels of one rotation selector and without a gain change
+        // in reach of a lead-in, gains below the "integer indefinite" bounds, AM / SSB rows that the one-wave DC pass takes
+        fused = shares_on && !chain_gated && !e->env_mixed_forked && e->env_path == 0 && !e->env_stream_wgs &&
+                !(e->flags & IQD_F_WBFM_STREAM);
+        if (fused && !e->h_lists[FAM_WBFM].empty()) {
+            const auto &l = e->h_lists[FAM_WBFM];
+            const int rot0 = e->h_params[first_ch + l[0]].rotation;
+            fused = e->stream_ok;
+            for (uint32_t c : l) {
+                fused = fused && e->h_params[first_ch + c].rotation == rot0 && e->wbfm_kmax[first_ch + c] * 3.1730f < 2147483648.0f;
+                fused = fused && !(e->wbfm_epochs_live && e->wbfm_epoch_left[first_ch + c] != 0);
+            }
+        }
+        if (fused)
+            for (uint32_t c : e->h_lists[FAM_FM]) fused = fused && e->fm_kmax[first_ch + c] * 6.35f < 2147483648.0f;
+        if (fused && (!e->h_lists[FAM_AM].empty() || !e->h_lists[FAM_SSB].empty()))
+            fused = vlen / 32 > 512 && (bytes_per_ch / 64 + DC_TILE - 1) / DC_TILE < 2;
+        if (shares_on && fused) plan_fused_shares(cost, FAM_COUNT, e->n_cus, fam_share);
+        else if (shares_on && !plan_family_shares(cost, FAM_COUNT, e->n_cus, fam_share)) shares_on = false;
+        if (!shares_on) fused = false;
     }
+    MixedStreamArgs mix{};
+    uint32_t mix_wgs = 0;
+    if (forked && !fused) HIP_TRY(e, hipEventRecord(e->fam_fork, s_main));
     float lane_load[4] = {0.f, 0.f, 0.f, 0.f};   // 0: the engine's stream, 1 to 3: the side streams
     bool lane_used[4] = {false, false, false, false};
     size_t (*dcr_layout)[2] = e->dcr_layout;
@@ -1239,7 +1273,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         const uint32_t n_list = (uint32_t)e->h_lists[f].size();
         if (!n_list) continue;
         int lane = 0;
-        if (forked) {
+        if (forked && !fused) {
             for (int k = 1; k < 4; k++)
                 if (lane_load[k] < lane_load[lane]) lane = k;
             lane_load[lane] += cost[f];
@@ -1317,7 +1351,8 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
                 use_d4 = true;
             }
         }
-        if (e->profiling && !timed) {
+        if (fused && !((f == FAM_WBFM && use_stream) || (f != FAM_WBFM && use_d4))) return e->fail(IQD_EINVAL, "a family of a fused launch fell off its streaming pipeline");
+        if (e->profiling && !timed && !fused) {
             if (e->ev_free_pairs.empty()) {
                 hipEvent_t a0, a1;
                 HIP_TRY(e, hipEventCreate(&a0));
@@ -1350,8 +1385,17 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
                 bool epochs_live = false;
                 if (e->wbfm_epochs_live)
                     for (uint32_t c : e->h_lists[FAM_WBFM]) epochs_live = epochs_live || e->wbfm_epoch_left[first_ch + c] != 0;
-                HIP_LAUNCH(e, launch_wbfm_stream(a, sa, stream_rot, fused_mag, epochs_live, grid, s));
-                HIP_LAUNCH(e, launch_wbfm_stream_fixup(a, sa, s));
+                if (fused) {   // a range of the one launch's workgroups; the fix-up rides in the launch behind it
+                    a.wg_first = mix_wgs;
+                    a.wg_count = grid;
+                    mix_wgs += grid;
+                    mix.a[f] = a;
+                    mix.sa = sa;
+                    mix.wbfm_rot = stream_rot;
+                } else {
+                    HIP_LAUNCH(e, launch_wbfm_stream(a, sa, stream_rot, fused_mag, epochs_live, grid, s));
+                    HIP_LAUNCH(e, launch_wbfm_stream_fixup(a, sa, s));
+                }
                 if (!chain_gated) e->stream_handoffs += (uint64_t)n_list * ((vlen + a.tile_len - 1) / a.tile_len - 1);
                 e->stats.stream_launches++;
             } else {
@@ -1362,7 +1406,15 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
                 const uint32_t wgs_needed = (d4.group_start[3] + ST_SEGS - 1) / ST_SEGS;
                 const uint32_t grid = wgs_needed < d4_wgs ? wgs_needed : d4_wgs;
                 d4.rounds = (wgs_needed + grid - 1) / grid;
-                HIP_LAUNCH(e, launch_d4_stream(a, d4, D4_FM, fused_mag, grid, s));
+                if (fused) {
+                    a.wg_first = mix_wgs;
+                    a.wg_count = grid;
+                    mix_wgs += grid;
+                    mix.a[f] = a;
+                    mix.d4[f] = d4;
+                } else {
+                    HIP_LAUNCH(e, launch_d4_stream(a, d4, D4_FM, fused_mag, grid, s));
+                }
                 e->stats.stream_launches++;
             } else {
                 HIP_LAUNCH(e, launch_fm(a, chain_gated, fused_mag, n_list * a.tiles_per_ch, s));
@@ -1388,8 +1440,16 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
             const uint32_t wgs_needed = (d4.group_start[3] + ST_SEGS - 1) / ST_SEGS;
             const uint32_t grid = wgs_needed < d4_wgs ? wgs_needed : d4_wgs;
             d4.rounds = (wgs_needed + grid - 1) / grid;
-            HIP_LAUNCH(e, launch_d4_stream(a, d4, f == FAM_AM ? D4_AM : D4_SSB, fused_mag, grid, s));
-            HIP_LAUNCH(e, launch_am_dc(a, f, s));
+            if (fused) {
+                a.wg_first = mix_wgs;
+                a.wg_count = grid;
+                mix_wgs += grid;
+                mix.a[f] = a;
+                mix.d4[f] = d4;
+            } else {
+                HIP_LAUNCH(e, launch_d4_stream(a, d4, f == FAM_AM ? D4_AM : D4_SSB, fused_mag, grid, s));
+                HIP_LAUNCH(e, launch_am_dc(a, f, s));
+            }
             e->stats.stream_launches++;
         } else {
             HIP_TRY(e, e->base8k.ensure((size_t)n_ch * base.pcm_stride * sizeof(int32_t)));
@@ -1411,12 +1471,13 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
             }
             HIP_LAUNCH(e, launch_am(a, f, chain_gated, fused_mag, n_list * a.tiles_per_ch, s));
         }
-        if (e->profiling && !timed) {
+        if (e->profiling && !timed && !fused) {
             HIP_TRY(e, hipEventRecord(evp.second, s));
             e->ev_pending.push_back(evp);
             timed = true;
         }
         e->stats.kernel_launches++;
+        if (fused) continue;   // (one launch for all the families and one for what follows them, behind this loop)
         if (f == FAM_WBFM && !chain_gated && e->wbfm_epochs_live)   // every channel of the family has consumed vlen samples
             for (uint32_t c : e->h_lists[FAM_WBFM]) {
                 uint32_t &left = e->wbfm_epoch_left[first_ch + c];
@@ -1446,6 +1507,34 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         }
     }
     s = s_main;
+    if (fused) {
+        if (e->profiling) {
+            if (e->ev_free_pairs.empty()) {
+                hipEvent_t a0, a1;
+                HIP_TRY(e, hipEventCreate(&a0));
+                HIP_TRY(e, hipEventCreate(&a1));
+                e->ev_free_pairs.emplace_back(a0, a1);
+            }
+            evp = e->ev_free_pairs.back();
+            e->ev_free_pairs.pop_back();
+            HIP_TRY(e, hipEventRecord(evp.first, s));
+        }
+        HIP_LAUNCH(e, launch_mixed_stream(mix, fused_mag, mix_wgs, s));
+        e->stats.mixed_launches++;
+        if (e->profiling) {
+            HIP_TRY(e, hipEventRecord(evp.second, s));
+            e->ev_pending.push_back(evp);
+        }
+        MixedTailArgs mt{};
+        for (int f = 0; f < FAM_COUNT; f++) mt.a[f] = mix.a[f];
+        mt.sa = mix.sa;
+        HIP_LAUNCH(e, launch_mixed_tail(mt, s));
+        if (mix.a[FAM_WBFM].wg_count) {   // repair check, state commit and tail of the WBFM channels: in the squelch launch below
+            tail_a = mix.a[FAM_WBFM];
+            tail_f = FAM_WBFM;
+            tail_pending = true;
+        }
+    }
     for (int k = 1; k < 4; k++)
         if (lane_used[k]) {
             HIP_TRY(e, hipEventRecord(e->fam_join[k - 1], e->fam_stream[k - 1]));

@@ -333,6 +333,46 @@ bool plan_family_shares(const float *cost, int n, uint32_t n_cus, uint32_t *shar
     return true;
 }
 
+// The same for ONE launch whose workgroups are split among the families (iqd_stream_mixed.hip): every workgroup has a CU
+// to itself and consecutive workgroups go round the XCDs, so the shares are plain integers in proportion to the cost
+// (largest remainders first), at least one workgroup for a family that is there, all n_wgs given out.
+void plan_fused_shares(const float *cost, int n, uint32_t n_wgs, uint32_t *share)
+{
+    float total = 0.f;
+    int present = 0;
+    for (int f = 0; f < n; f++) {
+        share[f] = 0;
+        if (cost[f] > 0.f) { total += cost[f]; present++; }
+    }
+    if (!present || n_wgs < (uint32_t)present) return;
+    uint32_t given = 0;
+    float rest[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int f = 0; f < n && f < 8; f++) {
+        if (!(cost[f] > 0.f)) continue;
+        const float want = (float)n_wgs * cost[f] / total;
+        uint32_t w = (uint32_t)want;
+        if (w < 1) w = 1;
+        share[f] = w;
+        rest[f] = want - (float)w;
+        given += w;
+    }
+    while (given < n_wgs) {       // hand out what the rounding left, largest remainder first
+        int best = -1;
+        for (int f = 0; f < n && f < 8; f++)
+            if (cost[f] > 0.f && (best < 0 || rest[f] > rest[best])) best = f;
+        share[best]++;
+        rest[best] -= 1.f;
+        given++;
+    }
+    while (given > n_wgs) {       // (the minimum of one per family overdrew it: take from the largest)
+        int big = 0;
+        for (int f = 1; f < n && f < 8; f++)
+            if (share[f] > share[big]) big = f;
+        share[big]--;
+        given--;
+    }
+}
+
 TilePlan plan_stream(uint32_t vlen, uint32_t n_channels, uint32_t streams, uint32_t granule)
 {
     TilePlan p;

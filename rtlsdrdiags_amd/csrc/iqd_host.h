@@ -36,6 +36,7 @@ TilePlan plan_stream(uint32_t vlen, uint32_t n_channels, uint32_t streams, uint3
 // get, in proportion to cost[f] (0 = family absent: its entry becomes n_cus).  Whole multiples of 8, at least 8, two CUs
 // per XCD left unplanned; false (and every entry n_cus) when that cannot be had.  See iqd_host.cpp.
 bool plan_family_shares(const float *cost, int n, uint32_t n_cus, uint32_t *share);
+void plan_fused_shares(const float *cost, int n, uint32_t n_wgs, uint32_t *share);   // several families as ranges of one launch
 
 uint32_t block_magic(uint32_t block_samples);
 

@@ -48,7 +48,14 @@ struct ChainLaunch {
     void *dc_records;             // long AM/SSB rows: [n_list][dc_tiles] DcRecord, then [n_list] redo flags
     uint32_t dc_tiles;            // tiles per channel of the many-wave DC pass (0: not used)
     unsigned long long *stamps;   // diagnostic builds (IQD_STAMPS): [16] phase cycle sums
+    // A launch that runs several families' streaming pipelines side by side (iqd_stream_mixed.hip) gives each a range of
+    // its workgroups; a kernel of its own leaves both zero (= the whole grid).
+    uint32_t wg_first, wg_count;
 };
+#if defined(__HIPCC__)
+__device__ __forceinline__ uint32_t chain_wg(const ChainLaunch &a) { return blockIdx.x - a.wg_first; }
+__device__ __forceinline__ uint32_t chain_wgs(const ChainLaunch &a) { return a.wg_count ? a.wg_count : gridDim.x; }
+#endif
 
 struct SquelchLaunch {
     uint32_t n_ch, first_ch, n_blocks, block_samples;

@@ -4,6 +4,7 @@
 #include "iqd_kernels.h"
 #include "iqd_chains.h"
 #include "iqd_wbfm.h"
+#include "iqd_stream_fix.h"
 
 namespace iqd {
 
@@ -525,6 +526,39 @@ __global__ __launch_bounds__(WB_THREADS, IQD_WBFM_MIN_WAVES) void wbfm_repair_sq
     else squelch_block_body(q, always_open, (blockIdx.x - a.n_list) * 256u + threadIdx.x);
 }
 
+// What follows a launch of several families' streaming pipelines (iqd_stream_mixed.hip), again as one launch: every
+// workgroup has one role - WBFM boundary fix-up (8 segments), DC removal of one AM or SSB channel (its first wave; the
+// one-wave pass of dc_wave_kernel), tail update of one AM / FM / SSB channel.  All of them depend on the stream launch only;
+// the WBFM repair check and state commit, which need the fix-up's verdicts, ride in the squelch launch behind this one.
+struct MixedTailRoles { uint32_t end[6]; };
+// (each launch descriptor a kernel argument of its own: see mixed_stream_kernel)
+__global__ __launch_bounds__(256) void mixed_tail_kernel(const ChainLaunch a_wbfm, const StreamArgs sa, const ChainLaunch a_am,
+                                                         const ChainLaunch a_fm, const ChainLaunch a_ssb, const MixedTailRoles roles)
+{
+    __shared__ DcLds lds;
+    const uint32_t b = blockIdx.x;
+    if (b < roles.end[0]) {
+        wbfm_stream_fixup_body(a_wbfm, sa, b);
+    } else if (b < roles.end[2]) {
+        if (threadIdx.x >= 64) return;
+        const int family = b < roles.end[1] ? FAM_AM : FAM_SSB;
+        const ChainLaunch &a = family == FAM_AM ? a_am : a_ssb;
+        const uint32_t li = b - (family == FAM_AM ? roles.end[0] : roles.end[1]);
+        const uint32_t ch = a.ch_list[li], ech = a.first_ch + ch;
+        DcCarry st = a.dc_carry[2 * (size_t)ech + (family == FAM_SSB ? 1 : 0)];
+        DeviceExec ex{(int)threadIdx.x};
+        dc_block_wave(ex, g_consts, lds, a.base8k + (size_t)ch * a.base_stride_ch, (int)(a.vlen / 32), a.params[ech].gain[family], st,
+                      a.pcm + (size_t)ch * a.pcm_stride);
+        if (threadIdx.x == 0) a.dc_carry[2 * (size_t)ech + (family == FAM_SSB ? 1 : 0)] = st;
+    } else if (b < roles.end[3]) {
+        tail_update_body(a_am, FAM_AM, b - roles.end[2]);
+    } else if (b < roles.end[4]) {
+        tail_update_body(a_fm, FAM_FM, b - roles.end[3]);
+    } else if (b < roles.end[5]) {
+        tail_update_body(a_ssb, FAM_SSB, b - roles.end[4]);
+    }
+}
+
 // Squelch, part 2, one thread per channel, blocks in order: the "signal present" comparison
 // (SignalDetector.cc:259-266) with the IF gain in force, the two-state tracker with its one-block tail
 // (SignalTracker.cc:104-145, Squelch.cc:240-269), the list of open blocks - and the magnitude callback into the
@@ -973,6 +1007,27 @@ hipError_t launch_squelch(const SquelchLaunch &q, bool always_open, hipStream_t 
         else
             hipLaunchKernelGGL(squelch_track_kernel, dim3((q.n_ch + 63) / 64), dim3(64), 0, s, q, always_open ? 1 : 0);
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_mixed_tail(const MixedTailArgs &m, hipStream_t s)
+{
+    // role k's workgroups end at roles.end[k]: fix-up, DC AM, DC SSB, tails AM, tails FM, tails SSB
+    MixedTailRoles roles;
+    uint32_t at = 0;
+    if (m.a[FAM_WBFM].wg_count) at += (m.sa.n_segments + FIX_SEGS - 1) / FIX_SEGS;
+    roles.end[0] = at;
+    if (m.a[FAM_AM].wg_count) at += m.a[FAM_AM].n_list;
+    roles.end[1] = at;
+    if (m.a[FAM_SSB].wg_count) at += m.a[FAM_SSB].n_list;
+    roles.end[2] = at;
+    if (m.a[FAM_AM].wg_count) at += m.a[FAM_AM].n_list;
+    roles.end[3] = at;
+    if (m.a[FAM_FM].wg_count) at += m.a[FAM_FM].n_list;
+    roles.end[4] = at;
+    if (m.a[FAM_SSB].wg_count) at += m.a[FAM_SSB].n_list;
+    roles.end[5] = at;
+    if (at) hipLaunchKernelGGL(mixed_tail_kernel, dim3(at), dim3(256), 0, s, m.a[FAM_WBFM], m.sa, m.a[FAM_AM], m.a[FAM_FM], m.a[FAM_SSB], roles);
     return hipGetLastError();
 }
 

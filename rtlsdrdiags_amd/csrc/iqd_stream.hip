@@ -6,6 +6,7 @@
 #include "iqd_stream.h"
 #include "iqd_wbfm.h"
 #include "iqd_mfma.h"
+#include "iqd_stream_fix.h"
 
 namespace iqd {
 
@@ -44,34 +45,6 @@ __device__ __forceinline__ int st_simd_id() { return (__builtin_amdgcn_s_getreg(
 #else
 #define ST_T(var) do { } while (0)
 #endif
-
-struct StSeg {           // what a lane knows about its segment
-    uint32_t valid, li, tile, ch, ech;
-    int32_t v0, tlen;
-    int32_t vlen;        // samples the channel consumes in this call: all of them, or those of its open blocks (squelch-gated call)
-};
-
-__device__ __forceinline__ StSeg st_segment(const ChainLaunch &a, uint32_t sid, uint32_t n_segments)
-{
-    StSeg s;
-    s.valid = sid < n_segments ? 1u : 0u;
-    const uint32_t id = s.valid ? sid : 0u;
-    s.li = id / a.tiles_per_ch;
-    s.tile = id - s.li * a.tiles_per_ch;
-    s.ch = a.ch_list[s.li];
-    s.ech = a.first_ch + s.ch;
-    // a squelch-gated call: the chain sees the concatenation of the channel's open blocks (IqDataProcessor.cc:793), a
-    // virtual stream of vlen_gated[ch] samples, and the segments are cut on that axis
-    const uint32_t vlen = a.vlen_gated ? a.vlen_gated[s.ch] : a.vlen;
-    s.vlen = (int32_t)vlen;
-    const int64_t v0 = (int64_t)s.tile * a.tile_len;
-    if (v0 >= (int64_t)vlen) { s.valid = 0; s.v0 = 0; s.tlen = 0; return s; }
-    s.v0 = (int32_t)v0;
-    const int64_t rest = (int64_t)vlen - v0;
-    s.tlen = (int32_t)(rest < (int64_t)a.tile_len ? rest : (int64_t)a.tile_len);
-    if (!s.valid) s.tlen = 0;
-    return s;
-}
 
 // ---- P wave: 16 segments, raw bytes -> u[n] -------------------------------------------------------
 // EPOCHS: some channel of the launch has a gain change whose samples a lead-in can still reach (GainEpochList; the host
@@ -114,8 +87,8 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
     asm volatile("" : "+s"(inv_2pi));
     uint32_t pc = 0;                                             // pieces this ring has seen (all rounds)
     for (uint32_t round = 0; round < sa.rounds; round++) {
-        if ((round * gridDim.x + blockIdx.x) * ST_SEGS >= sa.n_segments) break;   // nothing left for this workgroup
-        const uint32_t sid = (round * gridDim.x + blockIdx.x) * ST_SEGS + ring * 64 + row;
+        if ((round * chain_wgs(a) + chain_wg(a)) * ST_SEGS >= sa.n_segments) break;   // nothing left for this workgroup
+        const uint32_t sid = (round * chain_wgs(a) + chain_wg(a)) * ST_SEGS + ring * 64 + row;
         const StSeg sg = st_segment(a, sid, sa.n_segments);
         const ChanParams &p = a.params[sg.ech];
         const uint8_t *iq_ch = a.iq + (size_t)sg.ch * a.ch_stride_bytes;
@@ -543,8 +516,8 @@ __device__ __forceinline__ void st_iir_wave(const ChainLaunch &a, const StreamAr
     const int n_pieces = (ST_HALO + (int)a.tile_len) >> 5;       // a multiple of 4
     uint32_t wg = 0;                                             // pieces read so far (all rounds)
     for (uint32_t round = 0; round < sa.rounds; round++) {
-        if ((round * gridDim.x + blockIdx.x) * ST_SEGS >= sa.n_segments) break;
-        const uint32_t sid = (round * gridDim.x + blockIdx.x) * ST_SEGS + ring * 64 + lane;
+        if ((round * chain_wgs(a) + chain_wg(a)) * ST_SEGS >= sa.n_segments) break;
+        const uint32_t sid = (round * chain_wgs(a) + chain_wg(a)) * ST_SEGS + ring * 64 + lane;
         StIirSeg q;
         q.sg = st_segment(a, sid, sa.n_segments);
         q.pcm_row = a.pcm + (size_t)q.sg.ch * a.pcm_stride;
@@ -660,10 +633,11 @@ __device__ __forceinline__ void st_iir_wave(const ChainLaunch &a, const StreamAr
     }
 }
 
+// The workgroup's whole life: table into LDS, then the waves take their roles.  (A function of its own: the kernel below
+// calls it, and so does the launch that runs several families side by side, iqd_stream_mixed.hip.)
 template <int ROT, bool MAG, bool EPOCHS, bool GATED>
-__global__ __launch_bounds__(ST_THREADS, 4) void wbfm_stream_kernel(const ChainLaunch a, const StreamArgs sa)
+__device__ __forceinline__ void wbfm_stream_body(const ChainLaunch &a, const StreamArgs &sa, uint8_t *st_lds)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t st_lds[];
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)st_lds != 0u) __builtin_trap();   // st_table_read()
     uint32_t *sync = (uint32_t *)(st_lds + ST_TABLE_BYTES + ST_RINGS * ST_RING_SLOTS * ST_SLOT_BYTES);
     const int tid = (int)threadIdx.x;
@@ -675,85 +649,19 @@ __global__ __launch_bounds__(ST_THREADS, 4) void wbfm_stream_kernel(const ChainL
     else st_p_wave<ROT, MAG, EPOCHS, GATED>(a, sa, st_lds, sync, wave - ST_RINGS, lane);
 }
 
-// The first ST_FIX_PCM PCM samples of every cold segment, recomputed with the exact histories its predecessor left
-// (StHist): stage-1 output 0, stage-2 outputs 0..2, then the 40-tap audio decimator in the reference's MAC order with
-// the clamp after every MAC (Decimator_int16.cc:176-238) - which is also what the clamp-free fast path equals when
-// no clamp can fire.  A workgroup takes 8 consecutive segments: their 9 records (the predecessor of the first
-// included) are one contiguous 2304-byte read into LDS; then one thread per segment and PCM sample.
-constexpr int FIX_SEGS = 8;
+#ifndef IQD_STREAM_BODIES_ONLY
+template <int ROT, bool MAG, bool EPOCHS, bool GATED>
+__global__ __launch_bounds__(ST_THREADS, 4) void wbfm_stream_kernel(const ChainLaunch a, const StreamArgs sa)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t st_lds[];
+    wbfm_stream_body<ROT, MAG, EPOCHS, GATED>(a, sa, st_lds);
+}
+#endif
+
+#ifndef IQD_STREAM_BODIES_ONLY
 __global__ __launch_bounds__(32 * FIX_SEGS) void wbfm_stream_fixup_kernel(const ChainLaunch a, const StreamArgs sa)
 {
-    __shared__ uint32_t rec[(FIX_SEGS + 1) * 64];
-    __shared__ uint32_t y2x[FIX_SEGS][41];             // per segment: stage-2 pairs -40 .. 41 with the boundary ones exact
-    const uint32_t sid0 = blockIdx.x * FIX_SEGS;
-    const int tid = (int)threadIdx.x, sl = tid >> 5, i = tid & 31;
-    // Everything this workgroup needs from memory is asked for at once - the segment's channel, the two states of the
-    // hand-off, the nine records - instead of one dependent trip after the other (round 2: 17.6 us of latency for
-    // 47 662 boundaries).
-    const uint32_t sid = sid0 + (uint32_t)sl;
-    const StSeg sg = st_segment(a, sid < sa.n_segments ? sid : 0u, sa.n_segments);
-    const bool live = sid < sa.n_segments && sg.valid && sg.tile != 0;
-    float y_in = 0.f, y_end = 0.f;
-    if (live && i == 31) {
-        const WbfmRecord *r = a.records + (size_t)sg.li * a.tiles_per_ch;
-        y_in = r[sg.tile].y_in;
-        y_end = r[sg.tile - 1].y_end;
-    }
-    {
-        const uint32_t *src = (const uint32_t *)sa.hist + ((size_t)sid0 - (sid0 ? 1 : 0)) * 64;
-        const uint32_t n_avail = (sa.n_segments - sid0 < (uint32_t)FIX_SEGS ? sa.n_segments - sid0 : (uint32_t)FIX_SEGS) + (sid0 ? 1u : 0u);
-        for (uint32_t k = (uint32_t)tid; k < n_avail * 64; k += 32 * FIX_SEGS) rec[k + (sid0 ? 0 : 64)] = src[k];
-    }
-    __syncthreads();
-    const StHist &prev = *(const StHist *)&rec[sl * 64], &own = *(const StHist *)&rec[(sl + 1) * 64];
-    if (live && i < 3) {                               // stage-2 output i (0..2) of the segment, from y1[4i-8 .. 4i+3]
-        int acc = 1 << 14;                             // stage-1 output 0: w[-4 .. 3]
-        acc = dot2(prev.w_last[0], sa.d1p[0], acc);
-        acc = dot2(prev.w_last[1], sa.d1p[1], acc);
-        acc = dot2(own.w_first[0], sa.d1p[2], acc);
-        acc = dot2(own.w_first[1], sa.d1p[3], acc);
-        uint32_t y1[10];                               // pairs: outputs -8 .. 11
-#pragma unroll
-        for (int k = 0; k < 4; k++) y1[k] = prev.y1_last[k];
-#pragma unroll
-        for (int k = 0; k < 6; k++) y1[4 + k] = own.y1_first[k];
-        y1[4] = (y1[4] & 0xffff0000u) | ((uint32_t)(acc >> 15) & 0xffffu);
-        int s2 = 1 << 14;
-#pragma unroll
-        for (int q = 0; q < 6; q++) {
-            const uint32_t d = i == 0 ? y1[5 - q] : (i == 1 ? y1[7 - q] : y1[9 - q]);   // pairs 2i .. 2i+5, newest first
-            s2 = dot2(d, sa.p12p[q], s2);
-        }
-        ((int16_t *)&y2x[sl][20])[i] = (int16_t)(s2 >> 15);   // outputs 0, 1 -> pair 20; output 2 -> low half of pair 21
-    } else if (live) {                                 // the other pairs as they are (each thread a few)
-        for (int p = i - 3; p < 41; p += 29) {
-            if (p == 20) continue;
-            if (p == 21) ((int16_t *)&y2x[sl][21])[1] = (int16_t)(own.y2_first[1] >> 16);
-            else y2x[sl][p] = p < 20 ? prev.y2_last[p] : own.y2_first[p - 20];
-        }
-    }
-    // Hand-off verification of the same segments (what wbfm_verify_kernel does for tile launches): a cold segment's
-    // warmed-up state at its start must be its predecessor's end state, bit for bit.  Only mismatches touch the
-    // device counters (thousands of workgroups adding to one word would cost more than the whole kernel); the host
-    // knows how many hand-offs a launch has.
-    if (live && i == 31 && f2u(y_in) != f2u(y_end)) {   // (bit-equal is the rule; the sub-2^-100 exception needs the channel's K: rare)
-        if (!iir_states_agree(y_in, y_end, a.params[sg.ech].wbfm_k >= 1.0f)) {
-            atomicAdd(&a.counters[CNT_TILE_MISMATCH], 1u);
-            atomicAdd(&a.counters[CNT_STREAM_MISMATCH], 1u);
-            a.repair_flags[sg.li] = 1;
-        }
-    }
-    __syncthreads();   // y2x[sl] was written by this segment's 32 threads, each reads the others' entries (uniform control flow up to here)
-    if (!live || i >= ST_FIX_PCM || i >= sg.tlen / 32) return;
-    // PCM i from stage-2 outputs 2i-38 .. 2i+1: pairs i+1 .. i+20, newest first
-    int s3 = 1 << 14;
-#pragma unroll
-    for (int q = 0; q < 20; q++) {
-        const uint32_t pair = y2x[sl][20 + i - q];
-        s3 = clamp_q30(dot2(pair, sa.a40p[q] & 0xffff0000u, s3));
-        s3 = clamp_q30(dot2(pair, sa.a40p[q] & 0x0000ffffu, s3));
-    }
-    a.pcm[(size_t)sg.ch * a.pcm_stride + (sg.v0 >> 5) + i] = (int16_t)(s3 >> 15);
+    wbfm_stream_fixup_body(a, sa, blockIdx.x);
 }
 
 hipError_t launch_wbfm_stream_fixup(const ChainLaunch &a, const StreamArgs &sa, hipStream_t s)
@@ -789,5 +697,7 @@ hipError_t launch_wbfm_stream(const ChainLaunch &a, const StreamArgs &sa, int ro
     hipLaunchKernelGGL(st_kernels[rotation < 0 ? 0 : rotation > 0 ? 2 : 1][variant][epochs ? 1 : 0], dim3(grid), dim3(ST_THREADS), ST_LDS_BYTES, s, a, sa);
     return hipGetLastError();
 }
+
+#endif   // IQD_STREAM_BODIES_ONLY
 
 }  // namespace iqd

@@ -365,8 +365,8 @@ __device__ __forceinline__ void d4_p_wave(const ChainLaunch &a, const D4Args &da
     const uint32_t wr_off = MODE == D4_FM ? row * 16u + 4u * (uint32_t)g : d4_ring_off(row, (uint32_t)g);   // FM: one dword per lane
     uint32_t pg = 0;                                           // quads this ring has seen (all rounds)
     for (uint32_t round = 0; round < da.rounds; round++) {
-        if ((round * gridDim.x + blockIdx.x) * ST_SEGS >= da.group_start[3]) break;   // nothing left for this workgroup
-        const uint32_t sid0 = (round * gridDim.x + blockIdx.x) * ST_SEGS + ring * 64 + 16 * cg;
+        if ((round * chain_wgs(a) + chain_wg(a)) * ST_SEGS >= da.group_start[3]) break;   // nothing left for this workgroup
+        const uint32_t sid0 = (round * chain_wgs(a) + chain_wg(a)) * ST_SEGS + ring * 64 + 16 * cg;
         const D4Seg sg = d4_segment(a, da, sid0 + (uint32_t)c);
 #if IQD_D4_TRANSPOSE
         const D4Seg sgl = d4_segment(a, da, sid0 + (uint32_t)(lane >> 2));
@@ -539,8 +539,8 @@ __device__ __forceinline__ void d4_am_wave(const ChainLaunch &a, const D4Args &d
     const int n_pieces = (da.halo + (int)a.tile_len) >> 5;
     uint32_t pg = 0;
     for (uint32_t round = 0; round < da.rounds; round++) {
-        if ((round * gridDim.x + blockIdx.x) * ST_SEGS >= da.group_start[3]) break;
-        const uint32_t sid = (round * gridDim.x + blockIdx.x) * ST_SEGS + ring * 64 + lane;
+        if ((round * chain_wgs(a) + chain_wg(a)) * ST_SEGS >= da.group_start[3]) break;
+        const uint32_t sid = (round * chain_wgs(a) + chain_wg(a)) * ST_SEGS + ring * 64 + lane;
         const D4Seg sg = d4_segment(a, da, sid);
         const int lsb = a.params[sg.ech].ssb_lsb;
         int32_t *base_row = a.base8k + (size_t)sg.ch * a.base_stride_ch;
@@ -657,8 +657,8 @@ __device__ __forceinline__ void d4_fm_wave(const ChainLaunch &a, const D4Args &d
     const int n_pieces = (da.halo + (int)a.tile_len) >> 5;
     uint32_t pg = 0;
     for (uint32_t round = 0; round < da.rounds; round++) {
-        if ((round * gridDim.x + blockIdx.x) * ST_SEGS >= da.group_start[3]) break;
-        const uint32_t sid = (round * gridDim.x + blockIdx.x) * ST_SEGS + ring * 64 + lane;
+        if ((round * chain_wgs(a) + chain_wg(a)) * ST_SEGS >= da.group_start[3]) break;
+        const uint32_t sid = (round * chain_wgs(a) + chain_wg(a)) * ST_SEGS + ring * 64 + lane;
         const D4Seg sg = d4_segment(a, da, sid);
         int16_t *pcm_row = a.pcm + (size_t)sg.ch * a.pcm_stride;
         D4Fm s;
@@ -687,10 +687,11 @@ __device__ __forceinline__ void d4_fm_wave(const ChainLaunch &a, const D4Args &d
 #define IQD_D4_AM_TWO_WGS 0
 #endif
 #define D4_WAVES_PER_SIMD(MODE) ((MODE) == D4_AM && IQD_D4_AM_TWO_WGS ? 8 : 4)
+// (a function of its own: the kernel below calls it, and so does the launch that runs several families side by side,
+// iqd_stream_mixed.hip)
 template <int MODE, bool MAG, bool GATED>
-__global__ __launch_bounds__(ST_THREADS, D4_WAVES_PER_SIMD(MODE)) void d4_stream_kernel(const ChainLaunch a, const D4Args da)
+__device__ __forceinline__ void d4_stream_body(const ChainLaunch &a, const D4Args &da, uint8_t *d4_lds)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t d4_lds[];
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)d4_lds != 0u) __builtin_trap();   // st_maglut_chunk_at()
     uint32_t *sync = (uint32_t *)(d4_lds + ST_RINGS * D4_SLOTS * D4_SLOT_BYTES);
     const int tid = (int)threadIdx.x;
@@ -736,6 +737,14 @@ __global__ __launch_bounds__(ST_THREADS, D4_WAVES_PER_SIMD(MODE)) void d4_stream
 #endif
 }
 
+#ifndef IQD_STREAM_BODIES_ONLY
+template <int MODE, bool MAG, bool GATED>
+__global__ __launch_bounds__(ST_THREADS, D4_WAVES_PER_SIMD(MODE)) void d4_stream_kernel(const ChainLaunch a, const D4Args da)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t d4_lds[];
+    d4_stream_body<MODE, MAG, GATED>(a, da, d4_lds);
+}
+
 typedef void (*D4Kernel)(const ChainLaunch, const D4Args);
 // [chain][0: no magnitudes, 1: squelch magnitudes in the kernel, 2: squelch-gated launch (magnitudes taken by the pre-pass)]
 static const D4Kernel d4_kernels[3][3] = {{d4_stream_kernel<D4_AM, false, false>, d4_stream_kernel<D4_AM, true, false>, d4_stream_kernel<D4_AM, false, true>},
@@ -763,5 +772,7 @@ hipError_t launch_d4_stream(const ChainLaunch &a, const D4Args &da, int mode, bo
     hipLaunchKernelGGL(ks[m][gated ? 2 : (mag ? 1 : 0)], dim3(grid), dim3(ST_THREADS), D4_LDS_BYTES, s, a, da);
     return hipGetLastError();
 }
+
+#endif   // IQD_STREAM_BODIES_ONLY
 
 }  // namespace iqd

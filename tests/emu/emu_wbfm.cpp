@@ -233,6 +233,11 @@ void emu_agc_run(uint32_t type, int32_t operating_point, int32_t deadband, float
 }
 
 // host planning logic of the engine, for the CPU tier
+void emu_plan_fused_shares(const float *cost, int n, uint32_t n_wgs, uint32_t *share)
+{
+    iqd::plan_fused_shares(cost, n, n_wgs, share);
+}
+
 int emu_plan_family_shares(const float *cost, int n, uint32_t n_cus, uint32_t *share)
 {
     return iqd::plan_family_shares(cost, n, n_cus, share) ? 1 : 0;

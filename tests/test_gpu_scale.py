@@ -294,16 +294,57 @@ def _run_mixed_on_device(capi, oracle, n_ch, log2, expect_streams, wbfm_every=1,
 def test_config4_mixed_4096_channels_on_cu_shares(capi, oracle):
     """BASELINE configs[3] exactly as `bench.py --config 3` runs it on one GPU: 4096 channels x 2^16 samples,
     channel % 5 -> {AM, FM, WBFM, LSB, USB}, every channel its own data, the rotation selector varying inside the
-    AM / FM / SSB families.  Four streaming kernels run side by side on planned shares of the CUs (stream_launches
-    == 4 per call proves it); two consecutive calls; the first and last channel of every family and rotation group and
+    AM / FM / SSB families.  The four families' streaming pipelines run side by side on planned shares of the CUs, as
+    ranges of one launch's workgroups (stream_launches == 4 per call proves the pipelines ran); two consecutive calls; the first and last channel of every family and rotation group and
     two dozen more against the oracle, every PCM sample and magnitude."""
     checked = _run_mixed_on_device(capi, oracle, 4096, 16, expect_streams=4, extra=40)
     assert checked >= 64
 
 
+def test_one_launch_for_all_families_equals_a_kernel_per_family(capi):
+    """The mixed call runs its families' streaming pipelines as ranges of ONE launch's workgroups (iqd_stream_mixed.hip,
+    stats.mixed_launches); IQD_MIXED=forked keeps the earlier arrangement, a kernel per family on side streams.  Same
+    input, two engines, three calls with a gain change in between: EVERY PCM sample, magnitude and count of all 4096
+    channels identical (the sampled oracle comparison is the test above)."""
+    import os
+    n_ch, n = 4096, 1 << 16
+    u8 = _mixed_rows(n_ch, n, seed=99)
+    outs = []
+    for forked in (False, True):
+        if forked:
+            os.environ["IQD_MIXED"] = "forked"
+        try:
+            eng = capi.Engine(n_ch)          # (the variable is read once, by iqd_create)
+        finally:
+            os.environ.pop("IQD_MIXED", None)
+        _mixed_setup(eng, n_ch)
+        iq_d, pcm_d = eng.dev_alloc(u8.nbytes), eng.dev_alloc(n_ch * (n // 32) * 2)
+        nblk = 2 * n // 32768
+        cnt_d, mag_d = eng.dev_alloc(n_ch * 4), eng.dev_alloc(n_ch * nblk * 4)
+        eng.dev_upload(iq_d, u8)
+        got = []
+        for call in range(3):
+            if call == 2:
+                eng.set_gain("fm", 9000.0, first=1, n=1)          # an FM channel's gain: the next call's lead-ins reach back across it
+            eng.accept_device(iq_d, 2 * n, pcm_d, cnt_d, mag_d)
+            eng.synchronize()
+            got.append((eng.dev_download(pcm_d, n_ch * (n // 32) * 2, np.int16), eng.dev_download(cnt_d, n_ch * 4, np.uint32),
+                        eng.dev_download(mag_d, n_ch * nblk * 4, np.uint32)))
+        st = eng.stats()
+        assert st["mixed_launches"] == (0 if forked else 3) and st["stream_launches"] == 12 and st["state_repairs"] == 0, st
+        outs.append(got)
+        for p_ in (iq_d, pcm_d, cnt_d, mag_d):
+            eng.dev_free(p_)
+        eng.close()
+    for call in range(3):
+        for a, b in zip(outs[0][call], outs[1][call]):
+            assert np.array_equal(a, b), call
+    assert not np.array_equal(outs[0][0][0], outs[0][1][0])       # (the calls differ: state is carried)
+
+
 def test_mixed_1400_channels_at_the_share_threshold(capi, oracle):
     """The smallest mixed call that still plans CU shares (every family brings just enough samples for its share)."""
-    _run_mixed_on_device(capi, oracle, 1400, 16, expect_streams=4)
+    _run_mixed_on_device(capi, oracle, 1410, 16, expect_streams=4)
 
 
 def test_mixed_call_with_a_tiny_family(capi, oracle):

@@ -49,6 +49,33 @@ def test_family_shares_fit_side_by_side_on_every_xcd():
         assert np.all(np.abs(s[present].astype(np.float64) - due) < 16 + 8 * np.count_nonzero(present)), (cost, s)
 
 
+def test_fused_shares_hand_out_every_workgroup_in_proportion():
+    """Several families as ranges of ONE launch (iqd_stream_mixed.hip): plain integers, all workgroups given out."""
+    lib = emu_bind.lib()
+    lib.emu_plan_fused_shares.restype = None
+    lib.emu_plan_fused_shares.argtypes = [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p]
+    rng = np.random.default_rng(5)
+    for _ in range(2000):
+        cost = rng.uniform(0.0, 10000.0, 4).astype(np.float32)
+        cost[rng.random(4) < 0.3] = 0.0
+        if rng.random() < 0.1:
+            cost[cost > 0] *= rng.choice([1e-4, 1.0], size=np.count_nonzero(cost > 0)).astype(np.float32)   # a tiny family beside big ones
+        n_wgs = int(rng.choice([64, 240, 256, 304]))
+        out = np.full(4, 77, np.uint32)
+        lib.emu_plan_fused_shares(cost.ctypes.data, 4, n_wgs, out.ctypes.data)
+        present = cost > 0
+        assert np.all(out[~present] == 0)
+        if not present.any():
+            continue
+        assert out.sum() == n_wgs and np.all(out[present] >= 1)
+        due = n_wgs * cost[present].astype(np.float64) / cost[present].astype(np.float64).sum()
+        assert np.all(np.abs(out[present] - due) < 1.0 + np.count_nonzero(present)), (cost, out)
+    out = np.zeros(4, np.uint32)
+    cost = np.array([3.4 * 819, 6.3 * 819, 10.8 * 820, 3.6 * 1638], np.float32)   # the mixed bench configuration
+    lib.emu_plan_fused_shares(cost.ctypes.data, 4, 256, out.ctypes.data)
+    assert out.tolist() == [31, 58, 100, 67]
+
+
 def test_family_shares_of_the_mixed_bench_configuration(L):
     # 820 AM, 820 FM, 820 WBFM, 1638 SSB channels with the engine's weights 3.4 / 5.2 / 9.0 / 2.9
     ok, s = shares(L, [3.4 * 820, 5.2 * 820, 9.0 * 820, 2.9 * 1638])

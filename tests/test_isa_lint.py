@@ -26,3 +26,13 @@ def test_untracked_loads_are_not_touched_before_they_arrive():
     assert "0 finding(s)" in last and " 9 kernels" in last, last
     n_loads = int(last.split(" global loads")[0].split()[-1])
     assert n_loads > 100          # the lint saw the loads it is about
+
+
+def test_untracked_loads_of_the_mixed_launch():
+    """The launch that runs several families' pipelines side by side compiles the same workgroup bodies a second time."""
+    src = os.path.join(ROOT, "rtlsdrdiags_amd", "csrc", "iqd_stream_mixed.hip")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_lint.py"), src], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-4000:]
+    last = r.stdout.strip().splitlines()[-1]
+    assert "0 finding(s)" in last and " 2 kernels" in last, last
+    assert int(last.split(" global loads")[0].split()[-1]) > 100

@@ -315,13 +315,15 @@ def main():
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(seed)
     O = B.Oracle()
-    t0, cases = time.time(), 0
+    t0, cases, n_wide = time.time(), 0, 0
     while time.time() - t0 < seconds:
         wide = os.environ.get("FUZZ_WIDE") == "1" or (os.environ.get("FUZZ_WIDE") is None and rng.random() < 0.03)
         if not (wide_case(rng, O) if wide else one_case(rng, O)):
             sys.exit(1)
         cases += 1
-    print("gpu_fuzz: %d cases identical to the oracle in %.0f s (seed %d)" % (cases, time.time() - t0, seed))
+        n_wide += 1 if wide else 0
+    print("gpu_fuzz: %d cases (%d of them wide: hundreds to thousands of channels) identical to the oracle in %.0f s (seed %d)"
+          % (cases, n_wide, time.time() - t0, seed))
 
 
 if __name__ == "__main__":

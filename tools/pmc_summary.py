@@ -40,7 +40,7 @@ def code_object_notes(kernel_demangled):
     base = m.group(1)
     tpl = re.search(r"<(.*)>\(", kernel_demangled)
     out = {}
-    for unit in ("iqd_stream.hip", "iqd_stream2.hip", "iqd_kernels.hip"):
+    for unit in ("iqd_stream_mixed.hip", "iqd_stream.hip", "iqd_stream2.hip", "iqd_kernels.hip"):
         src = os.path.join(CSRC, unit)
         if base not in open(src).read():
             continue
