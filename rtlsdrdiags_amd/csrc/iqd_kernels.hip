@@ -535,10 +535,11 @@ struct MixedTailRoles { uint32_t end[6]; };
 __global__ __launch_bounds__(256) void mixed_tail_kernel(const ChainLaunch a_wbfm, const StreamArgs sa, const ChainLaunch a_am,
                                                          const ChainLaunch a_fm, const ChainLaunch a_ssb, const MixedTailRoles roles)
 {
-    __shared__ DcLds lds;
+    __shared__ union Lds { DcLds dc; FixLds fix; __device__ Lds() {} } u;   // (a workgroup has one role: 14 KB, eleven of them per CU)
+    DcLds &lds = u.dc;
     const uint32_t b = blockIdx.x;
     if (b < roles.end[0]) {
-        wbfm_stream_fixup_body(a_wbfm, sa, b);
+        wbfm_stream_fixup_body(a_wbfm, sa, b, u.fix);
     } else if (b < roles.end[2]) {
         if (threadIdx.x >= 64) return;
         const int family = b < roles.end[1] ? FAM_AM : FAM_SSB;

@@ -661,7 +661,8 @@ __global__ __launch_bounds__(ST_THREADS, 4) void wbfm_stream_kernel(const ChainL
 #ifndef IQD_STREAM_BODIES_ONLY
 __global__ __launch_bounds__(32 * FIX_SEGS) void wbfm_stream_fixup_kernel(const ChainLaunch a, const StreamArgs sa)
 {
-    wbfm_stream_fixup_body(a, sa, blockIdx.x);
+    __shared__ FixLds fl;
+    wbfm_stream_fixup_body(a, sa, blockIdx.x, fl);
 }
 
 hipError_t launch_wbfm_stream_fixup(const ChainLaunch &a, const StreamArgs &sa, hipStream_t s)

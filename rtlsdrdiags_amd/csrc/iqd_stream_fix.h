@@ -46,10 +46,14 @@ __device__ __forceinline__ StSeg st_segment(const ChainLaunch &a, uint32_t sid, 
 // no clamp can fire.  A workgroup takes 8 consecutive segments: their 9 records (the predecessor of the first
 // included) are one contiguous 2304-byte read into LDS; then one thread per segment and PCM sample.
 constexpr int FIX_SEGS = 8;
-__device__ __forceinline__ void wbfm_stream_fixup_body(const ChainLaunch &a, const StreamArgs &sa, const uint32_t block)
+struct FixLds {
+    uint32_t rec[(FIX_SEGS + 1) * 64];
+    uint32_t y2x[FIX_SEGS][41];             // per segment: stage-2 pairs -40 .. 41 with the boundary ones exact
+};
+__device__ __forceinline__ void wbfm_stream_fixup_body(const ChainLaunch &a, const StreamArgs &sa, const uint32_t block, FixLds &fl)
 {
-    __shared__ uint32_t rec[(FIX_SEGS + 1) * 64];
-    __shared__ uint32_t y2x[FIX_SEGS][41];             // per segment: stage-2 pairs -40 .. 41 with the boundary ones exact
+    uint32_t (&rec)[(FIX_SEGS + 1) * 64] = fl.rec;
+    uint32_t (&y2x)[FIX_SEGS][41] = fl.y2x;
     const uint32_t sid0 = block * FIX_SEGS;
     const int tid = (int)threadIdx.x, sl = tid >> 5, i = tid & 31;
     // Everything this workgroup needs from memory is asked for at once - the segment's channel, the two states of the

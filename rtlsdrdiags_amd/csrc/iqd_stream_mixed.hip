@@ -27,7 +27,7 @@ __global__ __launch_bounds__(ST_THREADS, 4) void mixed_stream_kernel(const Chain
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t mx_lds[];
     const uint32_t b = blockIdx.x;
-#if IQD_MIXED_TIMING   // diagnostic build: stamps[16 + workgroup] = its run time in 10 ns ticks, family in the top byte (tools/mixed_probe.py)
+#if IQD_MIXED_TIMING   // diagnostic build: stamps[16 + workgroup] = its run time in 10 ns ticks, family in the top byte, stamps[528 + workgroup] = when it started (tools/mixed_probe.py)
     const unsigned long long t_wg0 = wall_clock64();
     const int fam_of_wg = b - a_wbfm.wg_first < a_wbfm.wg_count ? FAM_WBFM : b - a_fm.wg_first < a_fm.wg_count ? FAM_FM : b - a_ssb.wg_first < a_ssb.wg_count ? FAM_SSB : FAM_AM;
 #endif
@@ -48,6 +48,7 @@ __global__ __launch_bounds__(ST_THREADS, 4) void mixed_stream_kernel(const Chain
     if (threadIdx.x == 0) {
         const unsigned long long dt = wall_clock64() - t_wg0;
         a_wbfm.stamps[16 + b] = dt | ((unsigned long long)fam_of_wg << 56);
+        a_wbfm.stamps[16 + 512 + b] = t_wg0;
     }
 #endif
 }

@@ -21,11 +21,14 @@ iq = eng.dev_alloc(2 * n * n_ch); pcm = eng.dev_alloc(2 * (n // 32) * n_ch)
 eng.dev_upload(iq, u8); eng.dev_tile(iq, 2 * n, 2 * n * n_ch)
 for k in range(3):
     eng.accept_device(iq, 2 * n, pcm); eng.synchronize()
-    st = eng.debug_stamps_ext(16 + 304)[16:]
+    raw = eng.debug_stamps_ext(16 + 512 + 304)
+    st, t0s = raw[16:16 + 304], [t for t in raw[16 + 512:] if t]
     fam = {0: "am", 1: "fm", 2: "wbfm", 3: "ssb"}
     rows = {}
     for v in st:
         if v:
             rows.setdefault(fam[v >> 56], []).append((v & ((1 << 56) - 1)) / 100.0)
+    ends = [t + (v & ((1 << 56) - 1)) for t, v in zip(raw[16 + 512:], st) if v]
+    print("launch", k, " first to last workgroup START %.1f us, first start to last END %.1f us" % ((max(t0s) - min(t0s)) / 100.0, (max(ends) - min(t0s)) / 100.0))
     print("launch", k, " workgroups, slowest / mean / fastest (us):",
           {f: (len(t), round(max(t), 1), round(sum(t) / len(t), 1), round(min(t), 1)) for f, t in rows.items()})
