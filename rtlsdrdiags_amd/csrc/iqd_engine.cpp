@@ -1238,9 +1238,9 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         }
         shares_on = forked && all_stream && total > 0.f && e->n_cus >= 64 && !e->env_full_grid;
         // ONE launch for all of them (iqd_stream_mixed.hip) when each family can take its streaming pipeline in the plain
-        // instantiation: nothing squelch-gated, the WBFM channels of one rotation selector and without a gain change
-        // in reach of a lead-in, gains below the "integer indefinite" bounds, AM / SSB rows that the one-wave DC pass takes
-        fused = shares_on && !chain_gated && !e->env_mixed_forked && e->env_path == 0 && !e->env_stream_wgs &&
+        // instantiation: the WBFM channels of one rotation selector and without a gain change in reach of a lead-in,
+        // gains below the "integer indefinite" bounds, AM / SSB rows that the one-wave DC pass takes
+        fused = shares_on && !e->env_mixed_forked && e->env_path == 0 && !e->env_stream_wgs &&
                 !(e->flags & IQD_F_WBFM_STREAM);
         if (fused && !e->h_lists[FAM_WBFM].empty()) {
             const auto &l = e->h_lists[FAM_WBFM];
@@ -1519,7 +1519,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
             e->ev_free_pairs.pop_back();
             HIP_TRY(e, hipEventRecord(evp.first, s));
         }
-        HIP_LAUNCH(e, launch_mixed_stream(mix, fused_mag, mix_wgs, s));
+        HIP_LAUNCH(e, launch_mixed_stream(mix, fused_mag, chain_gated, mix_wgs, s));
         e->stats.mixed_launches++;
         if (e->profiling) {
             HIP_TRY(e, hipEventRecord(evp.second, s));

@@ -548,7 +548,8 @@ __global__ __launch_bounds__(256) void mixed_tail_kernel(const ChainLaunch a_wbf
         const uint32_t ch = a.ch_list[li], ech = a.first_ch + ch;
         DcCarry st = a.dc_carry[2 * (size_t)ech + (family == FAM_SSB ? 1 : 0)];
         DeviceExec ex{(int)threadIdx.x};
-        dc_block_wave(ex, g_consts, lds, a.base8k + (size_t)ch * a.base_stride_ch, (int)(a.vlen / 32), a.params[ech].gain[family], st,
+        const uint32_t vlen = a.vlen_gated ? a.vlen_gated[ch] : a.vlen;
+        dc_block_wave(ex, g_consts, lds, a.base8k + (size_t)ch * a.base_stride_ch, (int)(vlen / 32), a.params[ech].gain[family], st,
                       a.pcm + (size_t)ch * a.pcm_stride);
         if (threadIdx.x == 0) a.dc_carry[2 * (size_t)ech + (family == FAM_SSB ? 1 : 0)] = st;
     } else if (b < roles.end[3]) {

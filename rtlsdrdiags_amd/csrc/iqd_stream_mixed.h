@@ -25,7 +25,7 @@ struct MixedTailArgs {
     StreamArgs sa;
 };
 hipError_t init_mixed_stream_kernels();
-hipError_t launch_mixed_stream(const MixedStreamArgs &m, bool mag, uint32_t grid, hipStream_t s);
+hipError_t launch_mixed_stream(const MixedStreamArgs &m, bool mag, bool gated, uint32_t grid, hipStream_t s);
 hipError_t launch_mixed_tail(const MixedTailArgs &m, hipStream_t s);
 
 }  // namespace iqd

@@ -19,7 +19,9 @@ namespace iqd {
 
 // (Every family's launch descriptor is a kernel argument of its own: as members of one 2.6 KB argument the compiler copied
 // the lot to scratch and read tap tables from there inside the piece loops.)
-template <bool MAG>
+// GATED: the call is squelch-gated (a pre-pass took the magnitudes and the decisions; the pipelines walk each channel's
+// open blocks).
+template <bool MAG, bool GATED>
 __global__ __launch_bounds__(ST_THREADS, 4) void mixed_stream_kernel(const ChainLaunch a_wbfm, const StreamArgs sa, const int32_t wbfm_rot,
                                                                      const ChainLaunch a_fm, const D4Args d_fm,
                                                                      const ChainLaunch a_ssb, const D4Args d_ssb,
@@ -33,15 +35,15 @@ __global__ __launch_bounds__(ST_THREADS, 4) void mixed_stream_kernel(const Chain
 #endif
     // (WBFM first: its workgroups start with 134 KB of table to fetch)
     if (b - a_wbfm.wg_first < a_wbfm.wg_count) {
-        if (wbfm_rot == 0) wbfm_stream_body<0, MAG, false, false>(a_wbfm, sa, mx_lds);
-        else if (wbfm_rot > 0) wbfm_stream_body<1, MAG, false, false>(a_wbfm, sa, mx_lds);
-        else wbfm_stream_body<-1, MAG, false, false>(a_wbfm, sa, mx_lds);
+        if (wbfm_rot == 0) wbfm_stream_body<0, MAG, false, GATED>(a_wbfm, sa, mx_lds);
+        else if (wbfm_rot > 0) wbfm_stream_body<1, MAG, false, GATED>(a_wbfm, sa, mx_lds);
+        else wbfm_stream_body<-1, MAG, false, GATED>(a_wbfm, sa, mx_lds);
     } else if (b - a_fm.wg_first < a_fm.wg_count) {
-        d4_stream_body<D4_FM, MAG, false>(a_fm, d_fm, mx_lds);
+        d4_stream_body<D4_FM, MAG, GATED>(a_fm, d_fm, mx_lds);
     } else if (b - a_ssb.wg_first < a_ssb.wg_count) {
-        d4_stream_body<D4_SSB, MAG, false>(a_ssb, d_ssb, mx_lds);
+        d4_stream_body<D4_SSB, MAG, GATED>(a_ssb, d_ssb, mx_lds);
     } else if (b - a_am.wg_first < a_am.wg_count) {
-        d4_stream_body<D4_AM, MAG, false>(a_am, d_am, mx_lds);
+        d4_stream_body<D4_AM, MAG, GATED>(a_am, d_am, mx_lds);
     }
 #if IQD_MIXED_TIMING
     __syncthreads();
@@ -55,21 +57,24 @@ __global__ __launch_bounds__(ST_THREADS, 4) void mixed_stream_kernel(const Chain
 
 constexpr int MX_LDS_BYTES = ST_LDS_BYTES > D4_LDS_BYTES ? ST_LDS_BYTES : D4_LDS_BYTES;
 
+typedef void (*MxKernel)(const ChainLaunch, const StreamArgs, const int32_t, const ChainLaunch, const D4Args, const ChainLaunch, const D4Args,
+                         const ChainLaunch, const D4Args);
+// [0: no magnitudes, 1: squelch magnitudes in the kernel, 2: squelch-gated call]
+static const MxKernel mx_kernels[3] = {mixed_stream_kernel<false, false>, mixed_stream_kernel<true, false>, mixed_stream_kernel<false, true>};
+
 hipError_t init_mixed_stream_kernels()
 {
-    hipError_t e = hipFuncSetAttribute((const void *)mixed_stream_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, MX_LDS_BYTES);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void *)mixed_stream_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, MX_LDS_BYTES);
+    for (int k = 0; k < 3; k++) {
+        const hipError_t e = hipFuncSetAttribute((const void *)mx_kernels[k], hipFuncAttributeMaxDynamicSharedMemorySize, MX_LDS_BYTES);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
-hipError_t launch_mixed_stream(const MixedStreamArgs &m, bool mag, uint32_t grid, hipStream_t s)
+hipError_t launch_mixed_stream(const MixedStreamArgs &m, bool mag, bool gated, uint32_t grid, hipStream_t s)
 {
-    if (mag)
-        hipLaunchKernelGGL(mixed_stream_kernel<true>, dim3(grid), dim3(ST_THREADS), MX_LDS_BYTES, s, m.a[FAM_WBFM], m.sa, m.wbfm_rot,
-                           m.a[FAM_FM], m.d4[FAM_FM], m.a[FAM_SSB], m.d4[FAM_SSB], m.a[FAM_AM], m.d4[FAM_AM]);
-    else
-        hipLaunchKernelGGL(mixed_stream_kernel<false>, dim3(grid), dim3(ST_THREADS), MX_LDS_BYTES, s, m.a[FAM_WBFM], m.sa, m.wbfm_rot,
-                           m.a[FAM_FM], m.d4[FAM_FM], m.a[FAM_SSB], m.d4[FAM_SSB], m.a[FAM_AM], m.d4[FAM_AM]);
+    hipLaunchKernelGGL(mx_kernels[gated ? 2 : (mag ? 1 : 0)], dim3(grid), dim3(ST_THREADS), MX_LDS_BYTES, s, m.a[FAM_WBFM], m.sa, m.wbfm_rot,
+                       m.a[FAM_FM], m.d4[FAM_FM], m.a[FAM_SSB], m.d4[FAM_SSB], m.a[FAM_AM], m.d4[FAM_AM]);
     return hipGetLastError();
 }
 

@@ -301,14 +301,20 @@ def test_config4_mixed_4096_channels_on_cu_shares(capi, oracle):
     assert checked >= 64
 
 
-def test_one_launch_for_all_families_equals_a_kernel_per_family(capi):
+@pytest.mark.parametrize("squelch", [None, -38])
+def test_one_launch_for_all_families_equals_a_kernel_per_family(capi, squelch):
     """The mixed call runs its families' streaming pipelines as ranges of ONE launch's workgroups (iqd_stream_mixed.hip,
     stats.mixed_launches); IQD_MIXED=forked keeps the earlier arrangement, a kernel per family on side streams.  Same
     input, two engines, three calls with a gain change in between: EVERY PCM sample, magnitude and count of all 4096
-    channels identical (the sampled oracle comparison is the test above)."""
+    channels identical (the sampled oracle comparison is the test above).  With a squelch threshold the call is gated -
+    a third of the rows have a quiet second block that closes behind the one-block tail - and the same launch runs the
+    pipelines' gated instantiations on each channel's open blocks."""
     import os
     n_ch, n = 4096, 1 << 16
     u8 = _mixed_rows(n_ch, n, seed=99)
+    if squelch is not None:
+        quiet = np.arange(n_ch) % 3 == 1
+        u8[quiet, 32768:98304] = 128 + ((u8[quiet, 32768:98304].astype(np.int16) - 128) // 32).astype(np.int16)   # blocks 1 and 2 of 4
     outs = []
     for forked in (False, True):
         if forked:
@@ -318,7 +324,10 @@ def test_one_launch_for_all_families_equals_a_kernel_per_family(capi):
         finally:
             os.environ.pop("IQD_MIXED", None)
         _mixed_setup(eng, n_ch)
+        if squelch is not None:
+            eng.set_squelch(squelch)
         iq_d, pcm_d = eng.dev_alloc(u8.nbytes), eng.dev_alloc(n_ch * (n // 32) * 2)
+        eng.dev_upload(pcm_d, np.zeros(n_ch * (n // 32), np.int16))     # (rows of a gated call are only partly written)
         nblk = 2 * n // 32768
         cnt_d, mag_d = eng.dev_alloc(n_ch * 4), eng.dev_alloc(n_ch * nblk * 4)
         eng.dev_upload(iq_d, u8)
@@ -332,6 +341,8 @@ def test_one_launch_for_all_families_equals_a_kernel_per_family(capi):
                         eng.dev_download(mag_d, n_ch * nblk * 4, np.uint32)))
         st = eng.stats()
         assert st["mixed_launches"] == (0 if forked else 3) and st["stream_launches"] == 12 and st["state_repairs"] == 0, st
+        if squelch is not None:
+            assert (got[0][1] < n // 32).any() and (got[0][1] > 0).all()   # some rows lost blocks, none lost everything
         outs.append(got)
         for p_ in (iq_d, pcm_d, cnt_d, mag_d):
             eng.dev_free(p_)
