@@ -175,7 +175,7 @@ def live_pmc(argv, needle, samples_per_launch):
     import pmc_summary
     tmp = tempfile.mkdtemp(prefix="iqd_pmc_", dir="/tmp")
     child = [sys.executable, os.path.abspath(__file__)] + [a for a in argv if a not in ("--gather",)] + \
-            ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-host-path", "--no-live-pmc"]
+            ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-host-path", "--no-live-pmc", "--prewarm-ms", "0"]
     env = dict(os.environ, TMPDIR="/tmp")
     try:
         for sub, counters in (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]),
@@ -304,6 +304,16 @@ def rank_body(args, rank, world, dev, make_engine, dist, torch, order_streams=No
             if order_streams is not None:
                 order_streams(eng, False)   # and the engine's next step waits for the gatherer's copies out of pcm / cnt
 
+    # Clock settle: the same step, untimed, for about --prewarm-ms.  A count, not a clock: every rank must run the same
+    # number of steps (a gather inside the step is a collective), so it is derived from the workload's size alone.
+    prewarm_steps = 0
+    if getattr(args, "prewarm_ms", 0.0) > 0:
+        est_step_s = max(float(n) * n_ch / 600e9, 20e-6)
+        prewarm_steps = int(min(2000, max(1, round(args.prewarm_ms * 1e-3 / est_step_s))))
+        for k in range(prewarm_steps):
+            step()
+            if k % 16 == 15:
+                eng.synchronize()       # (bounds the queue; the device stays busy: the host enqueues faster than it drains)
     for _ in range(args.warmup):
         step()
     eng.synchronize()
@@ -388,6 +398,8 @@ def rank_body(args, rank, world, dev, make_engine, dist, torch, order_streams=No
                                                 "resident in HBM (not a BASELINE configuration)"
                                                 % (args.mode.upper(), n_ch, args.log2_samples),
                        "channels_per_gpu": n_ch, "log2_samples_per_channel": args.log2_samples, "kernels": kernels_ran,
+                       "prewarm": "%d untimed steps of the same workload (about %g ms of load) before the %d warm-up steps: clock settle"
+                                  % (prewarm_steps, getattr(args, "prewarm_ms", 0.0), args.warmup),
                        "sharding": "independent channels, contiguous range per rank, no data-path collective"
                                    + ("; PCM gathered to rank 0 over RCCL (%s)" % ("iqd_gather_pcm, C ABI" if native_gather else "torch.distributed")
                                       if args.gather else "")},
@@ -414,6 +426,9 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--prewarm-ms", type=float, default=100.0,
+                    help="untimed load before the warm-up steps, so that the device's clocks have settled when the timed steps "
+                         "start (DESIGN.md section 6: the step time falls by a tenth over the first 25 ms of load); 0 = none")
     ap.add_argument("--config", type=int, default=None, choices=sorted(CONFIGS), help="BASELINE.json configs[N] preset (default 1)")
     ap.add_argument("--log2-samples", type=int, default=None, help="IQ samples per channel per step (overrides the preset)")
     ap.add_argument("--channels", type=int, default=None, help="channels per GPU (overrides the preset)")

@@ -144,7 +144,7 @@ def _run(argv, world=2):
 def test_bench_rank_body_mixed_channels_world_size_2():
     """configs[3] shape (mixed modes), 5 channels per rank: channel g of the job runs mode g % 5 whichever rank owns it."""
     argv = ["--gpus", "2", "--steps", "3", "--warmup", "1", "--mode", "mixed", "--channels", "5", "--log2-samples", "12",
-            "--gather", "--no-cpu-baseline", "--no-host-path"]
+            "--gather", "--no-cpu-baseline", "--no-host-path", "--prewarm-ms", "0"]
     out, rot_col, tag_col, counts, sizes, modes0, agc0 = _run(argv)
     assert sizes == [5, 5] and len(tag_col) == 10
     names = ["am", "fm", "wbfm", "lsb", "usb"]
@@ -162,11 +162,22 @@ def test_bench_rank_body_mixed_channels_world_size_2():
 def test_bench_rank_body_ssb_stress_world_size_2():
     """configs[4] shape: LSB/USB alternate and the rotation selector cycles with the JOB-wide channel index."""
     argv = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--mode", "ssb_stress", "--channels", "3", "--log2-samples", "12",
-            "--gather", "--no-cpu-baseline", "--no-host-path"]
+            "--gather", "--no-cpu-baseline", "--no-host-path", "--prewarm-ms", "0"]
     out, rot_col, tag_col, counts, sizes, modes0, agc0 = _run(argv)
     assert [t // 1000 for t in tag_col] == [4 if g % 2 == 0 else 5 for g in range(6)]
     assert rot_col == [(1, 0, -1)[g % 3] for g in range(6)]
     assert agc0 and out["metric"].startswith("IQ MSamples/s through SSB_STRESS chains")
+
+
+def test_prewarm_runs_the_same_number_of_steps_on_every_rank():
+    """The untimed clock-settle phase in front of the warm-up steps is a step COUNT derived from the workload alone - a
+    wall-clock loop would leave the ranks with different numbers of gather collectives."""
+    import bench
+    a = bench.parse_args(["--gpus", "2", "--steps", "2", "--warmup", "1", "--mode", "mixed", "--channels", "5", "--log2-samples", "12",
+                          "--gather", "--no-cpu-baseline", "--no-host-path", "--prewarm-ms", "0.1"])
+    eng = FakeEngine(5, 0, 0)
+    out = bench.rank_body(a, 0, 1, torch.device("cpu"), lambda n_channels, flags: eng, None, torch)
+    assert eng.calls == 5 + 1 + 2 and "5 untimed steps" in out["config"]["prewarm"], (eng.calls, out["config"]["prewarm"])
 
 
 def test_presets_name_the_baseline_configurations():
@@ -191,7 +202,7 @@ def test_bench_starts_its_own_ranks():
                                                            "TORCHELASTIC_RUN_ID")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
                         "--mode", "mixed", "--channels", "5", "--log2-samples", "12", "--gather", "--no-cpu-baseline",
-                        "--no-host-path", "--standin", "tests.test_shard_gloo:FakeEngine"],
+                        "--no-host-path", "--prewarm-ms", "0", "--standin", "tests.test_shard_gloo:FakeEngine"],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=300)
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     lines = [ln for ln in r.stdout.decode().splitlines() if ln.strip()]
