@@ -79,6 +79,7 @@ struct iqd_engine {
     // measurement knobs, read from the environment ONCE at creation (include/iqdemod.h): IQD_WBFM_PATH=stream|tiles
     // (+1 / -1, 0 = choose), IQD_FULL_GRID, IQD_STREAM_WGS=<n>, IQD_PLAN_CHUNKS=<k>
     int env_path = 0;
+    uint32_t env_d4_gran = 128;            // IQD_D4_GRAN: segment-length granule of the FM / AM / SSB pipelines (measurement runs)
     bool env_full_grid = false;
     bool env_mixed_forked = false;         // IQD_MIXED=forked: several families as kernels of their own side by side (A/B runs)
     float fam_weight[FAM_COUNT] = {3.4f, 6.3f, 10.8f, 3.6f};   // relative cost per channel-sample of the streaming pipelines: AM, FM, WBFM, SSB
@@ -238,6 +239,7 @@ int iqd_create(const iqd_config *cfg, iqd_t **out)
     e->flags = cfg->flags;
     if (const char *env = getenv("IQD_WBFM_PATH")) e->env_path = env[0] == 's' ? 1 : env[0] == 't' ? -1 : 0;
     e->env_full_grid = getenv("IQD_FULL_GRID") != nullptr;
+    if (const char *env = getenv("IQD_D4_GRAN")) e->env_d4_gran = (uint32_t)atoi(env);
     if (const char *env = getenv("IQD_MIXED")) e->env_mixed_forked = env[0] == 'f' && env[1] == 'o';
     if (const char *env = getenv("IQD_FAMILY_WEIGHTS")) {   // "am,fm,wbfm,ssb" (measurement runs)
         float w[FAM_COUNT];
@@ -1331,7 +1333,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
             if (ok && want >= 0 && (want > 0 || work >= (uint64_t)(shares_on ? fam_wgs : e->n_cus) * ST_SEGS * STREAM_MIN_PER_SEGMENT || shares_on)) {
                 d4_wgs = fam_wgs;
                 for (uint32_t spare = 0;; spare += 48) {   // (the rotation groups' padding may push an exact fit into a second round)
-                    const TilePlan sp = plan_stream(vlen, n_list, d4_wgs * ST_SEGS - spare);
+                    const TilePlan sp = plan_stream(vlen, n_list, d4_wgs * ST_SEGS - spare, e->env_d4_gran);   // (these pipelines store 8 or 16 bytes per 128 samples: no wide stores to keep whole)
                     a.tile_len = sp.tile_len;
                     a.tiles_per_ch = sp.tiles_per_ch;
                     uint32_t at = 0, li0 = 0;
