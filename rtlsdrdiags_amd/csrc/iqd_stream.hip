@@ -22,11 +22,15 @@ __device__ __forceinline__ uint32_t st_table_read(uint32_t byte_offset) { return
 
 // How long a wave sleeps between two looks at its ring counter (units of 64 cycles).  A waiting wave's polls are
 // instructions like any others, on a SIMD whose other waves are not waiting.
+// s_sleep argument (x 64 cycles) between two looks at a ring counter.  A waiting wave's poll loop takes issue slots from the
+// waves it waits for: with the counters read by ds_read_b32 (round 3: a flat_load before) one round of the loop is short, the
+// waiters spun twice as often, and 8 % of the kernel's instructions were polls.  0.343 -> 0.332 ms from 1 / 1 to 6 / 10
+// (3 / 3: 0.335, 10 / 10: 0.336, 16 / 16: 0.347, 24 / 24: 0.370).
 #ifndef IQD_ST_SLEEP_P
-#define IQD_ST_SLEEP_P 1
+#define IQD_ST_SLEEP_P 6
 #endif
 #ifndef IQD_ST_SLEEP_I
-#define IQD_ST_SLEEP_I 1
+#define IQD_ST_SLEEP_I 10
 #endif
 #ifndef IQD_ST_TRACE      // diagnostic build: workgroup 5 writes clock64() of (hardware wave, piece, event k) to stamps[64 + ((wave * 256 + piece) * 4 + k)]
 #define IQD_ST_TRACE 0
@@ -485,7 +489,7 @@ __device__ __forceinline__ void st_iir_lead_in(const StreamArgs &sa, uint8_t *ri
     const float a1 = sa.a1;
     for (int piece = 0; piece < ST_HALO / 32; piece++) {
         const uint32_t target = 4u * (wg / (uint32_t)ST_DEPTH + 1u);
-        while ((int32_t)(lds_load_relaxed(ST_DEPTH > 1 ? full + (wg & (uint32_t)(ST_DEPTH - 1)) : full) - target) < 0) __builtin_amdgcn_s_sleep(1);
+        while ((int32_t)(lds_load_relaxed(ST_DEPTH > 1 ? full + (wg & (uint32_t)(ST_DEPTH - 1)) : full) - target) < 0) __builtin_amdgcn_s_sleep(IQD_ST_SLEEP_I);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         u32x4 v[8];
 #pragma unroll

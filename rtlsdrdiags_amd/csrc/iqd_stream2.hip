@@ -51,6 +51,12 @@
 #ifndef IQD_D4_WAITSTAT
 #define IQD_D4_WAITSTAT 0
 #endif
+#ifndef IQD_D4_SLEEP_P      // s_sleep argument (x 64 cycles) between two looks at a ring counter: P waves / consumer waves
+#define IQD_D4_SLEEP_P 1
+#endif
+#ifndef IQD_D4_SLEEP_C
+#define IQD_D4_SLEEP_C 1
+#endif
 
 namespace iqd {
 
@@ -183,7 +189,7 @@ __device__ __forceinline__ void d4_p_round(const ChainLaunch &a, const D4Args &d
 #if IQD_D4_WAITSTAT
                     if (lane == 0) atomicAdd(&sync[D4_SYNC_WORDS - 2], 1u);
 #endif
-                    __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_s_sleep(IQD_D4_SLEEP_P);
                     seen = lds_load_relaxed(consumed);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -416,7 +422,7 @@ __device__ __forceinline__ void d4_wait_quad(const uint32_t *full, uint32_t pg) 
 #if IQD_D4_WAITSTAT
         if ((threadIdx.x & 63) == 0) atomicAdd(d4_stat_word(D4_SYNC_WORDS - 1), 1u);
 #endif
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(IQD_D4_SLEEP_C);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }

@@ -23,19 +23,5 @@ run ${R}_fm_4096 d4_stream_kernel 268435456 --config 2
 run ${R}_am_4096 d4_stream_kernel 268435456 --mode am --channels 4096 --log2-samples 16
 run ${R}_usb_4096 d4_stream_kernel 268435456 --mode usb --channels 4096 --log2-samples 16
 run ${R}_ssb_8192 d4_stream_kernel 536870912 --config 4
-# the mixed configuration: four streaming kernels side by side; one summary per kernel from the same passes
-tools/profile.sh ${R}_mixed_4096 --no-live-pmc --config 3 > /dev/null
-cp "$(ls -t gpurun_out/${R}_mixed_4096/kt/*/*kernel_stats.csv | head -1)" $OUT/${R}_mixed_4096_kernel_stats.csv
-python3 - <<PY
-import json, sys
-sys.path.insert(0, "tools")
-import pmc_summary
-n = 4096 * 65536
-parts = {"wbfm": ("wbfm_stream_kernel", n // 5), "am": ("d4_stream_kernel<0", n // 5), "ssb": ("d4_stream_kernel<1", 2 * n // 5), "fm": ("d4_stream_kernel<2", n // 5)}
-out = {"workload": "BASELINE configs[3]: 4096 channels x 2^16 samples, channel % 5 -> AM, FM, WBFM, LSB, USB; four streaming kernels on planned CU shares"}
-for k, (needle, samples) in parts.items():
-    out[k] = pmc_summary.summarize("gpurun_out/${R}_mixed_4096", needle, float(samples))
-    d = out[k]
-    print("${R}_mixed_4096", k, d.get("kernel", "?")[:50], "ms", round(d.get("kernel_ms_avg", 0), 4), "grid", d.get("grid_workgroups"), "traffic/algo", round(d["derived"].get("traffic_over_algorithmic", 0), 3))
-json.dump(out, open("$OUT/${R}_mixed_4096_pmc.json", "w"), indent=1)
-PY
+# the mixed configuration: the four families' pipelines as workgroup ranges of one launch
+run ${R}_mixed_4096 mixed_stream_kernel 268435456 --config 3
