@@ -350,8 +350,10 @@ def rank_body(args, rank, world, dev, make_engine, dist, torch, order_streams=No
         if mixed_one:
             kernels_ran = "every family's streaming pipeline as a range of one launch's workgroups (mixed_stream_kernel)"
         if args.mode == "mixed":
-            timed, timed_samples = ("mixed_stream_kernel: all families' streaming pipelines in one launch" if mixed_one else
-                                    "the first demodulator family launched (WBFM's stream / chain kernel)"), None
+            # (one launch + its followers: their HIP-event time against the step's algorithmic bytes; kernels on streams: only the
+            #  first family's is timed, so the step time is used instead)
+            timed, timed_samples = ("mixed_stream_kernel (all families' streaming pipelines in one launch) + mixed_tail_kernel" if mixed_one else
+                                    "the first demodulator family launched (WBFM's stream / chain kernel)"), (n * n_ch if mixed_one else None)
         elif args.mode in ("am", "lsb", "usb", "ssb_stress"):
             timed, timed_samples = ("d4_stream_kernel" if streamed else "am_chain_kernel") + " + its DC-removal kernels", n * n_ch
         elif args.mode == "fm":
@@ -360,7 +362,8 @@ def rank_body(args, rank, world, dev, make_engine, dist, torch, order_streams=No
             timed, timed_samples = ("wbfm_stream_kernel + wbfm_stream_fixup_kernel" if streamed else "wbfm_chain_kernel"), n * n_ch
         prof, prof_path = profile_summary(args.tag) if args.tag else (None, None)
         needle = {"wbfm": "wbfm_stream_kernel" if streamed else "wbfm_chain_kernel", "fm": "d4_stream_kernel" if streamed else "fm_chain_kernel",
-                  "am": "d4_stream_kernel" if streamed else "am_chain_kernel"}.get("am" if args.mode in ("am", "lsb", "usb", "ssb_stress") else args.mode)
+                  "am": "d4_stream_kernel" if streamed else "am_chain_kernel",
+                  "mixed": "mixed_stream_kernel"}.get("am" if args.mode in ("am", "lsb", "usb", "ssb_stress") else args.mode)
         live = None
         if world == 1 and dev.type == "cuda" and not args.no_live_pmc and timed_samples is not None:
             live = live_pmc(args.argv, needle, timed_samples)

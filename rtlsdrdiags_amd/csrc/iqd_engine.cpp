@@ -1523,14 +1523,14 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         }
         HIP_LAUNCH(e, launch_mixed_stream(mix, fused_mag, chain_gated, mix_wgs, s));
         e->stats.mixed_launches++;
-        if (e->profiling) {
-            HIP_TRY(e, hipEventRecord(evp.second, s));
-            e->ev_pending.push_back(evp);
-        }
         MixedTailArgs mt{};
         for (int f = 0; f < FAM_COUNT; f++) mt.a[f] = mix.a[f];
         mt.sa = mix.sa;
         HIP_LAUNCH(e, launch_mixed_tail(mt, s));
+        if (e->profiling) {   // (the timed region: the pipelines AND their followers - fix-up, DC passes, tails)
+            HIP_TRY(e, hipEventRecord(evp.second, s));
+            e->ev_pending.push_back(evp);
+        }
         if (mix.a[FAM_WBFM].wg_count) {   // repair check, state commit and tail of the WBFM channels: in the squelch launch below
             tail_a = mix.a[FAM_WBFM];
             tail_f = FAM_WBFM;
