@@ -356,6 +356,8 @@ def rank_body(args, rank, world, dev, make_engine, dist, torch, order_streams=No
                                     "the first demodulator family launched (WBFM's stream / chain kernel)"), (n * n_ch if mixed_one else None)
         elif args.mode in ("am", "lsb", "usb", "ssb_stress"):
             timed, timed_samples = ("d4_stream_kernel" if streamed else "am_chain_kernel") + " + its DC-removal kernels", n * n_ch
+            if gating or args.squelch is not None:   # a gated call: the timed kernels see the open blocks only and the magnitude
+                timed_samples = None                 # pre-pass is not among them - price the whole step against all its bytes
         elif args.mode == "fm":
             timed, timed_samples = ("d4_stream_kernel" if streamed else "fm_chain_kernel"), n * n_ch
         else:
@@ -365,8 +367,8 @@ def rank_body(args, rank, world, dev, make_engine, dist, torch, order_streams=No
                   "am": "d4_stream_kernel" if streamed else "am_chain_kernel",
                   "mixed": "mixed_stream_kernel"}.get("am" if args.mode in ("am", "lsb", "usb", "ssb_stress") else args.mode)
         live = None
-        if world == 1 and dev.type == "cuda" and not args.no_live_pmc and timed_samples is not None:
-            live = live_pmc(args.argv, needle, timed_samples)
+        if world == 1 and dev.type == "cuda" and not args.no_live_pmc and (timed_samples is not None or mixed_one or args.mode != "mixed"):
+            live = live_pmc(args.argv, needle, timed_samples or n * n_ch)   # (counters per launch of the dominant kernel)
         roof = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": timed, "kernel_ms": round(kern_ms, 4)}
         if timed_samples is not None and kern_ms > 0:
             achieved = ALGO_BYTES_PER_SAMPLE * timed_samples / (kern_ms * 1e-3) / 1e9
@@ -376,7 +378,9 @@ def rank_body(args, rank, world, dev, make_engine, dist, torch, order_streams=No
             achieved = ALGO_BYTES_PER_SAMPLE * n * n_ch / (elapsed / args.steps) / 1e9
             roof.update({"achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_SAMPLE * n * n_ch,
-                         "note": "achieved = algorithmic bytes of the step / step time (all families' kernels)"})
+                         "note": "achieved = algorithmic bytes of the step / step time (every kernel of the call: " +
+                                 ("the squelch's magnitude pre-pass and decisions, the gated pipeline on the open blocks, its followers)"
+                                  if args.mode != "mixed" else "all families' kernels)")})
         src = live or prof
         roof["traffic"] = src.get("derived", {}).get("hbm_bytes_per_launch") if src else None
         if src:   # the second ceiling: vector-ALU issue (SQ_ACTIVE_INST_VALU, 4 cycles per wave-instruction, 1024 SIMDs)
