@@ -76,7 +76,8 @@ typedef struct iqd_config {
  * More environment variables exist for measurements only, read once by iqd_create: IQD_MIXED=forked runs such a call's
  * families as kernels of their own on side streams instead (the round-2 arrangement), IQD_FULL_GRID=1 then gives every
  * family all CUs in turn instead of a share of them side by side, IQD_FAMILY_WEIGHTS=am,fm,wbfm,ssb replaces the
- * relative cost estimates, IQD_STREAM_WGS=<n> fixes the streaming kernels' workgroup count. */
+ * relative cost estimates, IQD_STREAM_WGS=<n> fixes the streaming kernels' workgroup count, IQD_STREAM_GRAN / IQD_D4_GRAN=128|256|512
+ * the granule of the WBFM / the other pipelines' segment lengths (defaults 512 / 128). */
 #define IQD_F_WBFM_TILES  0x2u
 #define IQD_F_WBFM_STREAM 0x4u
 
