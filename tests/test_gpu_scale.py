@@ -301,8 +301,8 @@ def test_config4_mixed_4096_channels_on_cu_shares(capi, oracle):
     assert checked >= 64
 
 
-@pytest.mark.parametrize("squelch", [None, -38])
-def test_one_launch_for_all_families_equals_a_kernel_per_family(capi, squelch):
+@pytest.mark.parametrize("squelch,flags", [(None, 0), (-38, 0), (None, 1)])
+def test_one_launch_for_all_families_equals_a_kernel_per_family(capi, squelch, flags):
     """The mixed call runs its families' streaming pipelines as ranges of ONE launch's workgroups (iqd_stream_mixed.hip,
     stats.mixed_launches); IQD_MIXED=forked keeps the earlier arrangement, a kernel per family on side streams.  Same
     input, two engines, three calls with a gain change in between: EVERY PCM sample, magnitude and count of all 4096
@@ -320,7 +320,8 @@ def test_one_launch_for_all_families_equals_a_kernel_per_family(capi, squelch):
         if forked:
             os.environ["IQD_MIXED"] = "forked"
         try:
-            eng = capi.Engine(n_ch)          # (the variable is read once, by iqd_create)
+            eng = capi.Engine(n_ch, flags=flags)   # (the variable is read once, by iqd_create; flags 1 = IQD_F_NO_MAGNITUDE: the
+                                                   #  launch's third variant, pipelines that take no squelch magnitudes)
         finally:
             os.environ.pop("IQD_MIXED", None)
         _mixed_setup(eng, n_ch)
@@ -330,12 +331,13 @@ def test_one_launch_for_all_families_equals_a_kernel_per_family(capi, squelch):
         eng.dev_upload(pcm_d, np.zeros(n_ch * (n // 32), np.int16))     # (rows of a gated call are only partly written)
         nblk = 2 * n // 32768
         cnt_d, mag_d = eng.dev_alloc(n_ch * 4), eng.dev_alloc(n_ch * nblk * 4)
+        eng.dev_upload(mag_d, np.zeros(n_ch * nblk, np.uint32))         # (not written when the engine takes no magnitudes)
         eng.dev_upload(iq_d, u8)
         got = []
         for call in range(3):
             if call == 2:
                 eng.set_gain("fm", 9000.0, first=1, n=1)          # an FM channel's gain: the next call's lead-ins reach back across it
-            eng.accept_device(iq_d, 2 * n, pcm_d, cnt_d, mag_d)
+            eng.accept_device(iq_d, 2 * n, pcm_d, cnt_d, 0 if flags & 1 else mag_d)
             eng.synchronize()
             got.append((eng.dev_download(pcm_d, n_ch * (n // 32) * 2, np.int16), eng.dev_download(cnt_d, n_ch * 4, np.uint32),
                         eng.dev_download(mag_d, n_ch * nblk * 4, np.uint32)))
