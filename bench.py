@@ -27,6 +27,7 @@ Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
+import re
 import os
 import sys
 import time
@@ -150,7 +151,7 @@ def profile_summary(tag):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import pmc_summary
     now = pmc_summary.source_hash()
-    for rnd in (3, 2, 1):
+    for rnd in (4, 3, 2, 1):
         path = os.path.join(ROOT, "profiles", "r%d_%s_pmc.json" % (rnd, tag))
         if os.path.exists(path):
             with open(path) as f:
@@ -170,24 +171,36 @@ def live_pmc(argv, needle, samples_per_launch):
     import tempfile
     rocprof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if not rocprof or not needle:
-        return None
+        return {"skipped": "rocprofv3 is not installed"} if needle else None
+    # never a profiler inside a profiler: `rocprofv3 -- python bench.py` preloads its tool library into this process
+    under = [k for k in os.environ if k.startswith(("ROCP_", "ROCPROFILER_", "ROCPROF_"))] + \
+            [k for k in ("LD_PRELOAD",) if "rocprof" in os.environ.get(k, "")]
+    if under:
+        return {"skipped": "this run is itself under a profiler (%s): no nested counter passes" % ", ".join(sorted(under)[:3])}
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import pmc_summary
     tmp = tempfile.mkdtemp(prefix="iqd_pmc_", dir="/tmp")
     child = [sys.executable, os.path.abspath(__file__)] + [a for a in argv if a not in ("--gather",)] + \
             ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-host-path", "--no-live-pmc", "--prewarm-ms", "0"]
     env = dict(os.environ, TMPDIR="/tmp")
+    child_ms = None
     try:
         for sub, counters in (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]),
                               ("sq1", ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE"])):
             r = subprocess.run([rocprof, "--pmc"] + counters + ["--output-format", "csv", "-d", os.path.join(tmp, sub), "--"] + child,
-                               cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+                               cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=240)
             if r.returncode != 0:
-                return None
+                return {"skipped": "the rocprofv3 --pmc %s pass exited with %d" % (" ".join(counters), r.returncode)}
+            if sub == "sq1":   # the kernel time of the very pass the VALU counters come from (its own HIP events)
+                m = re.search(r'"kernel_ms": ([0-9.]+)', r.stdout.decode(errors="replace"))
+                child_ms = float(m.group(1)) if m else None
         res = pmc_summary.summarize(tmp, needle, float(samples_per_launch), passes=("fetch", "write", "sq1"), notes=False)
-        return res if res.get("counters_per_launch", {}).get("FETCH_SIZE") else None
-    except Exception:
-        return None
+        if not res.get("counters_per_launch", {}).get("FETCH_SIZE"):
+            return {"skipped": "the counter passes ran but held no FETCH_SIZE rows for %s" % needle}
+        res["child_kernel_ms"] = child_ms
+        return res
+    except Exception as exc:
+        return {"skipped": "counter passes failed: %r" % (exc,)}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
@@ -228,6 +241,24 @@ def gating_rows(synth, n, block_samples=16384):
     return rows
 
 
+def per_channel_rows(torch, row_u8, n_ch, first_global, row_bytes, chunk=256):
+    """[n_ch][row_bytes] uint8 on row_u8's device: channel c (job-wide index g = first_global + c) gets the periodic
+    signal row_u8 rolled by 2 * ((g * 37) % 1009) bytes, with four bytes of its own at the front (g, little endian,
+    xor-ed in)."""
+    dev = row_u8.device
+    period = row_u8.numel()
+    out = torch.empty((n_ch, row_bytes), dtype=torch.uint8, device=dev)
+    t = torch.arange(row_bytes, device=dev, dtype=torch.int64)
+    for c0 in range(0, n_ch, chunk):
+        g = torch.arange(c0, min(c0 + chunk, n_ch), device=dev, dtype=torch.int64) + first_global
+        shift = 2 * ((g * 37) % 1009)
+        out[c0:c0 + g.numel()] = row_u8[(t.unsqueeze(0) + shift.unsqueeze(1)) % period]
+    g = torch.arange(n_ch, device=dev, dtype=torch.int64) + first_global
+    for b in range(4):
+        out[:, b] ^= ((g >> (8 * b)) & 0xff).to(torch.uint8)
+    return out
+
+
 def configure(eng, mode, n_ch, first_global, squelch):
     """Per-channel settings; `first_global` is this rank's first channel in the whole job, so that the mix is the
     same however many ranks share it."""
@@ -262,14 +293,24 @@ def rank_body(args, rank, world, dev, make_engine, dist, torch, order_streams=No
     first_global, _ = shard.channel_range(rank, world, n_ch * world)
     gating = args.mode == "ssb_stress" and args.signal == "fm_tone" and n == period
     if gating:   # configs[4]: loud / quiet blocks per channel class, so that the raised squelch really rejects blocks
-        classes = torch.from_numpy(np.stack(gating_rows(synth, n))).to(dev)
+        loud = torch.from_numpy(synth.fm_tone(n, seed=1234)).to(dev)
+        quiet = torch.from_numpy(synth.fm_tone(n, seed=1234, amplitude=2.0, sigma=1.0)).to(dev)
+        iq = per_channel_rows(torch, loud, n_ch, first_global, 2 * n)
+        lo = per_channel_rows(torch, quiet, n_ch, first_global, 2 * n)
         which = (torch.arange(n_ch, device=dev) + first_global) % len(GATE_PATTERNS)
-        iq = classes.index_select(0, which).contiguous()
-        del classes
-    else:
+        pat = torch.tensor(GATE_PATTERNS, dtype=torch.bool, device=dev)           # [class][block % 4]: True = loud
+        n_blk = max(1, 2 * n // 32768)
+        is_loud = pat.index_select(0, which)[:, torch.arange(n_blk, device=dev) % 4]   # [n_ch][n_blk]
+        v_iq, v_lo = iq.view(n_ch, n_blk, -1), lo.view(n_ch, n_blk, -1)
+        v_iq.copy_(torch.where(is_loud.unsqueeze(-1), v_iq, v_lo))
+        del lo, loud, quiet, v_iq, v_lo
+    elif n_ch == 1:
         iq = torch.from_numpy(period_u8).to(dev).repeat(n // period)
-        if n_ch > 1:
-            iq = iq.unsqueeze(0).repeat(n_ch, 1).contiguous()
+    else:
+        # Every channel its own data (SURVEY 8(d) Config 3; VERDICT r3: copies of one row make a P wave's lanes gather
+        # the same table cells at the same time): the seeded signal rolled by 2 * ((g * 37) % 1009) bytes - whole samples,
+        # g the channel's index in the whole job - and four bytes of the channel's own at the front.
+        iq = per_channel_rows(torch, torch.from_numpy(period_u8).to(dev), n_ch, first_global, 2 * n)
     n_blocks = max(1, 2 * n // 32768)
     pcm = torch.zeros(n_ch * (n // 32), dtype=torch.int16, device=dev)
     cnt = torch.zeros(n_ch, dtype=torch.int32, device=dev)
@@ -332,8 +373,24 @@ def rank_body(args, rank, world, dev, make_engine, dist, torch, order_streams=No
     elapsed = time.perf_counter() - t0
     k1 = eng.stats()
     eng.set_profiling(False)
+    per_rank_ms, rccl = None, None
     if dist is not None:
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank_ms = [round(1e3 * float(t.item()) / args.steps, 4) for t in every]
         elapsed = shard.max_over_ranks(elapsed, dev)
+        # what the collective library itself saw (SCALE records: "RCCL saw N ranks")
+        rccl = {"backend": dist.get_backend(), "ranks": dist.get_world_size()}
+        if native_gather:
+            info = gatherer.info()
+            rccl.update({"version": info["version"], "ranks": info["ranks"], "communicator": "iqd_gather_* (engine's own, C ABI)",
+                         "library_reused": info["library_reused"]})
+        elif dev.type == "cuda":
+            try:
+                rccl["version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:
+                pass
 
     out = None
     if rank == 0:
@@ -381,11 +438,14 @@ def rank_body(args, rank, world, dev, make_engine, dist, torch, order_streams=No
                          "note": "achieved = algorithmic bytes of the step / step time (every kernel of the call: " +
                                  ("the squelch's magnitude pre-pass and decisions, the gated pipeline on the open blocks, its followers)"
                                   if args.mode != "mixed" else "all families' kernels)")})
+        live_note = None
+        if live is not None and "skipped" in live:   # say why the line has no live counters
+            live_note, live = live["skipped"], None
         src = live or prof
         roof["traffic"] = src.get("derived", {}).get("hbm_bytes_per_launch") if src else None
         if src:   # the second ceiling: vector-ALU issue (SQ_ACTIVE_INST_VALU, 4 cycles per wave-instruction, 1024 SIMDs)
             c = src.get("counters_per_launch", {})
-            ms = kern_ms if live else src.get("kernel_ms_avg")
+            ms = (live.get("child_kernel_ms") or kern_ms) if live else src.get("kernel_ms_avg")   # time and counters of the same run
             ghz = min(c["GRBM_GUI_ACTIVE"] / 8 / (ms * 1e-3) / 1e9, 2.4) if (live and c.get("GRBM_GUI_ACTIVE") and ms) else src.get("clock_ghz", 2.3)
             if c.get("SQ_ACTIVE_INST_VALU") and ms:
                 roof["valu_issue_frac"] = round(c["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (ghz * 1e9) * 1e3 / ms, 3)
@@ -395,6 +455,8 @@ def rank_body(args, rank, world, dev, make_engine, dist, torch, order_streams=No
                                 "guide's gfx950 correction; per launch of %s)" % needle) if live else prof_path
         elif prof_path:
             roof["counters"] = prof_path   # (says why the committed summary was not used)
+        if live_note:
+            roof["counters_note"] = "no live counters: " + live_note
         out = {
             "metric": METRIC if args.mode == "wbfm" else METRIC.replace("WBFM chain", "%s chains" % args.mode.upper()),
             "value": round(total_samples / elapsed / 1e6, 1), "unit": "MSamples/s", "n_gpus": world, "steps": args.steps,
@@ -415,6 +477,9 @@ def rank_body(args, rank, world, dev, make_engine, dist, torch, order_streams=No
             "state_repairs": k1["state_repairs"] - k0["state_repairs"],
             "segment_repairs": k1["segment_repairs"] - k0["segment_repairs"],
         }
+        if per_rank_ms is not None:
+            out["per_rank_ms"] = per_rank_ms   # every rank's own clock over the K steps (value uses the slowest)
+            out["rccl"] = rccl
         if not args.no_magnitude:   # what the squelch did in the last step (rank 0's channels)
             open_frac = float(allowed.float().mean().item())
             out["config"]["squelch"] = {"threshold_dbfs": GATE_THRESHOLD_DBFS if (args.squelch is None and args.mode == "ssb_stress") else args.squelch,
@@ -558,6 +623,11 @@ def main():
         return config0(args)
     world_env = os.environ.get("WORLD_SIZE")
     if world_env is None and args.gpus > 1:
+        if not args.standin:   # before any rank starts (counting devices does not initialise the GPU on this image)
+            import torch
+            visible = torch.cuda.device_count()
+            if args.gpus > visible:
+                sys.exit("bench.py: --gpus %d but this host shows %d GPU(s); nothing was started" % (args.gpus, visible))
         sys.exit(self_launch(sys.argv[1:], args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

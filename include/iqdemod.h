@@ -209,6 +209,24 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch,
 
 int iqd_synchronize(iqd_t *e);
 
+/* Replaces {Am,Fm,WbFm,Ssb}Demodulator::acceptIqData(int8_t *bufferPtr, uint32_t bufferLength) - AmDemodulator.h:30,
+ * FmDemodulator.h:30, WbFmDemodulator.h:31 (WbFmDemodulator.cc:383-411), SsbDemodulator.h:33 - the demodulator's own
+ * entry, which the processor calls behind its squelch (IqDataProcessor.cc:793-836) and the reference's offline harness
+ * calls directly (demodulatorResearch/demodulators/demod.cc:262-285):
+ *   iq            [n_ch][bytes_per_ch] SIGNED interleaved I/Q as the processor hands it over (after the -128 and the
+ *                 rotation); NOT modified (the reference's WBFM chain filters its buffer in place)
+ *   bytes_per_ch  any positive multiple of 64 (32 samples = one PCM sample); the reference's own limit of 32768 per call
+ *                 (demodulatedData[16384]) does not apply
+ *   pcm           [n_ch][bytes_per_ch/64]: every sample reaches the demodulator - no squelch, no signal or magnitude
+ *                 notification, no AGC or scanner step; the channel's squelch tracker does not move
+ * The demodulators are the ones the channel's processor uses (Radio.cc:150-181): their filter state is shared with
+ * iqd_accept_iq of the same channel, in either order.  demod = IQD_DEMOD_*; the SSB sideband is the one last selected
+ * by iqd_set_mode(LSB / USB) or iqd_demod_set_sideband - SsbDemodulator::setLsbDemodulationMode / setUsbDemodulationMode
+ * (SsbDemodulator.cc:333-367; the reference's constructor starts in LSB, :143). */
+int iqd_demod_accept(iqd_t *e, uint32_t first_ch, uint32_t n_ch, int demod,
+                     const int8_t *iq, size_t bytes_per_ch, int16_t *pcm);
+int iqd_demod_set_sideband(iqd_t *e, uint32_t first_ch, uint32_t n_ch, int lsb);
+
 /* The front end alone, IqDataProcessor.cc:735-749: s = u - 128, then the channel's rotation; [n_ch][bytes_per_ch]
  * signed bytes out.  This is what the reference leaves in the caller's buffer (it works in place) and what its
  * IQ dump tap streams (:756-760, UdpClient::sendData); iqd_accept_* itself never modifies its input. */
@@ -282,6 +300,9 @@ int iqd_gather_unique_id(uint8_t *id128);
 int iqd_gather_create(iqd_t *e, const uint8_t *id128, uint32_t rank, uint32_t world, uint32_t root, iqd_gather_t **out);
 int iqd_gather_pcm(iqd_gather_t *g, const void *send_dev, const size_t *bytes_per_rank, void *recv_dev, size_t row_stride);
 void iqd_gather_destroy(iqd_gather_t *g);
+/* RCCL's version code, the rank count the communicator reports (ncclCommCount; g may be NULL: 0), and whether an RCCL the
+ * process had loaded already (a torch host's) was reused instead of opening a second copy.  Any pointer may be NULL. */
+int iqd_gather_info(iqd_gather_t *g, int *rccl_version, int *comm_ranks, int *library_reused);
 
 /* Small device-memory helpers so that non-HIP hosts (ctypes, cgo, JNI) can stage
  * device-resident buffers for iqd_accept_iq_device without linking the HIP runtime. */
@@ -297,6 +318,8 @@ int iqd_host_free(iqd_t *e, void *p);
 /* Fills dst_dev with `total` bytes by repeating the first `period` bytes already there. */
 int iqd_dev_tile(iqd_t *e, void *dst_dev, size_t period, size_t total);
 void *iqd_stream(iqd_t *e); /* the engine's hipStream_t */
+int iqd_device_count(void); /* HIP devices this process can see (0 without a usable runtime): what iqd_config::device may name */
+int iqd_get_device(iqd_t *e, int *device); /* the HIP device ordinal the engine lives on (iqd_config::device resolved) */
 /* Diagnostic builds (-DIQD_STAMPS) only: cycle sums per kernel phase; zeros otherwise. */
 int iqd_debug_stamps(iqd_t *e, unsigned long long *out16);
 int iqd_debug_stamps_ext(iqd_t *e, unsigned long long *out, uint32_t n);   /* the first n <= 32768 of them (IQD_ST_TIMING / IQD_ST_WAITSTAT / IQD_ST_TRACE builds) */

@@ -57,6 +57,7 @@ EXPORTS = [
     "iqd_scanner_get", "iqd_get_frequency_trace", "iqd_front_end", "iqd_front_end_device", "iqd_convert_fs_over_4",
     "iqd_resampler_create", "iqd_resampler_destroy", "iqd_resampler_reset", "iqd_resampler_out_count",
     "iqd_resampler_run", "iqd_resampler_run_device", "iqd_gather_unique_id", "iqd_gather_create", "iqd_gather_pcm", "iqd_gather_destroy",
+    "iqd_demod_accept", "iqd_demod_set_sideband", "iqd_get_device", "iqd_gather_info", "iqd_device_count",
 ]
 
 _LIB = None
@@ -89,6 +90,8 @@ def _lib():
     L.iqd_accept_iq.argtypes = [vp, u32, u32, vp, sz, vp, vp, vp, vp]
     L.iqd_accept_iq_device.argtypes = [vp, u32, u32, vp, sz, vp, vp, vp, vp]
     L.iqd_synchronize.argtypes = [vp]
+    L.iqd_demod_accept.argtypes = [vp, u32, u32, C.c_int, vp, sz, vp]
+    L.iqd_demod_set_sideband.argtypes = [vp, u32, u32, C.c_int]
     L.iqd_front_end.argtypes = [vp, u32, u32, vp, sz, vp]
     L.iqd_resampler_create.argtypes = [vp, C.c_int, vp, u32, u32, u32, C.POINTER(vp)]
     L.iqd_resampler_destroy.argtypes = [vp]
@@ -192,6 +195,20 @@ class Engine:
     def reset_demod(self, demod, first=0, n=None):
         f, n = self._range(first, n)
         self._check(self._L.iqd_reset_demod(self._h, f, n, int(DEMOD.get(demod, demod))))
+
+    def demod_accept(self, demod, iq_s8, first=0, n=None):
+        """{Am,Fm,WbFm,Ssb}Demodulator::acceptIqData: SIGNED bytes [n][bytes] (or one row) straight into the
+        demodulator, no squelch; 'lsb' / 'usb' select the sideband first, like the reference's harness does."""
+        f, n = self._range(first, n)
+        if demod in ("lsb", "usb"):
+            self._check(self._L.iqd_demod_set_sideband(self._h, f, n, 1 if demod == "lsb" else 0))
+            demod = "ssb"
+        iq_s8 = np.ascontiguousarray(iq_s8, dtype=np.int8)
+        one = iq_s8.ndim == 1
+        rows = iq_s8.reshape(n, -1)
+        pcm = np.zeros((n, rows.shape[1] // 64), np.int16)
+        self._check(self._L.iqd_demod_accept(self._h, f, n, int(DEMOD.get(demod, demod)), _np_ptr(rows), rows.shape[1], _np_ptr(pcm)))
+        return pcm[0] if one else pcm
 
     # ---- AutomaticGainControl: True/False like the reference's setters -----------------------
     def _agc(self, fn, value, first, n):
@@ -416,6 +433,15 @@ class Gatherer:
         rc = self._L.iqd_gather_pcm(self._h, C.c_void_p(send_dev), arr, C.c_void_p(recv_dev or None), int(row_stride))
         if rc != 0:
             raise IqdError(rc, "iqd_gather_pcm failed")
+
+    def info(self):
+        """{'version': RCCL's version code, 'ranks': what ncclCommCount says, 'library_reused': the process's own copy}"""
+        v, n, r = C.c_int(), C.c_int(), C.c_int()
+        self._L.iqd_gather_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        rc = self._L.iqd_gather_info(self._h, C.byref(v), C.byref(n), C.byref(r))
+        if rc != 0:
+            raise IqdError(rc, "iqd_gather_info failed")
+        return {"version": v.value, "ranks": n.value, "library_reused": bool(r.value)}
 
     def close(self):
         if self._h:

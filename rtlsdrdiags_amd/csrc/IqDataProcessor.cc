@@ -7,8 +7,45 @@
 
 // ---- demodulator handles ------------------------------------------------------------------
 DemodulatorHandle::DemodulatorHandle(int demod, float defaultGain, PcmCallback cb)
-    : demod(demod), demodulatorGain(defaultGain), pcmCallbackPtr(cb), engine(0)
+    : demod(demod), demodulatorGain(defaultGain), pcmCallbackPtr(cb), engine(0), ownsEngine(false), lastStatus(IQD_OK)
 {
+}
+
+DemodulatorHandle::~DemodulatorHandle(void)
+{
+  if (ownsEngine && engine != 0) iqd_destroy(engine);
+}
+
+// e.g. WbFmDemodulator.cc:383-411 + sendPcmData (:582-591): the demodulator alone, PCM to its callback
+void DemodulatorHandle::acceptIqData(int8_t *bufferPtr, uint32_t bufferLength)
+{
+  if (engine == 0) {   // nobody's demodulator: an engine of its own (there is no CPU path: without a device every call fails)
+    iqd_config cfg;
+    memset(&cfg, 0, sizeof(cfg));
+    cfg.abi_version = IQD_ABI_VERSION;
+    cfg.n_channels = 1;
+    cfg.device = -1;
+    lastStatus = iqd_create(&cfg, &engine);
+    if (lastStatus != IQD_OK) {
+      engine = 0;
+      fprintf(stderr, "DemodulatorHandle::acceptIqData: %s\n", iqd_strerror(lastStatus));
+      return;
+    }
+    ownsEngine = true;
+    iqd_set_gain(engine, 0, 1, demod, demodulatorGain);
+  }
+  if (bufferLength > 32768) {   // demodulatedData[16384], e.g. WbFmDemodulator.h:52
+    lastStatus = IQD_EINVAL;
+    fprintf(stderr, "DemodulatorHandle::acceptIqData: %u bytes exceed the demodulator's 32768-byte block\n", bufferLength);
+    return;
+  }
+  beforeAccept();
+  lastStatus = iqd_demod_accept(engine, 0, 1, demod, bufferPtr, bufferLength, pcmData);
+  if (lastStatus != IQD_OK) {
+    fprintf(stderr, "DemodulatorHandle::acceptIqData: %s\n", iqd_last_error(engine));
+    return;
+  }
+  if (pcmCallbackPtr != 0) pcmCallbackPtr(pcmData, bufferLength / 64);
 }
 
 void DemodulatorHandle::setDemodulatorGain(float gain)
@@ -37,6 +74,7 @@ SsbDemodulator::SsbDemodulator(PcmCallback cb) : DemodulatorHandle(IQD_DEMOD_SSB
 
 void SsbDemodulator::setLsbDemodulationMode(void) { lsbDemodulationMode = true; }
 void SsbDemodulator::setUsbDemodulationMode(void) { lsbDemodulationMode = false; }
+void SsbDemodulator::beforeAccept(void) { iqd_demod_set_sideband(engine, 0, 1, lsbDemodulationMode ? 1 : 0); }
 
 // ---- IqDataProcessor ------------------------------------------------------------------------
 IqDataProcessor::IqDataProcessor(char *hostIpAddress, int hostPort)

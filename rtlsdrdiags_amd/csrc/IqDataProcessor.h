@@ -25,15 +25,26 @@ class DemodulatorHandle
 
   void resetDemodulator(void);
   void setDemodulatorGain(float gain);
+  // {Am,Fm,WbFm,Ssb}Demodulator::acceptIqData (e.g. WbFmDemodulator.h:31, WbFmDemodulator.cc:383-411): signed bytes
+  // straight into the demodulator, the PCM to its callback.  bufferLength: a multiple of 64 up to 32768; the buffer is
+  // not modified.  A handle that no IqDataProcessor owns (the reference's offline harness,
+  // demodulatorResearch/demodulators/demod.cc:262-285) runs on an engine of its own, made at the first call.
+  void acceptIqData(int8_t *bufferPtr, uint32_t bufferLength);
   void displayInternalInformation(void);
+  int lastStatusCode(void) const { return lastStatus; }
+  ~DemodulatorHandle(void);
 
   protected:
   DemodulatorHandle(int demod, float defaultGain, PcmCallback pcmCallbackPtr);
+  virtual void beforeAccept(void) {}
 
   int demod;                 // IQD_DEMOD_*
   float demodulatorGain;
   PcmCallback pcmCallbackPtr;
   iqd_t *engine;             // null until attached
+  bool ownsEngine;           // made by acceptIqData() for a handle without a processor
+  int lastStatus;
+  int16_t pcmData[512];
 
   friend class IqDataProcessor;
 };
@@ -64,6 +75,7 @@ class SsbDemodulator : public DemodulatorHandle
   void setUsbDemodulationMode(void);              // SsbDemodulator.h:31
 
   private:
+  virtual void beforeAccept(void);
   bool lsbDemodulationMode;
   friend class IqDataProcessor;
 };

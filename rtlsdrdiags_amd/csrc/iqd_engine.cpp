@@ -86,6 +86,7 @@ struct iqd_engine {
     uint32_t env_stream_wgs = 0, env_plan_chunks = 0, env_stream_gran = 0;
     size_t dcr_layout[2][2] = {{~(size_t)0, 0}, {~(size_t)0, 0}};   // AM / SSB: where the DC redo flags sit in their buffer, and how many
     bool any_gated = false, any_agc = false;
+    bool demod_bypass = false;             // inside iqd_demod_accept: the demodulator alone - no squelch, tracker, AGC, scanner, magnitudes
     std::vector<AgcConfig> h_agc;           // per channel; the one-shot fields are cleared once applied
     std::vector<uint8_t> agc_touched;       // the device may have moved this channel's IF gain
     bool agc_dirty = true;
@@ -726,6 +727,19 @@ int iqd_reset_demod(iqd_t *e, uint32_t first_ch, uint32_t n_ch, int demod)
     return IQD_OK;
 }
 
+int iqd_device_count(void)
+{
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
+
+int iqd_get_device(iqd_t *e, int *device)
+{
+    if (!e || !device) return IQD_EINVAL;
+    *device = e->device;
+    return IQD_OK;
+}
+
 int iqd_get_channel_mode(iqd_t *e, uint32_t ch, int *mode)
 {
     if (!e || ch >= e->n_ch || !mode) return IQD_EINVAL;
@@ -1112,7 +1126,11 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         gated = e->any_gated;
         any_agc = e->any_agc;
     }
-    const bool want_mag = gated || any_agc || !(e->flags & IQD_F_NO_MAGNITUDE) || magnitude_dev;
+    if (e->demod_bypass) {   // {Am,Fm,WbFm,Ssb}Demodulator::acceptIqData: nothing of the processor's squelch path runs or moves
+        gated = any_agc = false;
+        pcm_count_dev = magnitude_dev = signal_present_dev = nullptr;
+    }
+    const bool want_mag = !e->demod_bypass && (gated || any_agc || !(e->flags & IQD_F_NO_MAGNITUDE) || magnitude_dev);
 
     {   // the sums start at zero: by memset, unless the previous call's squelch pass left this many of them zero
         const void *before = e->mag_sums.p;
@@ -1487,7 +1505,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
                 left = left > vlen ? left - vlen : 0u;
                 if (!left) e->wbfm_epochs_live--;
             }
-        const bool rides_with_squelch = !forked && !gated && (want_mag || pcm_count_dev || signal_present_dev || e->trace_on);
+        const bool rides_with_squelch = !forked && !gated && !e->demod_bypass && (want_mag || pcm_count_dev || signal_present_dev || e->trace_on);
         if (f == FAM_WBFM) {
             // hand-off verification (streaming launches: done by their fix-up kernel), repair of what it flags
             // (normally an immediate exit), then state commit + tail - in the squelch launch below when the call has
@@ -1500,7 +1518,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
             } else {
                 HIP_LAUNCH(e, launch_wbfm_repair(a, chain_gated, s));   // (ends with the channels' state commit and tail update)
             }
-        } else if (!forked && !gated && (want_mag || pcm_count_dev || signal_present_dev || e->trace_on)) {
+        } else if (rides_with_squelch) {
             tail_a = a;        // the only family of the call: its tail update rides in the squelch launch below
             tail_f = f;
             tail_pending = true;
@@ -1548,7 +1566,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         HIP_LAUNCH(e, launch_magnitude((const uint8_t *)iq_dev, bytes_per_ch, e->lists[FAM_COUNT].as<uint32_t>(),
                                     (uint32_t)e->h_lists[FAM_COUNT].size(), call_bs, n_blocks,
                                     e->mag_sums.as<uint32_t>(), s));
-    if (!gated && (want_mag || pcm_count_dev || signal_present_dev || e->trace_on)) {
+    if (!gated && !e->demod_bypass && (want_mag || pcm_count_dev || signal_present_dev || e->trace_on)) {
         q.zero_sums_after = any_agc ? 0u : 1u;   // (a running AGC reads them again in the tracking pass)
         HIP_LAUNCH(e, launch_squelch(q, true, s, tail_pending ? &tail_a : nullptr, tail_f));
         tail_pending = false;
@@ -1601,7 +1619,6 @@ static int accept_sliced(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const uint8
     const size_t st_blocks = st / bb;
     if (e->h_slice_counts_cap < 2 * sc) {
         if (e->h_slice_counts) (void)hipHostFree(e->h_slice_counts);
-    if (e->h_small) (void)hipHostFree(e->h_small);
         e->h_slice_counts = nullptr;
         e->h_slice_counts_cap = 0;
         HIP_TRY(e, hipHostMalloc((void **)&e->h_slice_counts, 2 * sc * sizeof(uint32_t), hipHostMallocDefault));
@@ -1659,6 +1676,8 @@ static int accept_sliced(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const uint8
                                   e->sl_count[b].p, magnitude ? e->sl_mag[b].p : nullptr,
                                   signal_present ? e->sl_allowed[b].p : nullptr);
         if (rc != IQD_OK) return rc;
+        if (e->demod_bypass)   // (no squelch pass, nothing dropped: every row of the slice is full)
+            HIP_COPY(e, hipMemsetD32Async((hipDeviceptr_t)e->sl_count[b].p, (int)(x.tb / 64), x.nc, s));
         if (k >= 1) {   // the previous slice's downloads are complete once its count copy is
             HIP_TRY(e, hipEventSynchronize(e->ev_free[b ^ 1]));
             settle(k - 1);
@@ -1742,6 +1761,84 @@ int iqd_accept_iq(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const uint8_t *iq,
     if (signal_present) HIP_COPY(e, hipMemcpyAsync(signal_present, e->st_allowed.p, nb, hipMemcpyDeviceToHost, s));
     HIP_TRY(e, hipStreamSynchronize(s));
     return IQD_OK;
+}
+
+// ---- the demodulators' own entry ----------------------------------------------------------------
+// {Am,Fm,WbFm,Ssb}Demodulator::acceptIqData(int8_t *bufferPtr, uint32_t bufferLength), e.g. WbFmDemodulator.cc:383-411:
+// SIGNED bytes as the processor hands them over (after the -128 and the rotation), straight into the demodulator -
+// no squelch, no notification, no AGC.  The demodulator objects are the ones the processor uses (Radio.cc:150-181), so
+// its filter state is shared with iqd_accept_iq of the same channel.  Run here as an accept of the same channel with
+// the front end neutralised: offset-binary bytes s ^ 0x80, rotation selector 0 (a channel's kept tail is stored as raw
+// bytes under its selector; retail_kernel rewrites it exactly when the selector moves, and back afterwards), the
+// squelch path bypassed.
+int iqd_demod_set_sideband(iqd_t *e, uint32_t first_ch, uint32_t n_ch, int lsb)
+{
+    if (!range_ok(e, first_ch, n_ch)) return IQD_EINVAL;
+    std::lock_guard<std::mutex> lk(e->mu);
+    for (uint32_t c = first_ch; c < first_ch + n_ch; c++) {
+        ChanParams &p = e->h_params[c];
+        p.ssb_lsb = lsb ? 1 : 0;
+        if (p.mode == IQD_MODE_LSB || p.mode == IQD_MODE_USB) p.mode = lsb ? IQD_MODE_LSB : IQD_MODE_USB;   // (one flag in the reference: SsbDemodulator.cc:333-367)
+    }
+    e->params_dirty = e->lists_dirty = true;
+    return IQD_OK;
+}
+
+int iqd_demod_accept(iqd_t *e, uint32_t first_ch, uint32_t n_ch, int demod, const int8_t *iq, size_t bytes_per_ch, int16_t *pcm)
+{
+    if (!range_ok(e, first_ch, n_ch) || !iq || !pcm) return e ? e->fail(IQD_EINVAL, "bad channel range or NULL buffer") : IQD_EINVAL;
+    if (demod < IQD_DEMOD_AM || demod > IQD_DEMOD_SSB) return e->fail(IQD_EINVAL, "demod must be IQD_DEMOD_AM .. IQD_DEMOD_SSB");
+    if (bytes_per_ch == 0 || bytes_per_ch % 64 != 0)
+        return e->fail(IQD_EINVAL, "bytes_per_ch (%zu) must be a positive multiple of 64", bytes_per_ch);
+    // the channels as this call needs them; what the caller had set comes back afterwards
+    std::vector<int32_t> mode0(n_ch), rot0(n_ch);
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        for (uint32_t c = 0; c < n_ch; c++) {
+            ChanParams &p = e->h_params[first_ch + c];
+            mode0[c] = p.mode;
+            rot0[c] = p.rotation;
+            p.mode = demod == IQD_DEMOD_AM ? IQD_MODE_AM : demod == IQD_DEMOD_FM ? IQD_MODE_FM : demod == IQD_DEMOD_WBFM ? IQD_MODE_WBFM
+                                           : (p.ssb_lsb ? IQD_MODE_LSB : IQD_MODE_USB);
+            p.rotation = 0;
+        }
+        e->params_dirty = e->lists_dirty = true;
+    }
+    e->demod_bypass = true;
+    int rc = IQD_OK;
+    // whole blocks first, then what is left as one short block; at most ~16 MiB of input per accept (the staging path)
+    const size_t bb = e->block_bytes, row_pcm = bytes_per_ch / 64;
+    size_t max_t = ((size_t)16 << 20) / n_ch / bb * bb;
+    if (max_t < bb) max_t = bb;
+    std::vector<uint8_t> u8;
+    std::vector<int16_t> part;
+    for (size_t t0 = 0; t0 < bytes_per_ch && rc == IQD_OK;) {
+        const size_t rest = bytes_per_ch - t0;
+        const size_t t = rest >= bb ? std::min(rest / bb * bb, max_t) : rest;
+        u8.resize((size_t)n_ch * t);
+        part.resize((size_t)n_ch * (t / 64));
+        for (uint32_t c = 0; c < n_ch; c++) {
+            const uint8_t *src = (const uint8_t *)iq + (size_t)c * bytes_per_ch + t0;
+            uint8_t *dst = u8.data() + (size_t)c * t;
+            for (size_t k = 0; k < t; k++) dst[k] = src[k] ^ 0x80u;
+        }
+        rc = iqd_accept_iq(e, first_ch, n_ch, u8.data(), t, part.data(), nullptr, nullptr, nullptr);
+        if (rc == IQD_OK)
+            for (uint32_t c = 0; c < n_ch; c++)
+                memcpy(pcm + (size_t)c * row_pcm + t0 / 64, part.data() + (size_t)c * (t / 64), (t / 64) * sizeof(int16_t));
+        t0 += t;
+    }
+    e->demod_bypass = false;
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        for (uint32_t c = 0; c < n_ch; c++) {
+            ChanParams &p = e->h_params[first_ch + c];
+            p.mode = mode0[c];
+            p.rotation = rot0[c];
+        }
+        e->params_dirty = e->lists_dirty = true;
+    }
+    return rc;
 }
 
 }  // extern "C"

@@ -11,8 +11,17 @@
 // pays for it.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
 #include <string.h>
+#if defined(__has_include) && __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#else
+// The handful of RCCL declarations this file uses (rccl.h: the NCCL 2 API), so that the library builds on a host without
+// the RCCL headers; the library itself is opened at run time either way.
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0, ncclUint8 = 1 } ncclDataType_t;
+#endif
 
 #include <mutex>
 #include <new>
@@ -32,7 +41,10 @@ struct Rccl {
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GetVersion)(int *) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
     bool ok = false;
+    bool reused = false;   // the process had an RCCL loaded already (torch's): that copy is used, not a second one
 };
 
 Rccl &rccl()
@@ -40,10 +52,17 @@ Rccl &rccl()
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-            r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
-            if (r.lib) break;
+        // A copy the process has loaded already (bench.py: torch brings its own) is the one to use - two RCCL instances
+        // in one process each set up their own transports and proxy threads.
+        for (const char *name : {"librccl.so.1", "librccl.so"}) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
+            if (r.lib) { r.reused = true; break; }
         }
+        if (!r.lib)
+            for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+                r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+                if (r.lib) break;
+            }
         if (!r.lib) return;
         auto sym = [&](const char *n) { return dlsym(r.lib, n); };
         r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
@@ -54,6 +73,8 @@ Rccl &rccl()
         r.Send = (decltype(r.Send))sym("ncclSend");
         r.Recv = (decltype(r.Recv))sym("ncclRecv");
         r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+        r.GetVersion = (decltype(r.GetVersion))sym("ncclGetVersion");
+        r.CommCount = (decltype(r.CommCount))sym("ncclCommCount");
         r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.GroupStart && r.GroupEnd && r.Send && r.Recv;
     });
     return r;
@@ -93,7 +114,8 @@ int iqd_gather_create(iqd_t *e, const uint8_t *id128, uint32_t rank, uint32_t wo
     g->rank = rank;
     g->world = world;
     g->root = root;
-    if (hipGetDevice(&g->device) != hipSuccess) { delete g; return IQD_ENODEV; }
+    // the communicator belongs to the ENGINE's device, whatever device the calling thread has current (like every iqd_* entry)
+    if (iqd_get_device(e, &g->device) != IQD_OK || hipSetDevice(g->device) != hipSuccess) { delete g; return IQD_ENODEV; }
     ncclUniqueId id;
     memcpy(&id, id128, sizeof(id));
     if (r.CommInitRank(&g->comm, (int)world, id, (int)rank) != ncclSuccess) {
@@ -107,6 +129,7 @@ int iqd_gather_create(iqd_t *e, const uint8_t *id128, uint32_t rank, uint32_t wo
 void iqd_gather_destroy(iqd_gather_t *g)
 {
     if (!g) return;
+    (void)hipSetDevice(g->device);
     (void)iqd_synchronize(g->e);
     if (g->comm) (void)rccl().CommDestroy(g->comm);
     delete g;
@@ -122,6 +145,7 @@ int iqd_gather_pcm(iqd_gather_t *g, const void *send_dev, const size_t *bytes_pe
     for (uint32_t r = 0; r < g->world; r++)
         if (bytes_per_rank[r] > row_stride) return IQD_EINVAL;
     Rccl &r = rccl();
+    if (hipSetDevice(g->device) != hipSuccess) return IQD_EHIP;
     hipStream_t s = (hipStream_t)iqd_stream(g->e);
     if (g->rank == g->root) {
         // the root's own rows: a device copy on the same stream
@@ -141,6 +165,24 @@ int iqd_gather_pcm(iqd_gather_t *g, const void *send_dev, const size_t *bytes_pe
     ok = ok && r.Send(send_dev, bytes_per_rank[g->rank], ncclUint8, (int)g->root, g->comm, s) == ncclSuccess;
     ok = (r.GroupEnd() == ncclSuccess) && ok;
     return ok ? IQD_OK : IQD_EHIP;
+}
+
+// What the communicator really is: RCCL's version code (major * 10000 + minor * 100 + patch for 2.9 and later), the rank
+// count the communicator itself reports (ncclCommCount), and whether the library was already in the process.
+int iqd_gather_info(iqd_gather_t *g, int *rccl_version, int *comm_ranks, int *library_reused)
+{
+    Rccl &r = rccl();
+    if (!r.ok) return IQD_ENODEV;
+    if (rccl_version) {
+        *rccl_version = 0;
+        if (r.GetVersion) (void)r.GetVersion(rccl_version);
+    }
+    if (comm_ranks) {
+        *comm_ranks = g ? (int)g->world : 0;
+        if (g && g->comm && r.CommCount && r.CommCount(g->comm, comm_ranks) != ncclSuccess) return IQD_EHIP;
+    }
+    if (library_reused) *library_reused = r.reused ? 1 : 0;
+    return IQD_OK;
 }
 
 }  // extern "C"

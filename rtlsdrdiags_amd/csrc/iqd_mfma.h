@@ -91,6 +91,58 @@ __device__ __forceinline__ uint32_t st_mag_raw_dword(uint32_t raw, uint32_t acc)
     return acc + __builtin_bit_cast(uint32_t, mx) + __builtin_bit_cast(uint32_t, (us2)(mn >> 1));
 }
 
+// The same with ONE quad-SAD: the dword's bytes are put in the order I0 I1 Q0 Q1 (v_perm_b32) and v_mqsad_pk_u16_u8 against
+// the reference 0x00000080 - only its byte 0 counts, at the four byte positions in turn - leaves |I0 - 128|, |I1 - 128| as
+// the halves of one register and |Q0 - 128|, |Q1 - 128| of the next: six instructions per dword against ten (the quad-SAD
+// issues at a quarter of the rate, tools/ubench: the kernel's time is the same either way, 0.3288 against 0.3324 ms on one
+// box).  IQD_ST_MQSAD=0 selects the single SADs below (A/B builds).
+__device__ __forceinline__ uint32_t st_mag_raw_dword_q(uint32_t raw, uint32_t acc)
+{
+    const uint32_t p = __builtin_amdgcn_perm(raw, raw, 0x03010200u);
+    uint32_t upper = 0;
+    upper = __builtin_nondeterministic_value(upper);             // (bytes 4-6 of the source are compared with masked reference bytes)
+    const uint64_t r = __builtin_amdgcn_mqsad_pk_u16_u8((uint64_t)p | ((uint64_t)upper << 32), 0x00000080u, 0ull);
+    const us2 a = __builtin_bit_cast(us2, (uint32_t)r), b = __builtin_bit_cast(us2, (uint32_t)(r >> 32));
+    const us2 mx = __builtin_elementwise_max(a, b), mn = __builtin_elementwise_min(a, b);
+    return acc + __builtin_bit_cast(uint32_t, mx) + __builtin_bit_cast(uint32_t, (us2)(mn >> 1));
+}
+#ifndef IQD_ST_MQSAD
+#define IQD_ST_MQSAD 1
+#endif
+
+// 8 raw samples (one lane's 16 bytes of a piece) added into the two 16-bit partial sums of acc
+__device__ __forceinline__ uint32_t st_mag_raw_chunk(const uint4 &raw, uint32_t acc)
+{
+    if (IQD_ST_MQSAD) {
+        acc = st_mag_raw_dword_q(raw.x, acc);
+        acc = st_mag_raw_dword_q(raw.y, acc);
+        acc = st_mag_raw_dword_q(raw.z, acc);
+        return st_mag_raw_dword_q(raw.w, acc);
+    }
+    // eight |u - 128| at a time, then their packed arithmetic: interleaved dword by dword the compiler pads the SAD ->
+    // packed-16 dependences with s_nop; all sixteen first costs eight more live registers (the launch that holds all four
+    // pipelines then spills vector registers to scratch)
+    const uint32_t w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+    for (int h = 0; h < 4; h += 2) {
+        uint32_t a0[2], b0[2], a1[2], b1[2];
+#pragma unroll
+        for (int d = 0; d < 2; d++) {
+            asm volatile("v_msad_u8 %0, %1, %2, 0" : "=v"(a0[d]) : "v"(w[h + d]), "s"(0x00000080u));
+            asm volatile("v_msad_u8 %0, %1, %2, 0" : "=v"(b0[d]) : "v"(w[h + d]), "s"(0x00008000u));
+            asm volatile("v_msad_u8 %0, %1, %2, 0" : "=v"(a1[d]) : "v"(w[h + d]), "s"(0x00800000u));
+            asm volatile("v_msad_u8 %0, %1, %2, 0" : "=v"(b1[d]) : "v"(w[h + d]), "s"(0x80000000u));
+        }
+#pragma unroll
+        for (int d = 0; d < 2; d++) {
+            const us2 a = __builtin_bit_cast(us2, a0[d] | (a1[d] << 16)), b = __builtin_bit_cast(us2, b0[d] | (b1[d] << 16));
+            const us2 mx = __builtin_elementwise_max(a, b), mn = __builtin_elementwise_min(a, b);
+            acc = acc + __builtin_bit_cast(uint32_t, mx) + __builtin_bit_cast(uint32_t, (us2)(mn >> 1));
+        }
+    }
+    return acc;
+}
+
 __device__ __forceinline__ uint32_t st_mag_chunk(const uint4 &s)   // 8 samples of signed bytes
 {
     uint32_t m16 = st_mag_dword(s.x, 0u);

@@ -33,9 +33,14 @@ constexpr int ST_HALO = FORCED_BACK;         // lead-in of every segment, 768 sa
                                             // with unknown histories: the 21 PCM samples those reach into are recomputed
                                             // from the boundary records (StHist) by wbfm_stream_fixup_kernel.
 #ifndef IQD_ST_AHEAD
-#define IQD_ST_AHEAD 4
+#define IQD_ST_AHEAD 2
 #endif
-constexpr int ST_AHEAD = IQD_ST_AHEAD;      // pieces of input a P wave keeps in flight (2 or 4: the piece loop is unrolled by it)
+constexpr int ST_AHEAD = IQD_ST_AHEAD;      // pieces of input a P wave keeps in flight (2 or 4: the piece loop is unrolled by it).
+                                            // Round 4: 2 - the same kernel time as 4 (0.3288 against 0.3297 ms, five interleaved
+                                            // runs on one box) with eight vector registers fewer; with 4 the launch that holds all
+                                            // four families' pipelines (iqd_stream_mixed.hip, 5 registers of spilled scalars) spilled
+                                            // vector registers to scratch, and that build ABORTED on the device (gpurun_out/dbg3.log):
+                                            // tests/test_isa_lint.py now refuses any streaming kernel with a private segment
 constexpr int ST_MIN_TILE = 768;            // a segment's own end histories must not reach back before its start
 constexpr int ST_FIX_PCM = 21;              // PCM samples of a cold segment that depend on its predecessor's histories
 constexpr int ST_ROW_FLOATS = 260;          // half-table row stride (1040 B: bank = x + 4 r)
@@ -50,7 +55,7 @@ constexpr int ST_SLOT_BYTES = 64 * 16 * 4;  // one window of one ring: 64 segmen
 #endif
 constexpr int ST_DEPTH = IQD_ST_DEPTH;      // pieces a ring holds (a power of two)
 constexpr int ST_RING_SLOTS = 2 * ST_DEPTH;
-constexpr int ST_SYNC_WORDS = 16;
+constexpr int ST_SYNC_WORDS = 24;            // per ring: [0..3] `full` of its slots, [4] `consumed`
 constexpr int ST_LDS_BYTES = ST_TABLE_BYTES + ST_RINGS * ST_RING_SLOTS * ST_SLOT_BYTES + ST_SYNC_WORDS * 4;
 static_assert(ST_LDS_BYTES <= 160 * 1024, "table + rings must fit the CU's LDS");
 static_assert(ST_HALO % 128 == 0 && ST_HALO + 32 <= TAIL, "the lead-in is whole 128-sample units inside the kept tail");

@@ -32,6 +32,9 @@ __device__ __forceinline__ uint32_t st_table_read(uint32_t byte_offset) { return
 #ifndef IQD_ST_SLEEP_I
 #define IQD_ST_SLEEP_I 10
 #endif
+#ifndef IQD_ST_RUNPTR     // 1: the P waves' input addresses as a running pointer (0: piece_address() per piece, A/B builds)
+#define IQD_ST_RUNPTR 1
+#endif
 #ifndef IQD_ST_TRACE      // diagnostic build: workgroup 5 writes clock64() of (hardware wave, piece, event k) to stamps[64 + ((wave * 256 + piece) * 4 + k)]
 #define IQD_ST_TRACE 0
 #endif
@@ -71,9 +74,9 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
     const int g = lane >> 4, c = lane & 15;
     const uint32_t row = (uint32_t)(16 * cg + c);                // ring row of this lane's segment
     uint8_t *ring_base = lds + ST_TABLE_BYTES + ring * (ST_RING_SLOTS * ST_SLOT_BYTES);
-    const uint32_t *full = sync + ring * 4;        // [slot of the ring]: pieces written into it, x 4 P waves
-    const uint32_t *consumed = sync + 12 + ring;   // pieces the IIR wave has read
-    asm volatile("" : "+v"(full), "+v"(consumed));   // (their LDS addresses stay in registers: else a move per use)
+    const uint32_t *full = sync + ring * 8;        // [slot of the ring]: pieces written into it, x 4 P waves
+    asm volatile("" : "+v"(full));                 // (the LDS address stays in a register: else a move per use)
+    const uint32_t *consumed = full + 4;           // pieces the IIR wave has read (one register for both: an offset in the instruction)
     const uint32_t wr_off = st_slot_off(row, (uint32_t)g);
     const int src_lane4 = ((lane - 16) & 63) << 2;               // whose theta[3] precedes this lane's theta[0]
 
@@ -103,13 +106,16 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
         const GainEpochList *ep = &a.epochs[sg.ech].wbfm;
         const bool ep_reach = EPOCHS && ep->since[0] < (uint32_t)TAIL && (int64_t)sg.v0 - ST_HALO - 32 < -(int64_t)ep->since[0];
         const bool ep_any = EPOCHS && __any(ep_reach);
-        uint32_t *mag_row = MAG ? a.mag_sums + (size_t)sg.ch * a.n_blocks : nullptr;
-        // squelch magnitude bookkeeping: this lane's chunks are 32 samples apart
-        const bool mcount = MAG && sg.valid;
-        const int32_t mlimit = sg.tlen - 8 * g;                  // chunks at pos < mlimit lie inside the segment
+        // squelch magnitude bookkeeping, once per group of ST_AHEAD pieces: segments start on multiples of 128 samples of their
+        // channel's stream, blocks and segment lengths are whole 128-sample units (iqd_create: block_bytes % 256 == 0; the
+        // engine streams only rows of whole 128-sample units), so a group never straddles a block boundary or a segment's
+        // end, and "inside the segment" is the same for the four lanes of a segment
+        const int32_t mlim = MAG && sg.valid ? sg.tlen : INT32_MIN;   // groups at pos < mlim lie inside the segment
         uint32_t macc = 0;
-        uint32_t mblk = (uint32_t)(sg.v0 + 8 * g) / a.block_samples;
-        uint32_t minblk = (uint32_t)(sg.v0 + 8 * g) - mblk * a.block_samples;
+        const uint32_t mblk0 = (uint32_t)sg.v0 / a.block_samples;
+        uint32_t minblk = (uint32_t)sg.v0 - mblk0 * a.block_samples;
+        uint32_t *mag_at = MAG ? a.mag_sums + (size_t)sg.ch * a.n_blocks + mblk0 : nullptr;   // the block's sum
+        uint32_t gm16 = 0;                                       // the group's magnitudes, two 16-bit partial sums
 
         // this lane's 8 samples of the piece at `pos`: virtual sample v = v0 + 8 g + pos, from the kept tail while v < 0
         const int32_t vlane = sg.v0 + 8 * g;
@@ -138,6 +144,13 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
         // CU cap the chip near 1.5 TB/s whatever the arithmetic costs).  The loads are the untracked ones of iqd_mfma.h:
         // the compiler's own wait placement would join the loop's back edge to vmcnt(0).  A buffer is re-asked right after
         // the last use of its old contents, in ST_AHEAD copies of the loop body with named buffers.
+        // Not GATED: the address of the next piece to ask for is a running pointer - 64 bytes on per piece, held at the
+        // last piece that lies wholly inside the channel's samples (what is computed from a repeated piece lies beyond the
+        // segment's end and is never stored or counted), and moved from the kept tail to the call's own samples when a
+        // first segment's lead-in ends (below, once per segment) - instead of piece_address()'s six operations per piece.
+        const int32_t pos_last = pos_max & ~31;
+        const bool from_tail = sg.v0 == 0;                       // (tile_len >= ST_MIN_TILE = ST_HALO: only a first segment's lead-in reads the tail inside the loop)
+        const uint8_t *nxt = piece_address(-ST_HALO + 32 * ST_AHEAD);
         uint4 prev = st_front<ROT>(*(const uint4 *)piece_address(-ST_HALO - 32), zero);
         v4u raw[ST_AHEAD];
 #pragma unroll
@@ -205,23 +218,18 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
                 }
             }
             uint32_t seen = lds_load_relaxed(consumed);          // asked early, needed only before the ring stores
-            // phase B: squelch magnitudes of this lane's 8 samples, while the gathers are in flight
+            // phase B: squelch magnitudes of this lane's 8 samples, while the gathers are in flight (two packed 16-bit sums,
+            // folded and booked once per group of pieces: at most 4 x 4 x 192 per half)
             if (MAG && pos >= 0) {
-                uint32_t m16 = st_mag_raw_dword(raw_cur.x, 0u);
-                m16 = st_mag_raw_dword(raw_cur.y, m16);
-                m16 = st_mag_raw_dword(raw_cur.z, m16);
-                m16 = st_mag_raw_dword(raw_cur.w, m16);
-                const uint32_t m = (m16 & 0xffffu) + (m16 >> 16);
-                macc += mcount && pos < mlimit ? m : 0u;
-                minblk += 32;
-                if (minblk >= a.block_samples) {                 // the next chunk belongs to the next block
-                    if (macc) atomicAdd(&mag_row[mblk], macc);
-                    macc = 0;
-                    mblk++;
-                    minblk -= a.block_samples;
-                }
+                gm16 = st_mag_raw_chunk(raw_cur, gm16);
             }
-            raw[j] = gload16_untracked(piece_address(pos + 32 * ST_AHEAD));   // (after the last use of its old contents)
+            // (after the last use of the buffer's old contents)
+            if (GATED || !IQD_ST_RUNPTR) {
+                raw[j] = gload16_untracked(piece_address(pos + 32 * ST_AHEAD));
+            } else {
+                raw[j] = gload16_untracked(nxt);
+                nxt += pos + 32 * ST_AHEAD < pos_last ? 64 : 0;
+            }
             // phase C, both windows: sign, delta theta, branch cut, K, b0
             float u[2][4];
 #pragma unroll
@@ -283,10 +291,25 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
                 do_piece(q + j, j, prev, other);
                 do_piece(q + j + 1, j + 1, other, prev);
             }
+            const int gpos = -ST_HALO + 32 * q;                  // the group's first sample
+            if (!GATED && IQD_ST_RUNPTR && gpos + 64 * ST_AHEAD == 0)   // (recomputed here, once per segment: two registers fewer through the loop)
+                nxt = from_tail ? a.iq + (size_t)sg.ch * a.ch_stride_bytes + 16 * g : nxt;   // the next piece asked for is the one at position 0
+            if (MAG && gpos >= 0) {
+                const uint32_t m = (gm16 & 0xffffu) + (gm16 >> 16);
+                gm16 = 0;
+                macc += gpos < mlim ? m : 0u;
+                minblk += 32 * ST_AHEAD;
+                if (minblk >= a.block_samples) {                 // the next group belongs to the next block
+                    if (macc) atomicAdd(mag_at, macc);
+                    macc = 0;
+                    mag_at++;
+                    minblk -= a.block_samples;
+                }
+            }
         }
 #pragma unroll
         for (int j = 0; j < ST_AHEAD; j++) gload_wait<0>(raw[j]);   // the loads asked for beyond the last piece: drained before their registers move on
-        if (MAG && macc) atomicAdd(&mag_row[mblk], macc);
+        if (MAG && macc) atomicAdd(mag_at, macc);
         if (IQD_ST_WAITSTAT && lane == 0) {
             atomicAdd(&a.stamps[0], (unsigned long long)n_sleeps);
             atomicAdd(&a.stamps[2], (unsigned long long)n_pieces);
@@ -514,8 +537,8 @@ __device__ __forceinline__ void st_iir_wave(const ChainLaunch &a, const StreamAr
                                             int ring, int lane)
 {
     uint8_t *ring_base = lds + ST_TABLE_BYTES + ring * (ST_RING_SLOTS * ST_SLOT_BYTES);
-    const uint32_t *full = sync + ring * 4;
-    uint32_t *consumed = sync + 12 + ring;
+    const uint32_t *full = sync + ring * 8;
+    uint32_t *consumed = sync + ring * 8 + 4;
     const uint32_t rd_off0 = (uint32_t)lane * 64u, rd_swz = ((uint32_t)lane >> 2) & 3u;
     const int n_pieces = (ST_HALO + (int)a.tile_len) >> 5;       // a multiple of 4
     uint32_t wg = 0;                                             // pieces read so far (all rounds)

@@ -11,6 +11,10 @@
 //     blocks=<n1,n2,...>               read blocks of these sizes in turn (default 32768): short reads
 //     timing=<file>                    wall time of every acceptIqData call (microseconds, one per line) and the
 //                                      device operations the engine queued, for bench.py --config 0
+//     demod                            the reference's offline harness instead (demodulatorResearch/demodulators/
+//                                      demod.cc:210-290): stdin holds SIGNED bytes, which go straight into a bare
+//                                      demodulator object - {Am,Fm,WbFm,Ssb}Demodulator::acceptIqData, no processor,
+//                                      no squelch; mode 4 / 5 select the SSB sideband first
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -37,6 +41,7 @@ int main(int argc, char **argv)
     return 2;
   }
   const char *scanSpec = 0, *dumpPath = 0, *blockSpec = 0, *timingPath = 0;
+  bool demodOnly = false;
   int npos = 0;
   char *pos[8];
   for (int i = 1; i < argc && npos < 8; i++) {
@@ -44,10 +49,41 @@ int main(int argc, char **argv)
     else if (strncmp(argv[i], "dump=", 5) == 0) dumpPath = argv[i] + 5;
     else if (strncmp(argv[i], "blocks=", 7) == 0) blockSpec = argv[i] + 7;
     else if (strncmp(argv[i], "timing=", 7) == 0) timingPath = argv[i] + 7;
+    else if (strcmp(argv[i], "demod") == 0) demodOnly = true;
     else pos[npos++] = argv[i];
   }
   argc = npos + 1;
   for (int i = 0; i < npos; i++) argv[i + 1] = pos[i];
+  static unsigned char block[32768];
+  size_t sizes[64], nsizes = 0, next = 0;
+  if (blockSpec != 0)
+    for (const char *q = blockSpec; *q != 0 && nsizes < 64;) {
+      sizes[nsizes++] = (size_t)strtoul(q, (char **)&q, 10);
+      if (*q == ',') q++;
+    }
+  if (demodOnly) {   // demod.cc: one demodulator object by itself, signed samples in, PCM out
+    AmDemodulator amAlone(processPcmData);
+    FmDemodulator fmAlone(processPcmData);
+    WbFmDemodulator wbfmAlone(processPcmData);
+    SsbDemodulator ssbAlone(processPcmData);
+    const int type = atoi(argv[1]);
+    if (type < 1 || type > 5) { fprintf(stderr, "iqdemod_file: demodulator type 1-5\n"); return 2; }
+    if (type == 4) ssbAlone.setLsbDemodulationMode();
+    if (type == 5) ssbAlone.setUsbDemodulationMode();
+    DemodulatorHandle *d = type == 1 ? (DemodulatorHandle *)&amAlone : type == 2 ? (DemodulatorHandle *)&fmAlone
+                         : type == 3 ? (DemodulatorHandle *)&wbfmAlone : (DemodulatorHandle *)&ssbAlone;
+    for (;;) {
+      size_t want = nsizes ? sizes[next++ % nsizes] : sizeof(block);
+      if (want == 0 || want > sizeof(block)) want = sizeof(block);
+      const size_t got = fread(block, 1, want, stdin);
+      if (got == 0) break;
+      d->acceptIqData((int8_t *)block, (uint32_t)got);
+      if (d->lastStatusCode() != IQD_OK) return 3;
+      if (got < want) break;
+    }
+    fflush(stdout);
+    return 0;
+  }
   static char host[] = "127.0.0.1";
   IqDataProcessor processor(host, 8001);
   if (!processor.isOperational()) {
@@ -93,14 +129,7 @@ int main(int argc, char **argv)
   // Blocks of 32768 bytes like Radio.cc:1895; a read that comes back short (a pipe, the end of the file) is handed
   // on as it is, like Radio.cc:1895-1906 does - the processor takes whole 64-byte units (256 in WBFM mode) and reports the rest.
   // Extra option blocks=<a,b,c,...>: read these block sizes in turn instead (short-read experiments).
-  static unsigned char block[32768];
   unsigned long timeStamp = 0;
-  size_t sizes[64], nsizes = 0, next = 0;
-  if (blockSpec != 0)
-    for (const char *q = blockSpec; *q != 0 && nsizes < 64;) {
-      sizes[nsizes++] = (size_t)strtoul(q, (char **)&q, 10);
-      if (*q == ',') q++;
-    }
   std::vector<double> blockMicroseconds;
   for (;;) {
     size_t want = nsizes ? sizes[next++ % nsizes] : sizeof(block);

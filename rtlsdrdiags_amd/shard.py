@@ -89,6 +89,11 @@ class NativeGatherer:
             return None, None
         return ([self.recv_pcm[r, :n] for r, n in enumerate(self.sizes)], [self.recv_cnt[r, :n] for r, n in enumerate(self.sizes)])
 
+    def info(self):
+        """What the communicator reports about itself: RCCL's version code, ncclCommCount, whether the process's own
+        copy of the library was reused."""
+        return self._g.info()
+
     def close(self):
         self._g.close()
 

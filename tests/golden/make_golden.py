@@ -41,8 +41,50 @@ def run_all_modes(R, u8, block_bytes=32768, threshold=None, rx_gain=None, gains=
     return out
 
 
+DEMOD_ENTRY_STEPS = [("proc", 32768), ("demod", 32768), ("demod", 8448), ("proc", 32768), ("demod", 256), ("demod", 24576),
+                     ("proc", 4096)]
+
+
+def demod_entry(R):
+    """The demodulators' own acceptIqData(int8_t *, uint32_t) (e.g. WbFmDemodulator.h:31; what
+    demodulatorResearch/demodulators/demod.cc:262-285 calls) interleaved with the processor's acceptIqData on the same
+    objects: "proc" steps are uint8 blocks through IqDataProcessor (-128, +Fs/4, squelch open), "demod" steps signed
+    bytes - full range, -128 included - straight into the demodulator; lengths are multiples of 256."""
+    rng = np.random.default_rng(29)
+    out = {"kinds": np.array([k for k, _ in DEMOD_ENTRY_STEPS]), "lengths": np.array([n for _, n in DEMOD_ENTRY_STEPS])}
+    tone = synth.fm_tone(2 * 16384 + 2048, seed=30)
+    inputs, at = [], 0
+    for k, (kind, n) in enumerate(DEMOD_ENTRY_STEPS):
+        if kind == "proc":
+            x = tone[at:at + n].copy()
+            at += n
+        else:
+            x = rng.integers(-128, 128, n).astype(np.int8)
+            if k == 1:                       # a tone the demodulators make something of, then the rails
+                x[:16384] = (synth.fm_tone(8192, seed=31).astype(np.int16) - 128).astype(np.int8)
+                x[16384:16384 + 64] = -128
+        inputs.append(x)
+        out["in%d" % k] = x
+    for mode in MODES:
+        c = R.chain()
+        c.set_mode(mode)
+        for k, (kind, n) in enumerate(DEMOD_ENTRY_STEPS):
+            if kind == "proc":
+                pcm, _, _ = c.accept_stream(inputs[k], n)
+            else:
+                pcm = c.demod_accept(mode, inputs[k])
+            out["pcm_%s_%d" % (mode, k)] = pcm
+        c.close()
+    np.savez_compressed(os.path.join(OUT, "demod_entry.npz"), **out)
+
+
 def main():
     R = B.Reference()
+    if len(sys.argv) > 1:                    # only the named fixtures (python make_golden.py demod_entry)
+        for name in sys.argv[1:]:
+            {"demod_entry": demod_entry}[name](R)
+        return
+    demod_entry(R)
     blk = 16384
 
     # (i) modulated tone at -Fs/4 + noise, moderate amplitude

@@ -144,3 +144,67 @@ def test_short_reads_in_64_byte_units(capi, oracle, mode):
         assert cnt[0] == len(ref) == nb // 64, (mode, k)
         assert np.array_equal(pcm[0, :cnt[0]], ref), (mode, k, nb)
         assert int(mag[0, 0]) == int(rmag[0]) and int(ok[0, 0]) == int(rok[0]), (mode, k)
+
+
+# ---- the demodulators' own entry (WbFmDemodulator.h:31 and its three siblings) -------------------------------------
+@pytest.mark.parametrize("mode", ["am", "fm", "wbfm", "lsb", "usb"])
+def test_demodulator_level_accept_golden(capi, golden, mode):
+    """iqd_demod_accept interleaved with iqd_accept_iq on one channel against what the reference's demodulator objects
+    produced for the same sequence (shared filter state, -128 bytes, short calls)."""
+    g = golden["demod_entry"]
+    eng = capi.Engine(1)
+    eng.set_mode(mode)
+    for k, (kind, n) in enumerate(zip(g["kinds"], g["lengths"])):
+        if kind == "proc":
+            pcm, cnt, _, _ = eng.accept(g["in%d" % k])
+            pcm = pcm[0, :cnt[0]]
+        else:
+            pcm = eng.demod_accept(mode, g["in%d" % k])
+        assert np.array_equal(pcm, g["pcm_%s_%d" % (mode, k)]), (mode, k)
+
+
+def test_demodulator_level_accept_leaves_the_squelch_path_alone(capi, oracle):
+    """No squelch, tracker, AGC or scanner step on a demodulator-level call, whatever the channel's processor has
+    configured; many channels with their own data, the channel's mode and rotation selector as they were afterwards."""
+    n_ch, n = 48, 2 * 32768
+    rng = np.random.default_rng(77)
+    s8 = rng.integers(-128, 128, (n_ch, n)).astype(np.int8)
+    u8 = np.stack([synth.fm_tone(16384, seed=900 + c) for c in range(n_ch)])
+    eng = capi.Engine(n_ch)
+    modes = ["am", "fm", "wbfm", "lsb", "usb"]
+    for c in range(n_ch):
+        eng.set_mode(modes[c % 5], first=c, n=1)
+        eng.set_rotation((1, 0, -1)[c % 3], first=c, n=1)
+    eng.set_squelch(10)                                  # every processor-level block would be rejected
+    eng.agc_enable(True)
+    agc_before = eng.agc_state(3)
+    for demod in ["wbfm", "usb", "fm", "am", "lsb"]:
+        got = eng.demod_accept(demod, s8)
+        for c in range(0, n_ch, 7):
+            ref = oracle.chain()
+            want = np.concatenate([ref.demod_accept(demod, s8[c, :32768]), ref.demod_accept(demod, s8[c, 32768:])])
+            assert np.array_equal(got[c], want), (demod, c)
+        eng.reset()
+    assert eng.agc_state(3) == agc_before and agc_before["rx_gain_db"] == 24     # the AGC never saw a block
+    eng.set_squelch(-200)
+    eng.agc_enable(False)
+    pcm, cnt, _, _ = eng.accept(u8)                     # modes and selectors are the caller's again
+    for c in range(0, n_ch, 5):
+        ref = oracle.chain()
+        ref.set_mode(modes[c % 5])
+        ref.set_rotation((1, 0, -1)[c % 3])
+        want, _, _ = ref.accept_stream(u8[c])
+        assert np.array_equal(pcm[c, :cnt[c]], want), c
+
+
+@pytest.mark.parametrize("mode", [1, 3, 4, 5])
+def test_offline_harness_through_the_cpp_demodulator_classes(oracle, mode):
+    """iqdemod_file <type> demod: signed bytes from stdin through a bare demodulator object's acceptIqData, the shape of
+    the reference's demodulatorResearch/demodulators/demod.cc."""
+    rng = np.random.default_rng(300 + mode)
+    s8 = rng.integers(-128, 128, 3 * 32768 + 4096).astype(np.int8)
+    c = oracle.chain()
+    ref = np.concatenate([c.demod_accept(MODES[mode], s8[o:o + 32768]) for o in range(0, len(s8), 32768)])
+    r = subprocess.run([TOOL, str(mode), "demod"], input=s8.tobytes(), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    assert np.array_equal(np.frombuffer(r.stdout, dtype=np.int16), ref)

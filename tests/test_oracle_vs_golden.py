@@ -197,3 +197,18 @@ def test_standalone_resamplers(oracle, golden, name):
     assert np.array_equal(oracle.interpolate_q15(h, f, g["x16"]), g["i16_" + name])
     hs = np.clip(4 * h, -1, 0.99997).astype(np.float32)
     assert np.array_equal(oracle.interpolate_q15(hs, f, g["xsat"]), g["i16sat_" + name])
+
+
+@pytest.mark.parametrize("mode", ["am", "fm", "wbfm", "lsb", "usb"])
+def test_demodulator_level_entry(oracle, golden, mode):
+    """{Am,Fm,WbFm,Ssb}Demodulator::acceptIqData(int8_t *, uint32_t) interleaved with the processor's acceptIqData on the
+    same demodulator objects (tests/golden/make_golden.py: demod_entry)."""
+    g = golden["demod_entry"]
+    c = oracle.chain()
+    c.set_mode(mode)
+    for k, (kind, n) in enumerate(zip(g["kinds"], g["lengths"])):
+        if kind == "proc":
+            pcm, _, _ = c.accept_stream(g["in%d" % k], int(n))
+        else:
+            pcm = c.demod_accept(mode, g["in%d" % k])
+        assert np.array_equal(pcm, g["pcm_%s_%d" % (mode, k)]), (mode, k)

@@ -222,3 +222,115 @@ def test_bench_relays_a_failing_rank():
                         "--standin", "tests.test_shard_gloo:NoSuchEngine"],
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=300)
     assert r.returncode != 0 and not r.stdout.decode().strip()
+
+
+# ---- shard.NativeGatherer's control flow against a stand-in for capi.Gatherer --------------------
+class FakeCapiGatherer:
+    """What csrc/iqd_gather.cpp does, over host memory and gloo point-to-point transfers: the root posts one receive per
+    peer into that peer's row, every other rank one send.  Keeps a log of the calls, so that the test can hold the
+    id hand-over, the per-rank byte tables and the two gathers per step to what the C ABI expects."""
+    UID = bytes(range(128))
+    made = []
+
+    def __init__(self, engine, unique_id, rank, world, root=0):
+        assert bytes(unique_id) == self.UID, "every rank must be handed the ROOT's id"
+        self.engine, self.rank, self.world, self.root = engine, rank, world, root
+        self.calls = []
+        FakeCapiGatherer.made.append(self)
+
+    @staticmethod
+    def unique_id():
+        assert dist.get_rank() == FakeCapiGatherer.expect_root, "only the root makes the id"
+        return FakeCapiGatherer.UID
+
+    def gather(self, send_dev, bytes_per_rank, recv_dev, row_stride):
+        assert len(bytes_per_rank) == self.world and all(b <= row_stride for b in bytes_per_rank)
+        assert (recv_dev != 0) == (self.rank == self.root)
+        self.calls.append((list(bytes_per_rank), row_stride))
+        mine = bytes_per_rank[self.rank]
+        src = torch.frombuffer((ctypes.c_uint8 * max(mine, 1)).from_address(send_dev), dtype=torch.uint8)[:mine]
+        if self.rank == self.root:
+            for p in range(self.world):
+                n = bytes_per_rank[p]
+                row = torch.frombuffer((ctypes.c_uint8 * max(n, 1)).from_address(recv_dev + p * row_stride), dtype=torch.uint8)[:n]
+                if p == self.root:
+                    row.copy_(src)
+                elif n:
+                    dist.recv(row, src=p)
+        elif mine:
+            dist.send(src.clone(), dst=self.root)
+
+    def info(self):
+        return {"version": 22606, "ranks": self.world, "library_reused": True}
+
+    def close(self):
+        self.calls.append("closed")
+
+
+def _native_worker(rank, world, port, root, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from rtlsdrdiags_amd import capi
+    real = capi.Gatherer
+    capi.Gatherer = FakeCapiGatherer
+    FakeCapiGatherer.expect_root = root
+    try:
+        n_local, row = (3, 8) if rank == 0 else (5, 8)          # uneven channel counts: rows are padded to the largest
+        engine = object()
+        g = shard.NativeGatherer(engine, n_local, row, torch.device("cpu"), dst=root)
+        assert g.sizes == [3, 5] and g.n_max == 5 and FakeCapiGatherer.made[-1].engine is engine
+        for step in range(3):
+            pcm = (torch.arange(n_local * row, dtype=torch.int16).view(n_local, row) + 1000 * rank + 100 * step).contiguous()
+            cnt = torch.full((n_local,), row - rank - step, dtype=torch.int32)
+            g.gather(pcm, cnt)
+        fake = FakeCapiGatherer.made[-1]
+        assert fake.calls == [([3 * row * 2, 5 * row * 2], 5 * row * 2), ([3 * 4, 5 * 4], 5 * 4)] * 3   # PCM then counts, every step
+        assert g.info()["ranks"] == world
+        if rank == root:
+            pcm_r, cnt_r = g.result()
+            got = [(p.numpy().copy(), c.numpy().copy()) for p, c in zip(pcm_r, cnt_r)]
+            q.put(got)
+        else:
+            assert g.result() == (None, None)
+        g.close()
+        assert fake.calls[-1] == "closed"
+    finally:
+        capi.Gatherer = real
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_native_gatherer_control_flow_with_a_standin_communicator():
+    """shard.NativeGatherer - id broadcast from the root, per-rank byte table, two gathers per step on persistent
+    buffers, a root that is not rank 0 - in two gloo processes with capi.Gatherer replaced by a host-memory stand-in:
+    what is left untested without a multi-GPU node is RCCL itself."""
+    world, root = 2, 1
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_native_worker, args=(r, world, port, root, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    step, row = 2, 8                                           # the last step's rows, each rank's trimmed to its channel count
+    for rank, (n_local, (pcm, cnt)) in enumerate(zip((3, 5), got)):
+        want = np.arange(n_local * row, dtype=np.int16).reshape(n_local, row) + 1000 * rank + 100 * step
+        assert pcm.shape == (n_local, row) and np.array_equal(pcm, want), rank
+        assert np.array_equal(cnt, np.full(n_local, row - rank - step, np.int32))
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`--gpus N` with N above the visible device count stops before any rank is started, with a message."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                           "TORCHELASTIC_RUN_ID")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1", "--warmup", "0"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=300)
+    assert r.returncode != 0 and not r.stdout.decode().strip()
+    assert "--gpus 64" in r.stderr.decode() and "nothing was started" in r.stderr.decode()

@@ -162,7 +162,17 @@ def main():
         seen.add(key)
         print("%s: line %d touches v%s of the untracked load(s) at line(s) %s before arrival:\n    %s"
               % (name, no, regs, owners, raw))
-    print("%s: %d kernels, %d global loads, %d finding(s)" % (os.path.basename(src), len(kernels), n_loads, len(seen)))
+    # Kernels with a private segment (vector registers spilled to scratch), from the code object's metadata.  The launch that
+    # holds all four families' pipelines must have none: a build of it with 4 spilled VGPRs beside its ~300 scalars spilled
+    # to vector lanes ABORTED on the device (round 4, gpurun_out/dbg3.log); the WBFM kernel's gain-epoch instantiations
+    # have always had one and run (tests/test_gpu_gain_epochs.py).  Listed here; tests/test_isa_lint.py says which may.
+    scratch = []
+    for m in re.finditer(r"\.name:\s+(\S+)\s*\n(?:.*\n)*?\s*\.private_segment_fixed_size:\s+(\d+)(?:.*\n)*?\s*\.vgpr_spill_count:\s+(\d+)", text):
+        name, priv, spills = m.group(1), int(m.group(2)), int(m.group(3))
+        if name in kernels and any("global_load_dword" in l for _, l in kernels[name]) and (priv or spills):
+            scratch.append(name)
+            print("scratch: %s: private segment of %d bytes, %d vector registers spilled" % (name, priv, spills))
+    print("%s: %d kernels, %d global loads, %d finding(s), %d kernel(s) with scratch" % (os.path.basename(src), len(kernels), n_loads, len(seen), len(scratch)))
     return 1 if seen else 0
 
 
