@@ -55,11 +55,10 @@ typedef struct iqd_config {
     uint32_t block_bytes;   /* squelch / acceptIqData granularity per channel.  0 -> 32768
                                (Radio.cc:16, 1895).  Multiple of 256, <= 32768 (the cap of
                                SignalDetector.h:49).  A call SHORTER than this is one short block
-                               (a short USB read, Radio.cc:1895-1906): a multiple of 64 bytes - 32
+                               (a short USB read, Radio.cc:1895-1906): any multiple of 64 bytes - 32
                                samples, one PCM sample, the period of the chains' /32 commutators
                                (the reference itself strides 8 bytes, IqDataProcessor.cc:567-611) -
-                               and of 256 bytes while a channel of the call is in WBFM mode (that
-                               chain's de-emphasis runs in 128-sample segments, one per lane). */
+                               in every mode. */
     int32_t device;         /* HIP device ordinal, -1 -> current device */
     uint32_t flags;         /* IQD_F_* */
     uint32_t reserved[3];
@@ -95,7 +94,7 @@ int iqd_set_mode(iqd_t *e, uint32_t first_ch, uint32_t n_ch, int mode);
 /* Replaces {Am,Fm,WbFm,Ssb}Demodulator::setDemodulatorGain (e.g. WbFmDemodulator.cc:341-348).  Takes effect with the
  * first sample of the next accept; what the filters already hold keeps the gain it was made with, exactly as in the
  * reference, for ANY sequence of changes: the engine keeps every change whose samples can still reach a filter
- * history (up to 16 per channel and demodulator - a change needs an accept of >= 128 samples in between, and the
+ * history (up to 64 per channel and demodulator - a change needs an accept of >= 32 samples in between, and the
  * histories reach back 2048 samples). */
 int iqd_set_gain(iqd_t *e, uint32_t first_ch, uint32_t n_ch, int demod, float gain);
 

@@ -169,7 +169,7 @@ void IqDataProcessor::acceptIqData(unsigned long timeStamp, unsigned char *buffe
   }
   // Whatever the read returned is one block (short USB reads included; the squelch averages over this call).
   // What the engine cannot take - an empty call, more than the 32768 bytes of SignalDetector.h:49, or a
-  // length that is not a whole number of 256-byte units - is refused by iqd_accept_iq and surfaced here.
+  // length that is not a whole number of 64-byte units - is refused by iqd_accept_iq and surfaced here.
   uint32_t pcmCount = 0, magnitude = 0;
   uint8_t allowed = 0;
   if (iqDumpEnabled && iqDumpCallbackPtr != 0 && byteCount <= blockBytes && byteCount % 8 == 0 &&   // IqDataProcessor.cc:756-760

@@ -6,7 +6,7 @@
 // One IqDataProcessor owns one single-channel engine.  Differences from the reference, all on
 // the host side: acceptIqData() does not modify the caller's buffer (the converted bytes are
 // available through the IQ dump tap); byteCount is whatever the read returned (Radio.cc:1895-1906
-// forwards short reads), as long as it is a whole number of 64-byte units (256-byte units in WbFm mode) up to 32768 - anything
+// forwards short reads), as long as it is a whole number of 64-byte units up to 32768 - anything
 // else is counted, reported through lastError() and a line on stderr, never dropped silently; the
 // IQ dump (IqDataProcessor.cc:756-760) hands its bytes to a callback instead of a UDP socket.
 #pragma once

@@ -215,7 +215,11 @@ IQD_DEV void fm_shift_e(FmLds &lds, int clen, int tid)
         lds.e_peak_hist = lds.e_peak > keep_e ? lds.e_peak : keep_e;
         lds.e_peak = 0;
     }
-    shift_hist(lds.e, 6, clen >> 3, tid, 24);
+    // (a 32-sample chunk - a gain change 32 samples before a call - brings 4 dwords against 6 of history: the ranges
+    // overlap; round 4: shift_hist() then did nothing at all and the next chunk read a stale history - found by the
+    // short-block fuzzer, tests/test_gpu_gain_epochs.py::test_gain_change_then_64_byte_calls)
+    if ((clen >> 3) >= 6) shift_hist(lds.e, 6, clen >> 3, tid, 24);
+    else if (tid == 24) shift_hist_serial(lds.e, 6, clen >> 3);
 }
 IQD_DEV void fm_shift_y2(FmLds &lds, int clen, int tid)
 {

@@ -854,23 +854,18 @@ int iqd_dev_download(iqd_t *e, void *dst, const void *src, size_t bytes)
 // forwards whatever rtlsdr_read_sync returned (Radio.cc:1895-1906; DataConsumer.cc:238-242 only counts short
 // reads) and acceptIqData averages the squelch over that call's samples (IqDataProcessor.cc:722-749).  A short
 // block is a whole number of 64-byte units (32 samples: the period of the chains' /32 commutators; USB reads are
-// multiples of 512 bytes) - of 256-byte units while a channel of the call is in WBFM mode: that chain's de-emphasis
-// is run in 128-sample segments, each lane of a wave one segment, and a call that ends inside a segment would leave
-// the carried state where the next call cannot pick it up.  Returns the block size in force for the call, 0 if the
-// length is not acceptable.
+// multiples of 512 bytes) in every mode - the WBFM chain's 128-sample de-emphasis segments take a ragged head and tail
+// since round 4 (iqd_wbfm.h: IirShape).  Returns the block size in force for the call, 0 if the length is not acceptable.
 static uint32_t call_block_bytes(iqd_t *e, uint32_t first_ch, uint32_t n_ch, size_t bytes_per_ch)
 {
+    (void)first_ch;
+    (void)n_ch;
     if (bytes_per_ch == 0) return 0;
     if (bytes_per_ch % e->block_bytes == 0) return e->block_bytes;
     if (bytes_per_ch >= e->block_bytes || bytes_per_ch % 64 != 0) return 0;
-    if (bytes_per_ch % 256 != 0) {
-        std::lock_guard<std::mutex> lk(e->mu);
-        for (uint32_t c = first_ch; c < first_ch + n_ch; c++)
-            if (e->h_params[c].mode == IQD_MODE_WBFM) return 0;
-    }
     return (uint32_t)bytes_per_ch;
 }
-#define IQD_LEN_MSG "bytes_per_ch (%zu) must be a positive multiple of block_bytes (%u), or one short block: a multiple of 64 below it (of 256 while a channel of the call is in WBFM mode)"
+#define IQD_LEN_MSG "bytes_per_ch (%zu) must be a positive multiple of block_bytes (%u), or one short block: a multiple of 64 below it"
 
 // The front end alone: what the reference leaves in the caller's buffer / sends from its IQ dump tap.
 int iqd_front_end_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void *iq_dev, size_t bytes_per_ch,

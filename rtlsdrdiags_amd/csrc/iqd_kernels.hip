@@ -277,12 +277,17 @@ __global__ __launch_bounds__(64) void dc_kernel(const ChainLaunch a, int family)
     const uint32_t which = family == FAM_SSB ? 1 : 0;
     const uint32_t ch = a.ch_list[li];
     const uint32_t ech = a.first_ch + ch;
-    const uint32_t n = (a.vlen_gated ? a.vlen_gated[ch] : a.vlen) / 32;   // multiple of 4
+    const uint32_t n = (a.vlen_gated ? a.vlen_gated[ch] : a.vlen) / 32;   // any count: a short block is a multiple of 64 bytes
     const float gain = a.params[ech].gain[family];
     DcCarry st = a.dc_carry[2 * (size_t)ech + which];
     const float a1 = g_consts.dc_a1;
     const int32_t *src = a.base8k + ch;                 // + t * base_stride_t
-    u32x2 *dst = (u32x2 *)(a.pcm + (size_t)ch * a.pcm_stride);
+    int16_t *row = a.pcm + (size_t)ch * a.pcm_stride;
+    u32x2 *dst = (u32x2 *)row;
+    // four samples per store where every row starts on an 8-byte boundary; else - rows of a PCM count that is not a multiple
+    // of 4, i.e. short blocks of 64 / 128 / 192 bytes more than a multiple of 256 - sample by sample, and never past the row's
+    // end (round 4: the wide store of a 26-sample row's tail used to land on the next channel's first two samples)
+    const bool wide = (a.pcm_stride & 3) == 0 && ((uintptr_t)a.pcm & 7) == 0;
     const size_t last = a.pcm_stride - 1;
     constexpr int B = 32;                               // steps per batch; one batch of row loads in flight
     int32_t cur[B], nxt[B];
@@ -306,7 +311,13 @@ __global__ __launch_bounds__(64) void dc_kernel(const ChainLaunch a, int family)
                 w[k] = (uint32_t)cast_i16(gain * y);
                 if (t0 + q + k < n) { st.x_prev = xf; st.y_prev = y; }
             }
-            if (t0 + q < n) dst[(t0 + q) / 4] = u32x2{pack_lo16(w[0], w[1]), pack_lo16(w[2], w[3])};
+            if (wide && t0 + q + 4 <= n) {
+                dst[(t0 + q) / 4] = u32x2{pack_lo16(w[0], w[1]), pack_lo16(w[2], w[3])};
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (t0 + q + k < n) row[t0 + q + k] = (int16_t)w[k];
+            }
         }
 #pragma unroll
         for (int k = 0; k < B; k++) cur[k] = nxt[k];

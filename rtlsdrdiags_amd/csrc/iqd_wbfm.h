@@ -371,6 +371,33 @@ IQD_DEV void wbfm_flush_mag(const WbfmTile &t, WbfmLds &lds, const ChunkBlocks &
 // ---- de-emphasis IIR -----------------------------------------------------------------------
 IQD_DEV float t_last(const WbfmLds &lds, int seg) { return u2f(lds.t4[t_slot(seg, 31)].w); }
 
+IQD_DEV float t_at(const WbfmLds &lds, int seg, int i)   // u of sample i (0..127) of a segment
+{
+    const u32x4 g = lds.t4[t_slot(seg, i >> 2)];
+    const uint32_t w[4] = {g.x, g.y, g.z, g.w};
+    return u2f(w[i & 3]);
+}
+
+// A chunk is whole 128-sample segments - except that a call may end (and a gain may have changed) on any multiple of 32
+// samples, and that a carried restart point may lie any multiple of 32 samples back (round 4: WBFM calls in 64-byte units,
+// IqDataProcessor.cc:586 strides 8 bytes, WbFmDemodulator.cc:383-411 takes what it is given).  Both are lane-local:
+//   last_len    samples of the chunk's LAST segment that exist (32 .. 128); its lane stops there, and the state it
+//               leaves is the chunk's end state
+//   first_skip  samples at the head of the tile's FIRST segment that lie before the carried restart point (0 .. 96): the
+//               lead-in is cut on the segment grid, the exact carried state applies first_skip samples into it, and what
+//               lies before is silence (no output can reach that far back: the decimators remember 696 samples)
+struct IirShape {
+    int nseg, last_len, first_skip;
+};
+IQD_DEV IirShape iir_shape(int clen, int first_skip)
+{
+    IirShape s;
+    s.nseg = (clen + SEG - 1) / SEG;
+    s.last_len = clen - SEG * (s.nseg - 1);
+    s.first_skip = first_skip;
+    return s;
+}
+
 IQD_DEV float iir_u_before(const WbfmLds &lds, int seg)  // u[n-1] at the start of a segment
 {
     return seg == 0 ? lds.u_carry : t_last(lds, seg - 1);
@@ -402,7 +429,7 @@ IQD_DEV void iir_guess(const Consts &c, WbfmLds &lds, int nseg, int lane, const 
     }
 
 // lane j >= 1: run segment j-1 from the guessed state to get the state entering segment j.
-IQD_DEV void iir_warm(const Consts &c, WbfmLds &lds, int nseg, int lane)
+IQD_DEV void iir_warm(const Consts &c, WbfmLds &lds, int nseg, int lane, int first_skip = 0)
 {
     if (lane >= nseg) return;
     if (lane == 0) { lds.g[0] = lds.y_carry; return; }
@@ -410,11 +437,11 @@ IQD_DEV void iir_warm(const Consts &c, WbfmLds &lds, int nseg, int lane)
     // approx y at the end of segment lane-2:  z[l-2] + A z[l-3] + A^2 z[l-4] + A^3 z[l-5]
     const float *zz = &lds.z[4 + lane - 2];
     float y = zz[0] + a * (zz[-1] + a * (zz[-2] + a * zz[-3]));
-    if (lane == 1) y = lds.y_carry;  // exact
+    if (lane == 1) y = lds.y_carry;  // exact (the carried state applies first_skip samples into segment 0)
     float up = iir_u_before(lds, lane - 1);
     const float a1 = c.deemph_a1;
 #pragma unroll 2
-    for (int gi = 0; gi < 32; gi += 2) {
+    for (int gi = lane == 1 ? first_skip >> 2 : 0; gi < 32; gi += 2) {
         const u32x4 a4 = lds.t4[t_slot(lane - 1, gi)], b4 = lds.t4[t_slot(lane - 1, gi + 1)];
         IQD_IIR_STEP(u2f(a4.x)) IQD_IIR_STEP(u2f(a4.y)) IQD_IIR_STEP(u2f(a4.z)) IQD_IIR_STEP(u2f(a4.w))
         IQD_IIR_STEP(u2f(b4.x)) IQD_IIR_STEP(u2f(b4.y)) IQD_IIR_STEP(u2f(b4.z)) IQD_IIR_STEP(u2f(b4.w))
@@ -425,15 +452,19 @@ IQD_DEV void iir_warm(const Consts &c, WbfmLds &lds, int nseg, int lane)
 // lane j: the real pass over segment j from g[j]; writes (int16)y and e[j].
 // bounded: the host proved |y| < 2^31 for this launch (|K| pi * 1.01 < 2^31), so the cast needs
 // no "integer indefinite" handling.
-IQD_DEV void iir_real(const Consts &c, WbfmLds &lds, int nseg, int lane, bool bounded)
+IQD_DEV void iir_real(const Consts &c, WbfmLds &lds, int nseg, int lane, bool bounded, int first_skip = 0, int last_len = SEG)
 {
     if (lane >= nseg) return;
     u32x4 *dst = (u32x4 *)&lds.w[lane * WSTRIDE];
     float up = iir_u_before(lds, lane), y = lds.g[lane];
     const float a1 = c.deemph_a1;
+    // granules (4 samples) of this lane's segment that are run: all 32, but for the head of the tile's first segment
+    // (silence before the carried restart point) and the tail of a chunk's last one (IirShape)
+    const int gi0 = lane == 0 ? first_skip >> 2 : 0, gi1 = lane == nseg - 1 ? last_len >> 2 : 32;
+    for (int gi = 0; gi < gi0; gi += 2) dst[gi >> 1] = u32x4{0u, 0u, 0u, 0u};
     if (bounded) {
 #pragma unroll 2
-        for (int gi = 0; gi < 32; gi += 2) {
+        for (int gi = gi0; gi < gi1; gi += 2) {
             const u32x4 a4 = lds.t4[t_slot(lane, gi)], b4 = lds.t4[t_slot(lane, gi + 1)];
             uint32_t w[8];
             IQD_IIR_STEP(u2f(a4.x)) w[0] = cast_i16_bounded(y);
@@ -451,7 +482,7 @@ IQD_DEV void iir_real(const Consts &c, WbfmLds &lds, int nseg, int lane, bool bo
         return;
     }
 #pragma unroll 2
-    for (int gi = 0; gi < 32; gi += 2) {
+    for (int gi = gi0; gi < gi1; gi += 2) {
         const u32x4 a4 = lds.t4[t_slot(lane, gi)], b4 = lds.t4[t_slot(lane, gi + 1)];
         uint32_t w[8];
         IQD_IIR_STEP(u2f(a4.x)) w[0] = (uint32_t)cast_i16(y) & 0xffffu;
@@ -705,18 +736,36 @@ IQD_DEV float epoch_gain(const GainEpochList *ep, float k_now, int v)
         }
     return k;
 }
-IQD_DEV int wbfm_chunk_len(const WbfmTile &t, int cs, int chunk)
+IQD_DEV int wbfm_chunk_len(const WbfmTile &t, int cs, int chunk, int lead_from = -TAIL)
 {
     if (cs < 0) {   // the lead-in ends at the tile start or at the next gain change, whichever comes first
-        int next = 0;
+        int next = 0;   // (a change at or before lead_from, the carried restart point, lies in the silence before it)
         if (t.epochs)
             for (int i = 0; i < EPOCHS; i++) {
                 const int sw = -(int)t.epochs->since[i];
-                if (t.epochs->since[i] < (uint32_t)TAIL && sw > cs && sw < next) next = sw;
+                if (t.epochs->since[i] < (uint32_t)TAIL && sw > cs && sw > lead_from && sw < next) next = sw;
             }
         return next - cs;
     }
     return t.tlen - cs < chunk ? t.tlen - cs : chunk;
+}
+
+// The restart point a tile leaves for whoever continues its stream: the last position at or before tlen - FORCED_BACK
+// where the exact state is at hand - a chunk's start (the carried state) or a segment boundary inside a chunk - and not
+// before `from`, the point where the tile's own exact state began.  wbfm_rec_at_start / wbfm_rec_in_chunk are called
+// chunk by chunk in stream order, so the last candidate that qualifies stays.
+struct WbfmRecPos { int target, from, pos; };
+IQD_DEV void wbfm_rec_at_start(WbfmRecPos &rp, WbfmRecord &rec, const WbfmLds &lds, int cstart)
+{
+    if (cstart >= rp.from && cstart <= rp.target) { rp.pos = cstart; rec.y_out = lds.y_carry; rec.u_out = lds.u_carry; }
+}
+IQD_DEV void wbfm_rec_in_chunk(WbfmRecPos &rp, WbfmRecord &rec, const WbfmLds &lds, int cstart, int clen)
+{
+    if (rp.target <= cstart) return;
+    int j = (rp.target - cstart) / SEG;                    // whole segments of this chunk that end at or before the target
+    if (j > clen / SEG) j = clen / SEG;
+    if (SEG * j == clen) j--;                              // (the chunk's very end is the next chunk's start - or the tile's end)
+    if (j >= 1 && cstart + SEG * j >= rp.from) { rp.pos = cstart + SEG * j; rec.y_out = lds.e[j - 1]; rec.u_out = t_last(lds, j - 1); }
 }
 IQD_DEV float wbfm_chunk_gain(const WbfmTile &t, int cs) { return cs < 0 ? epoch_gain(t.epochs, t.k, cs) : t.k; }
 // largest |K| and smallest K a tile can meet: now, and every earlier gain still inside its lead-in
@@ -737,7 +786,10 @@ template <bool GATED, bool MAG, class Exec>
 IQD_DEV void wbfm_tile(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLds &lds,
                        const WbfmStart &start, WbfmRecord *rec_out)
 {
-    const int halo = start.cold ? COLD_HALO : start.back;
+    // the lead-in starts on the segment grid; a carried restart point that is not on it (a stream of calls in 64-byte
+    // units) lies first_skip samples into the first segment (IirShape)
+    const int exact_from = start.cold ? -COLD_HALO : -start.back;
+    const int halo = start.cold ? COLD_HALO : (start.back + SEG - 1) / SEG * SEG;
     ex.all([&](int tid) {
         if (tid < 4) lds.y1[tid] = 0;
         if (tid < 20) lds.y2[tid] = 0;
@@ -753,20 +805,19 @@ IQD_DEV void wbfm_tile(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLds &ld
     });
     // restart point for whoever continues this stream: FORCED_BACK before the end when the
     // tile (plus its exact lead-in) is long enough, else the tile's own restart point.
-    int rec_pos = t.tlen - FORCED_BACK;
-    if (rec_pos < -halo) rec_pos = -halo;
+    WbfmRecPos rp{t.tlen - FORCED_BACK, exact_from, exact_from};
     WbfmRecord rec;
     rec.y_in = start.y;
     rec.y_out = start.y;
     rec.u_out = start.u;
-    rec.back_out = t.tlen - rec_pos;
 
     int prev_clen = 0;
     for (int cstart = -halo; cstart < t.tlen;) {
-        const int clen = wbfm_chunk_len(t, cstart, WBFM_CHUNK);
+        const int clen = wbfm_chunk_len(t, cstart, WBFM_CHUNK, exact_from);
         WbfmTile tc = t;
-        tc.k = wbfm_chunk_gain(t, cstart);
-        const int nseg = clen / SEG;
+        tc.k = wbfm_chunk_gain(t, cstart < exact_from ? exact_from : cstart);   // (the gain at the first sample that counts)
+        const IirShape sh = iir_shape(clen, cstart == -halo ? halo + exact_from : 0);
+        const int nseg = sh.nseg;
         const ChunkBlocks cb = chunk_blocks(t, cstart);
         ex.stamp(7);
         ex.all([&](int tid) {
@@ -776,27 +827,23 @@ IQD_DEV void wbfm_tile(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLds &ld
         ex.stamp(0);
         if (ex.in_wave0()) {
             ex.critical(true);
-            if (rec_pos == cstart) { rec.y_out = lds.y_carry; rec.u_out = lds.u_carry; }
+            wbfm_rec_at_start(rp, rec, lds, cstart);
             ex.wave0([&](int lane) { iir_guess(c, lds, nseg, lane); });
             ex.stamp(1);
-            ex.wave0([&](int lane) { iir_warm(c, lds, nseg, lane); });
+            ex.wave0([&](int lane) { iir_warm(c, lds, nseg, lane, sh.first_skip); });
             ex.stamp(2);
             int rounds = 0;
             do {
-                ex.wave0([&](int lane) { iir_real(c, lds, nseg, lane, t.bounded != 0); });
+                ex.wave0([&](int lane) { iir_real(c, lds, nseg, lane, t.bounded != 0, sh.first_skip, sh.last_len); });
                 rounds++;
             } while (!ex.wave0_all([&](int lane) { return iir_check(lds, nseg, lane, t.k_min >= 1.0f); }));
             ex.stamp(3);
-            if (rec_pos > cstart && rec_pos < cstart + clen) {
-                const int seg = (rec_pos - cstart) / SEG - 1;
-                rec.y_out = lds.e[seg];
-                rec.u_out = t_last(lds, seg);
-            }
+            wbfm_rec_in_chunk(rp, rec, lds, cstart, clen);
             if (start.cold && cstart < 0) rec.y_in = lds.e[(COLD_HALO - FORCED_BACK) / SEG - 1];
             ex.wave0([&](int lane) {
                 if (lane == 0) {
                     lds.y_carry = lds.e[nseg - 1];
-                    lds.u_carry = t_last(lds, nseg - 1);
+                    lds.u_carry = t_at(lds, nseg - 1, sh.last_len - 1);
                     lds.repair_count += (uint32_t)(rounds - 1);
                 }
             });
@@ -819,6 +866,7 @@ IQD_DEV void wbfm_tile(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLds &ld
         cstart += clen;
     }
     if (ex.in_wave0() && rec_out) {
+        rec.back_out = t.tlen - rp.pos;
         rec.y_end = lds.y_carry;
         rec.u_end = lds.u_carry;
         rec.pad[0] = rec.pad[1] = 0;
@@ -951,7 +999,8 @@ template <bool GATED, bool MAG, class Exec>
 IQD_DEV void wbfm_tile_pipe(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLds &lds,
                             const WbfmStart &start, WbfmRecord *rec_out)
 {
-    const int halo = start.cold ? COLD_HALO : start.back;
+    const int exact_from = start.cold ? -COLD_HALO : -start.back;   // (see wbfm_tile)
+    const int halo = start.cold ? COLD_HALO : (start.back + SEG - 1) / SEG * SEG;
     ex.all([&](int tid) {
         if (tid < 4) lds.y1[tid] = 0;
         if (tid < 20) lds.y2[tid] = 0;
@@ -966,17 +1015,15 @@ IQD_DEV void wbfm_tile_pipe(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLd
             lds.y2_peak_hist = 0;
         }
     });
-    int rec_pos = t.tlen - FORCED_BACK;
-    if (rec_pos < -halo) rec_pos = -halo;
+    WbfmRecPos rp{t.tlen - FORCED_BACK, exact_from, exact_from};
     WbfmRecord rec;
     rec.y_in = start.y;
     rec.y_out = start.y;
     rec.u_out = start.u;
-    rec.back_out = t.tlen - rec_pos;
 
     typename Exec::template Local<P1Pair> regs;
     typename Exec::template Local<P1Own> raw0;   // wave 0's prefetched group
-    auto chunk_len = [&](int cs) { return wbfm_chunk_len(t, cs, WBFM_CHUNK); };
+    auto chunk_len = [&](int cs) { return wbfm_chunk_len(t, cs, WBFM_CHUNK, exact_from); };
     const bool tiny_ok = t.k_min >= 1.0f;
 #ifdef IQD_ABL_NOMAG
     const bool mag_on = false;
@@ -992,37 +1039,34 @@ IQD_DEV void wbfm_tile_pipe(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLd
     int parity = 0;
     bool has_cur = false, has_next = true;
     while (has_cur || has_next || st_clen) {
-        const int nseg = clen / SEG;
+        const IirShape sh = iir_shape(clen, cstart == -halo ? halo + exact_from : 0);
+        const int nseg = sh.nseg;
         const ChunkBlocks ccb = chunk_blocks(t, cstart), ncb = chunk_blocks(t, next_cstart);
         const bool cur_mag = mag_on && has_cur && cstart >= 0;
         const bool next_mag = mag_on && has_next && next_cstart >= 0;
         const bool w0_share = W0_CAN_SHARE && has_next && (next_clen >> 4) > P1S_PER_WAVE * 6;   // slot 6: groups 378 ..
         WbfmTile tn = t;   // phase 1 of the next chunk runs with that chunk's gain
-        tn.k = wbfm_chunk_gain(t, next_cstart);
+        tn.k = wbfm_chunk_gain(t, next_cstart < exact_from ? exact_from : next_cstart);   // (the gain at the first sample that counts)
         // ---- X ----
         ex.stamp(7);
         if (ex.in_wave0()) {
             if (w0_share)   // fetch the raw bytes now: the loads fly during the IIR
                 ex.wave0([&](int lane) { raw0.at(lane) = p1s_load<GATED>(t, next_cstart, next_clen >> 4, p1s_group(6, lane)); });
             if (has_cur) {
-                if (rec_pos == cstart) { rec.y_out = lds.y_carry; rec.u_out = lds.u_carry; }
+                wbfm_rec_at_start(rp, rec, lds, cstart);
                 ex.wave0([&](int lane) { iir_guess(c, lds, nseg, lane, lds.part); });
-                ex.wave0([&](int lane) { iir_warm(c, lds, nseg, lane); });
+                ex.wave0([&](int lane) { iir_warm(c, lds, nseg, lane, sh.first_skip); });
                 int rounds = 0;
                 do {
-                    ex.wave0([&](int lane) { iir_real(c, lds, nseg, lane, t.bounded != 0); });
+                    ex.wave0([&](int lane) { iir_real(c, lds, nseg, lane, t.bounded != 0, sh.first_skip, sh.last_len); });
                     rounds++;
                 } while (!ex.wave0_all([&](int lane) { return iir_check(lds, nseg, lane, tiny_ok); }));
-                if (rec_pos > cstart && rec_pos < cstart + clen) {
-                    const int seg = (rec_pos - cstart) / SEG - 1;
-                    rec.y_out = lds.e[seg];
-                    rec.u_out = t_last(lds, seg);
-                }
+                wbfm_rec_in_chunk(rp, rec, lds, cstart, clen);
                 if (start.cold && cstart < 0) rec.y_in = lds.e[(COLD_HALO - FORCED_BACK) / SEG - 1];
                 ex.wave0([&](int lane) {
                     if (lane == 0) {
                         lds.y_carry = lds.e[nseg - 1];
-                        lds.u_carry = t_last(lds, nseg - 1);
+                        lds.u_carry = t_at(lds, nseg - 1, sh.last_len - 1);
                         lds.repair_count += (uint32_t)(rounds - 1);
                     }
                 });
@@ -1100,6 +1144,7 @@ IQD_DEV void wbfm_tile_pipe(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLd
     }
     ex.sync();
     if (ex.in_wave0() && rec_out) {
+        rec.back_out = t.tlen - rp.pos;
         rec.y_end = lds.y_carry;
         rec.u_end = lds.u_carry;
         rec.pad[0] = rec.pad[1] = 0;

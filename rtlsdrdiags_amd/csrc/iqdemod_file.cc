@@ -127,7 +127,7 @@ int main(int argc, char **argv)
   }
 
   // Blocks of 32768 bytes like Radio.cc:1895; a read that comes back short (a pipe, the end of the file) is handed
-  // on as it is, like Radio.cc:1895-1906 does - the processor takes whole 64-byte units (256 in WBFM mode) and reports the rest.
+  // on as it is, like Radio.cc:1895-1906 does - the processor takes whole 64-byte units and reports the rest.
   // Extra option blocks=<a,b,c,...>: read these block sizes in turn instead (short-read experiments).
   unsigned long timeStamp = 0;
   std::vector<double> blockMicroseconds;

@@ -105,3 +105,50 @@ def test_loud_and_quiet_sections(emu, oracle):
         assert np.array_equal(pcm, ref)
     a = np.abs(ref.astype(np.int32))
     assert a.max() > 17000 and min(a[k:k + 40].max() for k in range(0, len(a) - 40, 20)) < 3000
+
+
+# ---- calls in 64-byte units (32 samples): IqDataProcessor.cc:586 strides 8 bytes, WbFmDemodulator.cc:383-411 takes
+# whatever it is given; round 4 lifts the 256-byte unit the WBFM chain used to want ---------------------------------
+RAGGED = [
+    [32, 32, 32, 32, 96, 160, 4128, 64, 8224, 32, 16384, 992, 32],     # from a fresh stream: restart point off the grid at once
+    [16384, 96, 16384, 32, 32, 7680 + 64, 128, 2016],                  # long, short, long
+    [736, 32, 32, 32, 32, 32, 32, 7040 + 96, 14080 + 32],              # across the 768-sample restart distance, across chunk ends
+]
+
+
+@pytest.mark.parametrize("sizes", RAGGED)
+@pytest.mark.parametrize("tile_len", [7040, 16384])
+def test_calls_of_any_multiple_of_32_samples(emu, oracle, sizes, tile_len):
+    total = sum(sizes)
+    u8 = synth.fm_tone(total, seed=33)
+    c = oracle.chain()
+    c.set_mode("wbfm")
+    ch = emu_bind.WbfmChannel(emu, tile_len)
+    off = 0
+    for k, m in enumerate(sizes):
+        part = u8[2 * off:2 * (off + m)]
+        ref, ref_mag, _ = c.accept_stream(part, len(part) if len(part) < 32768 else 32768)
+        pcm, _ = ch.accept(part)
+        assert np.array_equal(pcm, ref), (k, m)
+        assert ch.carry.back % 32 == 0 and 0 < ch.carry.back <= 768 + 96
+        off += m
+    assert ch.hand_off_mismatches == 0
+
+
+def test_ragged_calls_around_a_reset(emu, oracle):
+    """resetDemodulator() between calls of odd lengths: the restart point falls back to the reset point (back = what has
+    been consumed since), off the 128-sample grid."""
+    u8 = synth.fm_tone(40000, seed=34)
+    c = oracle.chain()
+    c.set_mode("wbfm")
+    ch = emu_bind.WbfmChannel(emu, 7040)
+    off = 0
+    for k, m in enumerate([4128, 96, 32, 160, 32, 32, 7072, 352, 32, 9000 // 32 * 32]):
+        if k in (2, 7):
+            c.reset()
+            ch.reset()
+        part = u8[2 * off:2 * (off + m)]
+        ref, _, _ = c.accept_stream(part, min(len(part), 32768))
+        pcm, _ = ch.accept(part)
+        assert np.array_equal(pcm, ref), (k, m)
+        off += m

@@ -95,10 +95,12 @@ def test_unacceptable_lengths_are_reported_not_dropped(capi):
     with pytest.raises(capi.IqdError) as e:
         eng.accept(np.zeros(1000, np.uint8))
     assert "multiple of 64" in str(e.value)
-    eng.set_mode("wbfm")                               # the WBFM chain works in 128-sample segments: 256-byte units there
+    eng.set_mode("wbfm")                               # (round 4: the WBFM chain takes 64-byte units too)
+    pcm, cnt, _, _ = eng.accept(np.full(320, 128, np.uint8))
+    assert cnt[0] == 5 and not pcm.any()
     with pytest.raises(capi.IqdError) as e:
-        eng.accept(np.full(320, 128, np.uint8))
-    assert "256 while a channel of the call is in WBFM mode" in str(e.value)
+        eng.accept(np.full(96, 128, np.uint8))
+    assert "multiple of 64" in str(e.value)
     eng.set_mode("fm")
     u8 = synth.fm_tone(16384 + 500, seed=1)          # a trailing 1000-byte read
     r = subprocess.run([TOOL, "2"], input=u8.tobytes(), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
@@ -123,7 +125,7 @@ def test_public_fs_over_4_conversions(capi, oracle, direction):
         eng.convert_fs_over_4(direction, s8[:12])
 
 
-@pytest.mark.parametrize("mode", ["fm", "am", "lsb", "usb"])
+@pytest.mark.parametrize("mode", ["fm", "am", "lsb", "usb", "wbfm"])
 def test_short_reads_in_64_byte_units(capi, oracle, mode):
     """The reference's rotation strides 8 bytes and its chains take any length (PCM invariant under the
     block size from 8 to 32768 bytes).  Here a short block is a whole number of 64-byte units = 32 samples = one PCM
@@ -208,3 +210,93 @@ def test_offline_harness_through_the_cpp_demodulator_classes(oracle, mode):
     r = subprocess.run([TOOL, str(mode), "demod"], input=s8.tobytes(), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 0, r.stderr.decode()
     assert np.array_equal(np.frombuffer(r.stdout, dtype=np.int16), ref)
+
+
+@pytest.mark.parametrize("sizes", [[64, 64, 64, 64, 192, 320, 8256, 128, 16448, 64, 32768, 1984, 64],
+                                   [32768, 192, 32768, 64, 64, 15360 + 128, 256, 4032],
+                                   [1472, 64, 64, 64, 64, 64, 64, 14080 + 192, 28160 + 64]])
+@pytest.mark.parametrize("flags", [0, 4])
+def test_wbfm_calls_in_64_byte_units_with_resets_and_gain_changes(capi, oracle, sizes, flags):
+    """WBFM in the reference's granularity (the engine wanted 256-byte units): calls of any multiple of 64
+    bytes, from a fresh stream (the restart point leaves the 128-sample segment grid at once), across the 768-sample
+    restart distance and the tile kernel's chunk ends, with resetDemodulator() and setDemodulatorGain() in between, and
+    a long call on the streaming kernel picking up a restart point that is off the grid."""
+    u8 = synth.fm_tone(sum(sizes) // 2 + (1 << 20), seed=91)
+    eng = capi.Engine(1, flags=flags)                 # 4 = IQD_F_WBFM_STREAM: every call of whole 128-sample units streams
+    eng.set_mode("wbfm")
+    o = oracle.chain()
+    o.set_mode("wbfm")
+    off = 0
+    for k, nb in enumerate(sizes):
+        if k == 5:
+            eng.reset()
+            o.reset()
+        if k in (3, 7):
+            g = 40743.7 * (0.5 if k == 3 else 1.7)
+            eng.set_gain("wbfm", g)
+            o.set_gain(3, g)
+        blk = u8[off:off + nb]
+        off += nb
+        pcm, cnt, mag, ok = eng.accept(blk)
+        ref, rmag, rok = o.accept_stream(blk, min(nb, 32768))
+        assert cnt[0] == len(ref) == nb // 64, k
+        assert np.array_equal(pcm[0, :cnt[0]], ref), (k, nb)
+        assert int(mag[0, 0]) == int(rmag[0]), k
+    big = u8[off:off + (1 << 21)]                      # 2^20 samples (flags 4: the streaming pipeline, its first segment warm)
+    pcm, cnt, _, _ = eng.accept(big)
+    ref, _, _ = o.accept_stream(big)
+    assert np.array_equal(pcm[0, :cnt[0]], ref)
+    assert (eng.stats()["stream_launches"] >= 1) == (flags == 4) and eng.stats()["state_repairs"] == 0
+
+
+def test_wbfm_64_byte_units_many_channels_with_gating(capi, oracle):
+    """200 WBFM channels, own data and own call history each row... the same odd call sizes for all (one launch per call),
+    a squelch that rejects some channels' short blocks: a rejected call consumes nothing, so the channels' restart
+    distances drift apart."""
+    n_ch = 200
+    sizes = [192, 64, 8256, 64, 320, 32768, 64, 4160]
+    rng = np.random.default_rng(17)
+    amp = rng.choice([3.0, 60.0], size=(n_ch, len(sizes)), p=[0.3, 0.7])
+    eng = capi.Engine(n_ch)
+    eng.set_mode("wbfm")
+    eng.set_squelch(-45)
+    chains = []
+    for c in range(n_ch):
+        o = oracle.chain()
+        o.set_mode("wbfm")
+        o.set_squelch(-45)
+        chains.append(o)
+    open_calls = 0
+    for k, nb in enumerate(sizes):
+        rows = np.stack([synth.fm_tone(nb // 2, seed=1000 * k + c, amplitude=float(amp[c, k]), sigma=1.0) for c in range(n_ch)])
+        pcm, cnt, mag, ok = eng.accept(rows)
+        for c in range(0, n_ch, 3):
+            ref, rmag, rok = chains[c].accept_stream(rows[c], nb)
+            assert int(ok[c, 0]) == int(rok[0]) and int(mag[c, 0]) == int(rmag[0]), (k, c)
+            assert cnt[c] == len(ref) and np.array_equal(pcm[c, :cnt[c]], ref), (k, c)
+            open_calls += int(rok[0])
+    assert 0 < open_calls < len(sizes) * len(range(0, n_ch, 3))
+
+
+@pytest.mark.parametrize("nbytes", [64, 192, 1664, 8256 + 128])
+def test_short_blocks_of_several_channels_with_odd_pcm_counts(capi, oracle, nbytes):
+    """A short block whose PCM count is not a multiple of 4 (nbytes / 64 = 1, 3, 26, 131), several channels per family
+    in one call: every channel's row ends where it should (round 4: the AM / SSB DC pass stored four samples at a time
+    and a row's last store ran into the next channel's first samples; the short-block fuzzer found it)."""
+    modes = ["am", "usb", "lsb", "am", "fm", "wbfm", "usb", "fm", "wbfm", "am"]
+    n_ch = len(modes)
+    eng = capi.Engine(n_ch)
+    chains = []
+    for c, m in enumerate(modes):
+        eng.set_mode(m, first=c, n=1)
+        o = oracle.chain()
+        o.set_mode(m)
+        chains.append(o)
+    for call in range(3):
+        rows = np.stack([synth.fm_tone(nbytes // 2, seed=50 * call + c, amplitude=30.0 + 3 * c) for c in range(n_ch)])
+        pcm, cnt, mag, ok = eng.accept(rows)
+        for c in range(n_ch):
+            ref, rmag, _ = chains[c].accept_stream(rows[c], nbytes)
+            assert cnt[c] == len(ref) == nbytes // 64
+            assert np.array_equal(pcm[c, :cnt[c]], ref), (call, c, modes[c])
+            assert int(mag[c, 0]) == int(rmag[0])

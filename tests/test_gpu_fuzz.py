@@ -34,3 +34,13 @@ def test_random_wide_batches_match_the_oracle(oracle):
     rng = np.random.default_rng(9004)
     for case in range(10):
         assert gpu_fuzz.wide_case(rng, oracle), case
+
+
+def test_random_short_block_calls_match_the_oracle(oracle):
+    """Every call one short block of any multiple of 64 bytes (or a few whole blocks), WBFM included, operator changes in
+    between (tools/gpu_fuzz.py: short_case)."""
+    import gpu_fuzz
+    rng = np.random.default_rng(9005)
+    for case in range(60):
+        bad = gpu_fuzz.short_case(rng, oracle)
+        assert bad is None, (case, bad)

@@ -63,3 +63,28 @@ def test_two_changes_between_two_accepts_and_a_front_end_call_in_between(capi, o
     a1, _, _ = c.accept_stream(u8[32768:])
     p1, n1, _, _ = eng.accept(u8[32768:])
     assert np.array_equal(p0[0, :n0[0]], a0) and np.array_equal(p1[0, :n1[0]], a1)
+
+
+@pytest.mark.parametrize("mode,demod", [("wbfm", 3), ("fm", 2)])
+def test_gain_change_then_64_byte_calls(capi, oracle, mode, demod):
+    """A gain change, one 64-byte call, then more: the lead-in of the next call has a chunk of 32 samples with the new gain
+    behind a long one with the old (round 4: the FM chain's (int16)(K dtheta) history was not shifted behind a chunk that
+    short; found by the short-block fuzzer).  Then a change before EVERY one of 70 consecutive 64-byte calls - more
+    changes inside the filters' reach than the 16 the engine used to keep."""
+    u8 = synth.fm_tone(6 * 16384, seed=29, deviation=45e3)
+    c = oracle.chain()
+    c.set_mode(mode)
+    eng = capi.Engine(1, block_bytes=4096)
+    eng.set_mode(mode)
+    off = 0
+    plan = [(118784, None), (64, GAINS[0]), (64, None), (64, GAINS[1]), (192, None), (64, GAINS[2]), (4096, None)]
+    plan += [(64, GAINS[k % len(GAINS)] * (1 + 0.01 * k)) for k in range(70)] + [(64, None), (8192, None), (64, GAINS[4]), (32768, None)]
+    for k, (nbytes, gain) in enumerate(plan):
+        if gain is not None:
+            c.set_gain(demod, gain)
+            eng.set_gain(mode, gain)
+        piece = u8[off:off + nbytes]
+        off += nbytes
+        r, _, _ = c.accept_stream(piece, min(nbytes, 4096))
+        pcm, cnt, _, _ = eng.accept(piece)
+        assert cnt[0] == len(r) and np.array_equal(pcm[0, :cnt[0]], r), (k, nbytes, gain)

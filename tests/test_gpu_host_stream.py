@@ -100,3 +100,22 @@ def test_channel_slices_of_one_short_block_per_row(capi, oracle):
         ref, rmag, _ = o.accept_stream(iq[c], nbytes)          # one acceptIqData call of 16384 bytes
         assert np.array_equal(pcm[c], ref), c
         assert mag[c, 0] == rmag[0], c
+
+
+def test_small_call_sliced_call_small_call_on_one_engine(capi, oracle):
+    """One engine, three host-pointer paths in turn: a one-block call (straight out of page-locked host memory), a
+    64 MiB call (sliced and double-buffered), a one-block call again.  ADVICE r3: the sliced path used to free the small
+    path's pinned staging buffer without forgetting it, so the third call wrote into freed memory."""
+    eng = capi.Engine(1)
+    eng.set_mode("fm")
+    o = oracle.chain()
+    o.set_mode("fm")
+    small_a = synth.fm_tone(16384, seed=601)
+    big = np.tile(synth.fm_tone(1 << 21, seed=602), 16)        # 2^25 samples = 64 MiB: the sliced path
+    small_b = synth.fm_tone(16384, seed=603)
+    for part in (small_a, big, small_b, small_a):
+        pcm, cnt, mag, allowed = eng.accept(part)
+        ref, rmag, rallowed = o.accept_stream(part)
+        assert cnt[0] == len(ref) and np.array_equal(pcm[0, :cnt[0]], ref)
+        assert np.array_equal(mag[0], rmag) and np.array_equal(allowed[0], rallowed)
+    eng.close()

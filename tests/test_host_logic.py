@@ -96,3 +96,15 @@ def test_file_tool_fails_loudly_without_gpu():
     if not torch.cuda.is_available():
         r = subprocess.run([tool, "3"], input=b"\x80" * 32768, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
         assert r.returncode == 1 and b"no usable HIP device" in r.stderr and r.stdout == b""
+
+
+def test_bench_rows_numpy_twin_is_the_benchs_own_data():
+    """tests/oracle_pool.bench_rows feeds the oracle what bench.per_channel_rows feeds the engine."""
+    import torch
+    import bench
+    from oracle_pool import bench_rows
+    base = np.random.default_rng(3).integers(0, 256, 5000, dtype=np.uint8)
+    for first, n_ch, row_bytes in ((0, 7, 12000), (4096, 300, 5000), (11, 3, 4096)):
+        a = bench.per_channel_rows(torch, torch.from_numpy(base), n_ch, first, row_bytes, chunk=64).numpy()
+        assert np.array_equal(a, bench_rows(base, n_ch, first, row_bytes))
+    assert not np.array_equal(a[0], a[1])

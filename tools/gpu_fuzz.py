@@ -310,6 +310,69 @@ def wide_case(rng, O):
     return ok
 
 
+def short_case(rng, O):
+    """Calls in the reference's own granularity: every call is either a few whole blocks or ONE short block of any multiple
+    of 64 bytes (Radio.cc:1895-1906 forwards short reads; the rotation strides 8 bytes, IqDataProcessor.cc:586), WBFM
+    included since round 4.  A handful of channels in one engine, every mode, resets / gain / mode / rotation / threshold
+    changes between calls; PCM, magnitude and squelch flag of every channel and call against the oracle."""
+    bb = int(rng.choice([2048, 4096, 32768]))
+    n_ch = int(rng.integers(1, 9))
+    eng = capi.Engine(n_ch, block_bytes=bb)
+    chains, cfg = [], []
+    for c in range(n_ch):
+        mode = MODES[int(rng.integers(1, 6))] if rng.random() < 0.5 else "wbfm"
+        rot = int(rng.integers(-1, 2))
+        thr = int(rng.choice([-200, -200, -200, -45]))
+        o = O.chain()
+        o.set_mode(mode); o.set_rotation(rot); o.set_squelch(thr)
+        eng.set_mode(mode, first=c, n=1); eng.set_rotation(rot, first=c, n=1); eng.set_squelch(thr, first=c, n=1)
+        chains.append(o)
+        cfg.append((mode, rot, thr))
+    log, sizes = [], []
+    for call in range(int(rng.integers(4, 14))):
+        if rng.random() < 0.7:
+            nb = 64 * int(rng.integers(1, bb // 64))                       # one short block
+        else:
+            nb = bb * int(rng.integers(1, max(2, (1 << 17) // bb)))         # whole blocks
+        if rng.random() < 0.5:
+            c = int(rng.integers(0, n_ch))
+            what = int(rng.integers(0, 5))
+            log.append((call, c, what))
+            if what == 0:
+                chains[c].reset(); eng.reset(first=c, n=1)
+            elif what == 1:
+                d, g = int(rng.integers(1, 5)), float(np.float32(10.0 ** rng.uniform(0, 6)))
+                chains[c].set_gain(d, g); eng.set_gain(d, g, first=c, n=1)
+                log[-1] += (d, g)
+            elif what == 2:
+                m = MODES[int(rng.integers(1, 6))]
+                chains[c].set_mode(m); eng.set_mode(m, first=c, n=1)
+                log[-1] += (m,)
+            elif what == 3:
+                r = int(rng.integers(-1, 2))
+                chains[c].set_rotation(r); eng.set_rotation(r, first=c, n=1)
+                log[-1] += (r,)
+            else:
+                t = int(rng.choice([-200, -50, -35]))
+                chains[c].set_squelch(t); eng.set_squelch(t, first=c, n=1)
+                log[-1] += (t,)
+        sizes.append(nb)
+        rows = np.stack([signal(rng, nb // 2, min(bb, nb) // 2) for _ in range(n_ch)])
+        pcm, cnt, mag, allowed = eng.accept(rows)
+        for c in range(n_ch):
+            ref, rmag, rall = chains[c].accept_stream(rows[c], min(nb, bb))
+            if cnt[c] != len(ref) or not np.array_equal(pcm[c, :cnt[c]], ref) or not np.array_equal(mag[c], rmag) \
+                    or not np.array_equal(allowed[c], rall):
+                what = ("count %d vs %d" % (cnt[c], len(ref)) if cnt[c] != len(ref) else
+                        "allowed %s vs %s" % (allowed[c], rall) if not np.array_equal(allowed[c], rall) else
+                        "magnitude %s vs %s" % (mag[c], rmag) if not np.array_equal(mag[c], rmag) else
+                        "pcm: first difference at %d of %d" % (int(np.flatnonzero(pcm[c, :cnt[c]] != ref)[0]), len(ref)))
+                eng.close()
+                return "short-block case: bb=%d cfg=%r call %d of %d bytes (calls so far %r), channel %d differs in %s (ops %r)" % (bb, cfg, call, nb, sizes, c, what, log)
+    eng.close()
+    return None
+
+
 def main():
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -318,10 +381,19 @@ def main():
     t0, cases, n_wide = time.time(), 0, 0
     while time.time() - t0 < seconds:
         wide = os.environ.get("FUZZ_WIDE") == "1" or (os.environ.get("FUZZ_WIDE") is None and rng.random() < 0.03)
-        if not (wide_case(rng, O) if wide else one_case(rng, O)):
+        if os.environ.get("FUZZ_SHORT"):        # every call a short block / a few whole blocks (short_case)
+            bad = short_case(rng, O)
+            if bad:
+                print("MISMATCH:", bad)
+                sys.exit(1)
+        elif not (wide_case(rng, O) if wide else one_case(rng, O)):
             sys.exit(1)
         cases += 1
         n_wide += 1 if wide else 0
+    if os.environ.get("FUZZ_SHORT"):
+        print("gpu_fuzz: %d short-block cases (every call one short block of any multiple of 64 bytes, or a few whole blocks) "
+              "identical to the oracle in %.0f s (seed %d)" % (cases, time.time() - t0, seed))
+        return
     print("gpu_fuzz: %d cases (%d of them wide: hundreds to thousands of channels) identical to the oracle in %.0f s (seed %d)"
           % (cases, n_wide, time.time() - t0, seed))
 
