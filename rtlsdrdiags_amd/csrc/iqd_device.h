@@ -50,7 +50,10 @@ struct ChanParams {
 // Gain changes whose samples are still inside the kept tail, most recent first.  A gain can only change between
 // two accepts and an accept consumes at least 32 samples (one 64-byte unit; a call the squelch rejects consumes nothing
 // and its change replaces the one before it), so TAIL / 32 entries cover every possible history.
-constexpr int EPOCHS = TAIL / 32;    // (a call consumes at least 32 samples - one 64-byte unit - of the 2048 the tail keeps)
+#ifndef IQD_EPOCH_UNIT
+#define IQD_EPOCH_UNIT 32
+#endif
+constexpr int EPOCHS = TAIL / IQD_EPOCH_UNIT;    // (a call consumes at least 32 samples - one 64-byte unit - of the 2048 the tail keeps)
 struct GainEpochList {
     uint32_t since[EPOCHS];    // samples the family has consumed since change i (saturates at TAIL = out of reach)
     float k_before[EPOCHS];    // the K in force before change i

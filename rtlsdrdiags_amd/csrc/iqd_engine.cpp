@@ -33,6 +33,10 @@ using namespace iqd;
 // (WBFM 2^25: 0.118 vs 0.139 ms, 2^26: 0.200 vs 0.171; AM 512 x 2^16: 0.047 vs 0.065, 1024 x 2^16: 0.077 vs 0.072;
 // USB 1024 x 2^16: 0.088 vs 0.083), and side by side with other families' launches the streaming kernels do better.
 static const uint64_t STREAM_MIN_PER_SEGMENT = 1024;
+// AM / SSB rows at least this long (PCM samples) may take their streaming pipeline; the DC pass behind it is then the
+// one-wave pass whatever the row length (round 4: the rule used to be > 512, which kept the reference's own operating
+// point - one 64 ms block per channel per call, 512 PCM samples - on the tile kernels at 0.14 of the HBM peak).  IQD_AM_STREAM_MIN.
+
 
 
 namespace {
@@ -62,6 +66,9 @@ struct DevBuf {
 
 }  // namespace
 
+// AM / SSB rows at least this long (PCM samples) may take their streaming pipeline (see STREAM_MIN_PER_SEGMENT)
+static const uint32_t AM_STREAM_MIN_PCM = 128;
+
 struct iqd_engine {
     std::mutex mu;             // parameter mirror + dirty flags (setters vs. accept)
     int device = 0;
@@ -79,6 +86,7 @@ struct iqd_engine {
     // measurement knobs, read from the environment ONCE at creation (include/iqdemod.h): IQD_WBFM_PATH=stream|tiles
     // (+1 / -1, 0 = choose), IQD_FULL_GRID, IQD_STREAM_WGS=<n>, IQD_PLAN_CHUNKS=<k>
     int env_path = 0;
+    uint32_t env_am_stream_min = AM_STREAM_MIN_PCM;   // IQD_AM_STREAM_MIN (measurement runs: 513 = the rule of rounds 2-3)
     uint32_t env_d4_gran = 128;            // IQD_D4_GRAN: segment-length granule of the FM / AM / SSB pipelines (measurement runs)
     bool env_full_grid = false;
     bool env_mixed_forked = false;         // IQD_MIXED=forked: several families as kernels of their own side by side (A/B runs)
@@ -241,6 +249,7 @@ int iqd_create(const iqd_config *cfg, iqd_t **out)
     if (const char *env = getenv("IQD_WBFM_PATH")) e->env_path = env[0] == 's' ? 1 : env[0] == 't' ? -1 : 0;
     e->env_full_grid = getenv("IQD_FULL_GRID") != nullptr;
     if (const char *env = getenv("IQD_D4_GRAN")) e->env_d4_gran = (uint32_t)atoi(env);
+    if (const char *env = getenv("IQD_AM_STREAM_MIN")) e->env_am_stream_min = atoi(env) > 0 ? (uint32_t)atoi(env) : AM_STREAM_MIN_PCM;
     if (const char *env = getenv("IQD_MIXED")) e->env_mixed_forked = env[0] == 'f' && env[1] == 'o';
     if (const char *env = getenv("IQD_FAMILY_WEIGHTS")) {   // "am,fm,wbfm,ssb" (measurement runs)
         float w[FAM_COUNT];
@@ -1249,7 +1258,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
             const bool forced = (e->flags & IQD_F_WBFM_STREAM) != 0;
             const float due = total > 0.f ? (float)(e->n_cus - 16) * cost[f] / total : (float)e->n_cus;
             if (!forced && (float)((uint64_t)vlen * n_f) < due * (float)(ST_SEGS * STREAM_MIN_PER_SEGMENT)) all_stream = false;
-            if ((f == FAM_AM || f == FAM_SSB) && vlen / 32 <= 512) all_stream = false;
+            if ((f == FAM_AM || f == FAM_SSB) && vlen / 32 < e->env_am_stream_min) all_stream = false;
         }
         shares_on = forked && all_stream && total > 0.f && e->n_cus >= 64 && !e->env_full_grid;
         // ONE launch for all of them (iqd_stream_mixed.hip) when each family can take its streaming pipeline in the plain
@@ -1269,7 +1278,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         if (fused)
             for (uint32_t c : e->h_lists[FAM_FM]) fused = fused && e->fm_kmax[first_ch + c] * 6.35f < 2147483648.0f;
         if (fused && (!e->h_lists[FAM_AM].empty() || !e->h_lists[FAM_SSB].empty()))
-            fused = vlen / 32 > 512 && (bytes_per_ch / 64 + DC_TILE - 1) / DC_TILE < 2;
+            fused = vlen / 32 >= e->env_am_stream_min && (bytes_per_ch / 64 + DC_TILE - 1) / DC_TILE < 2;
         if (shares_on && fused) plan_fused_shares(cost, FAM_COUNT, e->n_cus, fam_share);
         else if (shares_on && !plan_family_shares(cost, FAM_COUNT, e->n_cus, fam_share)) shares_on = false;
         if (!shares_on) fused = false;
@@ -1311,22 +1320,39 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         // (int16)y can hit the "integer indefinite" value.  Results are identical either way.
         bool use_stream = false;
         int stream_rot = 0;
+        bool stream_grouped = false;   // channels of several rotation selectors: segment ids grouped by selector (StreamArgs::grouped)
+        uint32_t st_group_start[4] = {0, 0, 0, 0}, st_group_li0[3] = {0, 0, 0}, st_group_nseg[3] = {0, 0, 0};
         if (f == FAM_WBFM && e->stream_ok && !(e->flags & IQD_F_WBFM_TILES) && vlen % 128 == 0) {
             const auto &l = e->h_lists[FAM_WBFM];
             stream_rot = e->h_params[first_ch + l[0]].rotation;
             bool ok = true;
             for (uint32_t c : l) {
                 const ChanParams &p = e->h_params[first_ch + c];
-                ok = ok && p.rotation == stream_rot && e->wbfm_kmax[first_ch + c] * 3.1730f < 2147483648.0f;
+                stream_grouped = stream_grouped || p.rotation != stream_rot;
+                ok = ok && e->wbfm_kmax[first_ch + c] * 3.1730f < 2147483648.0f;
             }
+            if (fused && stream_grouped) ok = false;   // (the one-launch arrangement holds the single-selector instantiations only)
             int want = 0;   // 0 auto, 1 stream, -1 tiles
             if (e->flags & IQD_F_WBFM_STREAM) want = 1;
             if (e->env_path) want = e->env_path;
             const uint64_t work = (uint64_t)vlen * n_list;
             if (ok && want >= 0 && (want > 0 || work >= (uint64_t)(shares_on ? fam_wgs : e->n_cus) * ST_SEGS * STREAM_MIN_PER_SEGMENT || shares_on)) {
-                const TilePlan sp = plan_stream(vlen, n_list, fam_wgs * ST_SEGS, e->env_stream_gran);
-                a.tile_len = sp.tile_len;
-                a.tiles_per_ch = sp.tiles_per_ch;
+                for (uint32_t spare = 0;; spare += 48) {   // (the groups' padding may push an exact fit into a second round)
+                    const TilePlan sp = plan_stream(vlen, n_list, fam_wgs * ST_SEGS - (stream_grouped ? spare : 0u), e->env_stream_gran);
+                    a.tile_len = sp.tile_len;
+                    a.tiles_per_ch = sp.tiles_per_ch;
+                    if (!stream_grouped) break;
+                    uint32_t at = 0, li0 = 0;
+                    for (int r = 0; r < 3; r++) {   // the channel list is sorted +Fs/4, none, -Fs/4 (rebuild_lists)
+                        st_group_start[r] = at;
+                        st_group_li0[r] = li0;
+                        st_group_nseg[r] = e->rot_count[FAM_WBFM][r] * a.tiles_per_ch;
+                        at += (st_group_nseg[r] + 15u) / 16u * 16u;
+                        li0 += e->rot_count[FAM_WBFM][r];
+                    }
+                    st_group_start[3] = at;
+                    if (at <= fam_wgs * ST_SEGS || spare >= 48 || n_list * 1u >= fam_wgs * ST_SEGS) break;
+                }
                 use_stream = true;
             }
         }
@@ -1335,7 +1361,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         bool use_d4 = false;
         uint32_t d4_wgs = fam_wgs;
         D4Args d4 = e->d4_args;
-        if (f != FAM_WBFM && !(e->flags & IQD_F_WBFM_TILES) && vlen % 128 == 0 && (f == FAM_FM || vlen / 32 > 512)) {
+        if (f != FAM_WBFM && !(e->flags & IQD_F_WBFM_TILES) && vlen % 128 == 0 && (f == FAM_FM || vlen / 32 >= e->env_am_stream_min)) {
             bool ok = true;
             if (f == FAM_FM)
                 for (uint32_t c : e->h_lists[f]) ok = ok && e->fm_kmax[first_ch + c] * 6.35f < 2147483648.0f;
@@ -1391,7 +1417,15 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
                 sa.amat = e->d_amat[stream_rot + 1];
                 sa.half_lut = e->d_half_lut;
                 sa.n_segments = n_list * a.tiles_per_ch;
-                const uint32_t wgs_needed = (sa.n_segments + ST_SEGS - 1) / ST_SEGS;
+                sa.grouped = stream_grouped ? 1u : 0u;
+                for (int r = 0; r < 3; r++) {
+                    sa.group_start[r] = st_group_start[r];
+                    sa.group_li0[r] = st_group_li0[r];
+                    sa.group_nseg[r] = st_group_nseg[r];
+                    sa.amat3[r] = e->d_amat[2 - r];          // d_amat[] is indexed by selector + 1; the groups run +1, 0, -1
+                }
+                sa.group_start[3] = st_group_start[3];
+                const uint32_t wgs_needed = ((stream_grouped ? sa.group_start[3] : sa.n_segments) + ST_SEGS - 1) / ST_SEGS;
                 const uint32_t grid = wgs_needed < fam_wgs ? wgs_needed : fam_wgs;
                 sa.rounds = (wgs_needed + grid - 1) / grid;
                 HIP_TRY(e, e->stream_hist.ensure((size_t)sa.n_segments * sizeof(StHist)));
@@ -1463,7 +1497,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
                 mix.d4[f] = d4;
             } else {
                 HIP_LAUNCH(e, launch_d4_stream(a, d4, f == FAM_AM ? D4_AM : D4_SSB, fused_mag, grid, s));
-                HIP_LAUNCH(e, launch_am_dc(a, f, s));
+                HIP_LAUNCH(e, launch_am_dc(a, f, s, true));   // (the pipeline wrote the detector stream channel-major)
             }
             e->stats.stream_launches++;
         } else {

@@ -91,7 +91,7 @@ hipError_t init_d4_stream_kernels();
 hipError_t launch_wbfm_stream(const ChainLaunch &a, const StreamArgs &sa, int rotation, bool mag, bool epochs, uint32_t grid, hipStream_t s);
 struct D4Args;
 hipError_t launch_d4_stream(const ChainLaunch &a, const D4Args &da, int mode, bool mag, uint32_t grid, hipStream_t s);
-hipError_t launch_am_dc(const ChainLaunch &a, int family, hipStream_t s);   // the DC-removal passes behind an AM/SSB chain launch
+hipError_t launch_am_dc(const ChainLaunch &a, int family, hipStream_t s, bool channel_major = false);   // the DC-removal passes behind an AM/SSB chain launch
 hipError_t launch_wbfm_stream_fixup(const ChainLaunch &a, const StreamArgs &sa, hipStream_t s);
 hipError_t launch_retail(uint8_t *tails, const ChanParams *params, uint32_t n_ch, hipStream_t s);
 // kind: 0 float decimator, 1 float interpolator, 2 int16 interpolator

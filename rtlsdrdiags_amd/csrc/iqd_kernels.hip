@@ -955,13 +955,13 @@ hipError_t launch_am(const ChainLaunch &a_in, int family, bool gated, bool mag, 
     if (gated) hipLaunchKernelGGL((am_chain_kernel<true, false>), grid, block, 0, s, a, family);
     else if (mag) hipLaunchKernelGGL((am_chain_kernel<false, true>), grid, block, 0, s, a, family);
     else hipLaunchKernelGGL((am_chain_kernel<false, false>), grid, block, 0, s, a, family);
-    return launch_am_dc(a, family, s);
+    return launch_am_dc(a, family, s, false);
 }
 
-hipError_t launch_am_dc(const ChainLaunch &a_in, int family, hipStream_t s)
+hipError_t launch_am_dc(const ChainLaunch &a_in, int family, hipStream_t s, bool channel_major)
 {
     ChainLaunch a = a_in;
-    const bool batch = a.vlen / 32 <= 512;
+    const bool batch = !channel_major && a.vlen / 32 <= 512;   // (the streaming pipelines write the detector stream channel-major)
     a.base_stride_ch = batch ? 1 : a.pcm_stride;
     a.base_stride_t = batch ? a.n_ch_call : 1;
     // short streams: one lane per channel; long streams: one wave per channel, segmented

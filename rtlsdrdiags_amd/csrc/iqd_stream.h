@@ -78,6 +78,15 @@ struct StreamArgs {
     const float *half_lut;    // [129][ST_ROW_FLOATS]: |atan2(-r, x - 128)|
     uint32_t n_segments;      // n_list * tiles_per_ch
     uint32_t rounds;          // rounds per workgroup
+    // Channels of several rotation selectors in one launch (round 4; the kernel instantiation with ROT = 2): the channel
+    // list is sorted by selector (+Fs/4, none, -Fs/4) and each group's segment ids are padded to a multiple of 16, so that
+    // a P wave's 16 segments share their tap matrices - as the FM / AM / SSB pipelines do (D4Args).  grouped = 0: ids are
+    // li * tiles_per_ch + tile and `amat` is the launch's one selector.
+    uint32_t grouped;
+    uint32_t group_start[4];  // first id of each group; [3] = end of the ids
+    uint32_t group_li0[3];    // first channel-list index of each group
+    uint32_t group_nseg[3];   // real segments of each group
+    const uint32_t *amat3[3]; // tap matrices of the selectors +1, 0, -1
     uint32_t d1p[4];          // decimator taps as v_dot2 pairs (see build_stream_taps)
     uint32_t d1p2[4];         // stage 1 again with doubled taps (the IIR lanes: result in the accumulator's high half)
     uint32_t p12p[6];

@@ -59,9 +59,13 @@ __device__ __forceinline__ int st_simd_id() { return (__builtin_amdgcn_s_getreg(
 // in the piece loop as a 16-deep ladder twice over, costing registers (it spilled) and instruction cache for nothing.
 // GATED: a squelch-gated launch (some channel lost blocks): virtual sample v of a channel lives in its open block number
 // v / block_samples (ChainLaunch::blk_lists); a lane keeps the block it is in and looks the next one up when it leaves it.
-template <int ROT, bool MAG, bool EPOCHS, bool GATED>
+// BYGROUP: the launch holds channels of several rotation selectors (StreamArgs::grouped); this call takes the rounds in
+// which the wave's 16 segments belong to selector ROT and leaves the others to the calls for the other two selectors
+// (st_p_wave_any: +1, 0, -1 in turn - the order of the groups, so a wave still meets its rounds in ascending order).
+// pc: pieces the wave's ring has seen so far, carried through those calls.
+template <int ROT, bool MAG, bool EPOCHS, bool GATED, bool BYGROUP = false>
 __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs &sa, uint8_t *lds, uint32_t *sync,
-                                          int pw, int lane)
+                                          int pw, int lane, uint32_t &pc)
 {
     // a ring's four P waves are every third wave, not four in a row: the hardware issues oldest wave first, and with
     // rings of neighbouring waves ring 0 ran a third ahead of ring 2 (per-wave end times 115 / 137 / 155 us), which left
@@ -82,7 +86,7 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
 
     v4i A[8];
 #pragma unroll
-    for (int m = 0; m < 8; m++) A[m] = ((const v4i *)sa.amat)[m * 64 + lane];
+    for (int m = 0; m < 8; m++) A[m] = ((const v4i *)(BYGROUP ? sa.amat3[1 - ROT] : sa.amat))[m * 64 + lane];
     v4i cbias = {WB_BIAS, WB_BIAS, WB_BIAS, WB_BIAS};
     const v4i czero = {0, 0, 0, 0};
     asm volatile("" : "+v"(cbias));  // four VGPRs for the whole kernel: else the compiler rebuilds the quad from scalars for every piece
@@ -92,11 +96,12 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
     const int n_pieces = (ST_HALO + (int)a.tile_len) >> 5;
     uint64_t inv_2pi = 0x3e22f9843e22f984ull;                    // (float)(1 / (2 pi)) twice: the scalar operand of v_pk_mul_f32
     asm volatile("" : "+s"(inv_2pi));
-    uint32_t pc = 0;                                             // pieces this ring has seen (all rounds)
     for (uint32_t round = 0; round < sa.rounds; round++) {
-        if ((round * chain_wgs(a) + chain_wg(a)) * ST_SEGS >= sa.n_segments) break;   // nothing left for this workgroup
+        if ((round * chain_wgs(a) + chain_wg(a)) * ST_SEGS >= st_id_count(sa)) break;   // nothing left for this workgroup
         const uint32_t sid = (round * chain_wgs(a) + chain_wg(a)) * ST_SEGS + ring * 64 + row;
-        const StSeg sg = st_segment(a, sid, sa.n_segments);
+        int rot_of_id = ROT;
+        const StSeg sg = BYGROUP ? st_segment_of(a, sa, sid, rot_of_id) : st_segment(a, sid, sa.n_segments);
+        if (BYGROUP && __builtin_amdgcn_readfirstlane(rot_of_id) != ROT) continue;   // (uniform: groups are padded to 16 ids)
         const ChanParams &p = a.params[sg.ech];
         const uint8_t *iq_ch = a.iq + (size_t)sg.ch * a.ch_stride_bytes;
         const uint8_t *tail = a.tails + ((size_t)sg.ech * FAM_COUNT + FAM_WBFM) * TAIL_BYTES + TAIL_BYTES;
@@ -246,7 +251,7 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
                 const float before = u2f((uint32_t)__builtin_amdgcn_ds_bpermute(src_lane4, (int)f2u(give)));
                 last_prev = th[3];
                 float kk = kneg;
-                if (EPOCHS && ep_any && ep_reach) kk = -epoch_gain(ep, p.wbfm_k, sg.v0 + wpos);   // (rare: right after a gain change)
+                if (EPOCHS && ep_any && ep_reach) kk = -epoch_gain_search(ep, p.wbfm_k, sg.v0 + wpos);   // (rare: right after a gain change)
 #pragma unroll
                 for (int r = 0; r < 4; r += 2) {   // two samples per packed operation; wrap_delta() of iqd_prims.h operation by operation
                     v2f d = {th[r] - (r == 0 ? before : th[r - 1]), th[r + 1] - th[r]};   // = -(delta theta)
@@ -543,10 +548,11 @@ __device__ __forceinline__ void st_iir_wave(const ChainLaunch &a, const StreamAr
     const int n_pieces = (ST_HALO + (int)a.tile_len) >> 5;       // a multiple of 4
     uint32_t wg = 0;                                             // pieces read so far (all rounds)
     for (uint32_t round = 0; round < sa.rounds; round++) {
-        if ((round * chain_wgs(a) + chain_wg(a)) * ST_SEGS >= sa.n_segments) break;
+        if ((round * chain_wgs(a) + chain_wg(a)) * ST_SEGS >= st_id_count(sa)) break;
         const uint32_t sid = (round * chain_wgs(a) + chain_wg(a)) * ST_SEGS + ring * 64 + lane;
         StIirSeg q;
-        q.sg = st_segment(a, sid, sa.n_segments);
+        int rot_unused;
+        q.sg = st_segment_of(a, sa, sid, rot_unused);
         q.pcm_row = a.pcm + (size_t)q.sg.ch * a.pcm_stride;
         q.hist = sa.hist + (q.sg.valid ? (size_t)q.sg.li * a.tiles_per_ch + q.sg.tile : 0);
         q.back = -1;
@@ -672,8 +678,14 @@ __device__ __forceinline__ void wbfm_stream_body(const ChainLaunch &a, const Str
     if (tid < ST_SYNC_WORDS) sync[tid] = 0;
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    uint32_t pc = 0;                                             // pieces this wave's ring has seen (all rounds)
     if (wave < ST_RINGS) st_iir_wave(a, sa, st_lds, sync, wave, lane);
-    else st_p_wave<ROT, MAG, EPOCHS, GATED>(a, sa, st_lds, sync, wave - ST_RINGS, lane);
+    else if (ROT != 2) st_p_wave<ROT, MAG, EPOCHS, GATED>(a, sa, st_lds, sync, wave - ST_RINGS, lane, pc);
+    else {   // channels of several rotation selectors: the groups in their order
+        st_p_wave<1, MAG, EPOCHS, GATED, true>(a, sa, st_lds, sync, wave - ST_RINGS, lane, pc);
+        st_p_wave<0, MAG, EPOCHS, GATED, true>(a, sa, st_lds, sync, wave - ST_RINGS, lane, pc);
+        st_p_wave<-1, MAG, EPOCHS, GATED, true>(a, sa, st_lds, sync, wave - ST_RINGS, lane, pc);
+    }
 }
 
 #ifndef IQD_STREAM_BODIES_ONLY
@@ -704,14 +716,14 @@ typedef void (*StKernel)(const ChainLaunch, const StreamArgs);
 #define ST_K(R) {{wbfm_stream_kernel<R, false, false, false>, wbfm_stream_kernel<R, false, true, false>}, \
                  {wbfm_stream_kernel<R, true, false, false>, wbfm_stream_kernel<R, true, true, false>},   \
                  {wbfm_stream_kernel<R, false, false, true>, wbfm_stream_kernel<R, false, true, true>}}
-static const StKernel st_kernels[3][3][2] = {ST_K(-1), ST_K(0), ST_K(1)};
+static const StKernel st_kernels[4][3][2] = {ST_K(-1), ST_K(0), ST_K(1), ST_K(2)};   // [3]: selectors by group (StreamArgs::grouped)
 #undef ST_K
 
 // One workgroup takes nearly all of a CU's LDS; the attribute belongs to the current device's code object and is set
 // once per engine by iqd_create (serialised there).
 hipError_t init_wbfm_stream_kernels()
 {
-    for (int r = 0; r < 3; r++)
+    for (int r = 0; r < 4; r++)
         for (int g = 0; g < 6; g++) {
             const hipError_t e = hipFuncSetAttribute((const void *)st_kernels[r][g >> 1][g & 1], hipFuncAttributeMaxDynamicSharedMemorySize, ST_LDS_BYTES);
             if (e != hipSuccess) return e;
@@ -722,7 +734,7 @@ hipError_t init_wbfm_stream_kernels()
 hipError_t launch_wbfm_stream(const ChainLaunch &a, const StreamArgs &sa, int rotation, bool mag, bool epochs, uint32_t grid, hipStream_t s)
 {
     const int variant = a.vlen_gated ? 2 : (mag ? 1 : 0);
-    hipLaunchKernelGGL(st_kernels[rotation < 0 ? 0 : rotation > 0 ? 2 : 1][variant][epochs ? 1 : 0], dim3(grid), dim3(ST_THREADS), ST_LDS_BYTES, s, a, sa);
+    hipLaunchKernelGGL(st_kernels[sa.grouped ? 3 : rotation < 0 ? 0 : rotation > 0 ? 2 : 1][variant][epochs ? 1 : 0], dim3(grid), dim3(ST_THREADS), ST_LDS_BYTES, s, a, sa);
     return hipGetLastError();
 }
 

@@ -40,6 +40,24 @@ __device__ __forceinline__ StSeg st_segment(const ChainLaunch &a, uint32_t sid, 
     return s;
 }
 
+// The same for a launch whose ids are grouped by rotation selector (StreamArgs::grouped); rot = the id's selector.
+// (IQD_ST_NO_GROUPS: a translation unit whose launches are never grouped - the one that holds all four families' pipelines,
+// iqd_stream_mixed.hip, where every scalar register counts - compiles the plain mapping only.)
+#ifndef IQD_ST_NO_GROUPS
+#define IQD_ST_NO_GROUPS 0
+#endif
+__device__ __forceinline__ StSeg st_segment_of(const ChainLaunch &a, const StreamArgs &sa, uint32_t sid, int &rot)
+{
+    if (IQD_ST_NO_GROUPS || !sa.grouped) { rot = 0; return st_segment(a, sid, sa.n_segments); }
+    const uint32_t r = (sid >= sa.group_start[1] ? 1u : 0u) + (sid >= sa.group_start[2] ? 1u : 0u);
+    rot = 1 - (int)r;
+    const uint32_t local = sid - sa.group_start[r];
+    const bool there = sid < sa.group_start[3] && local < sa.group_nseg[r];
+    // (an id that is padding maps to no segment: st_segment() then hands back the launch's first channel with length 0)
+    return st_segment(a, there ? sa.group_li0[r] * a.tiles_per_ch + local : sa.n_segments, sa.n_segments);
+}
+__device__ __forceinline__ uint32_t st_id_count(const StreamArgs &sa) { return !IQD_ST_NO_GROUPS && sa.grouped ? sa.group_start[3] : sa.n_segments; }
+
 // The first ST_FIX_PCM PCM samples of every cold segment, recomputed with the exact histories its predecessor left
 // (StHist): stage-1 output 0, stage-2 outputs 0..2, then the 40-tap audio decimator in the reference's MAC order with
 // the clamp after every MAC (Decimator_int16.cc:176-238) - which is also what the clamp-free fast path equals when

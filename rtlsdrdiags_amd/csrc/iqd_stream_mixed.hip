@@ -7,6 +7,7 @@
 // The workgroup bodies are the stream kernels' own (iqd_stream.hip, iqd_stream2.hip), compiled into this translation unit
 // a second time; a workgroup runs exactly one of them.
 #define IQD_STREAM_BODIES_ONLY 1
+#define IQD_ST_NO_GROUPS 1        // (its WBFM family has one rotation selector: iqd_engine.cpp plans it so)
 #include "iqd_stream.hip"
 #include "iqd_stream2.hip"
 #include "iqd_stream_mixed.h"

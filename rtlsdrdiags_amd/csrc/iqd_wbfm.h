@@ -736,6 +736,26 @@ IQD_DEV float epoch_gain(const GainEpochList *ep, float k_now, int v)
         }
     return k;
 }
+// The same without a data-dependent loop, for the streaming kernels' piece loops: `since` ascends with the index (older
+// changes have consumed more; entries out of reach sit at TAIL, beyond any position a lead-in can have), so the number
+// m of changes that lie AFTER position v - since[i] < -v - is found by a binary search of log2(EPOCHS) steps, each a load
+// and a select; the gain is k_before[m - 1], or the current one when m = 0.  (Round 4: with 64 entries the linear scan
+// above became a real, divergent loop inside the FM pipeline's software-pipelined piece body, and that build faulted on
+// the device at launch geometries with few workgroups per family - tools/dbg_mixed.py, gpurun_out: "fm wgs 56".)
+IQD_DEV float epoch_gain_search(const GainEpochList *ep, float k_now, int v)
+{
+    static_assert((EPOCHS & (EPOCHS - 1)) == 0, "a power of two");
+    const uint32_t want = (uint32_t)(v < 0 ? -v : 0);            // entries with since < want lie after v
+    int m = 0;
+#pragma unroll
+    for (int step = EPOCHS / 2; step >= 1; step >>= 1)
+        m += ep->since[m + step - 1] < want ? step : 0;
+    // m in [0, EPOCHS - 1] entries qualify among the first EPOCHS - 1; the last one, if the list is full:
+    m += m == EPOCHS - 1 && ep->since[EPOCHS - 1] < want ? 1 : 0;
+    const float kb = ep->k_before[m > 0 ? m - 1 : 0];
+    return m > 0 ? kb : k_now;
+}
+
 IQD_DEV int wbfm_chunk_len(const WbfmTile &t, int cs, int chunk, int lead_from = -TAIL)
 {
     if (cs < 0) {   // the lead-in ends at the tile start or at the next gain change, whichever comes first

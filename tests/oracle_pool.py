@@ -1,54 +1,76 @@
-"""Test infrastructure: the oracle for MANY channels at once, one process per host core (the GPU boxes have 256 hardware
-threads, so every channel of a 4096-channel launch can be held to the oracle in a second or two instead of a sample of
-them - VERDICT r3 item 5).  The rows are inherited by fork (nothing is pickled on the way in)."""
-import multiprocessing as mp
+"""Test infrastructure: the oracle for MANY channels at once, one worker process per host core (the GPU boxes have 256
+hardware threads, so every channel of a 4096-channel launch can be held to the oracle in a second or two instead of a
+sample of them - VERDICT r3 item 5).
+
+The workers are plain child processes of their own (`python tests/oracle_pool.py <job directory> <k> <n>`), started with
+subprocess: nothing of the test process - its HIP runtime, its threads, its engine objects - is inherited (a fork of a
+process with a live GPU context is undefined behaviour, and a forked worker that dies in an inherited finaliser leaves a
+multiprocessing pool waiting for ever).  Rows go over as one .npy file that the workers map; results come back as one
+.npz per worker."""
+import json
 import os
+import shutil
+import subprocess
+import sys
+import tempfile
 
 import numpy as np
 
-_JOB = {}
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _work(chunk):
+def _worker_main(job_dir, k, n_workers):
+    sys.path.insert(0, ROOT)
     from oracle import bindings as B
+    with open(os.path.join(job_dir, "job.json")) as f:
+        job = json.load(f)
+    rows = np.load(os.path.join(job_dir, "rows.npy"), mmap_mode="r")
     O = B.Oracle()
-    rows, modes, rots, calls, threshold, agc = (_JOB[k] for k in ("rows", "modes", "rots", "calls", "threshold", "agc"))
-    out = []
-    for c in chunk:
+    out = {}
+    for c in range(k, len(rows), n_workers):
         ch = O.chain()
-        ch.set_mode(modes[c])
-        ch.set_rotation(rots[c])
-        if threshold is not None:
-            ch.set_squelch(threshold)
-        if agc is not None:
-            ch.agc_set_type(agc)
+        ch.set_mode(job["modes"][c])
+        ch.set_rotation(job["rots"][c])
+        if job["threshold"] is not None:
+            ch.set_squelch(job["threshold"])
+        if job["agc"] is not None:
+            ch.agc_set_type(job["agc"])
             ch.agc_enable(True)
-        res = [ch.accept_stream(rows[c]) for _ in range(calls)]
-        out.append((c, [r[0] for r in res], [r[1] for r in res], [r[2] for r in res]))
+        row = np.array(rows[c])
+        for call in range(job["calls"]):
+            pcm, mag, allowed = ch.accept_stream(row)
+            out["p_%d_%d" % (call, c)], out["m_%d_%d" % (call, c)], out["a_%d_%d" % (call, c)] = pcm, mag, allowed
         ch.close()
-    return out
+    np.savez(os.path.join(job_dir, "out_%d.npz" % k), **out)
 
 
-def oracle_all_channels(rows, modes, rots=None, calls=1, threshold=None, agc=None, workers=None):
+def oracle_all_channels(rows, modes, rots=None, calls=1, threshold=None, agc=None, workers=None, timeout=900):
     """rows [n_ch][bytes] uint8 (the same bytes go in at every call); modes / rots per channel.  Returns three lists
     indexed [call][channel]: PCM arrays, per-block magnitudes, per-block squelch results."""
     n_ch = len(rows)
-    _JOB.update(rows=rows, modes=list(modes), rots=list(rots) if rots is not None else [1] * n_ch, calls=calls,
-                threshold=threshold, agc=agc)
-    workers = workers or max(1, min(96, (os.cpu_count() or 2) - 2))
-    per = max(1, min(32, (n_ch + 4 * workers - 1) // (4 * workers)))
-    chunks = [list(range(i, min(i + per, n_ch))) for i in range(0, n_ch, per)]
-    pcm = [[None] * n_ch for _ in range(calls)]
-    mag = [[None] * n_ch for _ in range(calls)]
-    allowed = [[None] * n_ch for _ in range(calls)]
-    ctx = mp.get_context("fork")
-    with ctx.Pool(workers) as pool:
-        for part in pool.imap_unordered(_work, chunks):
-            for c, p, m, a in part:
-                for k in range(calls):
-                    pcm[k][c], mag[k][c], allowed[k][c] = p[k], m[k], a[k]
-    _JOB.clear()
-    return pcm, mag, allowed
+    workers = workers or max(1, min(96, (os.cpu_count() or 2) - 2, n_ch))
+    base = "/dev/shm" if os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 2 * rows.nbytes + (1 << 28) else None
+    job_dir = tempfile.mkdtemp(prefix="iqd_oracle_", dir=base)
+    try:
+        np.save(os.path.join(job_dir, "rows.npy"), np.ascontiguousarray(rows))
+        with open(os.path.join(job_dir, "job.json"), "w") as f:
+            json.dump({"modes": list(modes), "rots": [int(r) for r in (rots if rots is not None else [1] * n_ch)],
+                       "calls": calls, "threshold": threshold, "agc": agc}, f)
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), job_dir, str(k), str(workers)]) for k in range(workers)]
+        for p in procs:
+            rc = p.wait(timeout=timeout)
+            assert rc == 0, "an oracle worker exited with %d" % rc
+        pcm = [[None] * n_ch for _ in range(calls)]
+        mag = [[None] * n_ch for _ in range(calls)]
+        allowed = [[None] * n_ch for _ in range(calls)]
+        for k in range(workers):
+            with np.load(os.path.join(job_dir, "out_%d.npz" % k)) as z:
+                for c in range(k, n_ch, workers):
+                    for call in range(calls):
+                        pcm[call][c], mag[call][c], allowed[call][c] = z["p_%d_%d" % (call, c)], z["m_%d_%d" % (call, c)], z["a_%d_%d" % (call, c)]
+        return pcm, mag, allowed
+    finally:
+        shutil.rmtree(job_dir, ignore_errors=True)
 
 
 def bench_rows(base_u8, n_ch, first_global, row_bytes):
@@ -64,3 +86,7 @@ def bench_rows(base_u8, n_ch, first_global, row_bytes):
         out[c] = tiled[s:s + row_bytes]
         out[c, :4] ^= np.frombuffer(np.uint32(g).tobytes(), np.uint8)
     return out
+
+
+if __name__ == "__main__":
+    _worker_main(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]))

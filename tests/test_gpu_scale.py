@@ -366,7 +366,40 @@ def test_mixed_call_with_a_tiny_family(capi, oracle):
     _run_mixed_on_device(capi, oracle, 4096, 16, expect_streams=4, wbfm_every=10)
 
 
-def test_mixed_call_where_only_some_families_stream(capi, oracle):
-    """16384 channels x 2^14 samples: rows of 512 PCM samples keep AM and SSB on their tile kernels (batched DC pass),
-    so no CU shares are planned; FM and WBFM bring enough samples to stream on the whole chip in turn."""
-    _run_mixed_on_device(capi, oracle, 16384, 14, expect_streams=2)
+def test_mixed_call_of_one_block_per_channel(capi, oracle):
+    """16384 channels x 2^14 samples - one 64 ms block per channel per call, the reference's own operating point
+    (DataConsumer.cc:342).  Rounds 2-3 kept AM and SSB rows of 512 PCM samples on their tile kernels; since round 4 they
+    take their streaming pipelines like the other two families (the one-wave DC pass behind them), so the call plans CU
+    shares and runs as one launch."""
+    _run_mixed_on_device(capi, oracle, 16384, 14, expect_streams=4)
+
+
+def test_short_am_ssb_rows_stream_and_match_the_tile_kernels(capi, oracle, monkeypatch):
+    """AM / LSB / USB rows of 128 .. 512 PCM samples on the streaming pipelines (IQD_AM_STREAM_MIN: 128) against the oracle,
+    many channels, rotation selectors mixed, two calls - and the same call with the rule of rounds 2-3 (tile kernels)."""
+    n_ch = 3000
+    for log2 in (12, 13, 14):
+        n = 1 << log2
+        u8 = _mixed_rows(n_ch, n, seed=log2)
+        modes = [("am", "lsb", "usb")[c % 3] for c in range(n_ch)]
+        rots = [(1, 0, -1)[(c // 3) % 3] for c in range(n_ch)]
+        outs = []
+        for rule in ("128", "513"):
+            monkeypatch.setenv("IQD_AM_STREAM_MIN", rule)
+            eng = capi.Engine(n_ch, flags=4)               # IQD_F_WBFM_STREAM: every chain streams where its rules allow
+            for c in range(n_ch):
+                eng.set_mode(modes[c], first=c, n=1)
+                eng.set_rotation(rots[c], first=c, n=1)
+            got = [eng.accept(u8)[0].copy() for _ in range(2)]
+            assert (eng.stats()["stream_launches"] > 0) == (rule == "128"), (log2, rule, eng.stats())
+            outs.append(got)
+            eng.close()
+        for k in range(2):
+            assert np.array_equal(outs[0][k], outs[1][k]), (log2, k)
+        for c in range(0, n_ch, 211):
+            o = oracle.chain()
+            o.set_mode(modes[c])
+            o.set_rotation(rots[c])
+            for k in range(2):
+                ref, _, _ = o.accept_stream(u8[c])
+                assert np.array_equal(outs[0][k][c], ref), (log2, c, k)

@@ -166,3 +166,31 @@ def test_loud_but_bounded_gain(capi, oracle):
     pcm, cnt, _, _ = eng.accept(u8)
     assert eng.stats()["stream_launches"] == 1
     assert np.array_equal(pcm[0, :cnt[0]], ref)
+
+
+def test_channels_of_several_rotation_selectors_stream_in_one_launch(capi, oracle):
+    """WBFM channels with different rotation selectors used to send the whole launch to the tile kernels:
+    the channel list is sorted by selector, each group's segment ids padded to 16, a P wave takes its rounds' selector
+    (StreamArgs::grouped).  210 channels, selectors mixed unevenly, own data, two calls, every channel against the oracle."""
+    n_ch, n = 210, 1 << 15
+    rng = np.random.default_rng(8)
+    rots = [int(r) for r in rng.choice([1, 1, 1, 0, -1, -1], n_ch)]
+    u8 = np.stack([np.roll(synth.fm_tone(n, seed=300 + (c % 9), amplitude=25.0 + c % 40), 2 * ((c * 37) % 1009)) for c in range(n_ch)])
+    eng = capi.Engine(n_ch, flags=STREAM)
+    eng.set_mode("wbfm")
+    chains = []
+    for c in range(n_ch):
+        eng.set_rotation(rots[c], first=c, n=1)
+        o = oracle.chain()
+        o.set_mode("wbfm")
+        o.set_rotation(rots[c])
+        chains.append(o)
+    for call in range(2):
+        before = eng.stats()["stream_launches"]
+        pcm, cnt, mag, _ = eng.accept(u8)
+        assert eng.stats()["stream_launches"] - before == 1
+        for c in range(n_ch):
+            ref, rmag, _ = chains[c].accept_stream(u8[c])
+            assert cnt[c] == len(ref) and np.array_equal(pcm[c, :cnt[c]], ref), (call, c, rots[c])
+            assert np.array_equal(mag[c], rmag), (call, c)
+    assert eng.stats()["state_repairs"] == 0

@@ -14,7 +14,7 @@ def test_untracked_loads_of_the_wbfm_stream_kernel():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_lint.py"), src], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-4000:]
     last = r.stdout.strip().splitlines()[-1]
-    assert "0 finding(s)" in last and " 19 kernels" in last, last
+    assert "0 finding(s)" in last and " 25 kernels" in last, last
     # vector registers spilled to scratch: only in the instantiations with the gain-epoch lookup (third template flag),
     # which run for the few calls after a gain change - never in the kernels of the steady state
     spilled = [ln.split()[1].rstrip(":") for ln in r.stdout.splitlines() if ln.startswith("scratch: ")]
