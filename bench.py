@@ -320,6 +320,11 @@ def rank_body(args, rank, world, dev, make_engine, dist, torch, order_streams=No
     sync()
 
     flags = (1 if args.no_magnitude else 0) | {"tiles": 2, "stream": 4}.get(args.wbfm_path, 0)
+    # a squelch that can close: the pre-pass (magnitudes, decisions) of step N + 1 overlaps the pipelines of step N
+    # (IQD_F_PREPASS_OVERLAP; the input is resident and complete before any step is queued, which is what the flag asks for)
+    prepass_overlap = (args.mode == "ssb_stress" or args.squelch is not None) and not args.inline_prepass
+    if prepass_overlap:
+        flags |= 8
     eng = make_engine(n_channels=n_ch, flags=flags)
     configure(eng, args.mode, n_ch, first_global, args.squelch)
     gatherer, native_gather = None, False
@@ -481,6 +486,9 @@ def rank_body(args, rank, world, dev, make_engine, dist, torch, order_streams=No
             out["per_rank_ms"] = per_rank_ms   # every rank's own clock over the K steps (value uses the slowest)
             out["rccl"] = rccl
         if not args.no_magnitude:   # what the squelch did in the last step (rank 0's channels)
+            if gating or args.squelch is not None:
+                out["config"]["prepass"] = ("one step ahead on its own stream (IQD_F_PREPASS_OVERLAP: magnitudes and decisions of step N + 1 "
+                                            "overlap the pipelines of step N)" if prepass_overlap else "inline (each step: pre-pass, then pipelines)")
             open_frac = float(allowed.float().mean().item())
             out["config"]["squelch"] = {"threshold_dbfs": GATE_THRESHOLD_DBFS if (args.squelch is None and args.mode == "ssb_stress") else args.squelch,
                                         "blocks_rejected_frac": round(1.0 - open_frac, 4),
@@ -516,6 +524,8 @@ def parse_args(argv=None):
     ap.add_argument("--gather", action="store_true", help="also gather the PCM to rank 0 over RCCL each step")
     ap.add_argument("--torch-gather", action="store_true", help="with --gather: torch.distributed tensors instead of the engine's own iqd_gather_pcm")
     ap.add_argument("--no-live-pmc", action="store_true", help="do not collect HBM / VALU counters with rocprofv3 child runs")
+    ap.add_argument("--inline-prepass", action="store_true",
+                    help="squelch-gated runs: the magnitude pre-pass inside each step's own stream order (default: one step ahead, IQD_F_PREPASS_OVERLAP)")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="diagnostic: time the steps without the engine's per-kernel HIP events (no roofline.kernel_ms then)")
     ap.add_argument("--standin", default=None, help=argparse.SUPPRESS)   # module:Class of a host-memory engine (CPU tests of the launcher)

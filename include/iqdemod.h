@@ -79,6 +79,14 @@ typedef struct iqd_config {
  * the granule of the WBFM / the other pipelines' segment lengths (defaults 512 / 128). */
 #define IQD_F_WBFM_TILES  0x2u
 #define IQD_F_WBFM_STREAM 0x4u
+/* Squelch-gated iqd_accept_iq_device calls (some channel's threshold can reject a block) read their input twice: a pre-pass
+ * takes every block's magnitude and makes the decisions (Squelch.cc:227-273), then the pipelines walk the open blocks.  With
+ * this flag the pre-pass of a call runs on a stream of the engine's own, ordered only behind the PREVIOUS call's pre-pass, so
+ * that it overlaps the previous call's pipelines (a continuous stream of calls: magnitudes one call ahead).  The caller
+ * promises in return that `iq_dev` is complete when the call is MADE - ordering its producer on iqd_stream() is not enough,
+ * the pre-pass does not wait there - and that it does not reuse the small output buffers (pcm_count / magnitude /
+ * signal_present) of the call before.  Host-pointer calls ignore the flag.  Results are identical. */
+#define IQD_F_PREPASS_OVERLAP 0x8u
 
 /* Replaces: new IqDataProcessor(...) + new {Am,Fm,WbFm,Ssb}Demodulator(pcmCallback) +
  * set*Demodulator() wiring, Radio.cc:150-181.  Every channel starts like the reference:

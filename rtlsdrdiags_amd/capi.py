@@ -16,6 +16,7 @@ LIB = os.environ.get("IQD_LIB", _DEFAULT_LIB)   # experiments: alternative build
 MODE = {"none": 0, "am": 1, "fm": 2, "wbfm": 3, "lsb": 4, "usb": 5}
 DEMOD = {"am": 1, "fm": 2, "wbfm": 3, "ssb": 4}
 F_NO_MAGNITUDE = 0x1
+F_WBFM_TILES, F_WBFM_STREAM, F_PREPASS_OVERLAP = 0x2, 0x4, 0x8
 
 
 class Config(C.Structure):

@@ -141,6 +141,15 @@ struct iqd_engine {
     DevBuf stream_hist;   // boundary records of the streaming WBFM kernel, one StHist per segment
     DevBuf lists[FAM_COUNT + 1], mag_sums, blk_lists, vlen, records, base8k, gain_trace, freq_trace, dc_records, dc_records2, repair_flags;
     size_t mag_sums_zero = 0;            // leading elements of mag_sums known to be zero (left so by the last squelch pass)
+    // IQD_F_PREPASS_OVERLAP: a squelch-gated call's pre-pass (magnitudes of every block, decisions, open-block lists) runs on a
+    // stream of its own, one call ahead of the pipelines: pre-pass(N + 1) overlaps chain(N).  Two sets of its buffers.
+    hipStream_t pre_stream = nullptr;
+    hipEvent_t ev_pre_done[2] = {nullptr, nullptr}, ev_chain_done[2] = {nullptr, nullptr}, ev_main_decisions = nullptr;
+    DevBuf g_sums[2], g_blk[2], g_vlen[2];
+    int gate_set = 0;
+    bool chain_pending[2] = {false, false};   // ev_chain_done[set] has been recorded: the set's last reader may still run
+    bool decisions_on_main = false;           // the last squelch decision pass ran on the main stream (ev_main_decisions)
+    bool in_host_path = false;                // inside iqd_accept_iq: its staging copies are ordered on the main stream only
     DevBuf st_iq, st_pcm, st_count, st_mag, st_allowed;  // staging for host-pointer accepts
     // sliced host-pointer accepts: two staging sets, so that slice k+1 crosses PCIe while slice k runs
     DevBuf sl_iq[2], sl_pcm[2], sl_count[2], sl_mag[2], sl_allowed[2];
@@ -397,6 +406,16 @@ void iqd_destroy(iqd_t *e)
         e->sl_mag[b].release(); e->sl_allowed[b].release();
         if (e->ev_in[b]) (void)hipEventDestroy(e->ev_in[b]);
         if (e->ev_free[b]) (void)hipEventDestroy(e->ev_free[b]);
+    }
+    if (e->pre_stream) {
+        (void)hipStreamSynchronize(e->pre_stream);
+        (void)hipStreamDestroy(e->pre_stream);
+        for (int k = 0; k < 2; k++) {
+            (void)hipEventDestroy(e->ev_pre_done[k]);
+            (void)hipEventDestroy(e->ev_chain_done[k]);
+            e->g_sums[k].release(); e->g_blk[k].release(); e->g_vlen[k].release();
+        }
+        (void)hipEventDestroy(e->ev_main_decisions);
     }
     if (e->h_slice_counts) (void)hipHostFree(e->h_slice_counts);
     if (e->h_small) (void)hipHostFree(e->h_small);
@@ -1136,7 +1155,17 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
     }
     const bool want_mag = !e->demod_bypass && (gated || any_agc || !(e->flags & IQD_F_NO_MAGNITUDE) || magnitude_dev);
 
-    {   // the sums start at zero: by memset, unless the previous call's squelch pass left this many of them zero
+    // the pre-pass of a gated call one call ahead, on its own stream (include/iqdemod.h: IQD_F_PREPASS_OVERLAP)
+    const bool pre_overlap = gated && (e->flags & IQD_F_PREPASS_OVERLAP) && !e->trace_on && !e->in_host_path;
+    if (pre_overlap && !e->pre_stream) {
+        HIP_TRY(e, hipStreamCreateWithFlags(&e->pre_stream, hipStreamNonBlocking));
+        for (int k = 0; k < 2; k++) {
+            HIP_TRY(e, hipEventCreateWithFlags(&e->ev_pre_done[k], hipEventDisableTiming));
+            HIP_TRY(e, hipEventCreateWithFlags(&e->ev_chain_done[k], hipEventDisableTiming));
+        }
+        HIP_TRY(e, hipEventCreateWithFlags(&e->ev_main_decisions, hipEventDisableTiming));
+    }
+    if (!pre_overlap) {   // the sums start at zero: by memset, unless the previous call's squelch pass left this many of them zero
         const void *before = e->mag_sums.p;
         HIP_TRY(e, e->mag_sums.ensure((size_t)n_ch * n_blocks * sizeof(uint32_t)));
         if (e->mag_sums.p != before) e->mag_sums_zero = 0;
@@ -1167,8 +1196,36 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
     }
 
     const bool chain_gated = gated;   // the chain kernels walk each channel's open blocks (blk_lists, vlen_gated)
-    if (gated) {
+    DevBuf *gate_blk = &e->blk_lists, *gate_vlen = &e->vlen;
+    int pre_set = -1;
+    if (pre_overlap) {
+        // magnitudes, decisions and open-block lists of THIS call on the pre-pass stream, which the previous call's pipelines
+        // (main stream) do not hold up: it waits for the decision pass before it (its own stream order - or the main stream's,
+        // where the previous call was not gated), and for the last reader of the buffer set it is about to overwrite
+        hipStream_t ps = e->pre_stream;
+        pre_set = e->gate_set ^= 1;
+        DevBuf &sums = e->g_sums[pre_set];
+        gate_blk = &e->g_blk[pre_set];
+        gate_vlen = &e->g_vlen[pre_set];
+        if (e->chain_pending[pre_set]) HIP_TRY(e, hipStreamWaitEvent(ps, e->ev_chain_done[pre_set], 0));
+        if (e->decisions_on_main) {
+            HIP_TRY(e, hipStreamWaitEvent(ps, e->ev_main_decisions, 0));
+            e->decisions_on_main = false;
+        }
+        HIP_TRY(e, sums.ensure((size_t)n_ch * n_blocks * sizeof(uint32_t)));
+        HIP_TRY(e, gate_blk->ensure((size_t)n_ch * n_blocks * sizeof(uint32_t)));
+        HIP_TRY(e, gate_vlen->ensure((size_t)n_ch * sizeof(uint32_t)));
+        HIP_COPY(e, hipMemsetAsync(sums.p, 0, (size_t)n_ch * n_blocks * sizeof(uint32_t), ps));
+        HIP_LAUNCH(e, launch_magnitude((const uint8_t *)iq_dev, bytes_per_ch, nullptr, n_ch, call_bs, n_blocks, sums.as<uint32_t>(), ps));
+        q.mag_sums = sums.as<uint32_t>();
+        q.blk_lists = gate_blk->as<uint32_t>();
+        q.vlen_out = gate_vlen->as<uint32_t>();
+        HIP_LAUNCH(e, launch_squelch(q, false, ps));
+        HIP_TRY(e, hipEventRecord(e->ev_pre_done[pre_set], ps));
+        HIP_TRY(e, hipStreamWaitEvent(s, e->ev_pre_done[pre_set], 0));   // the pipelines read the lists
+    } else if (gated) {
         // pass 1: magnitudes of every block, then the squelch decisions and open-block lists
+        if (e->pre_stream) HIP_TRY(e, hipStreamSynchronize(e->pre_stream));   // (a call of the overlapped kind before this one)
         HIP_TRY(e, e->blk_lists.ensure((size_t)n_ch * n_blocks * sizeof(uint32_t)));
         HIP_TRY(e, e->vlen.ensure((size_t)n_ch * sizeof(uint32_t)));
         HIP_LAUNCH(e, launch_magnitude((const uint8_t *)iq_dev, bytes_per_ch, nullptr, n_ch, call_bs,
@@ -1180,14 +1237,15 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         // call stays asynchronous whatever the squelch decides.)
         HIP_LAUNCH(e, launch_squelch(q, false, s));
     }
+    if (!gated && e->pre_stream) HIP_TRY(e, hipStreamWaitEvent(s, e->ev_pre_done[e->gate_set], 0));   // (the tracker / AGC state this call's squelch pass continues from)
 
     ChainLaunch base{};
     base.iq = (const uint8_t *)iq_dev;
     base.ch_stride_bytes = bytes_per_ch;
     base.first_ch = first_ch;
     base.vlen = vlen;
-    base.vlen_gated = chain_gated ? e->vlen.as<uint32_t>() : nullptr;
-    base.blk_lists = chain_gated ? e->blk_lists.as<uint32_t>() : nullptr;
+    base.vlen_gated = chain_gated ? gate_vlen->as<uint32_t>() : nullptr;
+    base.blk_lists = chain_gated ? gate_blk->as<uint32_t>() : nullptr;
     base.n_blocks = n_blocks;
     base.block_samples = call_bs;
     base.block_magic = block_magic(call_bs);
@@ -1606,6 +1664,13 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         else HIP_LAUNCH(e, launch_tail_update(tail_a, tail_f, s));
     }
 
+    if (pre_set >= 0) {   // this call's pipelines are the last readers of its buffer set
+        HIP_TRY(e, hipEventRecord(e->ev_chain_done[pre_set], s_main));
+        e->chain_pending[pre_set] = true;
+    } else if (!gated && e->pre_stream && !e->demod_bypass) {   // a squelch pass on the main stream: the next pre-pass continues from it
+        HIP_TRY(e, hipEventRecord(e->ev_main_decisions, s_main));
+        e->decisions_on_main = true;
+    }
     e->stats.accepts++;
     e->stats.samples += (uint64_t)vlen * n_ch;
     return IQD_OK;
@@ -1741,6 +1806,7 @@ int iqd_accept_iq(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const uint8_t *iq,
     if (!call_bb) return e->fail(IQD_EINVAL, IQD_LEN_MSG, bytes_per_ch, e->block_bytes);
     (void)hipSetDevice(e->device);
     hipStream_t s = e->stream;
+    struct HostPath { iqd_t *e; HostPath(iqd_t *e_) : e(e_) { e->in_host_path = true; } ~HostPath() { e->in_host_path = false; } } host_path(e);
     const size_t in_bytes = (size_t)n_ch * bytes_per_ch;
     const size_t pcm_bytes = (size_t)n_ch * (bytes_per_ch / 64) * sizeof(int16_t);
     const size_t nb = (size_t)n_ch * (bytes_per_ch / call_bb);

@@ -35,6 +35,9 @@ __device__ __forceinline__ uint32_t st_table_read(uint32_t byte_offset) { return
 #ifndef IQD_ST_RUNPTR     // 1: the P waves' input addresses as a running pointer (0: piece_address() per piece, A/B builds)
 #define IQD_ST_RUNPTR 1
 #endif
+#ifndef IQD_ST_YOUNG_SHIFT
+#define IQD_ST_YOUNG_SHIFT 0
+#endif
 #ifndef IQD_ST_TRACE      // diagnostic build: workgroup 5 writes clock64() of (hardware wave, piece, event k) to stamps[64 + ((wave * 256 + piece) * 4 + k)]
 #define IQD_ST_TRACE 0
 #endif
@@ -73,7 +76,10 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
 #if IQD_RINGS_IN_A_ROW
     const int ring = pw / ST_P_PER_RING, cg = pw % ST_P_PER_RING;
 #else
-    const int ring = pw % ST_RINGS, cg = pw / ST_RINGS;
+    // (IQD_ST_YOUNG_SHIFT: the three youngest P waves - hardware waves 12-14, each the last-served wave of a SIMD that also
+    // carries an IIR wave - feed the ring of ANOTHER SIMD's IIR wave: a ring's IIR wave starts its burst when the ring's last
+    // writer has signalled, i.e. exactly when that writer begins its next piece)
+    const int cg = pw / ST_RINGS, ring = (pw + (cg == ST_P_PER_RING - 1 ? IQD_ST_YOUNG_SHIFT : 0)) % ST_RINGS;
 #endif
     const int g = lane >> 4, c = lane & 15;
     const uint32_t row = (uint32_t)(16 * cg + c);                // ring row of this lane's segment

@@ -258,3 +258,56 @@ def test_gated_streaming_many_channels_like_configs4(capi, oracle):
     assert rejected > n_ch                                    # the squelch really closed on many blocks
     for p_ in (iq_d, pcm_d, cnt_d, mag_d, al_d):
         eng.dev_free(p_)
+
+
+@pytest.mark.parametrize("mode", ["ssb_stress", "wbfm", "mixed"])
+def test_prepass_one_call_ahead_gives_the_same_as_inline(capi, mode):
+    """IQD_F_PREPASS_OVERLAP: the squelch pre-pass of call N + 1 on its own stream while call N's pipelines run.  Five
+    calls queued back to back WITHOUT a synchronisation in between (each call its own input and output buffers, different
+    data per call, an ungated call in the middle), then everything compared with an engine that runs the pre-pass inline:
+    PCM, counts, magnitudes, decisions, and the AGC's final gains."""
+    import bench
+    n_ch, n, calls = 1024, 1 << 16, 5
+    rng = np.random.default_rng(12)
+    rows = bench.gating_rows(synth, n)
+    inputs = []
+    for k in range(calls):
+        iq = np.stack([rows[(c + k) % 4] for c in range(n_ch)])
+        iq[:, 7000:7016] = rng.integers(0, 256, size=(n_ch, 16), dtype=np.uint8)
+        inputs.append(iq)
+    results = []
+    for flags in (0, 8):
+        eng = capi.Engine(n_ch, flags=flags)
+        if mode == "ssb_stress":
+            bench.configure(eng, "ssb_stress", n_ch, 0, None)
+        else:
+            bench.configure(eng, mode, n_ch, 0, -50)
+            eng.agc_enable(True, first=0, n=n_ch // 2)
+        bufs = []
+        for k in range(calls):
+            d = dict(iq=eng.dev_alloc(inputs[k].nbytes), pcm=eng.dev_alloc(n_ch * (n // 32) * 2), cnt=eng.dev_alloc(n_ch * 4),
+                     mag=eng.dev_alloc(n_ch * 16), al=eng.dev_alloc(n_ch * 4))
+            eng.dev_upload(d["iq"], inputs[k])
+            bufs.append(d)
+        eng.synchronize()
+        for k in range(calls):
+            if k == 2:
+                eng.set_squelch(-200)          # an ungated call between gated ones (its squelch pass runs on the main stream)
+            if k == 3:
+                eng.set_squelch(-60 if mode == "ssb_stress" else -50)
+            eng.accept_device(bufs[k]["iq"], 2 * n, bufs[k]["pcm"], bufs[k]["cnt"], bufs[k]["mag"], bufs[k]["al"])
+        eng.synchronize()
+        got = []
+        for d in bufs:
+            got.append((eng.dev_download(d["pcm"], n_ch * (n // 32) * 2, np.int16), eng.dev_download(d["cnt"], n_ch * 4, np.uint32),
+                        eng.dev_download(d["mag"], n_ch * 16, np.uint32), eng.dev_download(d["al"], n_ch * 4, np.uint8)))
+            for p_ in d.values():
+                eng.dev_free(p_)
+        gains = [eng.rx_gain_db(c) for c in range(0, n_ch, 37)]
+        results.append((got, gains))
+        eng.close()
+    for k in range(calls):
+        for a, b in zip(results[0][0][k], results[1][0][k]):
+            assert np.array_equal(a, b), (mode, k)
+    assert results[0][1] == results[1][1]
+    assert (results[0][0][0][3] == 0).any() and (results[0][0][2][3] == 1).all()   # calls 0 gated, call 2 all open

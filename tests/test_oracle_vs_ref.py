@@ -1,5 +1,7 @@
 """CPU, build container only: the oracle against the live reference (oracle/_ref) on fresh
 random inputs.  Skipped where /root/reference is absent (GPU box)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -108,3 +110,26 @@ def test_gain_changes_between_blocks(oracle, reference, mode):
             parts.append(c.accept_stream(u8[k * 32768:(k + 1) * 32768])[0])
         out.append(np.concatenate(parts))
     assert np.array_equal(out[0], out[1])
+
+
+# ---- the survey's own anchors: yoyo.iq through the boundary harness --------------------------------
+YOYO = "/root/reference/demodulatorResearch/yoyo.iq"
+YOYO_MD5 = {"am": "1105b36160c8", "fm": "312e523797d5", "wbfm": "0ba876d90f05", "lsb": "acc98d5d0f75", "usb": "02ccbc29006c"}
+
+
+@pytest.mark.skipif(not os.path.exists(YOYO), reason="build container only: the reference's capture is not copied (SURVEY 8(c))")
+@pytest.mark.parametrize("mode", MODES)
+def test_survey_md5_anchors_on_the_reference_capture(oracle, reference, mode):
+    """The survey's independent harness fed yoyo.iq (+128) through IqDataProcessor::acceptIqData and recorded md5(PCM) per
+    mode; oracle/_ref (the unmodified reference compiled in place) and the oracle restatement must both land on them.
+    Ties oracle/_ref to a harness this builder did not write; the capture itself stays where it is."""
+    import hashlib
+    s8 = np.fromfile(YOYO, dtype=np.int8)
+    assert len(s8) == 2 * (1 << 20)
+    u8 = (s8.astype(np.int16) + 128).astype(np.uint8)
+    for which in (reference, oracle):
+        c = which.chain()
+        c.set_mode(mode)
+        pcm, _, _ = c.accept_stream(u8)
+        assert pcm.nbytes == 65536
+        assert hashlib.md5(pcm.tobytes()).hexdigest().startswith(YOYO_MD5[mode]), (mode, which)
