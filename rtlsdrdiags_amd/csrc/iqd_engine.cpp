@@ -29,10 +29,21 @@
 using namespace iqd;
 
 // A chain launch takes its streaming kernel when it brings this many samples per segment of the persistent workgroups
-// (n_cus x 192 segments): measured crossovers against the tile kernels lie at 50-60 M samples per launch on 256 CUs
-// (WBFM 2^25: 0.118 vs 0.139 ms, 2^26: 0.200 vs 0.171; AM 512 x 2^16: 0.047 vs 0.065, 1024 x 2^16: 0.077 vs 0.072;
-// USB 1024 x 2^16: 0.088 vs 0.083), and side by side with other families' launches the streaming kernels do better.
-static const uint64_t STREAM_MIN_PER_SEGMENT = 1024;
+// (n_cus x 192 segments).  Round 4 re-measured the crossovers against the tile kernels on 256 CUs (tools/minseg_probe.sh,
+// ms per step streaming / tiles): FM 512 x 2^16 0.085 / 0.069, 1024 x 2^16 0.091 / 0.118, 4096 x 2^13 0.078 / 0.084; WBFM
+// 1 x 2^25 0.122 / 0.131, 512 x 2^16 0.129 / 0.142, 1 x 2^24 0.115 / 0.089; AM 1024 x 2^16 0.077 / 0.084, 512 x 2^16 0.075 / 0.055,
+// and rows of one or two blocks (where the tile path's DC pass has a lane per channel and nothing to hide its latency
+// behind) 1024 x 2^14 0.074 / 0.079, 2048 x 2^13 0.063 / 0.063.  A call with SEVERAL families takes the one-launch
+// arrangement (iqd_stream_mixed.hip) from the smallest sizes probed: 512 x 2^14 0.102 / 0.141, 4096 x 2^14 0.130 / 0.230,
+// 1400 x 2^16 0.130 / 0.268 - round 3's rule (1024 per segment for every family's share) dated from the kernels-on-streams
+// arrangement and kept such calls on the tile kernels.  IQD_STREAM_MIN_SEG overrides all of them (measurement runs).
+// (second probe, around the thresholds: FM 640 x 2^16 0.085 / 0.088, 768 x 2^16 0.087 / 0.095; WBFM 384 x 2^16 0.120 / 0.099; AM / USB
+// 768 x 2^16 0.075 / 0.074 and 0.087 / 0.082, 896 x 2^16 0.075 / 0.083 and 0.086 / 0.093, 1024 x 2^14 0.074 / 0.079 and 0.084 / 0.082;
+// several families: 128 x 2^14 0.099 / 0.125, 16 x 2^16 0.100 / 0.120, 1024 x 2^12 0.098 / 0.101, 512 x 2^12 0.096 / 0.076)
+static const uint64_t STREAM_MIN_SEG_WBFM = 600, STREAM_MIN_SEG_FM = 900, STREAM_MIN_SEG_AM = 1000, STREAM_MIN_SEG_SSB = 1100,
+                      STREAM_MIN_SEG_AM_SHORT = 320, STREAM_MIN_SEG_SSB_SHORT = 450,   // rows of up to 2^14 samples
+                      STREAM_MIN_SEG_MIXED = 16, STREAM_MIN_SEG_MIXED_SHORT = 96,      // one launch for all families; rows below 2^13 samples
+                      STREAM_MIN_SEG_FORKED = 1024;                                    // several families as kernels on streams
 // AM / SSB rows at least this long (PCM samples) may take their streaming pipeline; the DC pass behind it is then the
 // one-wave pass whatever the row length (round 4: the rule used to be > 512, which kept the reference's own operating
 // point - one 64 ms block per channel per call, 512 PCM samples - on the tile kernels at 0.14 of the HBM peak).  IQD_AM_STREAM_MIN.
@@ -86,6 +97,7 @@ struct iqd_engine {
     // measurement knobs, read from the environment ONCE at creation (include/iqdemod.h): IQD_WBFM_PATH=stream|tiles
     // (+1 / -1, 0 = choose), IQD_FULL_GRID, IQD_STREAM_WGS=<n>, IQD_PLAN_CHUNKS=<k>
     int env_path = 0;
+    uint64_t env_stream_min_seg = 0;     // IQD_STREAM_MIN_SEG (0: the measured per-family thresholds)
     uint32_t env_am_stream_min = AM_STREAM_MIN_PCM;   // IQD_AM_STREAM_MIN (measurement runs: 513 = the rule of rounds 2-3)
     uint32_t env_d4_gran = 128;            // IQD_D4_GRAN: segment-length granule of the FM / AM / SSB pipelines (measurement runs)
     bool env_full_grid = false;
@@ -139,7 +151,7 @@ struct iqd_engine {
 
     // per-call scratch
     DevBuf stream_hist;   // boundary records of the streaming WBFM kernel, one StHist per segment
-    DevBuf lists[FAM_COUNT + 1], mag_sums, blk_lists, vlen, records, base8k, gain_trace, freq_trace, dc_records, dc_records2, repair_flags;
+    DevBuf lists[FAM_COUNT + 1], mag_sums, blk_lists, vlen, records, base8k, base8k2, gain_trace, freq_trace, dc_records, dc_records2, repair_flags;
     size_t mag_sums_zero = 0;            // leading elements of mag_sums known to be zero (left so by the last squelch pass)
     // IQD_F_PREPASS_OVERLAP: a squelch-gated call's pre-pass (magnitudes of every block, decisions, open-block lists) runs on a
     // stream of its own, one call ahead of the pipelines: pre-pass(N + 1) overlaps chain(N).  Two sets of its buffers.
@@ -181,6 +193,19 @@ struct iqd_engine {
         return code;
     }
 };
+
+// samples per segment from which a launch of family f takes its streaming pipeline (see STREAM_MIN_SEG_*)
+// several_families: 0 a call of one family, 1 several families in one launch, 2 several families as kernels on streams
+static uint64_t stream_min_seg(const iqd_engine *e, int f, uint64_t vlen, int several_families)
+{
+    if (e->env_stream_min_seg) return e->env_stream_min_seg;
+    if (several_families == 2) return STREAM_MIN_SEG_FORKED;
+    if (several_families) return vlen < 8192 ? STREAM_MIN_SEG_MIXED_SHORT : STREAM_MIN_SEG_MIXED;
+    if (f == FAM_WBFM) return STREAM_MIN_SEG_WBFM;
+    if (f == FAM_FM) return STREAM_MIN_SEG_FM;
+    if (f == FAM_AM) return vlen <= 16384 ? STREAM_MIN_SEG_AM_SHORT : STREAM_MIN_SEG_AM;
+    return vlen <= 16384 ? STREAM_MIN_SEG_SSB_SHORT : STREAM_MIN_SEG_SSB;
+}
 
 #define HIP_TRY(e, call)                                                                          \
     do {                                                                                          \
@@ -258,6 +283,7 @@ int iqd_create(const iqd_config *cfg, iqd_t **out)
     if (const char *env = getenv("IQD_WBFM_PATH")) e->env_path = env[0] == 's' ? 1 : env[0] == 't' ? -1 : 0;
     e->env_full_grid = getenv("IQD_FULL_GRID") != nullptr;
     if (const char *env = getenv("IQD_D4_GRAN")) e->env_d4_gran = (uint32_t)atoi(env);
+    if (const char *env = getenv("IQD_STREAM_MIN_SEG")) e->env_stream_min_seg = atoi(env) > 0 ? (uint64_t)atoi(env) : 0;
     if (const char *env = getenv("IQD_AM_STREAM_MIN")) e->env_am_stream_min = atoi(env) > 0 ? (uint32_t)atoi(env) : AM_STREAM_MIN_PCM;
     if (const char *env = getenv("IQD_MIXED")) e->env_mixed_forked = env[0] == 'f' && env[1] == 'o';
     if (const char *env = getenv("IQD_FAMILY_WEIGHTS")) {   // "am,fm,wbfm,ssb" (measurement runs)
@@ -398,7 +424,7 @@ void iqd_destroy(iqd_t *e)
         if (p) (void)hipFree(p);
     if (e->h_counters) (void)hipHostFree(e->h_counters);
     for (auto &b : e->lists) b.release();
-    DevBuf *bufs[] = {&e->stream_hist, &e->mag_sums, &e->blk_lists, &e->vlen, &e->records, &e->base8k, &e->gain_trace, &e->freq_trace, &e->dc_records, &e->dc_records2, &e->repair_flags,
+    DevBuf *bufs[] = {&e->stream_hist, &e->mag_sums, &e->blk_lists, &e->vlen, &e->records, &e->base8k, &e->base8k2, &e->gain_trace, &e->freq_trace, &e->dc_records, &e->dc_records2, &e->repair_flags,
                       &e->st_iq, &e->st_pcm, &e->st_count, &e->st_mag, &e->st_allowed};
     for (DevBuf *b : bufs) b->release();
     for (int b = 0; b < 2; b++) {
@@ -1285,7 +1311,11 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
                 HIP_TRY(e, hipEventCreateWithFlags(&e->fam_join[k], hipEventDisableTiming));
             }
         }
-        HIP_TRY(e, e->base8k.ensure((size_t)n_ch * base.pcm_stride * sizeof(int32_t)));   // before the fork: shared by AM and SSB
+        // before the fork.  One buffer per family: short rows are written time-major by the tile kernels and channel-major by the
+        // streaming pipelines, and the two families of a call may take different paths (round 4's fuzzer: an AM family that
+        // streamed beside an SSB family on the tile kernels overwrote its detector stream)
+        if (!e->h_lists[FAM_AM].empty()) HIP_TRY(e, e->base8k.ensure((size_t)n_ch * base.pcm_stride * sizeof(int32_t)));
+        if (!e->h_lists[FAM_SSB].empty()) HIP_TRY(e, e->base8k2.ensure((size_t)n_ch * base.pcm_stride * sizeof(int32_t)));
     }
     // relative cost per channel-sample: AM, FM, WBFM, SSB (the families' workgroups side by side: 214 / 228 / 227 / 259 us on
     // 32 / 56 / 96 / 56 CUs for 819 / 819 / 820 / 1638 channels x 2^16, profiles/r3_mixed_4096_kernel_stats.csv)
@@ -1308,16 +1338,19 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         // (only when every family of the call will take its streaming kernel - here that means: brings enough samples
         // for ITS share of the CUs; tile kernels know nothing of shares, and a streaming kernel held to its share beside
         // them lost 12-16 % at 2500-3000 mixed channels)
-        bool all_stream = !(e->flags & IQD_F_WBFM_TILES) && vlen % 128 == 0;
-        all_stream = all_stream && e->env_path >= 0;
-        for (int f = 0; f < FAM_COUNT && all_stream; f++) {
-            const uint64_t n_f = e->h_lists[f].size();
-            if (!n_f) continue;
-            const bool forced = (e->flags & IQD_F_WBFM_STREAM) != 0;
-            const float due = total > 0.f ? (float)(e->n_cus - 16) * cost[f] / total : (float)e->n_cus;
-            if (!forced && (float)((uint64_t)vlen * n_f) < due * (float)(ST_SEGS * STREAM_MIN_PER_SEGMENT)) all_stream = false;
-            if ((f == FAM_AM || f == FAM_SSB) && vlen / 32 < e->env_am_stream_min) all_stream = false;
-        }
+        auto every_family_streams = [&](int arrangement) {   // 1: as ranges of one launch, 2: as kernels on streams (stream_min_seg)
+            bool all = !(e->flags & IQD_F_WBFM_TILES) && vlen % 128 == 0 && e->env_path >= 0;
+            for (int f = 0; f < FAM_COUNT && all; f++) {
+                const uint64_t n_f = e->h_lists[f].size();
+                if (!n_f) continue;
+                const bool forced = (e->flags & IQD_F_WBFM_STREAM) != 0;
+                const float due = total > 0.f ? (float)(e->n_cus - 16) * cost[f] / total : (float)e->n_cus;
+                if (!forced && (float)((uint64_t)vlen * n_f) < due * (float)(ST_SEGS * stream_min_seg(e, f, vlen, arrangement))) all = false;
+                if ((f == FAM_AM || f == FAM_SSB) && vlen / 32 < e->env_am_stream_min) all = false;
+            }
+            return all;
+        };
+        const bool all_stream = every_family_streams(1);
         shares_on = forked && all_stream && total > 0.f && e->n_cus >= 64 && !e->env_full_grid;
         // ONE launch for all of them (iqd_stream_mixed.hip) when each family can take its streaming pipeline in the plain
         // instantiation: the WBFM channels of one rotation selector and without a gain change in reach of a lead-in,
@@ -1337,6 +1370,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
             for (uint32_t c : e->h_lists[FAM_FM]) fused = fused && e->fm_kmax[first_ch + c] * 6.35f < 2147483648.0f;
         if (fused && (!e->h_lists[FAM_AM].empty() || !e->h_lists[FAM_SSB].empty()))
             fused = vlen / 32 >= e->env_am_stream_min && (bytes_per_ch / 64 + DC_TILE - 1) / DC_TILE < 2;
+        if (shares_on && !fused) shares_on = every_family_streams(2);   // (the kernels-on-streams arrangement pays from larger calls only)
         if (shares_on && fused) plan_fused_shares(cost, FAM_COUNT, e->n_cus, fam_share);
         else if (shares_on && !plan_family_shares(cost, FAM_COUNT, e->n_cus, fam_share)) shares_on = false;
         if (!shares_on) fused = false;
@@ -1394,7 +1428,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
             if (e->flags & IQD_F_WBFM_STREAM) want = 1;
             if (e->env_path) want = e->env_path;
             const uint64_t work = (uint64_t)vlen * n_list;
-            if (ok && want >= 0 && (want > 0 || work >= (uint64_t)(shares_on ? fam_wgs : e->n_cus) * ST_SEGS * STREAM_MIN_PER_SEGMENT || shares_on)) {
+            if (ok && want >= 0 && (want > 0 || work >= (uint64_t)(shares_on ? fam_wgs : e->n_cus) * ST_SEGS * stream_min_seg(e, f, vlen, 0) || shares_on)) {
                 for (uint32_t spare = 0;; spare += 48) {   // (the groups' padding may push an exact fit into a second round)
                     const TilePlan sp = plan_stream(vlen, n_list, fam_wgs * ST_SEGS - (stream_grouped ? spare : 0u), e->env_stream_gran);
                     a.tile_len = sp.tile_len;
@@ -1427,7 +1461,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
             if (e->flags & IQD_F_WBFM_STREAM) want = 1;
             if (e->env_path) want = e->env_path;
             const uint64_t work = (uint64_t)vlen * n_list;
-            if (ok && want >= 0 && (want > 0 || work >= (uint64_t)(shares_on ? fam_wgs : e->n_cus) * ST_SEGS * STREAM_MIN_PER_SEGMENT || shares_on)) {
+            if (ok && want >= 0 && (want > 0 || work >= (uint64_t)(shares_on ? fam_wgs : e->n_cus) * ST_SEGS * stream_min_seg(e, f, vlen, 0) || shares_on)) {
                 d4_wgs = fam_wgs;
                 for (uint32_t spare = 0;; spare += 48) {   // (the rotation groups' padding may push an exact fit into a second round)
                     const TilePlan sp = plan_stream(vlen, n_list, d4_wgs * ST_SEGS - spare, e->env_d4_gran);   // (these pipelines store 8 or 16 bytes per 128 samples: no wide stores to keep whole)
@@ -1527,8 +1561,9 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
                 HIP_LAUNCH(e, launch_fm(a, chain_gated, fused_mag, n_list * a.tiles_per_ch, s));
             }
         } else if (use_d4) {
-            HIP_TRY(e, e->base8k.ensure((size_t)n_ch * base.pcm_stride * sizeof(int32_t)));
-            a.base8k = e->base8k.as<int32_t>();
+            DevBuf &b8 = f == FAM_SSB ? e->base8k2 : e->base8k;
+            HIP_TRY(e, b8.ensure((size_t)n_ch * base.pcm_stride * sizeof(int32_t)));
+            a.base8k = b8.as<int32_t>();
             a.base_stride_ch = base.pcm_stride;   // channel-major (rows longer than 512 PCM samples)
             a.base_stride_t = 1;
             a.dc_tiles = (uint32_t)((base.pcm_stride + DC_TILE - 1) / DC_TILE);
@@ -1559,8 +1594,9 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
             }
             e->stats.stream_launches++;
         } else {
-            HIP_TRY(e, e->base8k.ensure((size_t)n_ch * base.pcm_stride * sizeof(int32_t)));
-            a.base8k = e->base8k.as<int32_t>();
+            DevBuf &b8 = f == FAM_SSB ? e->base8k2 : e->base8k;
+            HIP_TRY(e, b8.ensure((size_t)n_ch * base.pcm_stride * sizeof(int32_t)));
+            a.base8k = b8.as<int32_t>();
             a.dc_tiles = (uint32_t)((base.pcm_stride + DC_TILE - 1) / DC_TILE);
             DevBuf &dcr = f == FAM_SSB ? e->dc_records2 : e->dc_records;   // AM and SSB may run side by side
             {   // records, then one redo flag per channel: zero between calls (dc_redo_kernel clears what it used)

@@ -38,6 +38,9 @@ __device__ __forceinline__ uint32_t st_table_read(uint32_t byte_offset) { return
 #ifndef IQD_ST_YOUNG_SHIFT
 #define IQD_ST_YOUNG_SHIFT 0
 #endif
+#ifndef IQD_ST_LEVEL_PROBE
+#define IQD_ST_LEVEL_PROBE 0
+#endif
 #ifndef IQD_ST_TRACE      // diagnostic build: workgroup 5 writes clock64() of (hardware wave, piece, event k) to stamps[64 + ((wave * 256 + piece) * 4 + k)]
 #define IQD_ST_TRACE 0
 #endif
@@ -232,7 +235,19 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
             // phase B: squelch magnitudes of this lane's 8 samples, while the gathers are in flight (two packed 16-bit sums,
             // folded and booked once per group of pieces: at most 4 x 4 x 192 per half)
             if (MAG && pos >= 0) {
+#if IQD_ST_LEVEL_PROBE   // TIMING PROBE ONLY (wrong magnitudes): what levelling the SIMDs could buy at most - the P waves of the three
+                         // SIMDs that carry an IIR wave skip the magnitude arithmetic, those of the fourth do it four times
+                if (IQD_ST_LEVEL_PROBE == 1 && (pw & 3) == 0) {   // (2: nobody does them)
+                    uint4 rc = raw_cur;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        asm volatile("" : "+v"(rc.x), "+v"(rc.y), "+v"(rc.z), "+v"(rc.w));
+                        gm16 = st_mag_raw_chunk(rc, gm16);
+                    }
+                }
+#else
                 gm16 = st_mag_raw_chunk(raw_cur, gm16);
+#endif
             }
             // (after the last use of the buffer's old contents)
             if (GATED || !IQD_ST_RUNPTR) {

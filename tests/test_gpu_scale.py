@@ -403,3 +403,37 @@ def test_short_am_ssb_rows_stream_and_match_the_tile_kernels(capi, oracle, monke
             for k in range(2):
                 ref, _, _ = o.accept_stream(u8[c])
                 assert np.array_equal(outs[0][k][c], ref), (log2, c, k)
+
+
+def test_am_streams_beside_ssb_on_the_tile_kernels(capi, oracle, monkeypatch):
+    """Rows of one block: 1400 AM channels take their streaming pipeline (detector stream channel-major), 50 to 250 LSB / USB
+    channels of the same call stay on the tile kernels (time-major for rows this short).  Round 4's fuzzer found the two
+    families sharing one detector-stream buffer in that combination; each has its own now.  Every row of the small family
+    and every 97th of the large one against the oracle, two calls.  (IQD_MIXED=forked: a kernel per family, as for every
+    call that the one-launch arrangement does not take.)"""
+    monkeypatch.setenv("IQD_MIXED", "forked")
+    n_ch, n = 1500, 1 << 14                                # (below 64 MiB: one call, not slices)
+    u8 = _mixed_rows(n_ch, n, seed=77)
+    modes = ["am" if c % 29 else ("lsb", "usb")[(c // 29) % 2] for c in range(n_ch)]
+    n_ssb = sum(m != "am" for m in modes)
+    assert 40 <= n_ssb <= 60
+    # a larger SSB family (still below its streaming threshold) in a second engine
+    for extra in (0, 200):
+        mm = list(modes)
+        for c in range(extra):
+            mm[1 + 7 * c] = "usb"
+        eng = capi.Engine(n_ch)
+        for c in range(n_ch):
+            eng.set_mode(mm[c], first=c, n=1)
+            eng.set_rotation((1, 0, -1)[c % 3], first=c, n=1)
+        got = [eng.accept(u8)[0].copy() for _ in range(2)]
+        st = eng.stats()
+        assert st["stream_launches"] == 2 and st["mixed_launches"] == 0, st     # AM streamed (twice), SSB did not
+        eng.close()
+        for c in [c for c in range(n_ch) if mm[c] != "am"] + list(range(0, n_ch, 97)):
+            o = oracle.chain()
+            o.set_mode(mm[c])
+            o.set_rotation((1, 0, -1)[c % 3])
+            for k in range(2):
+                ref, _, _ = o.accept_stream(u8[c])
+                assert np.array_equal(got[k][c], ref), (extra, c, mm[c], k)

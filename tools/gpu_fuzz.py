@@ -204,7 +204,8 @@ def wide_case(rng, O):
     the batch, so that a few oracle runs check EVERY row; device-pointer calls, so that a big batch is one launch and
     not slices; one operator command on one template between the two calls."""
     k_tpl = int(rng.integers(3, 9))
-    n_ch = int(rng.integers(600, 4001))
+    lo, hi = (int(x) for x in os.environ.get("FUZZ_WIDE_RANGE", "600,4000").split(","))   # (24,600: the small calls that take
+    n_ch = int(rng.integers(lo, hi + 1))                                                   # the one-launch arrangement since round 4)
     nblk = int(rng.integers(1, 5))
     bb = 32768
     while n_ch * nblk * bb > (256 << 20):
