@@ -334,8 +334,18 @@ def rank_body(args, rank, world, dev, make_engine, dist, torch, order_streams=No
         else:                                              # torch.distributed tensors (the CPU tests run this one over gloo)
             gatherer = shard.PcmGatherer(n_ch, n // 32, dev)
 
+    chunks = max(1, min(getattr(args, "channel_chunks", 1), n_ch))
+
     def step():
-        if args.no_magnitude:
+        if chunks > 1:
+            # the call in channel chunks (sub-range accepts, one after the other on the engine's stream): with the overlapped
+            # pre-pass, chunk k + 1's magnitudes are taken while chunk k's pipelines run, and a chunk small enough for the
+            # Infinity Cache could be read from there the second time (DESIGN.md 4.6 has the measurement)
+            for k in range(chunks):
+                c0, c1 = n_ch * k // chunks, n_ch * (k + 1) // chunks
+                eng.accept_device(iq.data_ptr() + c0 * 2 * n, 2 * n, pcm.data_ptr() + c0 * (n // 32) * 2, cnt.data_ptr() + c0 * 4,
+                                  mag.data_ptr() + c0 * n_blocks * 4, allowed.data_ptr() + c0 * n_blocks, first=c0, n=c1 - c0)
+        elif args.no_magnitude:
             eng.accept_device(iq.data_ptr(), 2 * n, pcm.data_ptr())
         else:
             eng.accept_device(iq.data_ptr(), 2 * n, pcm.data_ptr(), cnt.data_ptr(), mag.data_ptr(), allowed.data_ptr())
@@ -524,6 +534,7 @@ def parse_args(argv=None):
     ap.add_argument("--gather", action="store_true", help="also gather the PCM to rank 0 over RCCL each step")
     ap.add_argument("--torch-gather", action="store_true", help="with --gather: torch.distributed tensors instead of the engine's own iqd_gather_pcm")
     ap.add_argument("--no-live-pmc", action="store_true", help="do not collect HBM / VALU counters with rocprofv3 child runs")
+    ap.add_argument("--channel-chunks", type=int, default=1, help="measurement: each step as this many sub-range calls (channel chunks)")
     ap.add_argument("--inline-prepass", action="store_true",
                     help="squelch-gated runs: the magnitude pre-pass inside each step's own stream order (default: one step ahead, IQD_F_PREPASS_OVERLAP)")
     ap.add_argument("--no-kernel-events", action="store_true",
