@@ -102,6 +102,11 @@ struct iqd_engine {
     uint32_t env_d4_gran = 128;            // IQD_D4_GRAN: segment-length granule of the FM / AM / SSB pipelines (measurement runs)
     bool env_full_grid = false;
     bool env_mixed_forked = false;         // IQD_MIXED=forked: several families as kernels of their own side by side (A/B runs)
+    // ns per sample of a segment (lead-in included) of one workgroup's 192 segments in lock step, inside the one launch that
+    // holds all four pipelines: WBFM 224 us for 3072 + 768, FM 225 for 5120 + 768, AM 214 for 9472 + 384, SSB 226 for 9472 + 1280
+    // (tools/mixed_probe.py, 4096 channels x 2^16).  IQD_FAMILY_NS=am,fm,wbfm,ssb; IQD_SHARES=cost keeps the proportional shares.
+    float fam_ns[FAM_COUNT] = {21.7f, 38.2f, 58.3f, 21.0f};
+    bool env_shares_by_cost = false;
     float fam_weight[FAM_COUNT] = {3.4f, 6.3f, 10.8f, 3.6f};   // relative cost per channel-sample of the streaming pipelines: AM, FM, WBFM, SSB
     uint32_t env_stream_wgs = 0, env_plan_chunks = 0, env_stream_gran = 0;
     size_t dcr_layout[2][2] = {{~(size_t)0, 0}, {~(size_t)0, 0}};   // AM / SSB: where the DC redo flags sit in their buffer, and how many
@@ -282,6 +287,12 @@ int iqd_create(const iqd_config *cfg, iqd_t **out)
     e->flags = cfg->flags;
     if (const char *env = getenv("IQD_WBFM_PATH")) e->env_path = env[0] == 's' ? 1 : env[0] == 't' ? -1 : 0;
     e->env_full_grid = getenv("IQD_FULL_GRID") != nullptr;
+    if (const char *env = getenv("IQD_SHARES")) e->env_shares_by_cost = env[0] == 'c';
+    if (const char *env = getenv("IQD_FAMILY_NS")) {
+        float w[FAM_COUNT];
+        if (sscanf(env, "%f,%f,%f,%f", &w[0], &w[1], &w[2], &w[3]) == 4 && w[0] > 0.f && w[1] > 0.f && w[2] > 0.f && w[3] > 0.f)
+            for (int f = 0; f < FAM_COUNT; f++) e->fam_ns[f] = w[f];
+    }
     if (const char *env = getenv("IQD_D4_GRAN")) e->env_d4_gran = (uint32_t)atoi(env);
     if (const char *env = getenv("IQD_STREAM_MIN_SEG")) e->env_stream_min_seg = atoi(env) > 0 ? (uint64_t)atoi(env) : 0;
     if (const char *env = getenv("IQD_AM_STREAM_MIN")) e->env_am_stream_min = atoi(env) > 0 ? (uint32_t)atoi(env) : AM_STREAM_MIN_PCM;
@@ -1371,7 +1382,17 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         if (fused && (!e->h_lists[FAM_AM].empty() || !e->h_lists[FAM_SSB].empty()))
             fused = vlen / 32 >= e->env_am_stream_min && (bytes_per_ch / 64 + DC_TILE - 1) / DC_TILE < 2;
         if (shares_on && !fused) shares_on = every_family_streams(2);   // (the kernels-on-streams arrangement pays from larger calls only)
-        if (shares_on && fused) plan_fused_shares(cost, FAM_COUNT, e->n_cus, fam_share);
+        if (shares_on && fused) {
+            FusedFamily ff[FAM_COUNT];
+            for (int f = 0; f < FAM_COUNT; f++) {
+                for (int r = 0; r < 3; r++) ff[f].rot_count[r] = e->h_lists[f].empty() ? 0u : e->rot_count[f][r];
+                ff[f].halo = f == FAM_WBFM ? (uint32_t)ST_HALO : f == FAM_FM ? (uint32_t)D4_HALO_FM : f == FAM_AM ? (uint32_t)D4_HALO_AM : (uint32_t)D4_HALO_SSB;
+                ff[f].granule = f == FAM_WBFM ? e->env_stream_gran : e->env_d4_gran;
+                ff[f].ns_per_sample = e->fam_ns[f];
+            }
+            if (e->env_shares_by_cost || !plan_fused_by_time((uint32_t)vlen, FAM_COUNT, ff, e->n_cus, fam_share))
+                plan_fused_shares(cost, FAM_COUNT, e->n_cus, fam_share);
+        }
         else if (shares_on && !plan_family_shares(cost, FAM_COUNT, e->n_cus, fam_share)) shares_on = false;
         if (!shares_on) fused = false;
     }

@@ -3,6 +3,8 @@
 
 #include <math.h>
 #include <string.h>
+#include <algorithm>
+#include <vector>
 
 #include "iqd_taps.h"
 #include "iqd_prims.h"
@@ -373,6 +375,77 @@ void plan_fused_shares(const float *cost, int n, uint32_t n_wgs, uint32_t *share
     }
 }
 
+// Shares by TIME (round 4).  Proportional shares ignore what a family's segments look like once they are cut: a segment is a
+// whole number of granules behind a fixed lead-in, and a channel is a whole number of segments, so with many short rows a
+// family sits between "one segment per channel" and "two" - 16 384 channels x 2^14 gave AM and SSB one 16 384-sample segment per
+// channel on half-empty shares while WBFM and FM finished in two thirds of the time.  Here every family lists what each
+// workgroup count would cost it - time = ns_per_sample x (segment + lead-in) for the shortest segment that fits one round of
+// that many workgroups - and the smallest common deadline T is taken for which the families' cheapest workgroup counts fit
+// the launch.  rot_count: the family's channels per rotation selector (segment ids are padded to 16 per selector group); pass
+// them all in [0] for a family whose launch is not grouped.  Returns false when no single-round plan exists (the caller keeps
+// the proportional shares, which run several rounds).
+bool plan_fused_by_time(uint32_t vlen, int n, const FusedFamily *fam, uint32_t n_wgs, uint32_t *share)
+{
+    struct Opt { uint32_t wgs; float t; };
+    std::vector<Opt> opts[8];
+    std::vector<float> deadlines;
+    if (n > 8) return false;
+    for (int f = 0; f < n; f++) {
+        share[f] = 0;
+        const uint32_t n_ch = fam[f].rot_count[0] + fam[f].rot_count[1] + fam[f].rot_count[2];
+        if (!n_ch) continue;
+        const uint32_t g = fam[f].granule == 128 || fam[f].granule == 256 ? fam[f].granule : 512;
+        uint32_t last_len = 0;
+        for (uint32_t k = 1; last_len != (uint32_t)ST_MIN_TILE && k <= vlen; k++) {   // (down to the shortest segment there is)
+            uint64_t len = ((uint64_t)vlen + k - 1) / k;
+            len = (len + g - 1) / g * g;
+            if (len < ST_MIN_TILE) len = ST_MIN_TILE;
+            if ((uint32_t)len == last_len) continue;
+            last_len = (uint32_t)len;
+            const uint32_t tiles = (uint32_t)(((uint64_t)vlen + len - 1) / len);
+            uint64_t ids = 0;
+            for (int r = 0; r < 3; r++) ids += ((uint64_t)fam[f].rot_count[r] * tiles + 15) / 16 * 16;
+            const uint64_t wgs = (ids + ST_SEGS - 1) / ST_SEGS;
+            if (wgs > n_wgs) break;                       // (shorter segments need even more)
+            const float t = fam[f].ns_per_sample * (float)(len + fam[f].halo);
+            if (!opts[f].empty() && opts[f].back().wgs == (uint32_t)wgs) opts[f].back().t = t;   // same workgroups, shorter segments
+            else opts[f].push_back(Opt{(uint32_t)wgs, t});
+            deadlines.push_back(t);
+        }
+        if (opts[f].empty()) return false;                // even one segment per channel does not fit one round
+    }
+    std::sort(deadlines.begin(), deadlines.end());
+    for (float T : deadlines) {
+        uint64_t total = 0;
+        bool ok = true;
+        for (int f = 0; f < n && ok; f++) {
+            if (opts[f].empty()) continue;
+            uint32_t best = 0;
+            for (const Opt &o : opts[f])                  // (ascending workgroups, descending time: the first that meets T)
+                if (o.t <= T) { best = o.wgs; break; }
+            if (!best) ok = false;
+            share[f] = best;
+            total += best;
+        }
+        if (ok && total <= n_wgs) {
+            // what the deadline leaves over goes round in proportion: more workgroups than a family needs mean shorter segments
+            // for it, an earlier end and less company for the family that sets the pace (small calls: 1 % on the clock)
+            uint32_t left = n_wgs - (uint32_t)total, given = 0;
+            uint32_t extra[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int f = 0; f < n; f++) {
+                extra[f] = (uint32_t)((uint64_t)left * share[f] / total);
+                given += extra[f];
+            }
+            for (int f = 0; given < left; f = (f + 1) % n)
+                if (share[f]) { extra[f]++; given++; }
+            for (int f = 0; f < n; f++) share[f] += extra[f];
+            return true;
+        }
+    }
+    for (int f = 0; f < n; f++) share[f] = 0;
+    return false;
+}
+
 TilePlan plan_stream(uint32_t vlen, uint32_t n_channels, uint32_t streams, uint32_t granule)
 {
     TilePlan p;
@@ -384,6 +457,9 @@ TilePlan plan_stream(uint32_t vlen, uint32_t n_channels, uint32_t streams, uint3
     if (granule != 128 && granule != 256) granule = 512;
     len = (len + granule - 1) / granule * granule;   // 512: whole 32-byte PCM sectors per segment (16 PCM samples)
     if (len < ST_MIN_TILE) len = ST_MIN_TILE;   // a segment's end histories must be its own
+    // (the minimum itself is not a multiple of the 512 granule: take it where it fits the round - 4096-sample rows on 6 segments
+    //  per channel are 6 x 768, not 4 x 1024)
+    if (len > ST_MIN_TILE && ((uint64_t)vlen + ST_MIN_TILE - 1) / ST_MIN_TILE <= per_ch) len = ST_MIN_TILE;
     p.tile_len = (uint32_t)len;
     p.tiles_per_ch = (uint32_t)(((uint64_t)vlen + len - 1) / len);
     if (p.tiles_per_ch == 0) p.tiles_per_ch = 1;

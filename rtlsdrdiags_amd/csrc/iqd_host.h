@@ -37,6 +37,8 @@ TilePlan plan_stream(uint32_t vlen, uint32_t n_channels, uint32_t streams, uint3
 // per XCD left unplanned; false (and every entry n_cus) when that cannot be had.  See iqd_host.cpp.
 bool plan_family_shares(const float *cost, int n, uint32_t n_cus, uint32_t *share);
 void plan_fused_shares(const float *cost, int n, uint32_t n_wgs, uint32_t *share);   // several families as ranges of one launch
+struct FusedFamily { uint32_t rot_count[3]; uint32_t halo, granule; float ns_per_sample; };
+bool plan_fused_by_time(uint32_t vlen, int n, const FusedFamily *fam, uint32_t n_wgs, uint32_t *share);
 
 uint32_t block_magic(uint32_t block_samples);
 

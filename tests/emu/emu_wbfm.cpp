@@ -243,6 +243,19 @@ int emu_plan_family_shares(const float *cost, int n, uint32_t n_cus, uint32_t *s
     return iqd::plan_family_shares(cost, n, n_cus, share) ? 1 : 0;
 }
 
+// fam: per family {rot_count[3], halo, granule} as six uint32 + ns_per_sample as a float array
+int emu_plan_fused_by_time(uint32_t vlen, int n, const uint32_t *fam6, const float *ns, uint32_t n_wgs, uint32_t *share)
+{
+    iqd::FusedFamily ff[8];
+    for (int f = 0; f < n && f < 8; f++) {
+        for (int r = 0; r < 3; r++) ff[f].rot_count[r] = fam6[6 * f + r];
+        ff[f].halo = fam6[6 * f + 3];
+        ff[f].granule = fam6[6 * f + 4];
+        ff[f].ns_per_sample = ns[f];
+    }
+    return iqd::plan_fused_by_time(vlen, n, ff, n_wgs, share) ? 1 : 0;
+}
+
 void emu_plan_stream(uint32_t vlen, uint32_t n_channels, uint32_t streams, uint32_t *tile_len, uint32_t *tiles_per_ch)
 {
     const iqd::TilePlan p = iqd::plan_stream(vlen, n_channels, streams);
