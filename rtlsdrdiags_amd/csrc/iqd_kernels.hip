@@ -628,6 +628,9 @@ __global__ void squelch_track_kernel(const SquelchLaunch q, int always_open)
 // together; with a fixed gain the decisions are independent (allowed = present | present of the block before) and
 // the open-block list is a ballot/popcount compaction; with a running AGC the wave steps through the 64 values in
 // order from registers (the recurrence stays serial, the memory latency is gone).
+#ifndef IQD_AGC_RUNS
+#define IQD_AGC_RUNS 1   // 0: every block of a channel with a running AGC takes the serial step (A/B builds)
+#endif
 __global__ __launch_bounds__(64) void squelch_track_wave_kernel(const SquelchLaunch q, int always_open)
 {
     const uint32_t ch = blockIdx.x, lane = threadIdx.x;
@@ -651,27 +654,104 @@ __global__ __launch_bounds__(64) void squelch_track_wave_kernel(const SquelchLau
     const ScanConfig sc = q.scan_cfg[ech];
     ScanState ss = q.scan[ech];
     const unsigned long long below = (1ull << lane) - 1ull;
+    auto sum_at = [&](uint32_t b) { return q.mag_sums[(size_t)ch * q.n_blocks + (b < q.n_blocks ? b : q.n_blocks - 1)]; };
+    // two trips to memory per group of 64 blocks (the sums, then the dB table) are asked for one group ahead each, so that a
+    // long row's walk does not stand still for them
+    uint32_t avg_next = sum_at(lane) / q.block_samples;
+    int32_t sig_next = magnitude_dbfs(g_consts, avg_next);
+    uint32_t sum_next2 = sum_at(lane + 64);
     for (uint32_t base = 0; base < q.n_blocks; base += 64) {
         const uint32_t b = base + lane;
         const bool valid = b < q.n_blocks;
         const size_t idx = (size_t)ch * q.n_blocks + (valid ? b : q.n_blocks - 1);
-        const uint32_t avg = q.mag_sums[idx] / q.block_samples;
+        const uint32_t avg = avg_next;
+        const int32_t my_sig = sig_next;
+        avg_next = sum_next2 / q.block_samples;
+        sig_next = magnitude_dbfs(g_consts, avg_next);
+        sum_next2 = sum_at(b + 128);
         const uint32_t count = q.n_blocks - base < 64 ? q.n_blocks - base : 64;
         uint32_t my_gain = gain, allowed = 0;
         unsigned long long my_freq = ss.current_hz;
         if (!cfg.enabled && !sc.scanning) {   // nothing moves from block to block but the tracker's one-block tail
             if (!always_open) {
-                const uint32_t m = avg > 127u ? 127u : avg;
-                int32_t dbfs = g_consts.db_table[m] - 42;
-                dbfs = (int32_t)((uint32_t)dbfs - gain);
+                const int32_t dbfs = (int32_t)((uint32_t)my_sig - gain);
                 const uint32_t present = (valid && dbfs >= threshold) ? 1u : 0u;
                 uint32_t before = (uint32_t)__shfl_up((int)present, 1);
                 if (lane == 0) before = tracking;
                 allowed = present | before;
                 tracking = (uint32_t)__shfl((int)present, (int)count - 1);
             }
+        } else if (IQD_AGC_RUNS && cfg.enabled && !sc.scanning) {
+            // A running AGC (round 4).  The recurrence over blocks is serial only where the AGC MOVES: while the error stays
+            // inside the deadband (or is pinned at a gain limit) a step changes nothing but the two "last seen" values, and
+            // while the measurements behind an adjustment are blanked it only counts.  Runs of such blocks are found with one
+            // ballot over the 64 blocks in the lanes and taken at once - the squelch's presence / tracker for them in parallel,
+            // the gain being constant - and only the blocks that adjust the gain take the serial step
+            // (AutomaticGainControl.cc:663-748; a settled AGC on a 2^28-sample row: 3.7 -> 0.8 ms per step).
+            uint32_t j0 = 0;
+            while (j0 < count) {
+                const bool adjusted = st.adjusted != 0;
+                uint32_t run = 0;
+                bool blanked = false;
+                if (adjusted && st.blank_ctr < cfg.blanking_limit) {     // blanked measurements: nothing but the counter moves
+                    run = cfg.blanking_limit - st.blank_ctr;
+                    run = run < count - j0 ? run : count - j0;
+                    blanked = true;
+                } else {
+                    // would a step with error 0 leave the filter where it is?  Harris: filtered + alpha * 0; lowpass: only at its
+                    // fixed point.  (in range, so that the clamp does nothing; not -0.0, which the addition would turn into +0.0)
+                    const float f = st.filtered;
+                    const float f1 = cfg.type == 0 ? (cfg.alpha * (float)(int32_t)gain) + ((1 - cfg.alpha) * f) : f + (cfg.alpha * 0.f);
+                    const bool steady = f2u(f1) == f2u(f) && f >= 0.f && f <= (float)AGC_MAX_GAIN && f2u(f) != 0x80000000u;
+                    if (steady) {
+                        int32_t error = cfg.operating_point - my_sig;
+                        const bool at_max = gain == AGC_MAX_GAIN, at_min = gain == 0;
+                        error = (at_max && error > 0) ? 0 : error;
+                        error = (!at_max && at_min && error < 0) ? 0 : error;
+                        error = ((error < 0 ? -error : error) <= cfg.deadband) ? 0 : error;
+                        const unsigned long long moves = __ballot(error != 0 || lane >= count) >> j0;   // bit k: block j0 + k adjusts (or is not there)
+                        run = moves ? (uint32_t)__builtin_ctzll(moves) : 64u - j0;
+                    }
+                }
+                if (run) {
+                    const uint32_t j1 = j0 + run;
+                    uint32_t al = 1;
+                    if (!always_open) {
+                        const int32_t dbfs = (int32_t)((uint32_t)my_sig - gain);
+                        const uint32_t present = dbfs >= threshold ? 1u : 0u;
+                        uint32_t before = (uint32_t)__shfl_up((int)present, 1);
+                        if (lane == j0) before = tracking;
+                        al = present | before;
+                        tracking = (uint32_t)__builtin_amdgcn_readlane((int)present, (int)j1 - 1);
+                    }
+                    if (lane >= j0 && lane < j1) { allowed = al; my_gain = gain; my_freq = ss.current_hz; }
+                    if (blanked) {
+                        st.if_gain = gain;
+                        st.blank_ctr += run;
+                    } else {
+                        st.blank_ctr = adjusted ? 0u : st.blank_ctr;
+                        st.adjusted = 0;
+                        st.signal_magnitude = (uint32_t)__builtin_amdgcn_readlane((int)avg, (int)j1 - 1);
+                        st.normalized = (int32_t)((uint32_t)__builtin_amdgcn_readlane(my_sig, (int)j1 - 1) - gain);
+                        st.if_gain = (uint32_t)st.filtered;
+                    }
+                    j0 = j1;
+                    continue;
+                }
+                const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)avg, (int)j0);
+                const int32_t sig = __builtin_amdgcn_readlane(my_sig, (int)j0);
+                uint32_t al = 1;
+                if (!always_open) {
+                    const int32_t dbfs = (int32_t)((uint32_t)sig - gain);
+                    const uint32_t present = dbfs >= threshold ? 1u : 0u;
+                    al = present | tracking;
+                    tracking = present;
+                }
+                if (lane == j0) { allowed = al; my_gain = gain; my_freq = ss.current_hz; }
+                gain = agc_run_dbfs(cfg, st, a, sig, gain);
+                j0++;
+            }
         } else {
-            const int32_t my_sig = magnitude_dbfs(g_consts, avg);   // the table look-ups of all 64 blocks at once
             for (uint32_t j = 0; j < count; j++) {   // wave-uniform state, block j's values from lane j
                 const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)avg, (int)j);
                 const int32_t sig = __builtin_amdgcn_readlane(my_sig, (int)j);

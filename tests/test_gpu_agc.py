@@ -232,3 +232,53 @@ def test_frequency_scanner_matches_the_reference(capi, golden, one_call):
     assert np.array_equal(flags, g["scan_flags"])
     assert np.array_equal(freq, g["scan_freq"]) and np.array_equal(count, g["scan_count"])
     assert np.array_equal(pcm, g["scan_pcm"]) and np.array_equal(final, g["scan_final"])
+
+
+@pytest.mark.parametrize("seed", range(300, 312))
+def test_long_rows_with_a_running_agc_and_a_closing_squelch(capi, oracle, seed):
+    """Thousands of blocks of one channel in ONE call (the wave-per-channel block loop): levels that sit still for a few
+    hundred blocks, jitter inside and outside the deadband, jumps; both AGC types, blanking, a squelch that the moving
+    gain opens and closes.  Since round 4 that loop takes the runs of blocks in which the AGC does not move at once;
+    gains after every block, squelch decisions and PCM against the oracle fed block by block, over three calls."""
+    rng = np.random.default_rng(seed)
+    nblk = int(rng.integers(700, 3000))
+    mags = []
+    while len(mags) < nblk:
+        level = int(rng.choice([0, 1, 3, 8, 20, 45, 90, 127, 150, 191]))
+        jitter = int(rng.choice([0, 0, 1, 2, 6]))
+        run = int(rng.choice([1, 2, 5, 40, 70, 200, 500]))
+        mags += [int(np.clip(level + rng.integers(-jitter, jitter + 1), 0, 191)) for _ in range(run)]
+    mags = mags[:nblk]
+    cfg = dict(mode="am", type=int(rng.integers(0, 2)), deadband=int(rng.integers(0, 5)), blanking=int(rng.choice([0, 1, 2, 7, 12])),
+               alpha=float(np.float32(rng.choice([0.05, 0.3, 0.8, 0.999]))), operating_point=int(rng.integers(-30, -5)),
+               gain=int(rng.integers(0, 47)), threshold=int(rng.choice([-200, -60, -40, -30])))
+    iq = np.concatenate([block_with_magnitude(m) for m in mags])
+    ref = oracle.chain()
+    A.configure(ref, cfg)
+    pcm_o, allowed_o, gains_o = A.stream(ref, iq, BB)
+    eng = capi.Engine(2, block_bytes=BB)
+    eng.set_gain_trace(True)
+
+    class Ch:
+        pass
+    ch = Ch()
+    for name in ("set_mode", "set_squelch", "set_rx_gain_db", "agc_set_type", "agc_set_deadband", "agc_set_blanking_limit",
+                 "agc_set_filter_coefficient", "agc_set_operating_point", "agc_enable"):
+        setattr(ch, name, (lambda fn: (lambda v=True: fn(v, first=1, n=1)))(getattr(eng, name)))
+    A.configure(ch, cfg)
+    cuts = sorted(int(c) for c in rng.integers(1, nblk, 2))
+    pcm, allowed, gains = [], [], []
+    for b0, b1 in zip([0] + cuts, cuts + [nblk]):
+        if b1 == b0:
+            continue
+        p, c, m, a = eng.accept(iq[b0 * BB:b1 * BB], first=1, n=1)
+        assert m[0].tolist() == mags[b0:b1]
+        trace = eng.gain_trace(b1 - b0, first=1, n=1)[0]
+        gains += list(trace[1:]) + [eng.rx_gain_db(1)]
+        allowed += a[0].tolist()
+        pcm.append(p[0, :c[0]])
+    first_bad = np.flatnonzero(np.array(gains, np.uint32) != gains_o)
+    assert first_bad.size == 0, (seed, cfg, int(first_bad[0]), mags[max(0, int(first_bad[0]) - 3):int(first_bad[0]) + 2])
+    assert np.array_equal(np.array(allowed, np.uint8), allowed_o), (seed, cfg)
+    assert np.array_equal(np.concatenate(pcm), pcm_o), (seed, cfg)
+    assert eng.agc_state(0)["rx_gain_db"] == 24           # the neighbour stays untouched
