@@ -135,6 +135,16 @@ struct iqd_engine {
     // with the piecewise-gain lookup while any channel of the launch is non-zero here).  Never cleared early: it goes
     // down only by samples the channel's WBFM chain really consumed.
     std::vector<uint32_t> wbfm_epoch_left;
+    // ... aged by arithmetic for ungated calls (every channel consumes the whole call); a squelch-gated call's consumption is
+    // known to the device only, which then reports: its WBFM tail updates set word [0] of a page-locked pair if any
+    // channel's newest change still lies inside its tail, a one-store kernel at the call's end writes the call's number to
+    // word [1], and a later call that finds its number there and word [0] clear drops the mirror of that call's channels.
+    std::vector<uint32_t> wbfm_epoch_seq;   // the first accept (accept_seq) whose chain ran with the channel's newest change
+    uint32_t accept_seq = 0;
+    uint32_t *h_epoch_report = nullptr;
+    bool epoch_report_pending = false;
+    uint32_t epoch_report_seq = 0;
+    std::vector<uint32_t> epoch_report_channels;
     uint32_t wbfm_epochs_live = 0;          // channels with wbfm_epoch_left != 0
     std::vector<int32_t> rot_applied;       // [n_ch]: the rotation the device last ran with
     bool rot_changed = false;               // some channel's tails need rewriting (retail_kernel)
@@ -319,6 +329,7 @@ int iqd_create(const iqd_config *cfg, iqd_t **out)
     std::vector<AgcState> agc_states(e->n_ch, st0);
     e->k_applied.resize(2 * (size_t)e->n_ch);
     e->wbfm_epoch_left.assign(e->n_ch, 0u);
+    e->wbfm_epoch_seq.assign(e->n_ch, 0u);
     for (uint32_t c = 0; c < e->n_ch; c++) {
         e->k_applied[2 * c] = e->h_params[c].wbfm_k;
         e->k_applied[2 * c + 1] = e->h_params[c].fm_k;
@@ -456,6 +467,7 @@ void iqd_destroy(iqd_t *e)
     }
     if (e->h_slice_counts) (void)hipHostFree(e->h_slice_counts);
     if (e->h_small) (void)hipHostFree(e->h_small);
+    if (e->h_epoch_report) (void)hipHostFree(e->h_epoch_report);
     if (e->d_closed) (void)hipFree(e->d_closed);
     if (e->h_closed) (void)hipHostFree(e->h_closed);
     if (e->copy_stream) (void)hipStreamDestroy(e->copy_stream);
@@ -599,6 +611,7 @@ static int upload_params(iqd_t *e)
             e->k_applied[2 * c] = p.wbfm_k;
             if (!e->wbfm_epoch_left[c]) e->wbfm_epochs_live++;
             e->wbfm_epoch_left[c] = (uint32_t)TAIL;
+            e->wbfm_epoch_seq[c] = e->accept_seq + 1;
         }
         if (f2u(p.fm_k) != f2u(e->k_applied[2 * c + 1])) {
             if (!(p.k_changed & 2u)) p.fm_k_prev = e->k_applied[2 * c + 1];
@@ -1166,10 +1179,20 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
     bool gated, any_agc;
     {
         std::lock_guard<std::mutex> lk(e->mu);
+        if (e->epoch_report_pending && ((volatile uint32_t *)e->h_epoch_report)[1] == e->epoch_report_seq) {   // (see wbfm_epoch_seq)
+            if (((volatile uint32_t *)e->h_epoch_report)[0] == 0u)
+                for (uint32_t c : e->epoch_report_channels)
+                    if (e->wbfm_epoch_left[c] && e->wbfm_epoch_seq[c] <= e->epoch_report_seq) {
+                        e->wbfm_epoch_left[c] = 0;
+                        e->wbfm_epochs_live--;
+                    }
+            e->epoch_report_pending = false;
+        }
         {
             int rc = upload_params(e);
             if (rc != IQD_OK) return rc;
         }
+        e->accept_seq++;
         if (e->lists_dirty || e->list_first != first_ch || e->list_n != n_ch) {
             rebuild_lists(e, first_ch, n_ch);
             for (int f = 0; f <= FAM_COUNT; f++) {
@@ -1398,6 +1421,7 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
     }
     MixedStreamArgs mix{};
     uint32_t mix_wgs = 0;
+    bool epoch_report_now = false;   // this call's WBFM tail updates report whether a gain change is still in reach (h_epoch_report)
     if (forked && !fused) HIP_TRY(e, hipEventRecord(e->fam_fork, s_main));
     float lane_load[4] = {0.f, 0.f, 0.f, 0.f};   // 0: the engine's stream, 1 to 3: the side streams
     bool lane_used[4] = {false, false, false, false};
@@ -1423,6 +1447,18 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         ChainLaunch a = base;
         a.ch_list = e->lists[f].as<uint32_t>();
         a.n_list = n_list;
+        if (f == FAM_WBFM && chain_gated && e->wbfm_epochs_live && !e->epoch_report_pending) {
+            bool any = false;
+            for (uint32_t c : e->h_lists[FAM_WBFM]) any = any || e->wbfm_epoch_left[first_ch + c] != 0;
+            if (any) {
+                if (!e->h_epoch_report) HIP_TRY(e, hipHostMalloc((void **)&e->h_epoch_report, 2 * sizeof(uint32_t), hipHostMallocDefault));
+                ((volatile uint32_t *)e->h_epoch_report)[0] = 0u;
+                a.epoch_report = e->h_epoch_report;
+                e->epoch_report_channels.clear();
+                for (uint32_t c : e->h_lists[FAM_WBFM]) e->epoch_report_channels.push_back(first_ch + c);
+                epoch_report_now = true;
+            }
+        }
         // workgroups a CU holds at once: WBFM 3 (LDS), the others 4 (registers)
         const TilePlan plan = f == FAM_WBFM ? plan_tiles(vlen, n_list, WBFM_CHUNK, COLD_HALO, 3 * e->n_cus, e->env_plan_chunks)
                                             : plan_tiles(vlen, n_list, CH_CHUNK, FIR_HALO, 4 * e->n_cus, e->env_plan_chunks);
@@ -1727,6 +1763,11 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
     } else if (!gated && e->pre_stream && !e->demod_bypass) {   // a squelch pass on the main stream: the next pre-pass continues from it
         HIP_TRY(e, hipEventRecord(e->ev_main_decisions, s_main));
         e->decisions_on_main = true;
+    }
+    if (epoch_report_now) {   // behind everything this call queued (the side streams have joined)
+        HIP_LAUNCH(e, launch_write_word(e->h_epoch_report + 1, e->accept_seq, s_main));
+        e->epoch_report_pending = true;
+        e->epoch_report_seq = e->accept_seq;
     }
     e->stats.accepts++;
     e->stats.samples += (uint64_t)vlen * n_ch;

@@ -39,6 +39,8 @@ struct ChainLaunch {
     uint32_t *mag_sums;           // [n_ch][n_blocks]
     WbfmRecord *records;          // [n_list][tiles_per_ch]
     uint32_t *repair_flags;       // [n_list]: set by the verification, cleared by the repair (zero between calls)
+    uint32_t *epoch_report;       // WBFM, optional (page-locked host word): set to 1 by the tail update of any channel whose newest gain
+                                  // change still lies inside its kept tail after this call (the host ages its mirror from it)
     uint32_t verify_at_end;       // streaming launches: a cold segment's y_in is its state at its own start, to be compared
                                   // with its predecessor's y_end (tile launches: both taken FORCED_BACK earlier, y_out)
     uint32_t *counters;           // [CNT_COUNT]
@@ -105,6 +107,7 @@ hipError_t launch_rotate_signed(int8_t *buf_dev, size_t bytes, int rotation, hip
 hipError_t launch_agc_apply(const AgcConfig *cfg, AgcState *st, const ScanConfig *scfg, ScanState *sst,
                             ChanParams *params, GainEpoch *epochs, uint32_t n_ch, hipStream_t s);
 hipError_t launch_tail_update(const ChainLaunch &a, int family, hipStream_t s);
+hipError_t launch_write_word(uint32_t *word, uint32_t value, hipStream_t s);   // one store, in stream order
 hipError_t launch_magnitude(const uint8_t *iq, size_t ch_stride_bytes, const uint32_t *ch_list, uint32_t n_list,
                             uint32_t block_samples, uint32_t n_blocks, uint32_t *mag_sums, hipStream_t s);
 // tail_of: a one-family call hands its pending tail update to the squelch launch (tail_squelch_kernel)

@@ -432,6 +432,9 @@ __device__ __forceinline__ void tail_update_body(const ChainLaunch &a, int famil
     const uint32_t ch = a.ch_list[li];
     const uint32_t ech = a.first_ch + ch;
     const uint32_t vlen = a.vlen_gated ? a.vlen_gated[ch] : a.vlen;
+    if (family == FAM_WBFM && a.epoch_report && threadIdx.x == 0 &&
+        (uint64_t)a.epochs[ech].wbfm.since[0] + vlen < (uint64_t)TAIL)
+        *(volatile uint32_t *)a.epoch_report = 1u;   // (every writer stores the same value: no atomic needed)
     if (vlen == 0) return;
     if (family == FAM_WBFM && threadIdx.x == 0) {
         const uint32_t ntiles = (vlen + a.tile_len - 1) / a.tile_len;
@@ -1074,6 +1077,13 @@ hipError_t launch_wbfm_repair(const ChainLaunch &a, bool gated, hipStream_t s)
 hipError_t launch_tail_update(const ChainLaunch &a, int family, hipStream_t s)
 {
     hipLaunchKernelGGL(tail_update_kernel, dim3(a.n_list), dim3(256), 0, s, a, family);
+    return hipGetLastError();
+}
+
+__global__ void write_word_kernel(uint32_t *word, uint32_t value) { *(volatile uint32_t *)word = value; }
+hipError_t launch_write_word(uint32_t *word, uint32_t value, hipStream_t s)
+{
+    hipLaunchKernelGGL(write_word_kernel, dim3(1), dim3(1), 0, s, word, value);
     return hipGetLastError();
 }
 

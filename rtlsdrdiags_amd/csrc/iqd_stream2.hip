@@ -280,6 +280,9 @@ __device__ __forceinline__ void d4_p_round(const ChainLaunch &a, const D4Args &d
                 m16 = st_mag_raw_dword(rawj.z, m16);
                 m16 = st_mag_raw_dword(rawj.w, m16);
                 const uint32_t m = (m16 & 0xffffu) + (m16 >> 16);
+#elif IQD_D4_MAGLUT == 3   // one quad-SAD per dword (iqd_mfma.h: st_mag_raw_dword_q), no table: AM -0.5 %, USB -1 %, FM +5 % (round 4)
+                const uint32_t m16 = st_mag_raw_chunk(rawj, 0u);
+                const uint32_t m = (m16 & 0xffffu) + (m16 >> 16);
 #else
                 const uint32_t m = st_mag_chunk(cur);
 #endif

@@ -452,7 +452,12 @@ IQD_DEV void iir_warm(const Consts &c, WbfmLds &lds, int nseg, int lane, int fir
 // lane j: the real pass over segment j from g[j]; writes (int16)y and e[j].
 // bounded: the host proved |y| < 2^31 for this launch (|K| pi * 1.01 < 2^31), so the cast needs
 // no "integer indefinite" handling.
-IQD_DEV void iir_real(const Consts &c, WbfmLds &lds, int nseg, int lane, bool bounded, int first_skip = 0, int last_len = SEG)
+// mark: the restart record of the tile falls INSIDE a segment of this chunk (a call that does not end on the 128-sample grid):
+// the lane that runs that segment leaves the state entering granule `gi` in z[0] (y) and z[1] (u) - two cells that only the
+// state guess uses, and rewrites before it does (iir_guess) - for wbfm_rec_in_chunk.
+struct IirMark { int lane, gi; };
+IQD_DEV void iir_real(const Consts &c, WbfmLds &lds, int nseg, int lane, bool bounded, int first_skip = 0, int last_len = SEG,
+                      IirMark mark = IirMark{-1, 0})
 {
     if (lane >= nseg) return;
     u32x4 *dst = (u32x4 *)&lds.w[lane * WSTRIDE];
@@ -465,6 +470,7 @@ IQD_DEV void iir_real(const Consts &c, WbfmLds &lds, int nseg, int lane, bool bo
     if (bounded) {
 #pragma unroll 2
         for (int gi = gi0; gi < gi1; gi += 2) {
+            if (lane == mark.lane && gi == mark.gi) { lds.z[0] = y; lds.z[1] = up; }
             const u32x4 a4 = lds.t4[t_slot(lane, gi)], b4 = lds.t4[t_slot(lane, gi + 1)];
             uint32_t w[8];
             IQD_IIR_STEP(u2f(a4.x)) w[0] = cast_i16_bounded(y);
@@ -483,6 +489,7 @@ IQD_DEV void iir_real(const Consts &c, WbfmLds &lds, int nseg, int lane, bool bo
     }
 #pragma unroll 2
     for (int gi = gi0; gi < gi1; gi += 2) {
+        if (lane == mark.lane && gi == mark.gi) { lds.z[0] = y; lds.z[1] = up; }
         const u32x4 a4 = lds.t4[t_slot(lane, gi)], b4 = lds.t4[t_slot(lane, gi + 1)];
         uint32_t w[8];
         IQD_IIR_STEP(u2f(a4.x)) w[0] = (uint32_t)cast_i16(y) & 0xffffu;
@@ -779,8 +786,21 @@ IQD_DEV void wbfm_rec_at_start(WbfmRecPos &rp, WbfmRecord &rec, const WbfmLds &l
 {
     if (cstart >= rp.from && cstart <= rp.target) { rp.pos = cstart; rec.y_out = lds.y_carry; rec.u_out = lds.u_carry; }
 }
-IQD_DEV void wbfm_rec_in_chunk(WbfmRecPos &rp, WbfmRecord &rec, const WbfmLds &lds, int cstart, int clen)
+// the target itself, when it lies inside a segment of this chunk (and not before the tile's own exact state began)
+IQD_DEV IirMark wbfm_mark_in_chunk(const WbfmRecPos &rp, int cstart, int clen)
 {
+    const int off = rp.target - cstart;
+    if (off <= 0 || off >= clen || rp.target < rp.from || off % SEG == 0) return IirMark{-1, 0};
+    return IirMark{off / SEG, (off % SEG) >> 2};
+}
+IQD_DEV void wbfm_rec_in_chunk(WbfmRecPos &rp, WbfmRecord &rec, const WbfmLds &lds, int cstart, int clen, IirMark mark = IirMark{-1, 0})
+{
+    if (mark.lane >= 0) {   // (round 4: exactly tlen - FORCED_BACK, so that `back` never exceeds the streaming kernel's lead-in)
+        rp.pos = rp.target;
+        rec.y_out = lds.z[0];
+        rec.u_out = lds.z[1];
+        return;
+    }
     if (rp.target <= cstart) return;
     int j = (rp.target - cstart) / SEG;                    // whole segments of this chunk that end at or before the target
     if (j > clen / SEG) j = clen / SEG;
@@ -848,17 +868,18 @@ IQD_DEV void wbfm_tile(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLds &ld
         if (ex.in_wave0()) {
             ex.critical(true);
             wbfm_rec_at_start(rp, rec, lds, cstart);
+            const IirMark mark = wbfm_mark_in_chunk(rp, cstart, clen);
             ex.wave0([&](int lane) { iir_guess(c, lds, nseg, lane); });
             ex.stamp(1);
             ex.wave0([&](int lane) { iir_warm(c, lds, nseg, lane, sh.first_skip); });
             ex.stamp(2);
             int rounds = 0;
             do {
-                ex.wave0([&](int lane) { iir_real(c, lds, nseg, lane, t.bounded != 0, sh.first_skip, sh.last_len); });
+                ex.wave0([&](int lane) { iir_real(c, lds, nseg, lane, t.bounded != 0, sh.first_skip, sh.last_len, mark); });
                 rounds++;
             } while (!ex.wave0_all([&](int lane) { return iir_check(lds, nseg, lane, t.k_min >= 1.0f); }));
             ex.stamp(3);
-            wbfm_rec_in_chunk(rp, rec, lds, cstart, clen);
+            wbfm_rec_in_chunk(rp, rec, lds, cstart, clen, mark);
             if (start.cold && cstart < 0) rec.y_in = lds.e[(COLD_HALO - FORCED_BACK) / SEG - 1];
             ex.wave0([&](int lane) {
                 if (lane == 0) {
@@ -1074,14 +1095,15 @@ IQD_DEV void wbfm_tile_pipe(Exec &ex, const WbfmTile &t, const Consts &c, WbfmLd
                 ex.wave0([&](int lane) { raw0.at(lane) = p1s_load<GATED>(t, next_cstart, next_clen >> 4, p1s_group(6, lane)); });
             if (has_cur) {
                 wbfm_rec_at_start(rp, rec, lds, cstart);
+                const IirMark mark = wbfm_mark_in_chunk(rp, cstart, clen);
                 ex.wave0([&](int lane) { iir_guess(c, lds, nseg, lane, lds.part); });
                 ex.wave0([&](int lane) { iir_warm(c, lds, nseg, lane, sh.first_skip); });
                 int rounds = 0;
                 do {
-                    ex.wave0([&](int lane) { iir_real(c, lds, nseg, lane, t.bounded != 0, sh.first_skip, sh.last_len); });
+                    ex.wave0([&](int lane) { iir_real(c, lds, nseg, lane, t.bounded != 0, sh.first_skip, sh.last_len, mark); });
                     rounds++;
                 } while (!ex.wave0_all([&](int lane) { return iir_check(lds, nseg, lane, tiny_ok); }));
-                wbfm_rec_in_chunk(rp, rec, lds, cstart, clen);
+                wbfm_rec_in_chunk(rp, rec, lds, cstart, clen, mark);
                 if (start.cold && cstart < 0) rec.y_in = lds.e[(COLD_HALO - FORCED_BACK) / SEG - 1];
                 ex.wave0([&](int lane) {
                     if (lane == 0) {

@@ -152,3 +152,25 @@ def test_ragged_calls_around_a_reset(emu, oracle):
         pcm, _ = ch.accept(part)
         assert np.array_equal(pcm, ref), (k, m)
         off += m
+
+
+def test_restart_point_is_never_further_back_than_the_streaming_lead_in(emu, oracle):
+    """The streaming kernel starts a call's first segment 768 samples back and applies the carried exact state where it
+    finds it at or after that point (iqd_stream.hip: st_iir_marks).  A tile kernel that ended a call off the 128-sample
+    grid used to leave its restart record at the last SEGMENT BOUNDARY at or before tlen - 768, i.e. up to 96 samples too
+    far back: the streaming kernel then never met it and ran the call from a zero state (round 4's fuzzer, with the streaming
+    path pinned: one PCM sample off by one in thousands of cases).  Now the record is taken exactly at tlen - 768."""
+    u8 = synth.fm_tone(60000, seed=35)
+    for tile_len in (7040, 2048):
+        c = oracle.chain()
+        c.set_mode("wbfm")
+        ch = emu_bind.WbfmChannel(emu, tile_len)
+        off = consumed = 0
+        for m in [832, 512, 800, 1024, 32, 64, 7072, 96, 2080, 4128, 1760, 128]:
+            part = u8[2 * off:2 * (off + m)]
+            ref, _, _ = c.accept_stream(part, min(len(part), 32768))
+            pcm, _ = ch.accept(part)
+            assert np.array_equal(pcm, ref), (tile_len, m)
+            off += m
+            consumed += m
+            assert ch.carry.back == min(consumed, 768), (tile_len, m, ch.carry.back)

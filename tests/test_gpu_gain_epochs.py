@@ -88,3 +88,41 @@ def test_gain_change_then_64_byte_calls(capi, oracle, mode, demod):
         r, _, _ = c.accept_stream(piece, min(nbytes, 4096))
         pcm, cnt, _, _ = eng.accept(piece)
         assert cnt[0] == len(r) and np.array_equal(pcm[0, :cnt[0]], r), (k, nbytes, gain)
+
+
+def test_gated_engine_returns_to_the_one_launch_path_after_a_gain_change_has_aged_out(capi, oracle):
+    """the host's mirror of "a gain change still lies inside this channel's tail" was aged by arithmetic for
+    ungated calls only, so ONE iqd_set_gain on an engine whose squelch can close kept every later call off the one-launch
+    arrangement for good.  Since round 4 a gated call's WBFM tail updates report it.  Mixed engine with a squelch that can
+    close (every block is loud enough to pass): one launch, gain change -> a launch per family, then one launch again;
+    PCM of the changed channel and of its neighbours against the oracle throughout."""
+    n_ch, n = 1500, 1 << 14
+    modes = ["am", "fm", "wbfm", "lsb", "usb"]
+    base = [synth.fm_tone(n, seed=700 + k, deviation=3000.0 + 500.0 * k, amplitude=60.0) for k in range(7)]
+    u8 = np.stack([np.roll(base[c % 7], 2 * ((c * 37) % 1009)) for c in range(n_ch)])
+    eng = capi.Engine(n_ch)
+    for c in range(n_ch):
+        eng.set_mode(modes[c % 5], first=c, n=1)
+    eng.set_squelch(-60)
+    chains = {}
+    for c in (2, 7, 12, 0, 1, 3, 4, 1497):
+        o = oracle.chain()
+        o.set_mode(modes[c % 5])
+        o.set_squelch(-60)
+        chains[c] = o
+
+    def call():
+        pcm, cnt, _, allowed = eng.accept(u8)
+        assert allowed.all()
+        for c, o in chains.items():
+            ref, _, _ = o.accept_stream(u8[c])
+            assert cnt[c] == len(ref) and np.array_equal(pcm[c, :cnt[c]], ref), c
+        return eng.stats()["mixed_launches"]
+
+    assert call() == 1                                   # one launch for the four families (gated instantiation)
+    eng.set_gain("wbfm", 700.0, first=7, n=1)
+    chains[7].set_gain(3, 700.0)
+    assert call() == 1                                   # the change lies inside channel 7's tail: a launch per family
+    assert call() == 2                                   # ... it has aged out, the device said so: one launch again
+    assert call() == 3
+    eng.close()

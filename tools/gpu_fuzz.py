@@ -211,7 +211,7 @@ def wide_case(rng, O):
     while n_ch * nblk * bb > (256 << 20):
         nblk -= 1
     n = nblk * bb // 2
-    flags = int(rng.choice([0, 0, 0, 4]))
+    flags = int(rng.choice([0, 0, 0, 4, 8, 12]))      # 4: every chain streams where its rules allow; 8: the gated calls' pre-pass one call ahead
     tpl = []
     for t in range(k_tpl):
         mode = MODES[int(rng.integers(1, 6))] if rng.random() < 0.95 else "none"
