@@ -13,3 +13,5 @@ run IQD_MIXED=forked FUZZ_WIDE=1 FUZZ_WIDE_RANGE=24,600 timeout 110 python3 tool
 run IQD_SHARES=cost FUZZ_WIDE=1 timeout 110 python3 tools/gpu_fuzz.py 90 80
 run IQD_STREAM_MIN_SEG=1 FUZZ_WIDE=1 FUZZ_WIDE_RANGE=24,600 timeout 110 python3 tools/gpu_fuzz.py 90 81
 run FUZZ_BIG=1 timeout 110 python3 tools/gpu_fuzz.py 90 82
+run IQD_STREAM_MIN_SEG=1 FUZZ_SHORT=1 timeout 110 python3 tools/gpu_fuzz.py 90 83
+run IQD_STREAM_MIN_SEG=1 timeout 110 python3 tools/gpu_fuzz.py 90 84
