@@ -67,16 +67,20 @@ typedef struct iqd_config {
 #define IQD_F_NO_MAGNITUDE 0x1u /* do not produce per-block magnitudes when no channel's squelch can close
                                    (the reference only reports them through an optional callback) */
 /* Every chain (WBFM, FM, AM, SSB) exists as two kernels with identical results: tiles (one workgroup per run of
- * samples) and a streaming pipeline (one persistent workgroup per CU, used for launches big enough to fill the chip
- * that are not squelch-gated).  These two flags pin the choice for all chains (tests, A/B measurements; the names
+ * samples) and a streaming pipeline (one persistent workgroup per CU, used for launches big enough to fill the chip,
+ * squelch-gated ones included).  These two flags pin the choice for all chains (tests, A/B measurements; the names
  * are from the round in which only WBFM had both); the environment variable IQD_WBFM_PATH=tiles|stream does the same.
  * A call with several families whose streaming pipelines all apply runs them as ranges of ONE launch's workgroups
- * (stats.mixed_launches), each family on a share of the CUs in proportion to its estimated cost.
+ * (stats.mixed_launches), each family on a share of the CUs chosen so that all of them end together (per-family segment
+ * lengths and lead-ins taken into account; IQD_SHARES=cost: in plain proportion to the estimated cost, the earlier rule).
  * More environment variables exist for measurements only, read once by iqd_create: IQD_MIXED=forked runs such a call's
  * families as kernels of their own on side streams instead (the round-2 arrangement), IQD_FULL_GRID=1 then gives every
  * family all CUs in turn instead of a share of them side by side, IQD_FAMILY_WEIGHTS=am,fm,wbfm,ssb replaces the
  * relative cost estimates, IQD_STREAM_WGS=<n> fixes the streaming kernels' workgroup count, IQD_STREAM_GRAN / IQD_D4_GRAN=128|256|512
- * the granule of the WBFM / the other pipelines' segment lengths (defaults 512 / 128). */
+ * the granule of the WBFM / the other pipelines' segment lengths (defaults 512 / 128), IQD_STREAM_MIN_SEG=<samples> replaces the
+ * measured per-family thresholds (samples a launch must bring per segment of the persistent workgroups before it streams),
+ * IQD_AM_STREAM_MIN=<PCM samples> the shortest AM / SSB row that may stream (128), IQD_FAMILY_NS=am,fm,wbfm,ssb the ns per
+ * segment sample the share planner works with. */
 #define IQD_F_WBFM_TILES  0x2u
 #define IQD_F_WBFM_STREAM 0x4u
 /* Squelch-gated iqd_accept_iq_device calls (some channel's threshold can reject a block) read their input twice: a pre-pass

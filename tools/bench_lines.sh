@@ -19,6 +19,9 @@ run --mode am --channels 4096 --log2-samples 14 --no-cpu-baseline
 run --mode usb --channels 4096 --log2-samples 14 --no-cpu-baseline
 IQD_WBFM_PATH=stream run --mode am --channels 4096 --log2-samples 14 --no-cpu-baseline
 IQD_WBFM_PATH=stream run --mode usb --channels 4096 --log2-samples 14 --no-cpu-baseline
+run --mode mixed --channels 16384 --log2-samples 14 --no-cpu-baseline
+run --mode mixed --channels 8192 --log2-samples 16 --no-cpu-baseline
+run --mode mixed --channels 1400 --log2-samples 16 --no-cpu-baseline
 run --no-cpu-baseline --prewarm-ms 0
 python3 - <<'PY'
 import json
