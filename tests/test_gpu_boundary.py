@@ -300,3 +300,49 @@ def test_short_blocks_of_several_channels_with_odd_pcm_counts(capi, oracle, nbyt
             assert cnt[c] == len(ref) == nbytes // 64
             assert np.array_equal(pcm[c, :cnt[c]], ref), (call, c, modes[c])
             assert int(mag[c, 0]) == int(rmag[0])
+
+
+MULTI = os.path.join(ROOT, "rtlsdrdiags_amd", "bin", "iqdemod_multi")
+
+
+@pytest.mark.parametrize("layout", ["files", "interleaved"])
+def test_many_channels_from_files_through_one_engine(oracle, tmp_path, layout):
+    """iqdemod_multi (multi-channel file layouts): N captures - or one capture whose blocks go round the
+    channels - through one engine over the C ABI, reading overlapped with the engine, one PCM file per channel.  Modes and
+    rotation selectors per channel, a squelch that closes on some blocks, captures that end inside a batch (the last call of
+    a channel is whole blocks + one short block): every channel's PCM file against the oracle fed block by block."""
+    n_ch, blocks = 7, 3
+    rng = np.random.default_rng(41)
+    modes = [2, 3, 1, 4, 5, 3, 2]
+    rots = [1, 0, -1]
+    rows = []
+    for c in range(n_ch):
+        nblk = 8 if layout == "interleaved" else int(rng.integers(4, 11))
+        n = nblk * 16384 + (0 if layout == "interleaved" else 32 * int(rng.integers(0, 400)))
+        u8 = synth.fm_tone(n, seed=900 + c, amplitude=50.0, deviation=3000.0 + 700.0 * c).copy()
+        for b in range(1, nblk, 3):                          # some quiet blocks: the squelch at -45 dBFS drops them
+            u8[2 * b * 16384:2 * (b + 1) * 16384] = synth.fm_tone(16384, seed=5000 + c * 16 + b, amplitude=1.5, sigma=0.7)
+        rows.append(u8)
+    if layout == "files":
+        for c in range(n_ch):
+            rows[c].tofile(tmp_path / ("cap_%d.iq" % c))
+        src = str(tmp_path / "cap_%d.iq")
+    else:
+        inter = np.stack([r.reshape(-1, 32768) for r in rows], axis=1).reshape(-1)    # block b of channel c = block b * N + c
+        inter.tofile(tmp_path / "cap_all.iq")
+        src = str(tmp_path / "cap_all.iq")
+    r = subprocess.run([MULTI, "channels=%d" % n_ch, "in=" + src, "out=" + str(tmp_path / "pcm_%d.s16"), "layout=" + layout,
+                        "modes=" + ",".join(map(str, modes)), "rotation=1,0,-1", "threshold=-45", "blocks=%d" % blocks],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    dropped = 0
+    for c in range(n_ch):
+        ref = oracle.chain()
+        ref.set_mode(MODES[modes[c]])
+        ref.set_rotation(rots[c % 3])
+        ref.set_squelch(-45)
+        want, _, allowed = ref.accept_stream(rows[c][:len(rows[c]) // 64 * 64])
+        dropped += int((np.asarray(allowed) == 0).sum())
+        got = np.fromfile(tmp_path / ("pcm_%d.s16" % c), dtype=np.int16)
+        assert np.array_equal(got, want), (layout, c, len(got), len(want))
+    assert dropped > 0                                       # (the squelch really closed somewhere)
