@@ -114,9 +114,8 @@ struct Reader {
         const size_t n = fread(b.iq + c * row, 1, row, files[c]);
         b.got[c] = n & ~(size_t)63;
         any = any || b.got[c] != 0;
-        if (n < row) b.last = true;
       }
-      return any;
+      return any;   // (captures of different lengths: the batches go on until no channel has anything left)
     }
     for (uint32_t c = 0; c < o.channels; c++) b.got[c] = 0;
     for (uint32_t k = 0; k < o.blocks && !b.last; k++)

@@ -320,8 +320,8 @@ def test_many_channels_from_files_through_one_engine(oracle, tmp_path, layout):
         nblk = 8 if layout == "interleaved" else int(rng.integers(4, 11))
         n = nblk * 16384 + (0 if layout == "interleaved" else 32 * int(rng.integers(0, 400)))
         u8 = synth.fm_tone(n, seed=900 + c, amplitude=50.0, deviation=3000.0 + 700.0 * c).copy()
-        for b in range(1, nblk, 3):                          # some quiet blocks: the squelch at -45 dBFS drops them
-            u8[2 * b * 16384:2 * (b + 1) * 16384] = synth.fm_tone(16384, seed=5000 + c * 16 + b, amplitude=1.5, sigma=0.7)
+        for b in range(1, nblk - 1, 4):                      # pairs of quiet blocks: the squelch at -45 dBFS drops the second of each
+            u8[2 * b * 16384:2 * (b + 2) * 16384] = synth.fm_tone(2 * 16384, seed=5000 + c * 16 + b, amplitude=1.5, sigma=0.7)   # (the tracker keeps one block open behind a signal)
         rows.append(u8)
     if layout == "files":
         for c in range(n_ch):
