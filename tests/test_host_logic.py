@@ -98,6 +98,21 @@ def test_file_tool_fails_loudly_without_gpu():
         assert r.returncode == 1 and b"no usable HIP device" in r.stderr and r.stdout == b""
 
 
+def test_many_channel_tool_fails_loudly_without_gpu(tmp_path):
+    import subprocess
+    import torch
+    tool = os.path.join(ROOT, "rtlsdrdiags_amd", "bin", "iqdemod_multi")
+    assert os.path.exists(tool)
+    r = subprocess.run([tool, "nonsense"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 1 and b"usage:" in r.stderr
+    if not torch.cuda.is_available():
+        (tmp_path / "cap_0.iq").write_bytes(b"\x80" * 32768)
+        r = subprocess.run([tool, "channels=1", "in=" + str(tmp_path / "cap_%d.iq"), "out=" + str(tmp_path / "pcm_%d.s16")],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert r.returncode == 1 and b"no usable HIP device" in r.stderr
+        assert not (tmp_path / "pcm_0.s16").exists()       # nothing is written, there is no CPU path
+
+
 def test_bench_rows_numpy_twin_is_the_benchs_own_data():
     """tests/oracle_pool.bench_rows feeds the oracle what bench.per_channel_rows feeds the engine."""
     import torch
