@@ -446,7 +446,9 @@ struct StIirSeg {
     int c14, c15;          // 1 << 14, 1 << 15 in registers (the decimators' rounding terms)
 };
 
-__device__ __forceinline__ void st_iir_marks(StIirSeg &q, StIir &s, int pos)
+// (q.sg.valid bit 1: the segment keeps the channel's restart state - WbfmRecord::pad - at q.rec_pos, and takes its own record
+//  where every full cold segment does, rec_pos_uniform)
+__device__ __forceinline__ void st_iir_marks(const ChainLaunch &a, StIirSeg &q, StIir &s, int pos, int rec_pos_uniform)
 {
     if (q.back >= 0) {                                 // warm segment: silence before the carried state applies
         if (pos == -q.back) { s.y = q.cy_y; s.up = q.cy_u; }
@@ -454,7 +456,16 @@ __device__ __forceinline__ void st_iir_marks(StIirSeg &q, StIir &s, int pos)
     } else if (pos == 0) {                             // cold segment: the warmed-up state, checked against the predecessor's end
         q.rec.y_in = s.y;
     }
-    if (pos == q.rec_pos) { q.rec.y_out = s.y; q.rec.u_out = s.up; }
+    if (pos == q.rec_pos) {
+        if (q.sg.valid & 2u) {   // (parked in the spare words of the segment's boundary record, whose address is at hand: no register for it)
+            q.hist->pad[0] = f2u(s.y);
+            q.hist->pad[1] = f2u(s.up);
+        } else {
+            q.rec.y_out = s.y;
+            q.rec.u_out = s.up;
+        }
+    }
+    if ((q.sg.valid & 2u) && pos == rec_pos_uniform) { q.rec.y_out = s.y; q.rec.u_out = s.up; }
     if (pos == q.sg.tlen) {                            // (a multiple of 128: the pair history sits in y2p[0..19] here)
         q.rec.y_end = s.y;
         q.rec.u_end = s.up;
@@ -471,7 +482,7 @@ __device__ __forceinline__ void st_iir_marks(StIirSeg &q, StIir &s, int pos)
 // particular positions happen at the SAME position in every lane - one scalar compare per window instead of a dozen
 // per-lane compare-and-select operations - and the lead-in has already been run by st_iir_lead_in().
 template <int V, bool FAST>
-__device__ __forceinline__ int st_iir_piece(const StreamArgs &sa, uint8_t *ring_base, const uint32_t *full, uint32_t *consumed,
+__device__ __forceinline__ int st_iir_piece(const ChainLaunch &a, const StreamArgs &sa, uint8_t *ring_base, const uint32_t *full, uint32_t *consumed,
                                              uint32_t &wg, StIirSeg &q, StIir &s, int pos, uint32_t rd_off0, uint32_t rd_swz, int lane,
                                              int rec_pos_uniform)
 {
@@ -508,7 +519,7 @@ __device__ __forceinline__ int st_iir_piece(const StreamArgs &sa, uint8_t *ring_
             { ST_T(tc); s.t_to_consumed += tc - s.t_seen; }
 #endif
         }
-        if (!FAST) st_iir_marks(q, s, wpos);
+        if (!FAST) st_iir_marks(a, q, s, wpos, rec_pos_uniform);
         else if (wpos == rec_pos_uniform) { q.rec.y_out = s.y; q.rec.u_out = s.up; }
         const int y2 = st_iir_window(sa, s, u, q.c14, q.c15);
         if (wpos >= 0 && wpos < 48 && q.sg.valid) {    // (uniform) the segment's first values, for the boundary fix-up
@@ -598,6 +609,14 @@ __device__ __forceinline__ void st_iir_wave(const ChainLaunch &a, const StreamAr
         q.rec.y_end = 0.f;
         q.rec.u_end = 0.f;
         q.rec.pad[0] = q.rec.pad[1] = 0;
+        // The channel's restart point vlen - FORCED_BACK in a segment that is not the channel's last - because the last one is
+        // shorter than FORCED_BACK (WbfmRecord::pad): that segment leaves the state there, outside the fast path.
+        const bool not_last = q.sg.vlen - q.sg.v0 > q.sg.tlen;
+        const bool keeps_restart = q.sg.valid && not_last && q.sg.vlen - FORCED_BACK >= q.sg.v0 && q.sg.vlen - FORCED_BACK < q.sg.v0 + q.sg.tlen;
+        if (keeps_restart) {   // (a full segment, not the channel's last: its own record sits where every such segment's does, back_out = FORCED_BACK above)
+            q.rec_pos = q.sg.vlen - FORCED_BACK - q.sg.v0;
+            q.sg.valid |= 2u;
+        }
         StIir s;
         s.y = 0.f; s.up = 0.f;
         s.wlast[0] = s.wlast[1] = 0;
@@ -621,7 +640,7 @@ __device__ __forceinline__ void st_iir_wave(const ChainLaunch &a, const StreamAr
         // wide stores need whole 512-sample groups per lane (tile_len a multiple of 512) and 32-byte aligned rows
         const bool wide = (a.tile_len & 511u) == 0 && (((uintptr_t)a.pcm | (a.pcm_stride * 2)) & 31u) == 0;
         // (a segment that is not there has tlen 0 and stores nothing: it may run along with any kind of wave)
-        const bool fast = __all(!q.sg.valid || (q.back < 0 && q.sg.tlen == (int32_t)a.tile_len)) != 0;
+        const bool fast = __all(!q.sg.valid || (q.back < 0 && q.sg.tlen == (int32_t)a.tile_len && !keeps_restart)) != 0;
         const int rec_pos_uniform = (int)a.tile_len - FORCED_BACK;
         int pq0 = 0;
         if (fast) {
@@ -633,15 +652,15 @@ __device__ __forceinline__ void st_iir_wave(const ChainLaunch &a, const StreamAr
             const int pos = -ST_HALO + 32 * pq;
             int p0, p1, p2, p3;
             if (fast) {
-                p0 = st_iir_piece<0, true>(sa, ring_base, full, consumed, wg, q, s, pos, rd_off0, rd_swz, lane, rec_pos_uniform);
-                p1 = st_iir_piece<1, true>(sa, ring_base, full, consumed, wg, q, s, pos + 32, rd_off0, rd_swz, lane, rec_pos_uniform);
-                p2 = st_iir_piece<2, true>(sa, ring_base, full, consumed, wg, q, s, pos + 64, rd_off0, rd_swz, lane, rec_pos_uniform);
-                p3 = st_iir_piece<3, true>(sa, ring_base, full, consumed, wg, q, s, pos + 96, rd_off0, rd_swz, lane, rec_pos_uniform);
+                p0 = st_iir_piece<0, true>(a, sa, ring_base, full, consumed, wg, q, s, pos, rd_off0, rd_swz, lane, rec_pos_uniform);
+                p1 = st_iir_piece<1, true>(a, sa, ring_base, full, consumed, wg, q, s, pos + 32, rd_off0, rd_swz, lane, rec_pos_uniform);
+                p2 = st_iir_piece<2, true>(a, sa, ring_base, full, consumed, wg, q, s, pos + 64, rd_off0, rd_swz, lane, rec_pos_uniform);
+                p3 = st_iir_piece<3, true>(a, sa, ring_base, full, consumed, wg, q, s, pos + 96, rd_off0, rd_swz, lane, rec_pos_uniform);
             } else {
-                p0 = st_iir_piece<0, false>(sa, ring_base, full, consumed, wg, q, s, pos, rd_off0, rd_swz, lane, 0);
-                p1 = st_iir_piece<1, false>(sa, ring_base, full, consumed, wg, q, s, pos + 32, rd_off0, rd_swz, lane, 0);
-                p2 = st_iir_piece<2, false>(sa, ring_base, full, consumed, wg, q, s, pos + 64, rd_off0, rd_swz, lane, 0);
-                p3 = st_iir_piece<3, false>(sa, ring_base, full, consumed, wg, q, s, pos + 96, rd_off0, rd_swz, lane, 0);
+                p0 = st_iir_piece<0, false>(a, sa, ring_base, full, consumed, wg, q, s, pos, rd_off0, rd_swz, lane, rec_pos_uniform);
+                p1 = st_iir_piece<1, false>(a, sa, ring_base, full, consumed, wg, q, s, pos + 32, rd_off0, rd_swz, lane, rec_pos_uniform);
+                p2 = st_iir_piece<2, false>(a, sa, ring_base, full, consumed, wg, q, s, pos + 64, rd_off0, rd_swz, lane, rec_pos_uniform);
+                p3 = st_iir_piece<3, false>(a, sa, ring_base, full, consumed, wg, q, s, pos + 96, rd_off0, rd_swz, lane, rec_pos_uniform);
             }
             // 128 samples = 4 PCM samples = 8 bytes.  Where the row allows it they are collected over 512 samples and
             // leave as one aligned 32-byte sector (segments start on multiples of 512 samples of their channel's
@@ -671,8 +690,17 @@ __device__ __forceinline__ void st_iir_wave(const ChainLaunch &a, const StreamAr
 #pragma unroll
             for (int k = 0; k < 20; k++) s.y2p[k] = s.y2p[k + 4];
         }
-        st_iir_marks(q, s, (int)a.tile_len);
-        if (q.sg.valid) a.records[(size_t)q.sg.li * a.tiles_per_ch + q.sg.tile] = q.rec;
+        st_iir_marks(a, q, s, (int)a.tile_len, rec_pos_uniform);
+        if (q.sg.valid) {
+            WbfmRecord *const r = a.records + (size_t)q.sg.li * a.tiles_per_ch + q.sg.tile;
+            if (q.sg.valid & 2u) {   // (the restart state this segment kept: st_iir_marks)
+                q.rec.pad[0] = q.hist->pad[0];
+                q.rec.pad[1] = q.hist->pad[1];
+            } else if (!(q.sg.vlen - q.sg.v0 > q.sg.tlen)) {
+                q.rec.pad[0] = WBFM_REC_STREAMED;   // the channel's last segment
+            }
+            *r = q.rec;
+        }
         if (IQD_ST_WAITSTAT && lane == 0) {
             atomicAdd(&a.stamps[1], (unsigned long long)s.n_sleeps);
             atomicAdd(&a.stamps[3], (unsigned long long)n_pieces);

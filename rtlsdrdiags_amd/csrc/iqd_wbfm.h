@@ -727,8 +727,13 @@ struct WbfmRecord {  // what the tile reports for hand-off verification and the 
     float y_out, u_out;
     int32_t back_out;
     float y_end, u_end;  // state after the tile's last sample (for resetDemodulator())
+    // Streaming launches (iqd_stream.hip).  A cold segment's state is exact from its own start on (verified there), not inside its
+    // 768-sample lead-in - so when a channel's LAST segment is shorter than FORCED_BACK, the restart point vlen - FORCED_BACK lies in
+    // the segment before it, which then keeps the state there in pad[0] (y) and pad[1] (u); the last segment's own record carries
+    // WBFM_REC_STREAMED in pad[0], so that the commit can tell it from the record a tile-kernel repair writes (exact as it is).
     uint32_t pad[2];
 };
+constexpr uint32_t WBFM_REC_STREAMED = 0x53545245u;
 
 // Chunk boundaries of a tile: the lead-in [-halo, 0) is one chunk - or two, split where the demodulator gain last
 // changed (the channel's GainEpochList), so that every chunk has one gain.

@@ -194,3 +194,44 @@ def test_channels_of_several_rotation_selectors_stream_in_one_launch(capi, oracl
             assert cnt[c] == len(ref) and np.array_equal(pcm[c, :cnt[c]], ref), (call, c, rots[c])
             assert np.array_equal(mag[c], rmag), (call, c)
     assert eng.stats()["state_repairs"] == 0
+
+
+@pytest.mark.parametrize("gain", [None, 5.0e7])
+def test_restart_state_when_the_last_streamed_segment_is_shorter_than_the_lead_in(capi, oracle, gain):
+    """A channel's restart state is its de-emphasis state 768 samples before its end.  When the channel's LAST streamed segment
+    is shorter than that, the point lies in the segment before it - a cold segment's state is exact from its own start on, not
+    inside its lead-in, where the short one used to take the record (since round 2; a converging state there left the NEXT
+    call's first PCM samples off by one now and then - round 4's fuzz campaign found it at a demodulator gain of 5e7, with the
+    streaming path pinned).  Calls whose rows are k segments of 768 samples + a remainder of 128 ... 640, streaming pinned,
+    three calls each, several channels with their own data; once with a squelch that closes on some 128-sample blocks, so that
+    the remainders differ from channel to channel."""
+    rng = np.random.default_rng(77)
+    for n, thr in ((5 * 768 + 128, -200), (768 + 128, -200), (9 * 768 + 640, -200), (3 * 768 + 384, -200), (40 * 128, -38)):
+        n_ch = 6
+        eng = capi.Engine(n_ch, block_bytes=256, flags=4)
+        chains = []
+        for c in range(n_ch):
+            o = oracle.chain()
+            o.set_mode("wbfm")
+            o.set_squelch(thr)
+            if gain is not None:
+                o.set_gain(3, gain)
+            chains.append(o)
+        eng.set_mode("wbfm")
+        eng.set_squelch(thr)
+        if gain is not None:
+            eng.set_gain("wbfm", gain)
+        for call in range(3):
+            rows = np.stack([synth.fm_tone(n, seed=int(rng.integers(1 << 30)), deviation=float(rng.uniform(1e3, 7e4)),
+                                           amplitude=float(rng.uniform(20, 120)), sigma=1.0) for _ in range(n_ch)])
+            if thr > -200:                                   # quiet stretches of a few blocks: the squelch drops all but the first of each
+                for c in range(n_ch):
+                    for b0 in rng.integers(0, n // 128 - 4, 3):
+                        rows[c, 256 * int(b0):256 * (int(b0) + int(rng.integers(2, 5)))] = 128
+            pcm, cnt, _, allowed = eng.accept(rows)
+            for c in range(n_ch):
+                ref, _, rall = chains[c].accept_stream(rows[c], 256)
+                assert np.array_equal(allowed[c], rall), (n, thr, call, c)
+                assert cnt[c] == len(ref) and np.array_equal(pcm[c, :cnt[c]], ref), (n, thr, call, c, np.flatnonzero(pcm[c, :cnt[c]] != ref)[:8])
+        assert eng.stats()["stream_launches"] == 3, eng.stats()
+        eng.close()

@@ -192,6 +192,7 @@ def one_case(rng, O):
                 bad = np.flatnonzero(g != r)
                 print("  first differing PCM sample %d of %d (%d differ, last %d): got %s, oracle %s; operations between calls: %s"
                       % (bad[0], len(r), len(bad), bad[-1], g[bad[0]:bad[0] + 6], r[bad[0]:bad[0] + 6], ops_log))
+                print("  the calls' first PCM samples: %s; all differing: %s; stats %s" % (np.cumsum([0] + [len(x) for x in got[c]]).tolist(), bad[:20].tolist(), eng.stats()))
             return False
     eng.close()
     return True
@@ -380,14 +381,31 @@ def main():
     rng = np.random.default_rng(seed)
     O = B.Oracle()
     t0, cases, n_wide = time.time(), 0, 0
+    import json
+    if os.environ.get("FUZZ_REPLAY"):       # the generator state a failed run left behind (gpurun_out/fuzz_fail_state.json): that one case again
+        rng.bit_generator.state = json.load(open(os.environ["FUZZ_REPLAY"]))
+        seconds = 0.0
+        wide = os.environ.get("FUZZ_WIDE") == "1" or (os.environ.get("FUZZ_WIDE") is None and rng.random() < 0.03)   # (as the loop below draws it)
+        ok = short_case(rng, O) is None if os.environ.get("FUZZ_SHORT") else (wide_case(rng, O) if wide else one_case(rng, O))
+        print("replayed case:", "identical" if ok else "MISMATCH")
+        sys.exit(0 if ok else 1)
+    def keep_state():
+        try:
+            os.makedirs("gpurun_out", exist_ok=True)
+            json.dump(state0, open("gpurun_out/fuzz_fail_state.json", "w"))
+        except Exception:
+            pass
     while time.time() - t0 < seconds:
+        state0 = rng.bit_generator.state
         wide = os.environ.get("FUZZ_WIDE") == "1" or (os.environ.get("FUZZ_WIDE") is None and rng.random() < 0.03)
         if os.environ.get("FUZZ_SHORT"):        # every call a short block / a few whole blocks (short_case)
             bad = short_case(rng, O)
             if bad:
                 print("MISMATCH:", bad)
+                keep_state()
                 sys.exit(1)
         elif not (wide_case(rng, O) if wide else one_case(rng, O)):
+            keep_state()
             sys.exit(1)
         cases += 1
         n_wide += 1 if wide else 0
