@@ -193,6 +193,9 @@ __device__ __forceinline__ void wbfm_repair_body(const ChainLaunch &a, WbfmLds &
             const bool ok = iir_states_agree(r[tile].y_in, a.verify_at_end ? prev.y_end : prev.y_out, strong);
             if (ok && !redo_next) break;
             redo_next = a.verify_at_end && !ok;
+            // (a re-run rewrites the tile's record: if it was the one that kept the channel's restart state for a short last
+            //  segment - WbfmRecord::pad - the last one is re-run as well, and its own record, exact then, is what the commit takes)
+            if (a.verify_at_end && tile + 2 == ntiles && vlen - (ntiles - 1) * a.tile_len < (uint32_t)FORCED_BACK) redo_next = true;
             WbfmStart start;
             start.y = prev.y_out; start.u = prev.u_out; start.back = prev.back_out; start.cold = 0;
             wbfm_run_tile<GATED, false>(a, lds, li, tile, ch, vlen, start);

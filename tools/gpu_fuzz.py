@@ -368,7 +368,9 @@ def short_case(rng, O):
                 what = ("count %d vs %d" % (cnt[c], len(ref)) if cnt[c] != len(ref) else
                         "allowed %s vs %s" % (allowed[c], rall) if not np.array_equal(allowed[c], rall) else
                         "magnitude %s vs %s" % (mag[c], rmag) if not np.array_equal(mag[c], rmag) else
-                        "pcm: first difference at %d of %d" % (int(np.flatnonzero(pcm[c, :cnt[c]] != ref)[0]), len(ref)))
+                        "pcm: first difference at %d of %d (all: %s; got %s, oracle %s; stats %s)" % (
+                            int(np.flatnonzero(pcm[c, :cnt[c]] != ref)[0]), len(ref), np.flatnonzero(pcm[c, :cnt[c]] != ref)[:12].tolist(),
+                            pcm[c, :cnt[c]][np.flatnonzero(pcm[c, :cnt[c]] != ref)[:4]].tolist(), ref[np.flatnonzero(pcm[c, :cnt[c]] != ref)[:4]].tolist(), eng.stats()))
                 eng.close()
                 return "short-block case: bb=%d cfg=%r call %d of %d bytes (calls so far %r), channel %d differs in %s (ops %r)" % (bb, cfg, call, nb, sizes, c, what, log)
     eng.close()
@@ -386,7 +388,13 @@ def main():
         rng.bit_generator.state = json.load(open(os.environ["FUZZ_REPLAY"]))
         seconds = 0.0
         wide = os.environ.get("FUZZ_WIDE") == "1" or (os.environ.get("FUZZ_WIDE") is None and rng.random() < 0.03)   # (as the loop below draws it)
-        ok = short_case(rng, O) is None if os.environ.get("FUZZ_SHORT") else (wide_case(rng, O) if wide else one_case(rng, O))
+        if os.environ.get("FUZZ_SHORT"):
+            bad = short_case(rng, O)
+            if bad:
+                print("MISMATCH:", bad)
+            ok = bad is None
+        else:
+            ok = wide_case(rng, O) if wide else one_case(rng, O)
         print("replayed case:", "identical" if ok else "MISMATCH")
         sys.exit(0 if ok else 1)
     def keep_state():
