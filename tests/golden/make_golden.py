@@ -78,13 +78,35 @@ def demod_entry(R):
     np.savez_compressed(os.path.join(OUT, "demod_entry.npz"), **out)
 
 
+CAPTURE = "/root/reference/demodulatorResearch/yoyo.iq"
+CAPTURE_FIRST_BLOCK, CAPTURE_BLOCKS = 56, 4
+
+
+def capture(R):
+    """An off-air signal: blocks 56..59 (32768 bytes each) of the reference's own recording
+    demodulatorResearch/yoyo.iq - signed bytes on disk, +128 here to give what the dongle delivers - through
+    IqDataProcessor::acceptIqData in every mode.  The excerpt holds a real dropout of the carrier (block 58: the
+    magnitude falls from 55 to 9 for a few milliseconds), so the second fixture runs it in 4096-byte blocks with the squelch
+    at -33 dBFS: three blocks are rejected in mid-stream and the chains skip them."""
+    s8 = np.fromfile(CAPTURE, dtype=np.int8)
+    at = CAPTURE_FIRST_BLOCK * 32768
+    u8 = (s8[at:at + CAPTURE_BLOCKS * 32768].astype(np.int16) + 128).astype(np.uint8)
+    np.savez_compressed(os.path.join(OUT, "capture_excerpt.npz"), iq=u8, block_bytes=32768,
+                        first_byte=at, **run_all_modes(R, u8))
+    g = run_all_modes(R, u8, block_bytes=4096, threshold=-33, rx_gain=24)
+    assert 0 < g["allowed"].sum() < len(g["allowed"])
+    np.savez_compressed(os.path.join(OUT, "capture_gated.npz"), iq=u8, block_bytes=4096, first_byte=at,
+                        threshold=-33, rx_gain_db=24, **g)
+
+
 def main():
     R = B.Reference()
-    if len(sys.argv) > 1:                    # only the named fixtures (python make_golden.py demod_entry)
+    if len(sys.argv) > 1:                    # only the named fixtures (python make_golden.py demod_entry capture)
         for name in sys.argv[1:]:
-            {"demod_entry": demod_entry}[name](R)
+            {"demod_entry": demod_entry, "capture": capture}[name](R)
         return
     demod_entry(R)
+    capture(R)
     blk = 16384
 
     # (i) modulated tone at -Fs/4 + noise, moderate amplitude

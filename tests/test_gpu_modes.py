@@ -16,7 +16,7 @@ def capi():
     return c
 
 
-@pytest.mark.parametrize("name", ["fm_tone", "am_tone", "ssb_tone", "white", "rails"])
+@pytest.mark.parametrize("name", ["fm_tone", "am_tone", "ssb_tone", "white", "rails", "capture_excerpt"])
 @pytest.mark.parametrize("mode", MODES)
 def test_golden_all_modes(capi, golden, name, mode):
     g = golden[name]
@@ -40,10 +40,12 @@ def test_golden_cast_overflow_gains(capi, golden, mode):
     assert np.array_equal(pcm[0, :cnt[0]], g["pcm_" + mode])
 
 
+@pytest.mark.parametrize("name", ["squelch_steps", "capture_gated"])
 @pytest.mark.parametrize("mode", MODES)
-def test_golden_squelch_gating(capi, golden, mode):
-    """Blocks that Squelch::run() rejects are skipped entirely: no PCM, no state advance."""
-    g = golden["squelch_steps"]
+def test_golden_squelch_gating(capi, golden, mode, name):
+    """Blocks that Squelch::run() rejects are skipped entirely: no PCM, no state advance.  capture_gated is the
+    reference's own recording with a real dropout of the carrier (tests/golden/make_golden.py: capture)."""
+    g = golden[name]
     eng = capi.Engine(1, block_bytes=int(g["block_bytes"]))
     eng.set_mode(mode)
     eng.set_squelch(int(g["threshold"]))

@@ -27,7 +27,7 @@ def oracle_run(oracle, u8, block_bytes=32768, gain=None, rotation=1):
     return c.accept_stream(u8, block_bytes)
 
 
-@pytest.mark.parametrize("name", ["fm_tone", "am_tone", "white", "rails"])
+@pytest.mark.parametrize("name", ["fm_tone", "am_tone", "white", "rails", "capture_excerpt"])
 def test_golden(capi, golden, name):
     g = golden[name]
     eng = capi.Engine(1, flags=STREAM)

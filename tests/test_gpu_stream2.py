@@ -27,7 +27,7 @@ def oracle_run(oracle, mode, u8, rotation=1, gain=None, block_bytes=32768):
 
 
 @pytest.mark.parametrize("mode", MODES)
-@pytest.mark.parametrize("name", ["fm_tone", "am_tone", "white", "rails"])
+@pytest.mark.parametrize("name", ["fm_tone", "am_tone", "white", "rails", "capture_excerpt"])
 def test_golden(capi, golden, mode, name):
     g = golden[name]
     if g["iq"].size < 2 * 16384 * 2:
@@ -38,6 +38,31 @@ def test_golden(capi, golden, mode, name):
     assert eng.stats()["stream_launches"] == 1
     assert np.array_equal(pcm[0, :cnt[0]], g["pcm_" + mode])
     assert np.array_equal(mag[0], g["magnitude"])
+
+
+@pytest.mark.parametrize("mode", MODES + ["wbfm"])
+def test_golden_capture_with_its_dropout_gated_on_the_streaming_kernels(capi, golden, mode):
+    """The reference's own recording (4 blocks of demodulatorResearch/yoyo.iq, tests/golden/make_golden.py: capture) in
+    4096-byte blocks with the squelch at -33 dBFS: the carrier's dropout closes it for three blocks in mid-stream; the
+    gated streaming pipelines must give the reference's PCM, in one call and in two."""
+    g = golden["capture_gated"]
+    bb = int(g["block_bytes"])
+    for cuts in ([0, len(g["iq"])], [0, 20 * bb, len(g["iq"])]):
+        eng = capi.Engine(1, block_bytes=bb, flags=STREAM)
+        eng.set_mode(mode)
+        eng.set_squelch(int(g["threshold"]))
+        eng.set_rx_gain_db(int(g["rx_gain_db"]))
+        out, flags, mags = [], [], []
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            pcm, cnt, mag, allowed = eng.accept(g["iq"][a:b])
+            out.append(pcm[0, :cnt[0]])
+            flags.append(allowed[0])
+            mags.append(mag[0])
+        assert eng.stats()["stream_launches"] == len(cuts) - 1
+        assert np.array_equal(np.concatenate(flags), g["allowed"])
+        assert np.array_equal(np.concatenate(mags), g["magnitude"])
+        assert np.array_equal(np.concatenate(out), g["pcm_" + mode])
+        eng.close()
 
 
 @pytest.mark.parametrize("mode", MODES)

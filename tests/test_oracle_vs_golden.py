@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 MODES = ["none", "am", "fm", "wbfm", "lsb", "usb"]
-STREAMS = ["fm_tone", "am_tone", "ssb_tone", "white", "rails"]
+STREAMS = ["fm_tone", "am_tone", "ssb_tone", "white", "rails", "capture_excerpt"]   # the last: an off-air capture
 
 
 @pytest.mark.parametrize("name", STREAMS)
@@ -32,9 +32,10 @@ def test_cast_overflow_gains(oracle, golden, mode):
     assert np.abs(pcm.astype(np.int32)).max() > 5000
 
 
+@pytest.mark.parametrize("name", ["squelch_steps", "capture_gated"])
 @pytest.mark.parametrize("mode", MODES)
-def test_squelch_gating(oracle, golden, mode):
-    g = golden["squelch_steps"]
+def test_squelch_gating(oracle, golden, mode, name):
+    g = golden[name]
     c = oracle.chain()
     c.set_mode(mode)
     c.set_squelch(int(g["threshold"]))
