@@ -262,25 +262,54 @@ def per_channel_rows(torch, row_u8, n_ch, first_global, row_bytes, chunk=256):
     return out
 
 
-def configure(eng, mode, n_ch, first_global, squelch):
-    """Per-channel settings; `first_global` is this rank's first channel in the whole job, so that the mix is the
-    same however many ranks share it."""
+def channel_plan(mode, n_ch, first_global):
+    """(modes, rotation selectors) of this rank's channels: a function of the channel's index in the whole JOB
+    (g = first_global + c), so that the mix is the same however many ranks share it.  The at-size tests run these very
+    lists for the offsets ranks 1..7 start at (tests/test_gpu_bench_paths.py)."""
     if mode == "mixed":          # BASELINE configs[3]: channel % 5 -> {AM, FM, WBFM, LSB, USB}
-        for c in range(n_ch):
-            eng.set_mode(["am", "fm", "wbfm", "lsb", "usb"][(first_global + c) % 5], first=c, n=1)
-    elif mode == "ssb_stress":   # BASELINE configs[4]
-        for c in range(n_ch):
-            g = first_global + c
-            eng.set_mode("lsb" if g % 2 == 0 else "usb", first=c, n=1)
-            eng.set_rotation((1, 0, -1)[g % 3], first=c, n=1)
+        return [["am", "fm", "wbfm", "lsb", "usb"][(first_global + c) % 5] for c in range(n_ch)], [1] * n_ch
+    if mode == "ssb_stress":     # BASELINE configs[4]
+        return (["lsb" if (first_global + c) % 2 == 0 else "usb" for c in range(n_ch)],
+                [(1, 0, -1)[(first_global + c) % 3] for c in range(n_ch)])
+    return [mode] * n_ch, [1] * n_ch
+
+
+def _set_runs(setter, values):
+    c0 = 0
+    for c in range(1, len(values) + 1):
+        if c == len(values) or values[c] != values[c0]:
+            setter(values[c0], first=c0, n=c - c0)
+            c0 = c
+
+
+def configure(eng, mode, n_ch, first_global, squelch):
+    """Per-channel settings; `first_global` is this rank's first channel in the whole job."""
+    modes, rots = channel_plan(mode, n_ch, first_global)
+    _set_runs(eng.set_mode, modes)
+    if any(r != 1 for r in rots):
+        _set_runs(eng.set_rotation, rots)
+    if mode == "ssb_stress":
         eng.agc_set_type(1)      # AGC_TYPE_HARRIS
         eng.agc_enable(True)
         if squelch is None:
             squelch = GATE_THRESHOLD_DBFS
-    else:
-        eng.set_mode(mode)
     if squelch is not None:
         eng.set_squelch(squelch)
+
+
+def gated_rows(torch, loud_u8, quiet_u8, n_ch, first_global, row_bytes, block_bytes=32768):
+    """configs[4]'s input: every channel's own roll of the loud and of the quiet signal (per_channel_rows), put together
+    block by block after the pattern of the channel's class (g % 4 classes, period 4 blocks)."""
+    dev = loud_u8.device
+    iq = per_channel_rows(torch, loud_u8, n_ch, first_global, row_bytes)
+    lo = per_channel_rows(torch, quiet_u8, n_ch, first_global, row_bytes)
+    which = (torch.arange(n_ch, device=dev) + first_global) % len(GATE_PATTERNS)
+    pat = torch.tensor(GATE_PATTERNS, dtype=torch.bool, device=dev)           # [class][block % 4]: True = loud
+    n_blk = max(1, row_bytes // block_bytes)
+    is_loud = pat.index_select(0, which)[:, torch.arange(n_blk, device=dev) % 4]   # [n_ch][n_blk]
+    v_iq, v_lo = iq.view(n_ch, n_blk, -1), lo.view(n_ch, n_blk, -1)
+    v_iq.copy_(torch.where(is_loud.unsqueeze(-1), v_iq, v_lo))
+    return iq
 
 
 def rank_body(args, rank, world, dev, make_engine, dist, torch, order_streams=None):
@@ -298,15 +327,8 @@ def rank_body(args, rank, world, dev, make_engine, dist, torch, order_streams=No
     if gating:   # configs[4]: loud / quiet blocks per channel class, so that the raised squelch really rejects blocks
         loud = torch.from_numpy(synth.fm_tone(n, seed=1234)).to(dev)
         quiet = torch.from_numpy(synth.fm_tone(n, seed=1234, amplitude=2.0, sigma=1.0)).to(dev)
-        iq = per_channel_rows(torch, loud, n_ch, first_global, 2 * n)
-        lo = per_channel_rows(torch, quiet, n_ch, first_global, 2 * n)
-        which = (torch.arange(n_ch, device=dev) + first_global) % len(GATE_PATTERNS)
-        pat = torch.tensor(GATE_PATTERNS, dtype=torch.bool, device=dev)           # [class][block % 4]: True = loud
-        n_blk = max(1, 2 * n // 32768)
-        is_loud = pat.index_select(0, which)[:, torch.arange(n_blk, device=dev) % 4]   # [n_ch][n_blk]
-        v_iq, v_lo = iq.view(n_ch, n_blk, -1), lo.view(n_ch, n_blk, -1)
-        v_iq.copy_(torch.where(is_loud.unsqueeze(-1), v_iq, v_lo))
-        del lo, loud, quiet, v_iq, v_lo
+        iq = gated_rows(torch, loud, quiet, n_ch, first_global, 2 * n)
+        del loud, quiet
     elif n_ch == 1:
         iq = torch.from_numpy(period_u8).to(dev).repeat(n // period)
     else:

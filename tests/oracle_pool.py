@@ -88,5 +88,18 @@ def bench_rows(base_u8, n_ch, first_global, row_bytes):
     return out
 
 
+def gated_rows(loud_u8, quiet_u8, n_ch, first_global, row_bytes, patterns, block_bytes=32768):
+    """numpy twin of bench.gated_rows (configs[4]): the channel's own roll of the loud and of the quiet signal, block by
+    block after the pattern of its class g % len(patterns)."""
+    rows = bench_rows(loud_u8, n_ch, first_global, row_bytes)
+    quiet = bench_rows(quiet_u8, n_ch, first_global, row_bytes)
+    for c in range(n_ch):
+        pat = patterns[(first_global + c) % len(patterns)]
+        for b in range(max(1, row_bytes // block_bytes)):
+            if not pat[b % 4]:
+                rows[c, b * block_bytes:(b + 1) * block_bytes] = quiet[c, b * block_bytes:(b + 1) * block_bytes]
+    return rows
+
+
 if __name__ == "__main__":
     _worker_main(sys.argv[1], int(sys.argv[2]), int(sys.argv[3]))

@@ -77,34 +77,36 @@ def test_bench_single_family_paths_at_size_every_channel(capi, mode):
     _compare_all(got, rows, modes)
 
 
-def test_bench_config3_mixed_at_size_every_channel(capi):
-    """`bench.py --config 3`: 4096 channels x 2^16, channel % 5 -> {AM, FM, WBFM, LSB, USB}, the bench's per-channel data:
-    the four families' pipelines as ranges of one launch, all 4096 channels against the oracle, two calls."""
-    n_ch, n = 4096, 1 << 16
-    rows = bench_rows(synth.fm_tone(n, seed=1234), n_ch, 0, 2 * n)
-    modes = [["am", "fm", "wbfm", "lsb", "usb"][c % 5] for c in range(n_ch)]
-    got = _run_on_device(capi, rows, modes, expect_streams=4, expect_mixed=1)
-    _compare_all(got, rows, modes)
-
-
-def test_bench_config4_gated_ssb_at_size_every_channel(capi):
-    """`bench.py --config 4` on one GPU: 8192 LSB / USB channels x 2^16, rotation selector by channel, Harris AGC, squelch
-    at -60 dBFS over the bench's loud / quiet block classes (a quarter of the blocks rejected in the steady state): the
-    gated streaming pipeline, three calls (the AGC moves), every channel against the oracle."""
+# What ranks 0, 1 and 7 of an 8-GPU job run: first_global = rank * channels per GPU, so the mode mix
+# starts at another residue of g % 5 (4096 % 5 = 1), the rotation selectors at another residue of g % 3 (8192 % 3 = 2), the
+# gating classes and the data rolls at other offsets.  One GPU can run each rank's slice.
+@pytest.mark.parametrize("rank", [0, 1, 7])
+def test_bench_config3_mixed_at_size_every_channel(capi, rank):
+    """`bench.py --config 3`: 4096 channels x 2^16 per GPU, job-wide channel g % 5 -> {AM, FM, WBFM, LSB, USB}, the bench's
+    per-channel data: the four families' pipelines as ranges of one launch, all 4096 channels against the oracle, two calls."""
     import bench
+    n_ch, n = 4096, 1 << 16
+    first_global = rank * n_ch
+    rows = bench_rows(synth.fm_tone(n, seed=1234), n_ch, first_global, 2 * n)
+    modes, rots = bench.channel_plan("mixed", n_ch, first_global)
+    assert modes[0] == ["am", "fm", "wbfm", "lsb", "usb"][first_global % 5]
+    got = _run_on_device(capi, rows, modes, rots, expect_streams=4, expect_mixed=1)
+    _compare_all(got, rows, modes, rots)
+
+
+@pytest.mark.parametrize("rank", [0, 1, 7])
+def test_bench_config4_gated_ssb_at_size_every_channel(capi, rank):
+    """`bench.py --config 4` on one GPU of eight: 8192 LSB / USB channels x 2^16, rotation selector by job-wide channel,
+    Harris AGC, squelch at -60 dBFS over the bench's loud / quiet block classes (a quarter of the blocks rejected in the
+    steady state): the gated streaming pipeline, three calls (the AGC moves), every channel against the oracle."""
+    import bench
+    from oracle_pool import gated_rows
     n_ch, n = 8192, 1 << 16
-    loud = bench_rows(synth.fm_tone(n, seed=1234), n_ch, 0, 2 * n)
-    quiet = bench_rows(synth.fm_tone(n, seed=1234, amplitude=2.0, sigma=1.0), n_ch, 0, 2 * n)
-    nblk = 2 * n // 32768
-    rows = loud
-    for c in range(n_ch):
-        pat = bench.GATE_PATTERNS[c % len(bench.GATE_PATTERNS)]
-        for b in range(nblk):
-            if not pat[b % 4]:
-                rows[c, b * 32768:(b + 1) * 32768] = quiet[c, b * 32768:(b + 1) * 32768]
-    del quiet
-    modes = ["lsb" if c % 2 == 0 else "usb" for c in range(n_ch)]
-    rots = [(1, 0, -1)[c % 3] for c in range(n_ch)]
+    first_global = rank * n_ch
+    rows = gated_rows(synth.fm_tone(n, seed=1234), synth.fm_tone(n, seed=1234, amplitude=2.0, sigma=1.0), n_ch, first_global,
+                      2 * n, bench.GATE_PATTERNS)
+    modes, rots = bench.channel_plan("ssb_stress", n_ch, first_global)
+    assert rots[0] == (1, 0, -1)[first_global % 3]
     got = _run_on_device(capi, rows, modes, rots, calls=3, threshold=bench.GATE_THRESHOLD_DBFS, agc=1, expect_streams=1)
     rejected = 1.0 - float(np.mean(got[-1][3]))
     assert 0.15 < rejected < 0.35, rejected

@@ -123,3 +123,23 @@ def test_bench_rows_numpy_twin_is_the_benchs_own_data():
         a = bench.per_channel_rows(torch, torch.from_numpy(base), n_ch, first, row_bytes, chunk=64).numpy()
         assert np.array_equal(a, bench_rows(base, n_ch, first, row_bytes))
     assert not np.array_equal(a[0], a[1])
+
+
+def test_gated_rows_and_channel_plan_at_the_offsets_of_other_ranks():
+    """configs[3] / configs[4] as ranks 1 and 7 of an 8-GPU job stage them (first_global = rank * channels per GPU):
+    tests/oracle_pool.gated_rows is bench.gated_rows, and bench.channel_plan is a function of the job-wide index only."""
+    import torch
+    import bench
+    from oracle_pool import gated_rows
+    rng = np.random.default_rng(4)
+    loud, quiet = rng.integers(0, 256, 6000, dtype=np.uint8), rng.integers(0, 256, 6000, dtype=np.uint8)
+    for rank in (0, 1, 7):
+        first = rank * 8192
+        a = bench.gated_rows(torch, torch.from_numpy(loud), torch.from_numpy(quiet), 13, first, 6 * 1024, block_bytes=1024).numpy()
+        assert np.array_equal(a, gated_rows(loud, quiet, 13, first, 6 * 1024, bench.GATE_PATTERNS, block_bytes=1024))
+    whole_m, whole_r = bench.channel_plan("ssb_stress", 8 * 64, 0)
+    whole3, _ = bench.channel_plan("mixed", 8 * 64, 0)
+    for rank in range(8):
+        m, r = bench.channel_plan("ssb_stress", 64, rank * 64)
+        assert m == whole_m[rank * 64:(rank + 1) * 64] and r == whole_r[rank * 64:(rank + 1) * 64]
+        assert bench.channel_plan("mixed", 64, rank * 64)[0] == whole3[rank * 64:(rank + 1) * 64]
