@@ -1,0 +1,52 @@
+"""GPU (MI355X): bounded slices of tools/gpu_fuzz.py under each path-pinning knob that found a bug in round 4
+(tools/fuzz_campaign.sh; VERDICT r4 item 4: the campaigns' evidence belongs where the driver runs it).  The knobs are read
+by iqd_create from the environment, so every pin is a subprocess of its own: a fixed seed for a fixed time, then a seed
+taken from the clock (printed on failure, together with the fuzzer's own description of the failing case; the generator
+state of the case is left in gpurun_out/fuzz_fail_state.json for `FUZZ_REPLAY=<file> python tools/gpu_fuzz.py`)."""
+import os
+import subprocess
+import sys
+import time
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+# (name, environment, seconds with the fixed seed, fixed seed)
+PINS = [
+    ("default_paths", {}, 28, 501),
+    ("wbfm_stream", {"IQD_WBFM_PATH": "stream"}, 28, 502),          # found: restart record further back than the lead-in reaches
+    ("wbfm_tiles", {"IQD_WBFM_PATH": "tiles"}, 25, 503),
+    ("short_blocks", {"FUZZ_SHORT": "1"}, 28, 504),                 # found: DC pass past odd PCM counts, fm_shift_e
+    ("stream_short_blocks", {"IQD_WBFM_PATH": "stream", "FUZZ_SHORT": "1"}, 25, 505),   # found: short last segment's restart state
+    ("wide", {"FUZZ_WIDE": "1"}, 28, 506),                          # found: AM / SSB detector-stream buffer shared
+    ("wide_small_calls", {"FUZZ_WIDE": "1", "FUZZ_WIDE_RANGE": "24,600"}, 25, 507),
+    ("mixed_forked", {"IQD_MIXED": "forked", "FUZZ_WIDE": "1"}, 25, 508),
+    ("shares_by_cost", {"IQD_SHARES": "cost", "FUZZ_WIDE": "1"}, 25, 509),
+    ("min_seg_1_wide", {"IQD_STREAM_MIN_SEG": "1", "FUZZ_WIDE": "1", "FUZZ_WIDE_RANGE": "24,600"}, 25, 510),   # found: repaired keeper re-runs the short last segment
+    ("min_seg_1_short", {"IQD_STREAM_MIN_SEG": "1", "FUZZ_SHORT": "1"}, 25, 511),
+]
+CLOCK_SECONDS = 8
+
+
+def _run(env_extra, seconds, seed):
+    env = dict(os.environ)
+    for k in ("IQD_WBFM_PATH", "IQD_MIXED", "IQD_SHARES", "IQD_STREAM_MIN_SEG", "FUZZ_SHORT", "FUZZ_WIDE", "FUZZ_WIDE_RANGE", "FUZZ_BIG",
+              "FUZZ_REPLAY"):
+        env.pop(k, None)
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_fuzz.py"), str(seconds), str(seed)], cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=seconds + 240)
+    return r.returncode, r.stdout.decode(errors="replace")
+
+
+@pytest.mark.parametrize("name,env_extra,seconds,seed", PINS, ids=[p[0] for p in PINS])
+def test_fuzz_slice_under_pin(name, env_extra, seconds, seed):
+    rc, out = _run(env_extra, seconds, seed)
+    assert rc == 0 and "identical to the oracle" in out, "pin %s %r seed %d:\n%s" % (name, env_extra, seed, out[-3000:])
+    cases = int(out.strip().splitlines()[-1].split("gpu_fuzz: ")[1].split()[0])
+    assert cases >= 3, (name, out[-500:])     # (a slice that ran no cases proves nothing)
+    clock_seed = int(time.time()) % 1000000007
+    rc, out = _run(env_extra, CLOCK_SECONDS, clock_seed)
+    assert rc == 0 and "identical to the oracle" in out, "pin %s %r CLOCK SEED %d:\n%s" % (name, env_extra, clock_seed, out[-3000:])
