@@ -338,9 +338,14 @@ def rank_body(args, rank, world, dev, make_engine, dist, torch, order_streams=No
         iq = per_channel_rows(torch, torch.from_numpy(period_u8).to(dev), n_ch, first_global, 2 * n)
     n_blocks = max(1, 2 * n // 32768)
     pcm = torch.zeros(n_ch * (n // 32), dtype=torch.int16, device=dev)
-    cnt = torch.zeros(n_ch, dtype=torch.int32, device=dev)
-    mag = torch.zeros(n_ch * n_blocks, dtype=torch.int32, device=dev)
-    allowed = torch.zeros(n_ch * n_blocks, dtype=torch.uint8, device=dev)
+    # Two sets of the small per-call outputs, used in turn: under IQD_F_PREPASS_OVERLAP the pre-pass of call N + 1
+    # writes pcm_count / magnitude / signal_present while call N's pipelines may still run, so a caller must not hand the
+    # call-before's buffers in again (include/iqdemod.h) - as a continuous receiver would not.  The PCM buffer is written by
+    # the pipelines, which run in order: one is enough.
+    outs = [(torch.zeros(n_ch, dtype=torch.int32, device=dev), torch.zeros(n_ch * n_blocks, dtype=torch.int32, device=dev),
+             torch.zeros(n_ch * n_blocks, dtype=torch.uint8, device=dev)) for _ in range(2)]
+    step_no = [0]
+    cnt, mag, allowed = outs[0]
     sync = (lambda: torch.cuda.synchronize()) if dev.type == "cuda" else (lambda: None)
     sync()
 
@@ -362,6 +367,8 @@ def rank_body(args, rank, world, dev, make_engine, dist, torch, order_streams=No
     chunks = max(1, min(getattr(args, "channel_chunks", 1), n_ch))
 
     def step():
+        cnt, mag, allowed = outs[step_no[0] & 1]
+        step_no[0] += 1
         if chunks > 1:
             # the call in channel chunks (sub-range accepts, one after the other on the engine's stream): with the overlapped
             # pre-pass, chunk k + 1's magnitudes are taken while chunk k's pipelines run, and a chunk small enough for the
@@ -384,6 +391,25 @@ def rank_body(args, rank, world, dev, make_engine, dist, torch, order_streams=No
             gatherer.gather(pcm.view(n_ch, -1), cnt)
             if order_streams is not None:
                 order_streams(eng, False)   # and the engine's next step waits for the gatherer's copies out of pcm / cnt
+
+    # From idle: what a default-length run measures on a device whose clocks have not settled - the W
+    # warm-up steps, then K steps on the host's clock - before the settle phase below.  Reported beside the settled figure.
+    from_idle_ms = None
+    if getattr(args, "prewarm_ms", 0.0) > 0 and not getattr(args, "no_from_idle", False):
+        eng.synchronize()
+        time.sleep(0.25)                                  # (staging the input was load, too: let the device fall idle)
+        for _ in range(args.warmup):
+            step()
+        eng.synchronize()
+        if dist is not None:
+            dist.barrier()
+        t_idle = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        eng.synchronize()
+        from_idle_ms = 1e3 * (time.perf_counter() - t_idle) / args.steps
+        if dist is not None:
+            dist.barrier()
 
     # Clock settle: the same step, untimed, for about --prewarm-ms.  A count, not a clock: every rank must run the same
     # number of steps (a gather inside the step is a collective), so it is derived from the workload's size alone.
@@ -459,6 +485,8 @@ def rank_body(args, rank, world, dev, make_engine, dist, torch, order_streams=No
             timed, timed_samples = ("d4_stream_kernel" if streamed else "fm_chain_kernel"), n * n_ch
         else:
             timed, timed_samples = ("wbfm_stream_kernel + wbfm_stream_fixup_kernel" if streamed else "wbfm_chain_kernel"), n * n_ch
+        if args.mode != "mixed" or mixed_one:   # (the engine's event pair closes behind the step's LAST launch: iqd_engine.cpp, evp_open)
+            timed += " + the step's closing launch (repair check, state commit, tails, squelch pass): every launch of the step"
         prof, prof_path = profile_summary(args.tag) if args.tag else (None, None)
         needle = {"wbfm": "wbfm_stream_kernel" if streamed else "wbfm_chain_kernel", "fm": "d4_stream_kernel" if streamed else "fm_chain_kernel",
                   "am": "d4_stream_kernel" if streamed else "am_chain_kernel",
@@ -490,6 +518,21 @@ def rank_body(args, rank, world, dev, make_engine, dist, torch, order_streams=No
             if c.get("SQ_ACTIVE_INST_VALU") and ms:
                 roof["valu_issue_frac"] = round(c["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (ghz * 1e9) * 1e3 / ms, 3)
                 roof["valu_lane_ops_per_sample"] = round(src.get("derived", {}).get("valu_lane_ops_per_sample", 0.0), 1)
+            if c.get("SQ_ACTIVE_INST_VALU") and ms and roof.get("achieved"):
+                # Which ceiling binds.  The vector ALUs' busy time, spread evenly over the chip's 1024 SIMDs, is
+                # the time this instruction stream would take on perfectly levelled, never-idle vector ALUs: the ceiling of
+                # the formulation.  The HBM ceiling is `peak`.  The lower one binds; `achieved_over_ceiling` is how close the
+                # kernel runs to it.
+                busy_ms = c["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (ghz * 1e9) * 1e3
+                algo = ALGO_BYTES_PER_SAMPLE * (timed_samples or n * n_ch)
+                ceil_gbs = algo / (busy_ms * 1e-3) / 1e9
+                roof["ceilings"] = {"hbm": {"GB/s": HBM_PEAK_GBS, "frac_of_hbm_peak": 1.0},
+                                    "valu_issue": {"GB/s": round(ceil_gbs, 1), "frac_of_hbm_peak": round(ceil_gbs / HBM_PEAK_GBS, 4),
+                                                   "valu_busy_ms_levelled": round(busy_ms, 4), "clock_ghz": round(ghz, 3),
+                                                   "how": "SQ_ACTIVE_INST_VALU x 4 cycles / 1024 SIMDs / clock: the instruction stream's time on "
+                                                          "perfectly levelled, never-idle vector ALUs"}}
+                roof["binds"] = "valu_issue" if ceil_gbs < HBM_PEAK_GBS else "hbm"
+                roof["achieved_over_binding_ceiling"] = round(roof["achieved"] / min(ceil_gbs, HBM_PEAK_GBS), 3)
             roof["traffic_over_algorithmic"] = round(roof["traffic"] / (ALGO_BYTES_PER_SAMPLE * (timed_samples or n * n_ch)), 3) if roof["traffic"] else None
             roof["counters"] = ("collected in this run: rocprofv3 --pmc passes of the same command (FETCH_SIZE x 2 + WRITE_SIZE per the "
                                 "guide's gfx950 correction; per launch of %s)" % needle) if live else prof_path
@@ -501,6 +544,7 @@ def rank_body(args, rank, world, dev, make_engine, dist, torch, order_streams=No
             "metric": METRIC if args.mode == "wbfm" else METRIC.replace("WBFM chain", "%s chains" % args.mode.upper()),
             "value": round(total_samples / elapsed / 1e6, 1), "unit": "MSamples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "from_idle_ms_per_step": None if from_idle_ms is None else round(from_idle_ms, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int8/int16 Q15 + f32", "data": "synthetic" if args.signal == "fm_tone" else "synthetic (%s)" % args.signal,
             "config": {"workload": args.what or "%s, %d channel(s) per GPU, 2^%d IQ samples per channel per step, uint8 I/Q "
@@ -524,6 +568,7 @@ def rank_body(args, rank, world, dev, make_engine, dist, torch, order_streams=No
             if gating or args.squelch is not None:
                 out["config"]["prepass"] = ("one step ahead on its own stream (IQD_F_PREPASS_OVERLAP: magnitudes and decisions of step N + 1 "
                                             "overlap the pipelines of step N)" if prepass_overlap else "inline (each step: pre-pass, then pipelines)")
+            cnt, mag, allowed = outs[(step_no[0] - 1) & 1]     # (the last step's)
             open_frac = float(allowed.float().mean().item())
             out["config"]["squelch"] = {"threshold_dbfs": GATE_THRESHOLD_DBFS if (args.squelch is None and args.mode == "ssb_stress") else args.squelch,
                                         "blocks_rejected_frac": round(1.0 - open_frac, 4),
@@ -544,6 +589,7 @@ def parse_args(argv=None):
     ap.add_argument("--prewarm-ms", type=float, default=100.0,
                     help="untimed load before the warm-up steps, so that the device's clocks have settled when the timed steps "
                          "start (DESIGN.md section 6: the step time falls by a tenth over the first 25 ms of load); 0 = none")
+    ap.add_argument("--no-from-idle", action="store_true", help="skip the from-idle figure (W + K steps before the clock-settle phase)")
     ap.add_argument("--config", type=int, default=None, choices=sorted(CONFIGS), help="BASELINE.json configs[N] preset (default 1)")
     ap.add_argument("--log2-samples", type=int, default=None, help="IQ samples per channel per step (overrides the preset)")
     ap.add_argument("--channels", type=int, default=None, help="channels per GPU (overrides the preset)")

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "iqd_host.h"
+#include "iqd_plan.h"
 #include "iqd_kernels.h"
 #include "iqd_stream.h"
 #include "iqd_stream_mixed.h"
@@ -28,27 +29,7 @@
 
 using namespace iqd;
 
-// A chain launch takes its streaming kernel when it brings this many samples per segment of the persistent workgroups
-// (n_cus x 192 segments).  Round 4 re-measured the crossovers against the tile kernels on 256 CUs (tools/minseg_probe.sh,
-// ms per step streaming / tiles): FM 512 x 2^16 0.085 / 0.069, 1024 x 2^16 0.091 / 0.118, 4096 x 2^13 0.078 / 0.084; WBFM
-// 1 x 2^25 0.122 / 0.131, 512 x 2^16 0.129 / 0.142, 1 x 2^24 0.115 / 0.089; AM 1024 x 2^16 0.077 / 0.084, 512 x 2^16 0.075 / 0.055,
-// and rows of one or two blocks (where the tile path's DC pass has a lane per channel and nothing to hide its latency
-// behind) 1024 x 2^14 0.074 / 0.079, 2048 x 2^13 0.063 / 0.063.  A call with SEVERAL families takes the one-launch
-// arrangement (iqd_stream_mixed.hip) from the smallest sizes probed: 512 x 2^14 0.102 / 0.141, 4096 x 2^14 0.130 / 0.230,
-// 1400 x 2^16 0.130 / 0.268 - round 3's rule (1024 per segment for every family's share) dated from the kernels-on-streams
-// arrangement and kept such calls on the tile kernels.  IQD_STREAM_MIN_SEG overrides all of them (measurement runs).
-// (second probe, around the thresholds: FM 640 x 2^16 0.085 / 0.088, 768 x 2^16 0.087 / 0.095; WBFM 384 x 2^16 0.120 / 0.099; AM / USB
-// 768 x 2^16 0.075 / 0.074 and 0.087 / 0.082, 896 x 2^16 0.075 / 0.083 and 0.086 / 0.093, 1024 x 2^14 0.074 / 0.079 and 0.084 / 0.082;
-// several families: 128 x 2^14 0.099 / 0.125, 16 x 2^16 0.100 / 0.120, 1024 x 2^12 0.098 / 0.101, 512 x 2^12 0.096 / 0.076)
-static const uint64_t STREAM_MIN_SEG_WBFM = 600, STREAM_MIN_SEG_FM = 900, STREAM_MIN_SEG_AM = 1000, STREAM_MIN_SEG_SSB = 1100,
-                      STREAM_MIN_SEG_AM_SHORT = 320, STREAM_MIN_SEG_SSB_SHORT = 450,   // rows of up to 2^14 samples
-                      STREAM_MIN_SEG_MIXED = 16, STREAM_MIN_SEG_MIXED_SHORT = 96,      // one launch for all families; rows below 2^13 samples
-                      STREAM_MIN_SEG_FORKED = 1024;                                    // several families as kernels on streams
-// AM / SSB rows at least this long (PCM samples) may take their streaming pipeline; the DC pass behind it is then the
-// one-wave pass whatever the row length (round 4: the rule used to be > 512, which kept the reference's own operating
-// point - one 64 ms block per channel per call, 512 PCM samples - on the tile kernels at 0.14 of the HBM peak).  IQD_AM_STREAM_MIN.
-
-
+// (the streaming thresholds STREAM_MIN_SEG_* and every tile / stream / one-launch decision: iqd_plan.h, iqd_plan.cpp)
 
 namespace {
 
@@ -77,9 +58,6 @@ struct DevBuf {
 
 }  // namespace
 
-// AM / SSB rows at least this long (PCM samples) may take their streaming pipeline (see STREAM_MIN_PER_SEGMENT)
-static const uint32_t AM_STREAM_MIN_PCM = 128;
-
 struct iqd_engine {
     std::mutex mu;             // parameter mirror + dirty flags (setters vs. accept)
     int device = 0;
@@ -94,21 +72,13 @@ struct iqd_engine {
     std::vector<uint32_t> h_lists[FAM_COUNT + 1];  // per family; [FAM_COUNT] = mode None
     uint32_t rot_count[FAM_COUNT][3] = {};         // channels of each family per rotation group (+Fs/4, none, -Fs/4)
     uint32_t n_cus = 256;
-    // measurement knobs, read from the environment ONCE at creation (include/iqdemod.h): IQD_WBFM_PATH=stream|tiles
-    // (+1 / -1, 0 = choose), IQD_FULL_GRID, IQD_STREAM_WGS=<n>, IQD_PLAN_CHUNKS=<k>
-    int env_path = 0;
-    uint64_t env_stream_min_seg = 0;     // IQD_STREAM_MIN_SEG (0: the measured per-family thresholds)
-    uint32_t env_am_stream_min = AM_STREAM_MIN_PCM;   // IQD_AM_STREAM_MIN (measurement runs: 513 = the rule of rounds 2-3)
-    uint32_t env_d4_gran = 128;            // IQD_D4_GRAN: segment-length granule of the FM / AM / SSB pipelines (measurement runs)
-    bool env_full_grid = false;
-    bool env_mixed_forked = false;         // IQD_MIXED=forked: several families as kernels of their own side by side (A/B runs)
-    // ns per sample of a segment (lead-in included) of one workgroup's 192 segments in lock step, inside the one launch that
-    // holds all four pipelines: WBFM 224 us for 3072 + 768, FM 225 for 5120 + 768, AM 214 for 9472 + 384, SSB 226 for 9472 + 1280
-    // (tools/mixed_probe.py, 4096 channels x 2^16).  IQD_FAMILY_NS=am,fm,wbfm,ssb; IQD_SHARES=cost keeps the proportional shares.
-    float fam_ns[FAM_COUNT] = {21.7f, 38.2f, 58.3f, 21.0f};
-    bool env_shares_by_cost = false;
-    float fam_weight[FAM_COUNT] = {3.4f, 6.3f, 10.8f, 3.6f};   // relative cost per channel-sample of the streaming pipelines: AM, FM, WBFM, SSB
-    uint32_t env_stream_wgs = 0, env_plan_chunks = 0, env_stream_gran = 0;
+    // iqd_config::flags and the measurement knobs, read from the environment ONCE at creation (include/iqdemod.h): what
+    // plan_call() decides from.  The plan of the last call is kept while the call's shape repeats (planning a
+    // 2^28-sample FM + WBFM call cost more host time than its kernels run).
+    PlanKnobs knobs;
+    CallShape plan_shape;
+    CallPlan plan;
+    bool plan_valid = false;
     size_t dcr_layout[2][2] = {{~(size_t)0, 0}, {~(size_t)0, 0}};   // AM / SSB: where the DC redo flags sit in their buffer, and how many
     bool any_gated = false, any_agc = false;
     bool demod_bypass = false;             // inside iqd_demod_accept: the demodulator alone - no squelch, tracker, AGC, scanner, magnitudes
@@ -209,19 +179,6 @@ struct iqd_engine {
     }
 };
 
-// samples per segment from which a launch of family f takes its streaming pipeline (see STREAM_MIN_SEG_*)
-// several_families: 0 a call of one family, 1 several families in one launch, 2 several families as kernels on streams
-static uint64_t stream_min_seg(const iqd_engine *e, int f, uint64_t vlen, int several_families)
-{
-    if (e->env_stream_min_seg) return e->env_stream_min_seg;
-    if (several_families == 2) return STREAM_MIN_SEG_FORKED;
-    if (several_families) return vlen < 8192 ? STREAM_MIN_SEG_MIXED_SHORT : STREAM_MIN_SEG_MIXED;
-    if (f == FAM_WBFM) return STREAM_MIN_SEG_WBFM;
-    if (f == FAM_FM) return STREAM_MIN_SEG_FM;
-    if (f == FAM_AM) return vlen <= 16384 ? STREAM_MIN_SEG_AM_SHORT : STREAM_MIN_SEG_AM;
-    return vlen <= 16384 ? STREAM_MIN_SEG_SSB_SHORT : STREAM_MIN_SEG_SSB;
-}
-
 #define HIP_TRY(e, call)                                                                          \
     do {                                                                                          \
         hipError_t err_ = (call);                                                                 \
@@ -295,26 +252,30 @@ int iqd_create(const iqd_config *cfg, iqd_t **out)
     e->block_bytes = bb;
     e->block_samples = bb / 2;
     e->flags = cfg->flags;
-    if (const char *env = getenv("IQD_WBFM_PATH")) e->env_path = env[0] == 's' ? 1 : env[0] == 't' ? -1 : 0;
-    e->env_full_grid = getenv("IQD_FULL_GRID") != nullptr;
-    if (const char *env = getenv("IQD_SHARES")) e->env_shares_by_cost = env[0] == 'c';
+    PlanKnobs &kn = e->knobs;
+    kn.flags = cfg->flags;
+    kn.n_cus = e->n_cus;
+    kn.wbfm_chunk = WBFM_CHUNK; kn.wbfm_cold_halo = COLD_HALO; kn.ch_chunk = CH_CHUNK; kn.fir_halo = FIR_HALO; kn.dc_tile = DC_TILE;
+    if (const char *env = getenv("IQD_WBFM_PATH")) kn.env_path = env[0] == 's' ? 1 : env[0] == 't' ? -1 : 0;
+    kn.env_full_grid = getenv("IQD_FULL_GRID") != nullptr;
+    if (const char *env = getenv("IQD_SHARES")) kn.env_shares_by_cost = env[0] == 'c';
     if (const char *env = getenv("IQD_FAMILY_NS")) {
         float w[FAM_COUNT];
         if (sscanf(env, "%f,%f,%f,%f", &w[0], &w[1], &w[2], &w[3]) == 4 && w[0] > 0.f && w[1] > 0.f && w[2] > 0.f && w[3] > 0.f)
-            for (int f = 0; f < FAM_COUNT; f++) e->fam_ns[f] = w[f];
+            for (int f = 0; f < FAM_COUNT; f++) kn.fam_ns[f] = w[f];
     }
-    if (const char *env = getenv("IQD_D4_GRAN")) e->env_d4_gran = (uint32_t)atoi(env);
-    if (const char *env = getenv("IQD_STREAM_MIN_SEG")) e->env_stream_min_seg = atoi(env) > 0 ? (uint64_t)atoi(env) : 0;
-    if (const char *env = getenv("IQD_AM_STREAM_MIN")) e->env_am_stream_min = atoi(env) > 0 ? (uint32_t)atoi(env) : AM_STREAM_MIN_PCM;
-    if (const char *env = getenv("IQD_MIXED")) e->env_mixed_forked = env[0] == 'f' && env[1] == 'o';
+    if (const char *env = getenv("IQD_D4_GRAN")) kn.env_d4_gran = (uint32_t)atoi(env);
+    if (const char *env = getenv("IQD_STREAM_MIN_SEG")) kn.env_stream_min_seg = atoi(env) > 0 ? (uint64_t)atoi(env) : 0;
+    if (const char *env = getenv("IQD_AM_STREAM_MIN")) kn.env_am_stream_min = atoi(env) > 0 ? (uint32_t)atoi(env) : AM_STREAM_MIN_PCM;
+    if (const char *env = getenv("IQD_MIXED")) kn.env_mixed_forked = env[0] == 'f' && env[1] == 'o';
     if (const char *env = getenv("IQD_FAMILY_WEIGHTS")) {   // "am,fm,wbfm,ssb" (measurement runs)
         float w[FAM_COUNT];
         if (sscanf(env, "%f,%f,%f,%f", &w[0], &w[1], &w[2], &w[3]) == 4 && w[0] > 0 && w[1] > 0 && w[2] > 0 && w[3] > 0)
-            for (int f = 0; f < FAM_COUNT; f++) e->fam_weight[f] = w[f];
+            for (int f = 0; f < FAM_COUNT; f++) kn.fam_weight[f] = w[f];
     }
-    if (const char *env = getenv("IQD_STREAM_WGS")) e->env_stream_wgs = atoi(env) > 0 ? (uint32_t)atoi(env) : 0u;
-    if (const char *env = getenv("IQD_STREAM_GRAN")) e->env_stream_gran = (uint32_t)atoi(env);
-    if (const char *env = getenv("IQD_PLAN_CHUNKS")) e->env_plan_chunks = atoi(env) > 0 ? (uint32_t)atoi(env) : 0u;
+    if (const char *env = getenv("IQD_STREAM_WGS")) kn.env_stream_wgs = atoi(env) > 0 ? (uint32_t)atoi(env) : 0u;
+    if (const char *env = getenv("IQD_STREAM_GRAN")) kn.env_stream_gran = (uint32_t)atoi(env);
+    if (const char *env = getenv("IQD_PLAN_CHUNKS")) kn.env_plan_chunks = atoi(env) > 0 ? (uint32_t)atoi(env) : 0u;
     build_consts(e->consts);
     e->h_params.resize(e->n_ch);
     for (auto &p : e->h_params) default_params(p);
@@ -353,6 +314,7 @@ int iqd_create(const iqd_config *cfg, iqd_t **out)
     build_fm_lut(fm_lut);
     std::vector<float> half_lut((size_t)129 * ST_ROW_FLOATS);
     e->stream_ok = build_half_lut(half_lut.data());
+    e->knobs.stream_ok = e->stream_ok;
     std::vector<uint32_t> amat[3];
     {
         int16_t pre[16];
@@ -1134,7 +1096,10 @@ int iqd_convert_fs_over_4(iqd_t *e, int direction, int8_t *buffer, size_t byte_c
     return IQD_OK;
 }
 
-// ---- accept ------------------------------------------------------------------------------------
+// ---- accept: describe, plan, then queue ----------------------------------------------------------
+// iqd_accept_iq_device() = prepare_call (parameter mirror, channel lists, under the lock) -> describe_call (the call as plain
+// data) -> plan_call (iqd_plan.cpp: every tile / stream / one-launch / share decision, nothing queued yet; cached while the
+// shape repeats) -> queue_prepass -> queue_family per family -> queue_commit.  The queue_* functions decide nothing.
 
 static void rebuild_lists(iqd_t *e, uint32_t first_ch, uint32_t n_ch)
 {
@@ -1162,89 +1127,158 @@ static void rebuild_lists(iqd_t *e, uint32_t first_ch, uint32_t n_ch)
     e->lists_dirty = false;
 }
 
-int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void *iq_dev, size_t bytes_per_ch,
-                         void *pcm_dev, void *pcm_count_dev, void *magnitude_dev, void *signal_present_dev)
+namespace {
+// What one accept call carries from phase to phase.
+struct CallCtx {
+    uint32_t first_ch = 0, n_ch = 0;
+    const void *iq_dev = nullptr;
+    size_t bytes_per_ch = 0;
+    void *pcm_dev = nullptr, *pcm_count_dev = nullptr, *magnitude_dev = nullptr, *signal_present_dev = nullptr;
+    uint32_t call_bb = 0, call_bs = 0, n_blocks = 0, vlen = 0;
+    bool gated = false, any_agc = false, want_mag = false, pre_overlap = false, fused_mag = false;
+    int pre_set = -1;                               // IQD_F_PREPASS_OVERLAP: the buffer set this call's pre-pass filled
+    DevBuf *gate_blk = nullptr, *gate_vlen = nullptr;
+    SquelchLaunch q{};
+    ChainLaunch base{};
+    const CallPlan *plan = nullptr;
+    hipStream_t s_main = nullptr;
+    bool lane_used[4] = {false, false, false, false};
+    bool timed = false, evp_open = false;           // profiling: the event pair of the call
+    std::pair<hipEvent_t, hipEvent_t> evp{nullptr, nullptr};
+    MixedStreamArgs mix{};
+    bool epoch_report_now = false;                  // this call's WBFM tail updates report whether a gain change is still in reach (h_epoch_report)
+    ChainLaunch tail_a{};                           // a tail update (WBFM: repair check + state commit + tail) that rides in the squelch launch
+    int tail_f = 0;
+    bool tail_pending = false;
+};
+
+int take_event_pair(iqd_t *e, CallCtx &x, hipStream_t s)
 {
-    if (!range_ok(e, first_ch, n_ch) || !iq_dev || !pcm_dev) return e ? e->fail(IQD_EINVAL, "bad channel range or NULL buffer") : IQD_EINVAL;
-    const uint32_t call_bb = call_block_bytes(e, first_ch, n_ch, bytes_per_ch);
-    if (!call_bb) return e->fail(IQD_EINVAL, IQD_LEN_MSG, bytes_per_ch, e->block_bytes);
-    const uint32_t call_bs = call_bb / 2;
-    if (bytes_per_ch / 2 > 0x7fff0000ull) return e->fail(IQD_EINVAL, "bytes_per_ch too large");
-    if (((uintptr_t)iq_dev & 15) != 0) return e->fail(IQD_EINVAL, "iq_dev must be 16-byte aligned");
-    (void)hipSetDevice(e->device);
+    if (e->ev_free_pairs.empty()) {
+        hipEvent_t a0, a1;
+        HIP_TRY(e, hipEventCreate(&a0));
+        HIP_TRY(e, hipEventCreate(&a1));
+        e->ev_free_pairs.emplace_back(a0, a1);
+    }
+    x.evp = e->ev_free_pairs.back();
+    e->ev_free_pairs.pop_back();
+    HIP_TRY(e, hipEventRecord(x.evp.first, s));
+    return IQD_OK;
+}
+}  // namespace
+
+// Under the lock: the epoch mirror's ageing report, parameter upload, channel lists, AGC configuration.
+static int prepare_call(iqd_t *e, CallCtx &x)
+{
     hipStream_t s = e->stream;
-
-    const uint32_t n_blocks = (uint32_t)(bytes_per_ch / call_bb);
-    const uint32_t vlen = (uint32_t)(bytes_per_ch / 2);
-    bool gated, any_agc;
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (e->epoch_report_pending && ((volatile uint32_t *)e->h_epoch_report)[1] == e->epoch_report_seq) {   // (see wbfm_epoch_seq)
+        if (((volatile uint32_t *)e->h_epoch_report)[0] == 0u)
+            for (uint32_t c : e->epoch_report_channels)
+                if (e->wbfm_epoch_left[c] && e->wbfm_epoch_seq[c] <= e->epoch_report_seq) {
+                    e->wbfm_epoch_left[c] = 0;
+                    e->wbfm_epochs_live--;
+                }
+        e->epoch_report_pending = false;
+    }
     {
-        std::lock_guard<std::mutex> lk(e->mu);
-        if (e->epoch_report_pending && ((volatile uint32_t *)e->h_epoch_report)[1] == e->epoch_report_seq) {   // (see wbfm_epoch_seq)
-            if (((volatile uint32_t *)e->h_epoch_report)[0] == 0u)
-                for (uint32_t c : e->epoch_report_channels)
-                    if (e->wbfm_epoch_left[c] && e->wbfm_epoch_seq[c] <= e->epoch_report_seq) {
-                        e->wbfm_epoch_left[c] = 0;
-                        e->wbfm_epochs_live--;
-                    }
-            e->epoch_report_pending = false;
-        }
-        {
-            int rc = upload_params(e);
-            if (rc != IQD_OK) return rc;
-        }
-        e->accept_seq++;
-        if (e->lists_dirty || e->list_first != first_ch || e->list_n != n_ch) {
-            rebuild_lists(e, first_ch, n_ch);
-            for (int f = 0; f <= FAM_COUNT; f++) {
-                const auto &l = e->h_lists[f];
-                if (l.empty()) continue;
-                HIP_TRY(e, e->lists[f].ensure(l.size() * sizeof(uint32_t)));
-                HIP_COPY(e, hipMemcpyAsync(e->lists[f].p, l.data(), l.size() * sizeof(uint32_t),
-                                          hipMemcpyHostToDevice, s));
-            }
-            HIP_TRY(e, hipStreamSynchronize(s));
-        }
-        int rc = agc_sync(e);
+        int rc = upload_params(e);
         if (rc != IQD_OK) return rc;
-        gated = e->any_gated;
-        any_agc = e->any_agc;
     }
-    if (e->demod_bypass) {   // {Am,Fm,WbFm,Ssb}Demodulator::acceptIqData: nothing of the processor's squelch path runs or moves
-        gated = any_agc = false;
-        pcm_count_dev = magnitude_dev = signal_present_dev = nullptr;
+    e->accept_seq++;
+    if (e->lists_dirty || e->list_first != x.first_ch || e->list_n != x.n_ch) {
+        rebuild_lists(e, x.first_ch, x.n_ch);
+        for (int f = 0; f <= FAM_COUNT; f++) {
+            const auto &l = e->h_lists[f];
+            if (l.empty()) continue;
+            HIP_TRY(e, e->lists[f].ensure(l.size() * sizeof(uint32_t)));
+            HIP_COPY(e, hipMemcpyAsync(e->lists[f].p, l.data(), l.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+        }
+        HIP_TRY(e, hipStreamSynchronize(s));
     }
-    const bool want_mag = !e->demod_bypass && (gated || any_agc || !(e->flags & IQD_F_NO_MAGNITUDE) || magnitude_dev);
+    int rc = agc_sync(e);
+    if (rc != IQD_OK) return rc;
+    x.gated = e->any_gated;
+    x.any_agc = e->any_agc;
+    return IQD_OK;
+}
 
+// The call as plain data for plan_call(): per family how many channels, per rotation selector, whether every gain keeps
+// the (int16) casts bounded, whether a WBFM gain change is still in reach of a lead-in.
+static void describe_call(const iqd_t *e, const CallCtx &x, CallShape &c)
+{
+    c = CallShape{};
+    c.vlen = x.vlen;
+    c.pcm_per_ch = (uint32_t)(x.bytes_per_ch / 64);
+    c.gated = x.gated;
+    for (int f = 0; f < FAM_COUNT; f++) {
+        const auto &l = e->h_lists[f];
+        FamilyShape &s = c.fam[f];
+        s.n_list = (uint32_t)l.size();
+        if (l.empty()) continue;
+        for (int r = 0; r < 3; r++) s.rot_count[r] = e->rot_count[f][r];
+        s.rot_first = e->h_params[x.first_ch + l[0]].rotation;
+        if (f == FAM_WBFM)
+            for (uint32_t ch : l) {
+                s.cast_bounded = s.cast_bounded && e->wbfm_kmax[x.first_ch + ch] * 3.1730f < 2147483648.0f;
+                s.epochs_in_reach = s.epochs_in_reach || (e->wbfm_epochs_live && e->wbfm_epoch_left[x.first_ch + ch] != 0);
+            }
+        if (f == FAM_FM)
+            for (uint32_t ch : l) s.cast_bounded = s.cast_bounded && e->fm_kmax[x.first_ch + ch] * 6.35f < 2147483648.0f;
+    }
+}
+
+static bool same_shape(const CallShape &a, const CallShape &b)
+{
+    if (a.vlen != b.vlen || a.pcm_per_ch != b.pcm_per_ch || a.gated != b.gated) return false;
+    for (int f = 0; f < FAM_COUNT; f++) {
+        const FamilyShape &p = a.fam[f], &q = b.fam[f];
+        if (p.n_list != q.n_list || p.rot_count[0] != q.rot_count[0] || p.rot_count[1] != q.rot_count[1] || p.rot_count[2] != q.rot_count[2] ||
+            p.rot_first != q.rot_first || p.cast_bounded != q.cast_bounded || p.epochs_in_reach != q.epochs_in_reach)
+            return false;
+    }
+    return true;
+}
+
+// The squelch's part in front of the pipelines: the block sums start at zero; a gated call's magnitudes, decisions and
+// open-block lists (inline on the engine's stream, or one call ahead on the pre-pass stream); the launch descriptor
+// every family's launch starts from.
+static int queue_prepass(iqd_t *e, CallCtx &x)
+{
+    hipStream_t s = x.s_main;
+    const uint32_t n_ch = x.n_ch, n_blocks = x.n_blocks;
     // the pre-pass of a gated call one call ahead, on its own stream (include/iqdemod.h: IQD_F_PREPASS_OVERLAP)
-    const bool pre_overlap = gated && (e->flags & IQD_F_PREPASS_OVERLAP) && !e->trace_on && !e->in_host_path;
-    if (pre_overlap && !e->pre_stream) {
+    if (x.pre_overlap && !e->pre_stream) {
         HIP_TRY(e, hipStreamCreateWithFlags(&e->pre_stream, hipStreamNonBlocking));
         for (int k = 0; k < 2; k++) {
             HIP_TRY(e, hipEventCreateWithFlags(&e->ev_pre_done[k], hipEventDisableTiming));
             HIP_TRY(e, hipEventCreateWithFlags(&e->ev_chain_done[k], hipEventDisableTiming));
         }
         HIP_TRY(e, hipEventCreateWithFlags(&e->ev_main_decisions, hipEventDisableTiming));
+        // whatever squelch pass ran before this one ran on the engine's stream, unrecorded: the new stream starts behind it
+        HIP_TRY(e, hipEventRecord(e->ev_main_decisions, s));
+        e->decisions_on_main = true;
     }
-    if (!pre_overlap) {   // the sums start at zero: by memset, unless the previous call's squelch pass left this many of them zero
+    if (!x.pre_overlap) {   // the sums start at zero: by memset, unless the previous call's squelch pass left this many of them zero
         const void *before = e->mag_sums.p;
         HIP_TRY(e, e->mag_sums.ensure((size_t)n_ch * n_blocks * sizeof(uint32_t)));
         if (e->mag_sums.p != before) e->mag_sums_zero = 0;
-        if (want_mag && e->mag_sums_zero < (size_t)n_ch * n_blocks)
+        if (x.want_mag && e->mag_sums_zero < (size_t)n_ch * n_blocks)
             HIP_COPY(e, hipMemsetAsync(e->mag_sums.p, 0, (size_t)n_ch * n_blocks * sizeof(uint32_t), s));
         e->mag_sums_zero = 0;   // from here on the call writes into them
     }
 
-    SquelchLaunch q{};
-    q.n_ch = n_ch; q.first_ch = first_ch; q.n_blocks = n_blocks; q.block_samples = call_bs;
+    SquelchLaunch &q = x.q;
+    q.n_ch = n_ch; q.first_ch = x.first_ch; q.n_blocks = n_blocks; q.block_samples = x.call_bs;
     q.params = e->d_params;
     q.mag_sums = e->mag_sums.as<uint32_t>();
     q.tracker = e->d_tracker;
-    q.magnitude = (uint32_t *)magnitude_dev;
-    q.allowed = (uint8_t *)signal_present_dev;
-    q.pcm_count = (uint32_t *)pcm_count_dev;
+    q.magnitude = (uint32_t *)x.magnitude_dev;
+    q.allowed = (uint8_t *)x.signal_present_dev;
+    q.pcm_count = (uint32_t *)x.pcm_count_dev;
     q.agc_cfg = e->d_agc_cfg;
     q.agc = e->d_agc;
-    q.any_agc = any_agc ? 1u : 0u;
+    q.any_agc = x.any_agc ? 1u : 0u;
     q.scan_cfg = e->d_scan_cfg;
     q.scan = e->d_scan;
     if (e->trace_on) {
@@ -1252,44 +1286,42 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         q.gain_trace = e->gain_trace.as<uint32_t>();
         HIP_TRY(e, e->freq_trace.ensure((size_t)n_ch * n_blocks * sizeof(unsigned long long)));
         q.freq_trace = e->freq_trace.as<unsigned long long>();
-        e->trace_first = first_ch; e->trace_n = n_ch; e->trace_blocks = n_blocks;
+        e->trace_first = x.first_ch; e->trace_n = n_ch; e->trace_blocks = n_blocks;
     }
 
-    const bool chain_gated = gated;   // the chain kernels walk each channel's open blocks (blk_lists, vlen_gated)
-    DevBuf *gate_blk = &e->blk_lists, *gate_vlen = &e->vlen;
-    int pre_set = -1;
-    if (pre_overlap) {
+    x.gate_blk = &e->blk_lists;
+    x.gate_vlen = &e->vlen;
+    if (x.pre_overlap) {
         // magnitudes, decisions and open-block lists of THIS call on the pre-pass stream, which the previous call's pipelines
         // (main stream) do not hold up: it waits for the decision pass before it (its own stream order - or the main stream's,
-        // where the previous call was not gated), and for the last reader of the buffer set it is about to overwrite
+        // where the previous call's pass ran there), and for the last reader of the buffer set it is about to overwrite
         hipStream_t ps = e->pre_stream;
-        pre_set = e->gate_set ^= 1;
-        DevBuf &sums = e->g_sums[pre_set];
-        gate_blk = &e->g_blk[pre_set];
-        gate_vlen = &e->g_vlen[pre_set];
-        if (e->chain_pending[pre_set]) HIP_TRY(e, hipStreamWaitEvent(ps, e->ev_chain_done[pre_set], 0));
+        x.pre_set = e->gate_set ^= 1;
+        DevBuf &sums = e->g_sums[x.pre_set];
+        x.gate_blk = &e->g_blk[x.pre_set];
+        x.gate_vlen = &e->g_vlen[x.pre_set];
+        if (e->chain_pending[x.pre_set]) HIP_TRY(e, hipStreamWaitEvent(ps, e->ev_chain_done[x.pre_set], 0));
         if (e->decisions_on_main) {
             HIP_TRY(e, hipStreamWaitEvent(ps, e->ev_main_decisions, 0));
             e->decisions_on_main = false;
         }
         HIP_TRY(e, sums.ensure((size_t)n_ch * n_blocks * sizeof(uint32_t)));
-        HIP_TRY(e, gate_blk->ensure((size_t)n_ch * n_blocks * sizeof(uint32_t)));
-        HIP_TRY(e, gate_vlen->ensure((size_t)n_ch * sizeof(uint32_t)));
+        HIP_TRY(e, x.gate_blk->ensure((size_t)n_ch * n_blocks * sizeof(uint32_t)));
+        HIP_TRY(e, x.gate_vlen->ensure((size_t)n_ch * sizeof(uint32_t)));
         HIP_COPY(e, hipMemsetAsync(sums.p, 0, (size_t)n_ch * n_blocks * sizeof(uint32_t), ps));
-        HIP_LAUNCH(e, launch_magnitude((const uint8_t *)iq_dev, bytes_per_ch, nullptr, n_ch, call_bs, n_blocks, sums.as<uint32_t>(), ps));
+        HIP_LAUNCH(e, launch_magnitude((const uint8_t *)x.iq_dev, x.bytes_per_ch, nullptr, n_ch, x.call_bs, n_blocks, sums.as<uint32_t>(), ps));
         q.mag_sums = sums.as<uint32_t>();
-        q.blk_lists = gate_blk->as<uint32_t>();
-        q.vlen_out = gate_vlen->as<uint32_t>();
+        q.blk_lists = x.gate_blk->as<uint32_t>();
+        q.vlen_out = x.gate_vlen->as<uint32_t>();
         HIP_LAUNCH(e, launch_squelch(q, false, ps));
-        HIP_TRY(e, hipEventRecord(e->ev_pre_done[pre_set], ps));
-        HIP_TRY(e, hipStreamWaitEvent(s, e->ev_pre_done[pre_set], 0));   // the pipelines read the lists
-    } else if (gated) {
+        HIP_TRY(e, hipEventRecord(e->ev_pre_done[x.pre_set], ps));
+        HIP_TRY(e, hipStreamWaitEvent(s, e->ev_pre_done[x.pre_set], 0));   // the pipelines read the lists
+    } else if (x.gated) {
         // pass 1: magnitudes of every block, then the squelch decisions and open-block lists
         if (e->pre_stream) HIP_TRY(e, hipStreamSynchronize(e->pre_stream));   // (a call of the overlapped kind before this one)
         HIP_TRY(e, e->blk_lists.ensure((size_t)n_ch * n_blocks * sizeof(uint32_t)));
         HIP_TRY(e, e->vlen.ensure((size_t)n_ch * sizeof(uint32_t)));
-        HIP_LAUNCH(e, launch_magnitude((const uint8_t *)iq_dev, bytes_per_ch, nullptr, n_ch, call_bs,
-                                    n_blocks, e->mag_sums.as<uint32_t>(), s));
+        HIP_LAUNCH(e, launch_magnitude((const uint8_t *)x.iq_dev, x.bytes_per_ch, nullptr, n_ch, x.call_bs, n_blocks, e->mag_sums.as<uint32_t>(), s));
         q.blk_lists = e->blk_lists.as<uint32_t>();
         q.vlen_out = e->vlen.as<uint32_t>();
         // (Round 2 read one word back here - did any channel lose a block? - to let an all-open call take the streaming
@@ -1297,18 +1329,18 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         // call stays asynchronous whatever the squelch decides.)
         HIP_LAUNCH(e, launch_squelch(q, false, s));
     }
-    if (!gated && e->pre_stream) HIP_TRY(e, hipStreamWaitEvent(s, e->ev_pre_done[e->gate_set], 0));   // (the tracker / AGC state this call's squelch pass continues from)
+    if (!x.gated && e->pre_stream) HIP_TRY(e, hipStreamWaitEvent(s, e->ev_pre_done[e->gate_set], 0));   // (the tracker / AGC state this call's squelch pass continues from)
 
-    ChainLaunch base{};
-    base.iq = (const uint8_t *)iq_dev;
-    base.ch_stride_bytes = bytes_per_ch;
-    base.first_ch = first_ch;
-    base.vlen = vlen;
-    base.vlen_gated = chain_gated ? gate_vlen->as<uint32_t>() : nullptr;
-    base.blk_lists = chain_gated ? gate_blk->as<uint32_t>() : nullptr;
+    ChainLaunch &base = x.base;
+    base.iq = (const uint8_t *)x.iq_dev;
+    base.ch_stride_bytes = x.bytes_per_ch;
+    base.first_ch = x.first_ch;
+    base.vlen = x.vlen;
+    base.vlen_gated = x.gated ? x.gate_vlen->as<uint32_t>() : nullptr;   // the chain kernels walk each channel's open blocks
+    base.blk_lists = x.gated ? x.gate_blk->as<uint32_t>() : nullptr;
     base.n_blocks = n_blocks;
-    base.block_samples = call_bs;
-    base.block_magic = block_magic(call_bs);
+    base.block_samples = x.call_bs;
+    base.block_magic = block_magic(x.call_bs);
     base.tails = e->d_tails;
     base.params = e->d_params;
     base.wbfm_carry = e->d_wcarry;
@@ -1316,26 +1348,312 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
     base.epochs = e->d_epochs;
     base.atan_lut = e->d_atan;
     base.fm_lut = e->d_fmlut;
-    base.pcm = (int16_t *)pcm_dev;
-    base.pcm_stride = bytes_per_ch / 64;
+    base.pcm = (int16_t *)x.pcm_dev;
+    base.pcm_stride = x.bytes_per_ch / 64;
     base.mag_sums = e->mag_sums.as<uint32_t>();
     base.counters = e->d_counters;
     base.stamps = e->d_stamps;
     base.n_ch_call = n_ch;
+    return IQD_OK;
+}
 
-    const bool fused_mag = want_mag && !gated;
-    bool timed = false;
-    std::pair<hipEvent_t, hipEvent_t> evp{nullptr, nullptr};
-    // More than one demodulator family in the call: the (often small) per-family launches run side by side on up
-    // to three lanes - the engine's stream and two side streams of other priorities between a fork and a join event
-    // (the runtime multiplexes equal-priority streams onto a handful of hardware queues; streams that land on one
-    // queue run one after the other) - instead of each draining the GPU in turn.  Families go to the least loaded
-    // lane, longest first.
-    int n_fams = 0;
-    for (int f = 0; f < FAM_COUNT; f++) n_fams += e->h_lists[f].empty() ? 0 : 1;
-    const bool forked = n_fams > 1;
-    hipStream_t const s_main = s;
-    if (forked) {
+// AM / SSB: the detector stream's buffer and the DC pass's records of this launch.  One buffer per family: short rows are
+// written time-major by the tile kernels and channel-major by the streaming pipelines, and the two families of a call may
+// take different paths (round 4's fuzzer: an AM family that streamed beside an SSB family on the tile kernels overwrote its
+// detector stream).
+static int attach_dc_buffers(iqd_t *e, CallCtx &x, int f, ChainLaunch &a, hipStream_t s)
+{
+    DevBuf &b8 = f == FAM_SSB ? e->base8k2 : e->base8k;
+    HIP_TRY(e, b8.ensure((size_t)x.n_ch * x.base.pcm_stride * sizeof(int32_t)));
+    a.base8k = b8.as<int32_t>();
+    a.dc_tiles = (uint32_t)((x.base.pcm_stride + DC_TILE - 1) / DC_TILE);
+    DevBuf &dcr = f == FAM_SSB ? e->dc_records2 : e->dc_records;   // AM and SSB may run side by side
+    // records, then one redo flag per channel: zero between calls (dc_redo_kernel clears what it used)
+    const size_t rec_bytes = (size_t)a.n_list * a.dc_tiles * sizeof(DcRecord);
+    const bool grown = dcr.cap < rec_bytes + a.n_list * sizeof(uint32_t);
+    HIP_TRY(e, dcr.ensure(rec_bytes + a.n_list * sizeof(uint32_t)));
+    a.dc_records = dcr.p;
+    // the flags sit behind the records, whose extent changes with the call: clear them whenever it may have
+    // (same offset but more channels than last time: the new flags lie over old record bytes)
+    size_t (&layout)[2] = e->dcr_layout[f == FAM_SSB];
+    if (grown || layout[0] != rec_bytes || layout[1] < a.n_list) {
+        HIP_COPY(e, hipMemsetAsync((char *)dcr.p + rec_bytes, 0, a.n_list * sizeof(uint32_t), s));
+        layout[0] = rec_bytes;
+        layout[1] = a.n_list;
+    }
+    return IQD_OK;
+}
+
+// One family's launches as the plan says: its tile kernel or streaming pipeline (as a kernel of its own, or as a range of the
+// one launch that queue_commit() starts), then what follows it - hand-off verification, repair, DC pass, tail update - unless
+// that rides in the squelch launch at the call's end.
+static int queue_family(iqd_t *e, CallCtx &x, int f)
+{
+    const CallPlan &plan = *x.plan;
+    const FamilyPlan &fp = plan.fam[f];
+    const bool fused = plan.fused, forked = plan.forked, streams = fp.path == PLAN_STREAM;
+    const uint32_t n_list = (uint32_t)e->h_lists[f].size();
+    hipStream_t s = fp.lane == 0 ? x.s_main : e->fam_stream[fp.lane - 1];
+    if (fp.lane != 0 && !x.lane_used[fp.lane]) HIP_TRY(e, hipStreamWaitEvent(s, e->fam_fork, 0));
+    x.lane_used[fp.lane] = true;
+
+    ChainLaunch a = x.base;
+    a.ch_list = e->lists[f].as<uint32_t>();
+    a.n_list = n_list;
+    a.tile_len = fp.tile_len;
+    a.tiles_per_ch = fp.tiles_per_ch;
+    if (f == FAM_WBFM && x.gated && e->wbfm_epochs_live && !e->epoch_report_pending) {
+        bool any = false;
+        for (uint32_t c : e->h_lists[FAM_WBFM]) any = any || e->wbfm_epoch_left[x.first_ch + c] != 0;
+        if (any) {
+            if (!e->h_epoch_report) HIP_TRY(e, hipHostMalloc((void **)&e->h_epoch_report, 2 * sizeof(uint32_t), hipHostMallocDefault));
+            ((volatile uint32_t *)e->h_epoch_report)[0] = 0u;
+            a.epoch_report = e->h_epoch_report;
+            e->epoch_report_channels.clear();
+            for (uint32_t c : e->h_lists[FAM_WBFM]) e->epoch_report_channels.push_back(x.first_ch + c);
+            x.epoch_report_now = true;
+        }
+    }
+    if (e->profiling && !x.timed && !fused) {
+        int rc = take_event_pair(e, x, s);
+        if (rc != IQD_OK) return rc;
+    }
+    if (fused) {   // a range of the one launch's workgroups
+        a.wg_first = fp.wg_first;
+        a.wg_count = fp.grid;
+    }
+    if (f == FAM_WBFM) {
+        HIP_TRY(e, e->records.ensure((size_t)n_list * a.tiles_per_ch * sizeof(WbfmRecord)));
+        a.records = e->records.as<WbfmRecord>();
+        if (e->repair_flags.cap < n_list * sizeof(uint32_t)) {   // zero between calls: the repair kernel clears what it used
+            HIP_TRY(e, e->repair_flags.ensure(n_list * sizeof(uint32_t)));
+            HIP_COPY(e, hipMemsetAsync(e->repair_flags.p, 0, e->repair_flags.cap, s));
+        }
+        a.repair_flags = e->repair_flags.as<uint32_t>();
+        if (streams) {
+            const int stream_rot = e->h_params[x.first_ch + e->h_lists[FAM_WBFM][0]].rotation;
+            StreamArgs sa = e->stream_args;
+            sa.amat = e->d_amat[stream_rot + 1];
+            sa.half_lut = e->d_half_lut;
+            sa.n_segments = n_list * a.tiles_per_ch;
+            sa.grouped = fp.grouped ? 1u : 0u;
+            for (int r = 0; r < 3; r++) {
+                sa.group_start[r] = fp.grouped ? fp.group_start[r] : 0u;
+                sa.group_li0[r] = fp.grouped ? fp.group_li0[r] : 0u;
+                sa.group_nseg[r] = fp.grouped ? fp.group_nseg[r] : 0u;
+                sa.amat3[r] = e->d_amat[2 - r];          // d_amat[] is indexed by selector + 1; the groups run +1, 0, -1
+            }
+            sa.group_start[3] = fp.grouped ? fp.group_start[3] : 0u;
+            sa.rounds = fp.rounds;
+            HIP_TRY(e, e->stream_hist.ensure((size_t)sa.n_segments * sizeof(StHist)));
+            sa.hist = e->stream_hist.as<StHist>();
+            a.verify_at_end = x.gated ? 2u : 1u;   // (2: the hand-offs are counted on the device - how many tiles a channel has depends on its squelch)
+            if (fused) {   // the fix-up rides in the launch behind the one launch
+                x.mix.a[f] = a;
+                x.mix.sa = sa;
+                x.mix.wbfm_rot = stream_rot;
+            } else {
+                HIP_LAUNCH(e, launch_wbfm_stream(a, sa, stream_rot, x.fused_mag, fp.epochs, fp.grid, s));
+                HIP_LAUNCH(e, launch_wbfm_stream_fixup(a, sa, s));
+            }
+            if (!x.gated) e->stream_handoffs += (uint64_t)n_list * ((x.vlen + a.tile_len - 1) / a.tile_len - 1);
+            e->stats.stream_launches++;
+        } else {
+            HIP_LAUNCH(e, launch_wbfm(a, x.gated, x.fused_mag, n_list * a.tiles_per_ch, s));
+        }
+    } else {
+        D4Args d4 = e->d4_args;
+        if (streams) {
+            for (int r = 0; r < 3; r++) {
+                d4.group_start[r] = fp.group_start[r];
+                d4.group_li0[r] = fp.group_li0[r];
+                d4.group_nseg[r] = fp.group_nseg[r];
+            }
+            d4.group_start[3] = fp.group_start[3];
+            d4.amat = e->d_amat4 + (size_t)(f == FAM_FM ? 0 : 3) * 4 * 64 * 4;
+            d4.fm_lut = e->d_fmlut;
+            d4.halo = f == FAM_FM ? D4_HALO_FM : (f == FAM_AM ? D4_HALO_AM : D4_HALO_SSB);
+            d4.rounds = fp.rounds;
+        }
+        if (f != FAM_FM) {
+            int rc = attach_dc_buffers(e, x, f, a, s);
+            if (rc != IQD_OK) return rc;
+            if (streams) {   // (the pipeline writes the detector stream channel-major)
+                a.base_stride_ch = x.base.pcm_stride;
+                a.base_stride_t = 1;
+            }
+        }
+        if (streams) {
+            if (fused) {
+                x.mix.a[f] = a;
+                x.mix.d4[f] = d4;
+            } else {
+                HIP_LAUNCH(e, launch_d4_stream(a, d4, f == FAM_FM ? D4_FM : f == FAM_AM ? D4_AM : D4_SSB, x.fused_mag, fp.grid, s));
+                if (f != FAM_FM) HIP_LAUNCH(e, launch_am_dc(a, f, s, true));
+            }
+            e->stats.stream_launches++;
+        } else if (f == FAM_FM) {
+            HIP_LAUNCH(e, launch_fm(a, x.gated, x.fused_mag, n_list * a.tiles_per_ch, s));
+        } else {
+            HIP_LAUNCH(e, launch_am(a, f, x.gated, x.fused_mag, n_list * a.tiles_per_ch, s));
+        }
+    }
+    if (e->profiling && !x.timed && !fused) {
+        // a call of one family: the pair closes behind the step's last launch (queue_commit), so that the timed region holds
+        // EVERY launch of the step (the repair-check / commit / squelch launch was left out);
+        // several families on their own streams: only the first family's launches, as before
+        if (forked) {
+            HIP_TRY(e, hipEventRecord(x.evp.second, s));
+            e->ev_pending.push_back(x.evp);
+        } else {
+            x.evp_open = true;
+        }
+        x.timed = true;
+    }
+    e->stats.kernel_launches++;
+    if (fused) return IQD_OK;   // (one launch for all the families and one for what follows them: queue_commit)
+    if (f == FAM_WBFM && !x.gated && e->wbfm_epochs_live)   // every channel of the family has consumed vlen samples
+        for (uint32_t c : e->h_lists[FAM_WBFM]) {
+            uint32_t &left = e->wbfm_epoch_left[x.first_ch + c];
+            if (!left) continue;
+            left = left > x.vlen ? left - x.vlen : 0u;
+            if (!left) e->wbfm_epochs_live--;
+        }
+    const bool rides_with_squelch = !forked && !x.gated && !e->demod_bypass &&
+                                    (x.want_mag || x.pcm_count_dev || x.signal_present_dev || e->trace_on);
+    if (f == FAM_WBFM) {
+        // hand-off verification (streaming launches: done by their fix-up kernel), repair of what it flags
+        // (normally an immediate exit), then state commit + tail - in the squelch launch at the call's end when the call has
+        // no other family
+        if (!streams) HIP_LAUNCH(e, launch_wbfm_verify(a, s));
+        if (rides_with_squelch) {
+            x.tail_a = a;
+            x.tail_f = f;
+            x.tail_pending = true;
+        } else {
+            HIP_LAUNCH(e, launch_wbfm_repair(a, x.gated, s));   // (ends with the channels' state commit and tail update)
+        }
+    } else if (rides_with_squelch) {
+        x.tail_a = a;        // the only family of the call: its tail update rides in the squelch launch
+        x.tail_f = f;
+        x.tail_pending = true;
+    } else {
+        HIP_LAUNCH(e, launch_tail_update(a, f, s));
+    }
+    return IQD_OK;
+}
+
+// Behind the families: the one launch that holds all of them (fused plans) and its follower, the side streams' join, the
+// magnitudes of channels in mode None, the squelch pass with whatever rides in it, the call's events and counters.
+static int queue_commit(iqd_t *e, CallCtx &x)
+{
+    const CallPlan &plan = *x.plan;
+    hipStream_t s = x.s_main;
+    if (plan.fused) {
+        if (e->profiling) {
+            int rc = take_event_pair(e, x, s);
+            if (rc != IQD_OK) return rc;
+        }
+        HIP_LAUNCH(e, launch_mixed_stream(x.mix, x.fused_mag, x.gated, plan.mix_wgs, s));
+        e->stats.mixed_launches++;
+        MixedTailArgs mt{};
+        for (int f = 0; f < FAM_COUNT; f++) mt.a[f] = x.mix.a[f];
+        mt.sa = x.mix.sa;
+        HIP_LAUNCH(e, launch_mixed_tail(mt, s));
+        if (e->profiling) x.evp_open = true;   // (the timed region: the pipelines AND every follower - fix-up, DC passes, tails, the squelch launch)
+        if (x.mix.a[FAM_WBFM].wg_count) {   // repair check, state commit and tail of the WBFM channels: in the squelch launch below
+            x.tail_a = x.mix.a[FAM_WBFM];
+            x.tail_f = FAM_WBFM;
+            x.tail_pending = true;
+        }
+        // (the WBFM family's epoch mirror: a fused plan has no gain change in reach, nothing to age)
+    }
+    for (int k = 1; k < 4; k++)
+        if (x.lane_used[k]) {
+            HIP_TRY(e, hipEventRecord(e->fam_join[k - 1], e->fam_stream[k - 1]));
+            HIP_TRY(e, hipStreamWaitEvent(s, e->fam_join[k - 1], 0));
+        }
+
+    // channels in mode None still report their magnitudes
+    if (x.fused_mag && !e->h_lists[FAM_COUNT].empty())
+        HIP_LAUNCH(e, launch_magnitude((const uint8_t *)x.iq_dev, x.bytes_per_ch, e->lists[FAM_COUNT].as<uint32_t>(),
+                                    (uint32_t)e->h_lists[FAM_COUNT].size(), x.call_bs, x.n_blocks, e->mag_sums.as<uint32_t>(), s));
+    if (!x.gated && !e->demod_bypass && (x.want_mag || x.pcm_count_dev || x.signal_present_dev || e->trace_on)) {
+        x.q.zero_sums_after = x.any_agc ? 0u : 1u;   // (a running AGC reads them again in the tracking pass)
+        HIP_LAUNCH(e, launch_squelch(x.q, true, s, x.tail_pending ? &x.tail_a : nullptr, x.tail_f));
+        x.tail_pending = false;
+        if (x.q.zero_sums_after) e->mag_sums_zero = (size_t)x.n_ch * x.n_blocks;
+    }
+    if (x.tail_pending) {   // (no squelch launch to ride in)
+        if (x.tail_f == FAM_WBFM) HIP_LAUNCH(e, launch_wbfm_repair(x.tail_a, x.gated, s));
+        else HIP_LAUNCH(e, launch_tail_update(x.tail_a, x.tail_f, s));
+    }
+
+    if (x.evp_open) {
+        HIP_TRY(e, hipEventRecord(x.evp.second, s));
+        e->ev_pending.push_back(x.evp);
+    }
+    if (x.pre_set >= 0) {   // this call's pipelines are the last readers of its buffer set
+        HIP_TRY(e, hipEventRecord(e->ev_chain_done[x.pre_set], s));
+        e->chain_pending[x.pre_set] = true;
+    } else if (e->pre_stream && !e->demod_bypass) {
+        // a squelch pass on the main stream - this call's closing pass, or a gated call's inline decisions (those left
+        // no event behind) - : the next pre-pass continues from it
+        HIP_TRY(e, hipEventRecord(e->ev_main_decisions, s));
+        e->decisions_on_main = true;
+    }
+    if (x.epoch_report_now) {   // behind everything this call queued (the side streams have joined)
+        HIP_LAUNCH(e, launch_write_word(e->h_epoch_report + 1, e->accept_seq, s));
+        e->epoch_report_pending = true;
+        e->epoch_report_seq = e->accept_seq;
+    }
+    e->stats.accepts++;
+    e->stats.samples += (uint64_t)x.vlen * x.n_ch;
+    return IQD_OK;
+}
+
+int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void *iq_dev, size_t bytes_per_ch,
+                         void *pcm_dev, void *pcm_count_dev, void *magnitude_dev, void *signal_present_dev)
+{
+    if (!range_ok(e, first_ch, n_ch) || !iq_dev || !pcm_dev) return e ? e->fail(IQD_EINVAL, "bad channel range or NULL buffer") : IQD_EINVAL;
+    const uint32_t call_bb = call_block_bytes(e, first_ch, n_ch, bytes_per_ch);
+    if (!call_bb) return e->fail(IQD_EINVAL, IQD_LEN_MSG, bytes_per_ch, e->block_bytes);
+    if (bytes_per_ch / 2 > 0x7fff0000ull) return e->fail(IQD_EINVAL, "bytes_per_ch too large");
+    if (((uintptr_t)iq_dev & 15) != 0) return e->fail(IQD_EINVAL, "iq_dev must be 16-byte aligned");
+    (void)hipSetDevice(e->device);
+
+    CallCtx x;
+    x.first_ch = first_ch; x.n_ch = n_ch; x.iq_dev = iq_dev; x.bytes_per_ch = bytes_per_ch;
+    x.pcm_dev = pcm_dev; x.pcm_count_dev = pcm_count_dev; x.magnitude_dev = magnitude_dev; x.signal_present_dev = signal_present_dev;
+    x.call_bb = call_bb;
+    x.call_bs = call_bb / 2;
+    x.n_blocks = (uint32_t)(bytes_per_ch / call_bb);
+    x.vlen = (uint32_t)(bytes_per_ch / 2);
+    x.s_main = e->stream;
+    int rc = prepare_call(e, x);
+    if (rc != IQD_OK) return rc;
+    if (e->demod_bypass) {   // {Am,Fm,WbFm,Ssb}Demodulator::acceptIqData: nothing of the processor's squelch path runs or moves
+        x.gated = x.any_agc = false;
+        x.pcm_count_dev = x.magnitude_dev = x.signal_present_dev = nullptr;
+    }
+    x.want_mag = !e->demod_bypass && (x.gated || x.any_agc || !(e->flags & IQD_F_NO_MAGNITUDE) || x.magnitude_dev);
+    x.pre_overlap = x.gated && (e->flags & IQD_F_PREPASS_OVERLAP) && !e->trace_on && !e->in_host_path;
+    x.fused_mag = x.want_mag && !x.gated;
+
+    // the plan: decided before anything of the call is queued, kept while the call's shape repeats
+    CallShape shape;
+    describe_call(e, x, shape);
+    if (!e->plan_valid || !same_shape(shape, e->plan_shape)) {
+        plan_call(e->knobs, shape, e->plan);
+        e->plan_shape = shape;
+        e->plan_valid = true;
+    }
+    x.plan = &e->plan;
+    const CallPlan &plan = e->plan;
+
+    rc = queue_prepass(e, x);
+    if (rc != IQD_OK) return rc;
+    if (plan.forked) {
         if (!e->fam_fork) {
             int lo = 0, hi = 0;   // numerically lower = higher priority
             (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
@@ -1345,433 +1663,18 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
                 HIP_TRY(e, hipEventCreateWithFlags(&e->fam_join[k], hipEventDisableTiming));
             }
         }
-        // before the fork.  One buffer per family: short rows are written time-major by the tile kernels and channel-major by the
-        // streaming pipelines, and the two families of a call may take different paths (round 4's fuzzer: an AM family that
-        // streamed beside an SSB family on the tile kernels overwrote its detector stream)
-        if (!e->h_lists[FAM_AM].empty()) HIP_TRY(e, e->base8k.ensure((size_t)n_ch * base.pcm_stride * sizeof(int32_t)));
-        if (!e->h_lists[FAM_SSB].empty()) HIP_TRY(e, e->base8k2.ensure((size_t)n_ch * base.pcm_stride * sizeof(int32_t)));
+        // the detector-stream buffers before the fork (an allocation that grows one must not free what a side stream still reads)
+        if (!e->h_lists[FAM_AM].empty()) HIP_TRY(e, e->base8k.ensure((size_t)n_ch * x.base.pcm_stride * sizeof(int32_t)));
+        if (!e->h_lists[FAM_SSB].empty()) HIP_TRY(e, e->base8k2.ensure((size_t)n_ch * x.base.pcm_stride * sizeof(int32_t)));
+        if (!plan.fused) HIP_TRY(e, hipEventRecord(e->fam_fork, x.s_main));
     }
-    // relative cost per channel-sample: AM, FM, WBFM, SSB (the families' workgroups side by side: 214 / 228 / 227 / 259 us on
-    // 32 / 56 / 96 / 56 CUs for 819 / 819 / 820 / 1638 channels x 2^16, profiles/r3_mixed_4096_kernel_stats.csv)
-    const float *weight = e->fam_weight;
-    int order[FAM_COUNT] = {0, 1, 2, 3};
-    float cost[FAM_COUNT];
-    for (int f = 0; f < FAM_COUNT; f++) cost[f] = weight[f] * (float)e->h_lists[f].size();
-    std::sort(order, order + FAM_COUNT, [&](int x, int y) { return cost[x] > cost[y]; });
-    // Several families side by side: each one's persistent workgroups take a share of the CUs in proportion to its
-    // estimated cost, so that the families' streaming kernels run at the same time (a CU's LDS holds one such
-    // workgroup) on longer segments - less lead-in overhead, which is what small families pay most for.  (Mixed
-    // configuration, 4096 channels x 2^16: 0.45 ms per step with every family on all CUs in turn, 0.39 with shares.)
-    uint32_t fam_share[FAM_COUNT];
-    bool shares_on = false;   // the families of this call run their streaming kernels side by side, each on a share of the CUs
-    bool fused = false;       // ... as ranges of one launch's workgroups
-    {
-        float total = 0.f;
-        for (int f = 0; f < FAM_COUNT; f++) total += cost[f];
-        for (int f = 0; f < FAM_COUNT; f++) fam_share[f] = e->n_cus;
-        // (only when every family of the call will take its streaming kernel - here that means: brings enough samples
-        // for ITS share of the CUs; tile kernels know nothing of shares, and a streaming kernel held to its share beside
-        // them lost 12-16 % at 2500-3000 mixed channels)
-        auto every_family_streams = [&](int arrangement) {   // 1: as ranges of one launch, 2: as kernels on streams (stream_min_seg)
-            bool all = !(e->flags & IQD_F_WBFM_TILES) && vlen % 128 == 0 && e->env_path >= 0;
-            for (int f = 0; f < FAM_COUNT && all; f++) {
-                const uint64_t n_f = e->h_lists[f].size();
-                if (!n_f) continue;
-                const bool forced = (e->flags & IQD_F_WBFM_STREAM) != 0;
-                const float due = total > 0.f ? (float)(e->n_cus - 16) * cost[f] / total : (float)e->n_cus;
-                if (!forced && (float)((uint64_t)vlen * n_f) < due * (float)(ST_SEGS * stream_min_seg(e, f, vlen, arrangement))) all = false;
-                if ((f == FAM_AM || f == FAM_SSB) && vlen / 32 < e->env_am_stream_min) all = false;
-            }
-            return all;
-        };
-        const bool all_stream = every_family_streams(1);
-        shares_on = forked && all_stream && total > 0.f && e->n_cus >= 64 && !e->env_full_grid;
-        // ONE launch for all of them (iqd_stream_mixed.hip) when each family can take its streaming pipeline in the plain
-        // instantiation: the WBFM channels of one rotation selector and without a gain change in reach of a lead-in,
-        // gains below the "integer indefinite" bounds, AM / SSB rows that the one-wave DC pass takes
-        fused = shares_on && !e->env_mixed_forked && e->env_path == 0 && !e->env_stream_wgs &&
-                !(e->flags & IQD_F_WBFM_STREAM);
-        if (fused && !e->h_lists[FAM_WBFM].empty()) {
-            const auto &l = e->h_lists[FAM_WBFM];
-            const int rot0 = e->h_params[first_ch + l[0]].rotation;
-            fused = e->stream_ok;
-            for (uint32_t c : l) {
-                fused = fused && e->h_params[first_ch + c].rotation == rot0 && e->wbfm_kmax[first_ch + c] * 3.1730f < 2147483648.0f;
-                fused = fused && !(e->wbfm_epochs_live && e->wbfm_epoch_left[first_ch + c] != 0);
-            }
-        }
-        if (fused)
-            for (uint32_t c : e->h_lists[FAM_FM]) fused = fused && e->fm_kmax[first_ch + c] * 6.35f < 2147483648.0f;
-        if (fused && (!e->h_lists[FAM_AM].empty() || !e->h_lists[FAM_SSB].empty()))
-            fused = vlen / 32 >= e->env_am_stream_min && (bytes_per_ch / 64 + DC_TILE - 1) / DC_TILE < 2;
-        if (shares_on && !fused) shares_on = every_family_streams(2);   // (the kernels-on-streams arrangement pays from larger calls only)
-        if (shares_on && fused) {
-            FusedFamily ff[FAM_COUNT];
-            for (int f = 0; f < FAM_COUNT; f++) {
-                for (int r = 0; r < 3; r++) ff[f].rot_count[r] = e->h_lists[f].empty() ? 0u : e->rot_count[f][r];
-                ff[f].halo = f == FAM_WBFM ? (uint32_t)ST_HALO : f == FAM_FM ? (uint32_t)D4_HALO_FM : f == FAM_AM ? (uint32_t)D4_HALO_AM : (uint32_t)D4_HALO_SSB;
-                ff[f].granule = f == FAM_WBFM ? e->env_stream_gran : e->env_d4_gran;
-                ff[f].ns_per_sample = e->fam_ns[f];
-            }
-            if (e->env_shares_by_cost || !plan_fused_by_time((uint32_t)vlen, FAM_COUNT, ff, e->n_cus, fam_share))
-                plan_fused_shares(cost, FAM_COUNT, e->n_cus, fam_share);
-        }
-        else if (shares_on && !plan_family_shares(cost, FAM_COUNT, e->n_cus, fam_share)) shares_on = false;
-        if (!shares_on) fused = false;
-    }
-    MixedStreamArgs mix{};
-    uint32_t mix_wgs = 0;
-    bool epoch_report_now = false;   // this call's WBFM tail updates report whether a gain change is still in reach (h_epoch_report)
-    if (forked && !fused) HIP_TRY(e, hipEventRecord(e->fam_fork, s_main));
-    float lane_load[4] = {0.f, 0.f, 0.f, 0.f};   // 0: the engine's stream, 1 to 3: the side streams
-    bool lane_used[4] = {false, false, false, false};
-    size_t (*dcr_layout)[2] = e->dcr_layout;
-    ChainLaunch tail_a{};
-    int tail_f = 0;
-    bool tail_pending = false;
     for (int oi = 0; oi < FAM_COUNT; oi++) {
-        const int f = order[oi];
-        const uint32_t n_list = (uint32_t)e->h_lists[f].size();
-        if (!n_list) continue;
-        int lane = 0;
-        if (forked && !fused) {
-            for (int k = 1; k < 4; k++)
-                if (lane_load[k] < lane_load[lane]) lane = k;
-            lane_load[lane] += cost[f];
-        }
-        s = lane == 0 ? s_main : e->fam_stream[lane - 1];
-        if (lane != 0 && !lane_used[lane]) HIP_TRY(e, hipStreamWaitEvent(s, e->fam_fork, 0));
-        lane_used[lane] = true;
-        uint32_t fam_wgs = fam_share[f];
-        if (e->env_stream_wgs) fam_wgs = e->env_stream_wgs;   // (experiments)
-        ChainLaunch a = base;
-        a.ch_list = e->lists[f].as<uint32_t>();
-        a.n_list = n_list;
-        if (f == FAM_WBFM && chain_gated && e->wbfm_epochs_live && !e->epoch_report_pending) {
-            bool any = false;
-            for (uint32_t c : e->h_lists[FAM_WBFM]) any = any || e->wbfm_epoch_left[first_ch + c] != 0;
-            if (any) {
-                if (!e->h_epoch_report) HIP_TRY(e, hipHostMalloc((void **)&e->h_epoch_report, 2 * sizeof(uint32_t), hipHostMallocDefault));
-                ((volatile uint32_t *)e->h_epoch_report)[0] = 0u;
-                a.epoch_report = e->h_epoch_report;
-                e->epoch_report_channels.clear();
-                for (uint32_t c : e->h_lists[FAM_WBFM]) e->epoch_report_channels.push_back(first_ch + c);
-                epoch_report_now = true;
-            }
-        }
-        // workgroups a CU holds at once: WBFM 3 (LDS), the others 4 (registers)
-        const TilePlan plan = f == FAM_WBFM ? plan_tiles(vlen, n_list, WBFM_CHUNK, COLD_HALO, 3 * e->n_cus, e->env_plan_chunks)
-                                            : plan_tiles(vlen, n_list, CH_CHUNK, FIR_HALO, 4 * e->n_cus, e->env_plan_chunks);
-        a.tile_len = plan.tile_len;
-        a.tiles_per_ch = plan.tiles_per_ch;
-        // WBFM: the streaming pipeline (iqd_stream.hip) when the launch can fill the chip with it and nothing it does
-        // not handle is in play: squelch-gated rows, channels with different rotation selectors, a K so large that
-        // (int16)y can hit the "integer indefinite" value.  Results are identical either way.
-        bool use_stream = false;
-        int stream_rot = 0;
-        bool stream_grouped = false;   // channels of several rotation selectors: segment ids grouped by selector (StreamArgs::grouped)
-        uint32_t st_group_start[4] = {0, 0, 0, 0}, st_group_li0[3] = {0, 0, 0}, st_group_nseg[3] = {0, 0, 0};
-        if (f == FAM_WBFM && e->stream_ok && !(e->flags & IQD_F_WBFM_TILES) && vlen % 128 == 0) {
-            const auto &l = e->h_lists[FAM_WBFM];
-            stream_rot = e->h_params[first_ch + l[0]].rotation;
-            bool ok = true;
-            for (uint32_t c : l) {
-                const ChanParams &p = e->h_params[first_ch + c];
-                stream_grouped = stream_grouped || p.rotation != stream_rot;
-                ok = ok && e->wbfm_kmax[first_ch + c] * 3.1730f < 2147483648.0f;
-            }
-            if (fused && stream_grouped) ok = false;   // (the one-launch arrangement holds the single-selector instantiations only)
-            int want = 0;   // 0 auto, 1 stream, -1 tiles
-            if (e->flags & IQD_F_WBFM_STREAM) want = 1;
-            if (e->env_path) want = e->env_path;
-            const uint64_t work = (uint64_t)vlen * n_list;
-            if (ok && want >= 0 && (want > 0 || work >= (uint64_t)(shares_on ? fam_wgs : e->n_cus) * ST_SEGS * stream_min_seg(e, f, vlen, 0) || shares_on)) {
-                for (uint32_t spare = 0;; spare += 48) {   // (the groups' padding may push an exact fit into a second round)
-                    const TilePlan sp = plan_stream(vlen, n_list, fam_wgs * ST_SEGS - (stream_grouped ? spare : 0u), e->env_stream_gran);
-                    a.tile_len = sp.tile_len;
-                    a.tiles_per_ch = sp.tiles_per_ch;
-                    if (!stream_grouped) break;
-                    uint32_t at = 0, li0 = 0;
-                    for (int r = 0; r < 3; r++) {   // the channel list is sorted +Fs/4, none, -Fs/4 (rebuild_lists)
-                        st_group_start[r] = at;
-                        st_group_li0[r] = li0;
-                        st_group_nseg[r] = e->rot_count[FAM_WBFM][r] * a.tiles_per_ch;
-                        at += (st_group_nseg[r] + 15u) / 16u * 16u;
-                        li0 += e->rot_count[FAM_WBFM][r];
-                    }
-                    st_group_start[3] = at;
-                    if (at <= fam_wgs * ST_SEGS || spare >= 48 || n_list * 1u >= fam_wgs * ST_SEGS) break;
-                }
-                use_stream = true;
-            }
-        }
-        // FM / AM / SSB: the streaming pipelines of iqd_stream2.hip under the same conditions (channels of different
-        // rotation selectors are fine here: the list is sorted by selector and the groups are padded)
-        bool use_d4 = false;
-        uint32_t d4_wgs = fam_wgs;
-        D4Args d4 = e->d4_args;
-        if (f != FAM_WBFM && !(e->flags & IQD_F_WBFM_TILES) && vlen % 128 == 0 && (f == FAM_FM || vlen / 32 >= e->env_am_stream_min)) {
-            bool ok = true;
-            if (f == FAM_FM)
-                for (uint32_t c : e->h_lists[f]) ok = ok && e->fm_kmax[first_ch + c] * 6.35f < 2147483648.0f;
-            int want = 0;
-            if (e->flags & IQD_F_WBFM_STREAM) want = 1;
-            if (e->env_path) want = e->env_path;
-            const uint64_t work = (uint64_t)vlen * n_list;
-            if (ok && want >= 0 && (want > 0 || work >= (uint64_t)(shares_on ? fam_wgs : e->n_cus) * ST_SEGS * stream_min_seg(e, f, vlen, 0) || shares_on)) {
-                d4_wgs = fam_wgs;
-                for (uint32_t spare = 0;; spare += 48) {   // (the rotation groups' padding may push an exact fit into a second round)
-                    const TilePlan sp = plan_stream(vlen, n_list, d4_wgs * ST_SEGS - spare, e->env_d4_gran);   // (these pipelines store 8 or 16 bytes per 128 samples: no wide stores to keep whole)
-                    a.tile_len = sp.tile_len;
-                    a.tiles_per_ch = sp.tiles_per_ch;
-                    uint32_t at = 0, li0 = 0;
-                    for (int r = 0; r < 3; r++) {
-                        d4.group_start[r] = at;
-                        d4.group_li0[r] = li0;
-                        d4.group_nseg[r] = e->rot_count[f][r] * a.tiles_per_ch;
-                        at += (d4.group_nseg[r] + 15u) / 16u * 16u;
-                        li0 += e->rot_count[f][r];
-                    }
-                    d4.group_start[3] = at;
-                    if (at <= d4_wgs * ST_SEGS || spare >= 48 || n_list * 1u >= d4_wgs * ST_SEGS) break;
-                }
-                d4.amat = e->d_amat4 + (size_t)(f == FAM_FM ? 0 : 3) * 4 * 64 * 4;
-                d4.fm_lut = e->d_fmlut;
-                d4.halo = f == FAM_FM ? D4_HALO_FM : (f == FAM_AM ? D4_HALO_AM : D4_HALO_SSB);
-                use_d4 = true;
-            }
-        }
-        if (fused && !((f == FAM_WBFM && use_stream) || (f != FAM_WBFM && use_d4))) return e->fail(IQD_EINVAL, "a family of a fused launch fell off its streaming pipeline");
-        if (e->profiling && !timed && !fused) {
-            if (e->ev_free_pairs.empty()) {
-                hipEvent_t a0, a1;
-                HIP_TRY(e, hipEventCreate(&a0));
-                HIP_TRY(e, hipEventCreate(&a1));
-                e->ev_free_pairs.emplace_back(a0, a1);
-            }
-            evp = e->ev_free_pairs.back();
-            e->ev_free_pairs.pop_back();
-            HIP_TRY(e, hipEventRecord(evp.first, s));
-        }
-        if (f == FAM_WBFM) {
-            HIP_TRY(e, e->records.ensure((size_t)n_list * a.tiles_per_ch * sizeof(WbfmRecord)));
-            a.records = e->records.as<WbfmRecord>();
-            if (e->repair_flags.cap < n_list * sizeof(uint32_t)) {   // zero between calls: the repair kernel clears what it used
-                HIP_TRY(e, e->repair_flags.ensure(n_list * sizeof(uint32_t)));
-                HIP_COPY(e, hipMemsetAsync(e->repair_flags.p, 0, e->repair_flags.cap, s));
-            }
-            a.repair_flags = e->repair_flags.as<uint32_t>();
-            if (use_stream) {
-                StreamArgs sa = e->stream_args;
-                sa.amat = e->d_amat[stream_rot + 1];
-                sa.half_lut = e->d_half_lut;
-                sa.n_segments = n_list * a.tiles_per_ch;
-                sa.grouped = stream_grouped ? 1u : 0u;
-                for (int r = 0; r < 3; r++) {
-                    sa.group_start[r] = st_group_start[r];
-                    sa.group_li0[r] = st_group_li0[r];
-                    sa.group_nseg[r] = st_group_nseg[r];
-                    sa.amat3[r] = e->d_amat[2 - r];          // d_amat[] is indexed by selector + 1; the groups run +1, 0, -1
-                }
-                sa.group_start[3] = st_group_start[3];
-                const uint32_t wgs_needed = ((stream_grouped ? sa.group_start[3] : sa.n_segments) + ST_SEGS - 1) / ST_SEGS;
-                const uint32_t grid = wgs_needed < fam_wgs ? wgs_needed : fam_wgs;
-                sa.rounds = (wgs_needed + grid - 1) / grid;
-                HIP_TRY(e, e->stream_hist.ensure((size_t)sa.n_segments * sizeof(StHist)));
-                sa.hist = e->stream_hist.as<StHist>();
-                a.verify_at_end = chain_gated ? 2u : 1u;   // (2: the hand-offs are counted on the device - how many tiles a channel has depends on its squelch)
-                bool epochs_live = false;
-                if (e->wbfm_epochs_live)
-                    for (uint32_t c : e->h_lists[FAM_WBFM]) epochs_live = epochs_live || e->wbfm_epoch_left[first_ch + c] != 0;
-                if (fused) {   // a range of the one launch's workgroups; the fix-up rides in the launch behind it
-                    a.wg_first = mix_wgs;
-                    a.wg_count = grid;
-                    mix_wgs += grid;
-                    mix.a[f] = a;
-                    mix.sa = sa;
-                    mix.wbfm_rot = stream_rot;
-                } else {
-                    HIP_LAUNCH(e, launch_wbfm_stream(a, sa, stream_rot, fused_mag, epochs_live, grid, s));
-                    HIP_LAUNCH(e, launch_wbfm_stream_fixup(a, sa, s));
-                }
-                if (!chain_gated) e->stream_handoffs += (uint64_t)n_list * ((vlen + a.tile_len - 1) / a.tile_len - 1);
-                e->stats.stream_launches++;
-            } else {
-                HIP_LAUNCH(e, launch_wbfm(a, chain_gated, fused_mag, n_list * a.tiles_per_ch, s));
-            }
-        } else if (f == FAM_FM) {
-            if (use_d4) {
-                const uint32_t wgs_needed = (d4.group_start[3] + ST_SEGS - 1) / ST_SEGS;
-                const uint32_t grid = wgs_needed < d4_wgs ? wgs_needed : d4_wgs;
-                d4.rounds = (wgs_needed + grid - 1) / grid;
-                if (fused) {
-                    a.wg_first = mix_wgs;
-                    a.wg_count = grid;
-                    mix_wgs += grid;
-                    mix.a[f] = a;
-                    mix.d4[f] = d4;
-                } else {
-                    HIP_LAUNCH(e, launch_d4_stream(a, d4, D4_FM, fused_mag, grid, s));
-                }
-                e->stats.stream_launches++;
-            } else {
-                HIP_LAUNCH(e, launch_fm(a, chain_gated, fused_mag, n_list * a.tiles_per_ch, s));
-            }
-        } else if (use_d4) {
-            DevBuf &b8 = f == FAM_SSB ? e->base8k2 : e->base8k;
-            HIP_TRY(e, b8.ensure((size_t)n_ch * base.pcm_stride * sizeof(int32_t)));
-            a.base8k = b8.as<int32_t>();
-            a.base_stride_ch = base.pcm_stride;   // channel-major (rows longer than 512 PCM samples)
-            a.base_stride_t = 1;
-            a.dc_tiles = (uint32_t)((base.pcm_stride + DC_TILE - 1) / DC_TILE);
-            DevBuf &dcr = f == FAM_SSB ? e->dc_records2 : e->dc_records;
-            {
-                const size_t rec_bytes = (size_t)n_list * a.dc_tiles * sizeof(DcRecord);
-                const bool grown = dcr.cap < rec_bytes + n_list * sizeof(uint32_t);
-                HIP_TRY(e, dcr.ensure(rec_bytes + n_list * sizeof(uint32_t)));
-                a.dc_records = dcr.p;
-                if (grown || dcr_layout[f == FAM_SSB][0] != rec_bytes || dcr_layout[f == FAM_SSB][1] < n_list) {
-                    HIP_COPY(e, hipMemsetAsync((char *)dcr.p + rec_bytes, 0, n_list * sizeof(uint32_t), s));
-                    dcr_layout[f == FAM_SSB][0] = rec_bytes;
-                    dcr_layout[f == FAM_SSB][1] = n_list;
-                }
-            }
-            const uint32_t wgs_needed = (d4.group_start[3] + ST_SEGS - 1) / ST_SEGS;
-            const uint32_t grid = wgs_needed < d4_wgs ? wgs_needed : d4_wgs;
-            d4.rounds = (wgs_needed + grid - 1) / grid;
-            if (fused) {
-                a.wg_first = mix_wgs;
-                a.wg_count = grid;
-                mix_wgs += grid;
-                mix.a[f] = a;
-                mix.d4[f] = d4;
-            } else {
-                HIP_LAUNCH(e, launch_d4_stream(a, d4, f == FAM_AM ? D4_AM : D4_SSB, fused_mag, grid, s));
-                HIP_LAUNCH(e, launch_am_dc(a, f, s, true));   // (the pipeline wrote the detector stream channel-major)
-            }
-            e->stats.stream_launches++;
-        } else {
-            DevBuf &b8 = f == FAM_SSB ? e->base8k2 : e->base8k;
-            HIP_TRY(e, b8.ensure((size_t)n_ch * base.pcm_stride * sizeof(int32_t)));
-            a.base8k = b8.as<int32_t>();
-            a.dc_tiles = (uint32_t)((base.pcm_stride + DC_TILE - 1) / DC_TILE);
-            DevBuf &dcr = f == FAM_SSB ? e->dc_records2 : e->dc_records;   // AM and SSB may run side by side
-            {   // records, then one redo flag per channel: zero between calls (dc_redo_kernel clears what it used)
-                const size_t rec_bytes = (size_t)n_list * a.dc_tiles * sizeof(DcRecord);
-                const bool grown = dcr.cap < rec_bytes + n_list * sizeof(uint32_t);
-                HIP_TRY(e, dcr.ensure(rec_bytes + n_list * sizeof(uint32_t)));
-                a.dc_records = dcr.p;
-                // the flags sit behind the records, whose extent changes with the call: clear them whenever it may have
-                // (same offset but more channels than last time: the new flags lie over old record bytes)
-                if (grown || dcr_layout[f == FAM_SSB][0] != rec_bytes || dcr_layout[f == FAM_SSB][1] < n_list) {
-                    HIP_COPY(e, hipMemsetAsync((char *)dcr.p + rec_bytes, 0, n_list * sizeof(uint32_t), s));
-                    dcr_layout[f == FAM_SSB][0] = rec_bytes;
-                    dcr_layout[f == FAM_SSB][1] = n_list;
-                }
-            }
-            HIP_LAUNCH(e, launch_am(a, f, chain_gated, fused_mag, n_list * a.tiles_per_ch, s));
-        }
-        if (e->profiling && !timed && !fused) {
-            HIP_TRY(e, hipEventRecord(evp.second, s));
-            e->ev_pending.push_back(evp);
-            timed = true;
-        }
-        e->stats.kernel_launches++;
-        if (fused) continue;   // (one launch for all the families and one for what follows them, behind this loop)
-        if (f == FAM_WBFM && !chain_gated && e->wbfm_epochs_live)   // every channel of the family has consumed vlen samples
-            for (uint32_t c : e->h_lists[FAM_WBFM]) {
-                uint32_t &left = e->wbfm_epoch_left[first_ch + c];
-                if (!left) continue;
-                left = left > vlen ? left - vlen : 0u;
-                if (!left) e->wbfm_epochs_live--;
-            }
-        const bool rides_with_squelch = !forked && !gated && !e->demod_bypass && (want_mag || pcm_count_dev || signal_present_dev || e->trace_on);
-        if (f == FAM_WBFM) {
-            // hand-off verification (streaming launches: done by their fix-up kernel), repair of what it flags
-            // (normally an immediate exit), then state commit + tail - in the squelch launch below when the call has
-            // no other family
-            if (!use_stream) HIP_LAUNCH(e, launch_wbfm_verify(a, s));
-            if (rides_with_squelch) {
-                tail_a = a;
-                tail_f = f;
-                tail_pending = true;
-            } else {
-                HIP_LAUNCH(e, launch_wbfm_repair(a, chain_gated, s));   // (ends with the channels' state commit and tail update)
-            }
-        } else if (rides_with_squelch) {
-            tail_a = a;        // the only family of the call: its tail update rides in the squelch launch below
-            tail_f = f;
-            tail_pending = true;
-        } else {
-            HIP_LAUNCH(e, launch_tail_update(a, f, s));
-        }
+        const int f = plan.order[oi];
+        if (!plan.fam[f].present) continue;
+        rc = queue_family(e, x, f);
+        if (rc != IQD_OK) return rc;
     }
-    s = s_main;
-    if (fused) {
-        if (e->profiling) {
-            if (e->ev_free_pairs.empty()) {
-                hipEvent_t a0, a1;
-                HIP_TRY(e, hipEventCreate(&a0));
-                HIP_TRY(e, hipEventCreate(&a1));
-                e->ev_free_pairs.emplace_back(a0, a1);
-            }
-            evp = e->ev_free_pairs.back();
-            e->ev_free_pairs.pop_back();
-            HIP_TRY(e, hipEventRecord(evp.first, s));
-        }
-        HIP_LAUNCH(e, launch_mixed_stream(mix, fused_mag, chain_gated, mix_wgs, s));
-        e->stats.mixed_launches++;
-        MixedTailArgs mt{};
-        for (int f = 0; f < FAM_COUNT; f++) mt.a[f] = mix.a[f];
-        mt.sa = mix.sa;
-        HIP_LAUNCH(e, launch_mixed_tail(mt, s));
-        if (e->profiling) {   // (the timed region: the pipelines AND their followers - fix-up, DC passes, tails)
-            HIP_TRY(e, hipEventRecord(evp.second, s));
-            e->ev_pending.push_back(evp);
-        }
-        if (mix.a[FAM_WBFM].wg_count) {   // repair check, state commit and tail of the WBFM channels: in the squelch launch below
-            tail_a = mix.a[FAM_WBFM];
-            tail_f = FAM_WBFM;
-            tail_pending = true;
-        }
-    }
-    for (int k = 1; k < 4; k++)
-        if (lane_used[k]) {
-            HIP_TRY(e, hipEventRecord(e->fam_join[k - 1], e->fam_stream[k - 1]));
-            HIP_TRY(e, hipStreamWaitEvent(s_main, e->fam_join[k - 1], 0));
-        }
-
-    // channels in mode None still report their magnitudes
-    if (fused_mag && !e->h_lists[FAM_COUNT].empty())
-        HIP_LAUNCH(e, launch_magnitude((const uint8_t *)iq_dev, bytes_per_ch, e->lists[FAM_COUNT].as<uint32_t>(),
-                                    (uint32_t)e->h_lists[FAM_COUNT].size(), call_bs, n_blocks,
-                                    e->mag_sums.as<uint32_t>(), s));
-    if (!gated && !e->demod_bypass && (want_mag || pcm_count_dev || signal_present_dev || e->trace_on)) {
-        q.zero_sums_after = any_agc ? 0u : 1u;   // (a running AGC reads them again in the tracking pass)
-        HIP_LAUNCH(e, launch_squelch(q, true, s, tail_pending ? &tail_a : nullptr, tail_f));
-        tail_pending = false;
-        if (q.zero_sums_after) e->mag_sums_zero = (size_t)n_ch * n_blocks;
-    }
-    if (tail_pending) {   // (no squelch launch to ride in)
-        if (tail_f == FAM_WBFM) HIP_LAUNCH(e, launch_wbfm_repair(tail_a, chain_gated, s));
-        else HIP_LAUNCH(e, launch_tail_update(tail_a, tail_f, s));
-    }
-
-    if (pre_set >= 0) {   // this call's pipelines are the last readers of its buffer set
-        HIP_TRY(e, hipEventRecord(e->ev_chain_done[pre_set], s_main));
-        e->chain_pending[pre_set] = true;
-    } else if (!gated && e->pre_stream && !e->demod_bypass) {   // a squelch pass on the main stream: the next pre-pass continues from it
-        HIP_TRY(e, hipEventRecord(e->ev_main_decisions, s_main));
-        e->decisions_on_main = true;
-    }
-    if (epoch_report_now) {   // behind everything this call queued (the side streams have joined)
-        HIP_LAUNCH(e, launch_write_word(e->h_epoch_report + 1, e->accept_seq, s_main));
-        e->epoch_report_pending = true;
-        e->epoch_report_seq = e->accept_seq;
-    }
-    e->stats.accepts++;
-    e->stats.samples += (uint64_t)vlen * n_ch;
-    return IQD_OK;
+    return queue_commit(e, x);
 }
 
 // Large host-pointer accepts are cut into slices of about SLICE_BYTES that go through two sets of device

@@ -396,12 +396,17 @@ bool plan_fused_by_time(uint32_t vlen, int n, const FusedFamily *fam, uint32_t n
         if (!n_ch) continue;
         const uint32_t g = fam[f].granule == 128 || fam[f].granule == 256 ? fam[f].granule : 512;
         uint32_t last_len = 0;
-        for (uint32_t k = 1; last_len != (uint32_t)ST_MIN_TILE && k <= vlen; k++) {   // (down to the shortest segment there is)
+        for (uint32_t k = 1; last_len != (uint32_t)ST_MIN_TILE && k <= vlen;) {   // (down to the shortest segment there is)
             uint64_t len = ((uint64_t)vlen + k - 1) / k;
             len = (len + g - 1) / g * g;
             if (len < ST_MIN_TILE) len = ST_MIN_TILE;
-            if ((uint32_t)len == last_len) continue;
+            // the next k worth a look is the first that gives a shorter segment: ceil(vlen / k) <= len - g (one k at a
+            // time this walked vlen / 768 values of k - 2 ms of host time for a 2^28-sample row, more than its kernels run)
+            const uint64_t shorter = len > g ? len - g : 1;
+            const uint32_t k_next = (uint32_t)std::max<uint64_t>(k + 1, ((uint64_t)vlen + shorter - 1) / shorter);
+            if ((uint32_t)len == last_len) { k = k_next; continue; }
             last_len = (uint32_t)len;
+            k = k_next;
             const uint32_t tiles = (uint32_t)(((uint64_t)vlen + len - 1) / len);
             uint64_t ids = 0;
             for (int r = 0; r < 3; r++) ids += ((uint64_t)fam[f].rot_count[r] * tiles + 15) / 16 * 16;

@@ -13,6 +13,8 @@
 #include <vector>
 
 #include "iqd_host.h"
+#include "iqd_plan.h"
+#include "iqd_stream.h"
 #include "iqd_chains.h"
 #include "iqd_wbfm.h"
 
@@ -261,6 +263,52 @@ void emu_plan_stream(uint32_t vlen, uint32_t n_channels, uint32_t streams, uint3
     const iqd::TilePlan p = iqd::plan_stream(vlen, n_channels, streams);
     *tile_len = p.tile_len;
     *tiles_per_ch = p.tiles_per_ch;
+}
+
+// plan_call (iqd_plan.cpp) on plain arrays.  knobs: {flags, n_cus, stream_ok, env_path (+1 / 0 / -1 as 1 / 0 / 2), env_stream_min_seg,
+// env_am_stream_min (0 = default), env_mixed_forked, env_shares_by_cost, env_stream_wgs, env_full_grid}; fam: per family
+// {n_list, rot_count[3], cast_bounded, epochs_in_reach}; out: {n_fams, forked, shares_on, fused, mix_wgs, order[4]} then per family
+// {present, path, lane, wgs, tile_len, tiles_per_ch, grouped, group_start[4], group_nseg[3], grid, rounds, wg_first, epochs} (18 words).
+void emu_plan_call(const uint32_t *knobs, uint32_t vlen, uint32_t pcm_per_ch, uint32_t gated, const uint32_t *fam, uint32_t *out)
+{
+    iqd::PlanKnobs k;
+    k.flags = knobs[0]; k.n_cus = knobs[1]; k.stream_ok = knobs[2] != 0;
+    k.env_path = knobs[3] == 1 ? 1 : knobs[3] == 2 ? -1 : 0;
+    k.env_stream_min_seg = knobs[4];
+    if (knobs[5]) k.env_am_stream_min = knobs[5];
+    k.env_mixed_forked = knobs[6] != 0; k.env_shares_by_cost = knobs[7] != 0; k.env_stream_wgs = knobs[8]; k.env_full_grid = knobs[9] != 0;
+    k.wbfm_chunk = iqd::WBFM_CHUNK; k.wbfm_cold_halo = iqd::COLD_HALO; k.ch_chunk = iqd::CH_CHUNK; k.fir_halo = iqd::FIR_HALO; k.dc_tile = iqd::DC_TILE;
+    iqd::CallShape c;
+    c.vlen = vlen; c.pcm_per_ch = pcm_per_ch; c.gated = gated != 0;
+    for (int f = 0; f < iqd::FAM_COUNT; f++) {
+        c.fam[f].n_list = fam[6 * f];
+        for (int r = 0; r < 3; r++) c.fam[f].rot_count[r] = fam[6 * f + 1 + r];
+        c.fam[f].cast_bounded = fam[6 * f + 4] != 0;
+        c.fam[f].epochs_in_reach = fam[6 * f + 5] != 0;
+    }
+    iqd::CallPlan p;
+    iqd::plan_call(k, c, p);
+    uint32_t *o = out;
+    *o++ = (uint32_t)p.n_fams; *o++ = p.forked; *o++ = p.shares_on; *o++ = p.fused; *o++ = p.mix_wgs;
+    for (int f = 0; f < iqd::FAM_COUNT; f++) *o++ = (uint32_t)p.order[f];
+    for (int f = 0; f < iqd::FAM_COUNT; f++) {
+        const iqd::FamilyPlan &q = p.fam[f];
+        *o++ = q.present; *o++ = (uint32_t)q.path; *o++ = (uint32_t)q.lane; *o++ = q.wgs; *o++ = q.tile_len; *o++ = q.tiles_per_ch; *o++ = q.grouped;
+        for (int r = 0; r < 4; r++) *o++ = q.group_start[r];
+        for (int r = 0; r < 3; r++) *o++ = q.group_nseg[r];
+        *o++ = q.grid; *o++ = q.rounds; *o++ = q.wg_first; *o++ = q.epochs;
+    }
+}
+
+uint32_t emu_plan_const(int which)   // geometry constants the plan tests need
+{
+    switch (which) {
+    case 0: return iqd::ST_SEGS;
+    case 1: return iqd::ST_MIN_TILE;
+    case 2: return iqd::ST_HALO;
+    case 3: return iqd::DC_TILE;
+    default: return 0;
+    }
 }
 
 }  // extern "C"

@@ -171,3 +171,182 @@ def test_shares_by_time_fit_one_round_and_beat_proportional_shares_where_rows_ar
     # 16 384 channels x 2^14 (one block per channel and call): AM and SSB get two segments per channel instead of one
     ok, share = _by_time(16384, [(3276, 0, 0), (3276, 0, 0), (3277, 0, 0), (6555, 0, 0)])
     assert ok and share.tolist() == [38, 56, 90, 72]      # (35 / 52 / 86 / 69 meet the deadline; the 14 left over go round in proportion)
+
+
+# ---- plan_call (iqd_plan.cpp): the whole call's plan, decided before anything is queued ---------------------------------
+FAMS = ("am", "fm", "wbfm", "ssb")
+F_TILES, F_STREAM = 0x2, 0x4
+PLAN_TILES, PLAN_STREAM = 0, 1
+
+
+_PLAN_LIB = []
+
+
+def _plan_lib():
+    if not _PLAN_LIB:          # (emu_bind.lib() runs make: once)
+        lib = emu_bind.lib()
+        lib.emu_plan_call.restype = None
+        lib.emu_plan_call.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+        lib.emu_plan_const.restype = C.c_uint32
+        _PLAN_LIB.append(lib)
+    return _PLAN_LIB[0]
+
+
+def plan_call(vlen, fams, flags=0, n_cus=256, stream_ok=True, env_path=0, min_seg=0, am_min=0, mixed_forked=False, by_cost=False,
+              stream_wgs=0, full_grid=False, gated=False):
+    """fams: {family: (rot_count tuple | channels, cast_bounded, epochs_in_reach)} -> the plan as a dict."""
+    lib = _plan_lib()
+    knobs = np.array([flags, n_cus, int(stream_ok), {0: 0, 1: 1, -1: 2}[env_path], min_seg, am_min, int(mixed_forked), int(by_cost),
+                      stream_wgs, int(full_grid)], np.uint32)
+    fam = np.zeros((4, 6), np.uint32)
+    for f, name in enumerate(FAMS):
+        if name in fams:
+            rc, bounded, epochs = fams[name]
+            rc = (rc, 0, 0) if isinstance(rc, int) else rc
+            fam[f] = [sum(rc), rc[0], rc[1], rc[2], int(bounded), int(epochs)]
+    out = np.zeros(9 + 4 * 18, np.uint32)
+    lib.emu_plan_call(knobs.ctypes.data, vlen, vlen // 32, int(gated), fam.ctypes.data, out.ctypes.data)
+    keys = ("present", "path", "lane", "wgs", "tile_len", "tiles_per_ch", "grouped", "gs0", "gs1", "gs2", "gs3", "gn0", "gn1", "gn2",
+            "grid", "rounds", "wg_first", "epochs")
+    plan = {"n_fams": int(out[0]), "forked": bool(out[1]), "shares_on": bool(out[2]), "fused": bool(out[3]), "mix_wgs": int(out[4]),
+            "order": out[5:9].tolist(), "fam": {}}
+    for f, name in enumerate(FAMS):
+        plan["fam"][name] = dict(zip(keys, (int(v) for v in out[9 + 18 * f: 9 + 18 * f + 18])))
+        plan["fam"][name]["n"] = int(fam[f][0])
+        plan["fam"][name]["rot_count"] = fam[f][1:4].tolist()
+    return plan
+
+
+def check_plan(p, vlen, flags, env_path, stream_ok, n_cus, fams):
+    lib = _plan_lib()
+    st_segs, min_tile, dc_tile = lib.emu_plan_const(0), lib.emu_plan_const(1), lib.emu_plan_const(3)
+    present = [n for n in FAMS if p["fam"][n]["n"]]
+    assert p["n_fams"] == len(present) and p["forked"] == (len(present) > 1)
+    assert sorted(p["order"]) == [0, 1, 2, 3]
+    if p["fused"]:
+        assert p["shares_on"] and p["forked"]
+    at = 0
+    ranges = []
+    for name in FAMS:
+        q = p["fam"][name]
+        assert bool(q["present"]) == (q["n"] > 0)
+        if not q["n"]:
+            continue
+        assert q["tile_len"] > 0 and q["tile_len"] * q["tiles_per_ch"] >= vlen, (name, q)     # the tiles / segments cover the row
+        assert 0 <= q["lane"] <= 3 and (q["lane"] == 0 or (p["forked"] and not p["fused"]))
+        rc, bounded, epochs = fams[name]
+        if q["path"] == PLAN_STREAM:
+            assert vlen % 128 == 0 and not (flags & F_TILES) and env_path >= 0, (name, q)
+            assert q["tile_len"] >= min_tile and q["tile_len"] % 128 == 0
+            assert q["grid"] >= 1 and q["rounds"] >= 1 and q["grid"] <= max(q["wgs"], 1)
+            if name == "wbfm":
+                assert stream_ok and bounded
+                assert bool(q["epochs"]) == bool(epochs)
+            if name == "fm":
+                assert bounded
+            if name in ("am", "ssb"):
+                assert vlen // 32 >= 128
+            if q["grouped"]:
+                starts = [q["gs0"], q["gs1"], q["gs2"], q["gs3"]]
+                nseg = [q["gn0"], q["gn1"], q["gn2"]]
+                assert starts[0] == 0 and all(s % 16 == 0 for s in starts)
+                assert nseg == [c * q["tiles_per_ch"] for c in q["rot_count"]]
+                assert all(starts[r + 1] - starts[r] == -(-nseg[r] // 16) * 16 for r in range(3))
+                ids = starts[3]
+            else:
+                assert name == "wbfm" and sum(1 for c in q["rot_count"] if c) == 1
+                ids = q["n"] * q["tiles_per_ch"]
+            assert q["grid"] * q["rounds"] * st_segs >= ids                                  # every segment id has a workgroup and a round
+            assert (q["grid"] - 1) * q["rounds"] * st_segs < ids or q["rounds"] > 1 or q["grid"] == 1   # and no workgroup is launched for nothing
+        else:
+            if name == "wbfm":
+                assert not q["epochs"]
+        if flags & F_TILES or env_path < 0:
+            assert q["path"] == PLAN_TILES
+        if p["fused"]:
+            assert q["path"] == PLAN_STREAM                  # a fused plan in which a family fell off its pipeline cannot exist
+            ranges.append((q["wg_first"], q["grid"]))
+            if name == "wbfm":
+                assert not q["grouped"] and not q["epochs"]
+            if name in ("am", "ssb"):
+                assert vlen // 32 <= dc_tile
+    if p["fused"]:
+        ranges.sort()
+        for first, count in ranges:
+            assert first == at and count >= 1
+            at += count
+        assert at == p["mix_wgs"] <= n_cus                   # contiguous, disjoint, every workgroup a CU of its own
+    if not p["forked"]:
+        assert not p["shares_on"] and not p["fused"]
+
+
+def test_plan_call_over_everything_the_fuzzers_draw():
+    """Every family subset x row length x pin (flags, IQD_WBFM_PATH, IQD_MIXED, IQD_SHARES, IQD_STREAM_MIN_SEG) x gain / epoch
+    condition, with channel counts from one to thousands: the plan is whole (every family has a path, its segments cover the
+    row, a streaming grid covers its ids), a fused plan holds streaming families only - so the launch loop's old guard has
+    nothing left to guard - and the pins pin."""
+    import itertools
+    rng = np.random.default_rng(17)
+    n_plans = n_fused = n_stream = 0
+    vlens = [32, 96, 128, 1024, 2048, 4096, 8192, 16384, 65536, 1 << 18, 1 << 22]
+    for subset in range(1, 16):
+        names = [FAMS[f] for f in range(4) if subset >> f & 1]
+        for vlen, (flags, env_path), (mixed_forked, by_cost, min_seg) in itertools.product(
+                vlens, [(0, 0), (F_TILES, 0), (F_STREAM, 0), (0, 1), (0, -1)], [(False, False, 0), (True, False, 0), (False, True, 0), (False, False, 1)]):
+            for scale in (1, 24, 700, 4096):
+                fams = {}
+                for name in names:
+                    n = max(1, int(rng.integers(max(1, scale // 2), scale + 1)))
+                    a = int(rng.integers(0, n + 1)); b = int(rng.integers(0, n - a + 1))
+                    rc = (n, 0, 0) if rng.random() < 0.5 else (a, b, n - a - b)
+                    fams[name] = (rc, rng.random() > 0.1, name == "wbfm" and rng.random() < 0.15)
+                stream_ok = rng.random() > 0.05
+                p = plan_call(vlen, fams, flags=flags, env_path=env_path, mixed_forked=mixed_forked, by_cost=by_cost, min_seg=min_seg, stream_ok=stream_ok)
+                check_plan(p, vlen, flags, env_path, stream_ok, 256, fams)
+                assert p == plan_call(vlen, fams, flags=flags, env_path=env_path, mixed_forked=mixed_forked, by_cost=by_cost, min_seg=min_seg,
+                                      stream_ok=stream_ok)   # a pure function of its inputs (the engine keeps the plan while the shape repeats)
+                n_plans += 1
+                n_fused += p["fused"]
+                n_stream += any(q["path"] == PLAN_STREAM for q in p["fam"].values())
+                if mixed_forked:
+                    assert not p["fused"]
+                if flags & F_STREAM and vlen % 128 == 0 and vlen >= 4096:
+                    assert all(q["path"] == PLAN_STREAM for n_, q in p["fam"].items() if q["n"] and (n_ != "wbfm" or (stream_ok and fams[n_][1]))
+                               and (n_ != "fm" or fams[n_][1])), (vlen, fams, p)
+    assert n_plans > 10000 and n_fused > 150 and n_stream > 3000, (n_plans, n_fused, n_stream)
+
+
+def test_plan_call_known_configurations():
+    # BASELINE configs[1]: one WBFM row of 2^28 samples - one streaming launch over the whole chip, 5632-sample segments
+    p = plan_call(1 << 28, {"wbfm": (1, True, False)})
+    q = p["fam"]["wbfm"]
+    assert (q["path"], q["tile_len"], q["grid"], q["rounds"], q["grouped"]) == (PLAN_STREAM, 5632, 249, 1, 0) and not p["forked"]
+    # configs[2]: 4096 FM channels x 2^16
+    q = plan_call(1 << 16, {"fm": (4096, True, False)})["fam"]["fm"]
+    assert q["path"] == PLAN_STREAM and q["rounds"] == 1 and q["grid"] <= 256
+    # configs[3]: the four families as ranges of one launch
+    p = plan_call(1 << 16, {"am": (819, True, False), "fm": (819, True, False), "wbfm": (820, True, False), "ssb": (1638, True, False)})
+    assert p["fused"] and p["mix_wgs"] <= 256 and all(q["path"] == PLAN_STREAM and q["rounds"] == 1 for q in p["fam"].values())
+    # the same with a WBFM gain change in reach of a lead-in, or WBFM channels of two selectors: kernels of their own, still streaming
+    for wb in ((820, True, True), ((400, 420, 0), True, False)):
+        p = plan_call(1 << 16, {"am": (819, True, False), "fm": (819, True, False), "wbfm": wb, "ssb": (1638, True, False)})
+        assert not p["fused"] and p["shares_on"] and p["fam"]["wbfm"]["path"] == PLAN_STREAM
+        assert len({q["lane"] for q in p["fam"].values()}) >= 3          # side by side on the side streams
+    # a WBFM gain so large that (int16)y can hit the integer-indefinite value: that family on the tile kernel, and no share for anyone
+    p = plan_call(1 << 16, {"am": (819, True, False), "wbfm": (820, False, False)})
+    assert not p["fused"] and p["fam"]["wbfm"]["path"] == PLAN_TILES
+    # a row that is not whole 128-sample units (one short block of 96 samples): tile kernels
+    assert plan_call(96, {"wbfm": (3, True, False), "am": (2, True, False)})["fam"]["am"]["path"] == PLAN_TILES
+
+
+def test_planning_a_long_row_is_cheap_now():
+    """plan_fused_by_time walked vlen / 768 values of k per call (2 ms at 2^28 samples, on the submit path of a
+    call whose kernels take 0.3 ms); it visits only the k that shorten the segment now."""
+    import time
+    fams = {"fm": (1, True, False), "wbfm": (1, True, False)}
+    plan_call(1 << 28, fams)
+    t0 = time.perf_counter()
+    for _ in range(20):
+        p = plan_call(1 << 28, fams)
+    per_call = (time.perf_counter() - t0) / 20
+    assert p["fused"] and per_call < 1.5e-3, per_call       # (ctypes and numpy around it included; it was 2 ms in C alone)

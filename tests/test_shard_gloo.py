@@ -177,7 +177,13 @@ def test_prewarm_runs_the_same_number_of_steps_on_every_rank():
                           "--gather", "--no-cpu-baseline", "--no-host-path", "--prewarm-ms", "0.1"])
     eng = FakeEngine(5, 0, 0)
     out = bench.rank_body(a, 0, 1, torch.device("cpu"), lambda n_channels, flags: eng, None, torch)
-    assert eng.calls == 5 + 1 + 2 and "5 untimed steps" in out["config"]["prewarm"], (eng.calls, out["config"]["prewarm"])
+    # (W + K steps for the from-idle figure, the settle phase, then W + K again)
+    assert eng.calls == (1 + 2) + 5 + 1 + 2 and "5 untimed steps" in out["config"]["prewarm"], (eng.calls, out["config"]["prewarm"])
+    assert out["from_idle_ms_per_step"] is not None
+    a.no_from_idle = True
+    eng = FakeEngine(5, 0, 0)
+    out = bench.rank_body(a, 0, 1, torch.device("cpu"), lambda n_channels, flags: eng, None, torch)
+    assert eng.calls == 5 + 1 + 2 and out["from_idle_ms_per_step"] is None
 
 
 def test_presets_name_the_baseline_configurations():
