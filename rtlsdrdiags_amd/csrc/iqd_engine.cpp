@@ -276,6 +276,7 @@ int iqd_create(const iqd_config *cfg, iqd_t **out)
     if (const char *env = getenv("IQD_STREAM_WGS")) kn.env_stream_wgs = atoi(env) > 0 ? (uint32_t)atoi(env) : 0u;
     if (const char *env = getenv("IQD_STREAM_GRAN")) kn.env_stream_gran = (uint32_t)atoi(env);
     if (const char *env = getenv("IQD_PLAN_CHUNKS")) kn.env_plan_chunks = atoi(env) > 0 ? (uint32_t)atoi(env) : 0u;
+    if (const char *env = getenv("IQD_RINGS")) kn.env_rings = atoi(env) > 0 ? (uint32_t)atoi(env) : 0u;
     build_consts(e->consts);
     e->h_params.resize(e->n_ch);
     for (auto &p : e->h_params) default_params(p);
@@ -1150,6 +1151,7 @@ struct CallCtx {
     ChainLaunch tail_a{};                           // a tail update (WBFM: repair check + state commit + tail) that rides in the squelch launch
     int tail_f = 0;
     bool tail_pending = false;
+    bool tail_dc = false;                           // ... and the family's one-wave DC-removal pass with it (AM / SSB streaming launches)
 };
 
 int take_event_pair(iqd_t *e, CallCtx &x, hipStream_t s)
@@ -1445,6 +1447,7 @@ static int queue_family(iqd_t *e, CallCtx &x, int f)
             }
             sa.group_start[3] = fp.grouped ? fp.group_start[3] : 0u;
             sa.rounds = fp.rounds;
+            sa.rings = fp.rings;
             HIP_TRY(e, e->stream_hist.ensure((size_t)sa.n_segments * sizeof(StHist)));
             sa.hist = e->stream_hist.as<StHist>();
             a.verify_at_end = x.gated ? 2u : 1u;   // (2: the hand-offs are counted on the device - how many tiles a channel has depends on its squelch)
@@ -1474,6 +1477,7 @@ static int queue_family(iqd_t *e, CallCtx &x, int f)
             d4.fm_lut = e->d_fmlut;
             d4.halo = f == FAM_FM ? D4_HALO_FM : (f == FAM_AM ? D4_HALO_AM : D4_HALO_SSB);
             d4.rounds = fp.rounds;
+            d4.rings = fp.rings;
         }
         if (f != FAM_FM) {
             int rc = attach_dc_buffers(e, x, f, a, s);
@@ -1489,7 +1493,11 @@ static int queue_family(iqd_t *e, CallCtx &x, int f)
                 x.mix.d4[f] = d4;
             } else {
                 HIP_LAUNCH(e, launch_d4_stream(a, d4, f == FAM_FM ? D4_FM : f == FAM_AM ? D4_AM : D4_SSB, x.fused_mag, fp.grid, s));
-                if (f != FAM_FM) HIP_LAUNCH(e, launch_am_dc(a, f, s, true));
+                // the DC-removal pass: a role of the call's closing launch where there is one to ride in and the rows take the
+                // one-wave pass (round 5: 0.019 ms and a queue gap less per step); else its own launches
+                x.tail_dc = f != FAM_FM && a.dc_tiles < 2 && !forked && !x.gated && !e->demod_bypass &&
+                            (x.want_mag || x.pcm_count_dev || x.signal_present_dev || e->trace_on);
+                if (f != FAM_FM && !x.tail_dc) HIP_LAUNCH(e, launch_am_dc(a, f, s, true));
             }
             e->stats.stream_launches++;
         } else if (f == FAM_FM) {
@@ -1580,7 +1588,7 @@ static int queue_commit(iqd_t *e, CallCtx &x)
                                     (uint32_t)e->h_lists[FAM_COUNT].size(), x.call_bs, x.n_blocks, e->mag_sums.as<uint32_t>(), s));
     if (!x.gated && !e->demod_bypass && (x.want_mag || x.pcm_count_dev || x.signal_present_dev || e->trace_on)) {
         x.q.zero_sums_after = x.any_agc ? 0u : 1u;   // (a running AGC reads them again in the tracking pass)
-        HIP_LAUNCH(e, launch_squelch(x.q, true, s, x.tail_pending ? &x.tail_a : nullptr, x.tail_f));
+        HIP_LAUNCH(e, launch_squelch(x.q, true, s, x.tail_pending ? &x.tail_a : nullptr, x.tail_f, x.tail_pending && x.tail_dc));
         x.tail_pending = false;
         if (x.q.zero_sums_after) e->mag_sums_zero = (size_t)x.n_ch * x.n_blocks;
     }
@@ -1886,19 +1894,24 @@ int iqd_demod_accept(iqd_t *e, uint32_t first_ch, uint32_t n_ch, int demod, cons
     if (demod < IQD_DEMOD_AM || demod > IQD_DEMOD_SSB) return e->fail(IQD_EINVAL, "demod must be IQD_DEMOD_AM .. IQD_DEMOD_SSB");
     if (bytes_per_ch == 0 || bytes_per_ch % 64 != 0)
         return e->fail(IQD_EINVAL, "bytes_per_ch (%zu) must be a positive multiple of 64", bytes_per_ch);
-    // the channels as this call needs them; what the caller had set comes back afterwards
-    std::vector<int32_t> mode0(n_ch), rot0(n_ch);
+    // The channels as this call needs them; what the caller had set comes back afterwards.  A channel that already is in the
+    // wanted mode with selector 0 is left alone: a bare demodulator object driven call after call (demod.cc, one block per
+    // call) then costs no parameter upload, no list rebuild and no tail rewrite at all.
+    std::vector<int32_t> mode0(n_ch), rot0(n_ch), mode1(n_ch);
+    bool touched = false;
     {
         std::lock_guard<std::mutex> lk(e->mu);
         for (uint32_t c = 0; c < n_ch; c++) {
             ChanParams &p = e->h_params[first_ch + c];
             mode0[c] = p.mode;
             rot0[c] = p.rotation;
-            p.mode = demod == IQD_DEMOD_AM ? IQD_MODE_AM : demod == IQD_DEMOD_FM ? IQD_MODE_FM : demod == IQD_DEMOD_WBFM ? IQD_MODE_WBFM
-                                           : (p.ssb_lsb ? IQD_MODE_LSB : IQD_MODE_USB);
+            mode1[c] = demod == IQD_DEMOD_AM ? IQD_MODE_AM : demod == IQD_DEMOD_FM ? IQD_MODE_FM : demod == IQD_DEMOD_WBFM ? IQD_MODE_WBFM
+                                             : (p.ssb_lsb ? IQD_MODE_LSB : IQD_MODE_USB);
+            touched = touched || p.mode != mode1[c] || p.rotation != 0;
+            p.mode = mode1[c];
             p.rotation = 0;
         }
-        e->params_dirty = e->lists_dirty = true;
+        if (touched) e->params_dirty = e->lists_dirty = true;
     }
     e->demod_bypass = true;
     int rc = IQD_OK;
@@ -1925,12 +1938,14 @@ int iqd_demod_accept(iqd_t *e, uint32_t first_ch, uint32_t n_ch, int demod, cons
         t0 += t;
     }
     e->demod_bypass = false;
-    {
+    if (touched) {
+        // only what this call wrote and nobody has changed since: a setter that ran meanwhile (the mutex is there for setters
+        // against accepts) keeps its value
         std::lock_guard<std::mutex> lk(e->mu);
         for (uint32_t c = 0; c < n_ch; c++) {
             ChanParams &p = e->h_params[first_ch + c];
-            p.mode = mode0[c];
-            p.rotation = rot0[c];
+            if (p.mode == mode1[c]) p.mode = mode0[c];
+            if (p.rotation == 0) p.rotation = rot0[c];
         }
         e->params_dirty = e->lists_dirty = true;
     }

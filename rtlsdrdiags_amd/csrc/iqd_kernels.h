@@ -111,7 +111,8 @@ hipError_t launch_write_word(uint32_t *word, uint32_t value, hipStream_t s);   /
 hipError_t launch_magnitude(const uint8_t *iq, size_t ch_stride_bytes, const uint32_t *ch_list, uint32_t n_list,
                             uint32_t block_samples, uint32_t n_blocks, uint32_t *mag_sums, hipStream_t s);
 // tail_of: a one-family call hands its pending tail update to the squelch launch (tail_squelch_kernel)
-hipError_t launch_squelch(const SquelchLaunch &q, bool always_open, hipStream_t s, const ChainLaunch *tail_of = nullptr, int tail_family = 0);
+// tail_dc: the riding family is AM or SSB on its streaming pipeline and its one-wave DC-removal pass rides along too
+hipError_t launch_squelch(const SquelchLaunch &q, bool always_open, hipStream_t s, const ChainLaunch *tail_of = nullptr, int tail_family = 0, bool tail_dc = false);
 hipError_t launch_tile_fill(uint8_t *dst, size_t period, size_t total, hipStream_t s);
 
 }  // namespace iqd

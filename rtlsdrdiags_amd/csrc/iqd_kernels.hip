@@ -540,6 +540,30 @@ __global__ __launch_bounds__(256) void tail_squelch_kernel(const ChainLaunch a, 
     else squelch_block_body(q, always_open, (blockIdx.x - a.n_list) * 256u + threadIdx.x);
 }
 
+// ... and for a call whose one family is AM or SSB on its streaming pipeline (round 5): the DC-removal pass of the channels - the
+// one-wave pass of dc_wave_kernel, which used to be a launch of its own between the pipeline and this one (0.019 ms + a queue gap
+// of the 0.2 ms step) - is a third role: workgroups n_list .. 2 n_list - 1, their first wave.  It depends on the pipeline only.
+__global__ __launch_bounds__(256) void tail_dc_squelch_kernel(const ChainLaunch a, int family, const SquelchLaunch q, int always_open)
+{
+    __shared__ DcLds lds;
+    if (blockIdx.x < a.n_list) {
+        tail_update_body(a, family, blockIdx.x);
+    } else if (blockIdx.x < 2 * a.n_list) {
+        if (threadIdx.x >= 64) return;
+        const uint32_t li = blockIdx.x - a.n_list;
+        const uint32_t ch = a.ch_list[li], ech = a.first_ch + ch;
+        const uint32_t vlen = a.vlen_gated ? a.vlen_gated[ch] : a.vlen;
+        const ChanParams &p = a.params[ech];
+        DcCarry st = a.dc_carry[2 * (size_t)ech + (family == FAM_SSB ? 1 : 0)];
+        DeviceExec ex{(int)threadIdx.x};
+        dc_block_wave(ex, g_consts, lds, a.base8k + (size_t)ch * a.base_stride_ch, (int)(vlen / 32), p.gain[family], st,
+                      a.pcm + (size_t)ch * a.pcm_stride);
+        if (threadIdx.x == 0) a.dc_carry[2 * (size_t)ech + (family == FAM_SSB ? 1 : 0)] = st;
+    } else {
+        squelch_block_body(q, always_open, (blockIdx.x - 2 * a.n_list) * 256u + threadIdx.x);
+    }
+}
+
 // The same for a call whose one family is WBFM: hand-off repair check, state commit and tail (workgroups 0 .. n_list-1)
 // beside the squelch pass's first part.
 __global__ __launch_bounds__(WB_THREADS, IQD_WBFM_MIN_WAVES) void wbfm_repair_squelch_kernel(const ChainLaunch a, const SquelchLaunch q, int always_open)
@@ -1104,10 +1128,12 @@ hipError_t launch_magnitude(const uint8_t *iq, size_t ch_stride_bytes, const uin
     return hipGetLastError();
 }
 
-hipError_t launch_squelch(const SquelchLaunch &q, bool always_open, hipStream_t s, const ChainLaunch *tail_of, int tail_family)
+hipError_t launch_squelch(const SquelchLaunch &q, bool always_open, hipStream_t s, const ChainLaunch *tail_of, int tail_family, bool tail_dc)
 {
     const uint32_t n = q.n_ch * q.n_blocks;
-    if (tail_of && tail_family == FAM_WBFM)
+    if (tail_of && tail_dc)
+        hipLaunchKernelGGL(tail_dc_squelch_kernel, dim3(2 * tail_of->n_list + (n + 255) / 256), dim3(256), 0, s, *tail_of, tail_family, q, always_open ? 1 : 0);
+    else if (tail_of && tail_family == FAM_WBFM)
         hipLaunchKernelGGL(wbfm_repair_squelch_kernel, dim3(tail_of->n_list + (n + 255) / 256), dim3(WB_THREADS), 0, s, *tail_of, q, always_open ? 1 : 0);
     else if (tail_of)
         hipLaunchKernelGGL(tail_squelch_kernel, dim3(tail_of->n_list + (n + 255) / 256), dim3(256), 0, s, *tail_of, tail_family, q, always_open ? 1 : 0);

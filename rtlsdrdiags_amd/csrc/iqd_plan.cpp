@@ -43,6 +43,34 @@ uint32_t group_ids(const FamilyShape &s, FamilyPlan &p)
     return at;
 }
 
+// Rings of 64 segments per workgroup of family f's streaming launch (StreamArgs::rings), round 5.  A launch too small to give
+// every CU a full workgroup of three rings used to fill a part of the chip with full workgroups of minimum-length segments;
+// spread over all CUs as workgroups of one or two rings its segments are longer (less lead-in per sample) and a ring's pieces go
+// by faster with fewer rings beside it: per piece 0.80 (two rings) and 0.62 (one) of the three-ring time for FM and WBFM, 0.72
+// and 0.50 for AM / SSB (whose P waves are the lighter), fitted to tools/rings_probe.sh on 256 CUs (256 to 16 384 channels x
+// 2^14 .. 2^16; profiles/r5_rings_probe.txt: the rule picks the fastest arrangement in 14 of the 15 cases measured, second by
+// 2 % in the other).  The estimate is pieces per segment x that factor.  Streaming launches of 1024 channels x 2^14: AM 0.076 ->
+// 0.064 ms per step, FM 0.087 -> 0.076, WBFM 0.124 -> 0.104; 4096 x 2^14: AM 0.085 -> 0.081, WBFM 0.164 -> 0.158; larger: three rings.
+uint32_t rings_of(const PlanKnobs &k, const CallShape &c, int f, uint32_t wgs, bool fused, bool grouped)
+{
+    if (fused) return (uint32_t)ST_RINGS;   // (the shares of the one launch are planned in workgroups of three rings: plan_fused_by_time)
+    if (k.env_rings >= 1 && k.env_rings <= (uint32_t)ST_RINGS) return k.env_rings;
+    static const float heavy[4] = {0.f, 0.62f, 0.80f, 1.0f}, light[4] = {0.f, 0.50f, 0.72f, 1.0f};
+    const float *per_piece = f == FAM_AM || f == FAM_SSB ? light : heavy;
+    const FamilyShape &s = c.fam[f];
+    const uint32_t granule = f == FAM_WBFM ? k.env_stream_gran : k.env_d4_gran;
+    uint32_t best = (uint32_t)ST_RINGS;
+    float best_t = 0.f;
+    for (uint32_t r = (uint32_t)ST_RINGS; r >= 1; r--) {
+        const uint32_t slots = wgs * 64u * r;
+        const TilePlan sp = plan_stream(c.vlen, s.n_list, slots > 48 ? slots - (grouped ? 48u : 0u) : slots, granule);
+        if ((uint64_t)sp.tiles_per_ch * s.n_list > slots) continue;        // (a second round: never better)
+        const float t = per_piece[r] * (float)(sp.tile_len + halo_of(f));
+        if (r == (uint32_t)ST_RINGS || t < 0.99f * best_t) { best = r; best_t = t; }
+    }
+    return best;
+}
+
 // One pass over the call with the one-launch arrangement allowed or not.  Returns false when `allow_fused` was taken and a
 // family then fell off its streaming pipeline - which the predicates below exclude by construction; plan_call() then plans
 // again without it, BEFORE anything is queued (round 4 had this as a guard inside the launch loop, behind the pre-pass).
@@ -153,18 +181,24 @@ bool plan_once(const PlanKnobs &k, const CallShape &c, bool allow_fused, CallPla
             if (ok && want >= 0 && enough) {
                 p.path = PLAN_STREAM;
                 p.grouped = mixed_selectors;
-                for (uint32_t spare = 0;; spare += 48) {   // (the groups' padding may push an exact fit into a second round)
-                    const TilePlan sp = plan_stream(vlen, s.n_list, p.wgs * ST_SEGS - (p.grouped ? spare : 0u), k.env_stream_gran);
-                    p.tile_len = sp.tile_len;
-                    p.tiles_per_ch = sp.tiles_per_ch;
-                    if (!p.grouped) break;
-                    const uint32_t at = group_ids(s, p);
-                    if (at <= p.wgs * ST_SEGS || spare >= 48 || s.n_list * 1u >= p.wgs * ST_SEGS) break;
+                p.rings = rings_of(k, c, f, p.wgs, fused, p.grouped);
+                for (;;) {
+                    const uint32_t wg_segs = 64u * p.rings;
+                    for (uint32_t spare = 0;; spare += 48) {   // (the groups' padding may push an exact fit into a second round)
+                        const TilePlan sp = plan_stream(vlen, s.n_list, p.wgs * wg_segs - (p.grouped ? spare : 0u), k.env_stream_gran);
+                        p.tile_len = sp.tile_len;
+                        p.tiles_per_ch = sp.tiles_per_ch;
+                        if (!p.grouped) break;
+                        const uint32_t at = group_ids(s, p);
+                        if (at <= p.wgs * wg_segs || spare >= 48 || s.n_list * 1u >= p.wgs * wg_segs) break;
+                    }
+                    const uint32_t ids = p.grouped ? p.group_start[3] : s.n_list * p.tiles_per_ch;
+                    const uint32_t wgs_needed = (ids + wg_segs - 1) / wg_segs;
+                    p.grid = wgs_needed < p.wgs ? wgs_needed : p.wgs;
+                    p.rounds = (wgs_needed + p.grid - 1) / p.grid;
+                    if (p.rounds == 1 || p.rings == (uint32_t)ST_RINGS || k.env_rings) break;
+                    p.rings = (uint32_t)ST_RINGS;   // (workgroups of fewer rings are for launches of one round)
                 }
-                const uint32_t ids = p.grouped ? p.group_start[3] : s.n_list * p.tiles_per_ch;
-                const uint32_t wgs_needed = (ids + ST_SEGS - 1) / ST_SEGS;
-                p.grid = wgs_needed < p.wgs ? wgs_needed : p.wgs;
-                p.rounds = (wgs_needed + p.grid - 1) / p.grid;
                 p.epochs = s.epochs_in_reach;
             }
         } else if (whole_units && (f == FAM_FM || vlen / 32 >= k.env_am_stream_min)) {
@@ -174,17 +208,23 @@ bool plan_once(const PlanKnobs &k, const CallShape &c, bool allow_fused, CallPla
             if (ok && want >= 0 && enough) {
                 p.path = PLAN_STREAM;
                 p.grouped = true;
-                for (uint32_t spare = 0;; spare += 48) {   // (the rotation groups' padding may push an exact fit into a second round)
-                    // (these pipelines store 8 or 16 bytes per 128 samples: no wide stores to keep whole)
-                    const TilePlan sp = plan_stream(vlen, s.n_list, p.wgs * ST_SEGS - spare, k.env_d4_gran);
-                    p.tile_len = sp.tile_len;
-                    p.tiles_per_ch = sp.tiles_per_ch;
-                    const uint32_t at = group_ids(s, p);
-                    if (at <= p.wgs * ST_SEGS || spare >= 48 || s.n_list * 1u >= p.wgs * ST_SEGS) break;
+                p.rings = rings_of(k, c, f, p.wgs, fused, true);
+                for (;;) {
+                    const uint32_t wg_segs = 64u * p.rings;
+                    for (uint32_t spare = 0;; spare += 48) {   // (the rotation groups' padding may push an exact fit into a second round)
+                        // (these pipelines store 8 or 16 bytes per 128 samples: no wide stores to keep whole)
+                        const TilePlan sp = plan_stream(vlen, s.n_list, p.wgs * wg_segs - spare, k.env_d4_gran);
+                        p.tile_len = sp.tile_len;
+                        p.tiles_per_ch = sp.tiles_per_ch;
+                        const uint32_t at = group_ids(s, p);
+                        if (at <= p.wgs * wg_segs || spare >= 48 || s.n_list * 1u >= p.wgs * wg_segs) break;
+                    }
+                    const uint32_t wgs_needed = (p.group_start[3] + wg_segs - 1) / wg_segs;
+                    p.grid = wgs_needed < p.wgs ? wgs_needed : p.wgs;
+                    p.rounds = (wgs_needed + p.grid - 1) / p.grid;
+                    if (p.rounds == 1 || p.rings == (uint32_t)ST_RINGS || k.env_rings) break;
+                    p.rings = (uint32_t)ST_RINGS;   // (workgroups of fewer rings are for launches of one round)
                 }
-                const uint32_t wgs_needed = (p.group_start[3] + ST_SEGS - 1) / ST_SEGS;
-                p.grid = wgs_needed < p.wgs ? wgs_needed : p.wgs;
-                p.rounds = (wgs_needed + p.grid - 1) / p.grid;
             }
         }
         if (fused) {

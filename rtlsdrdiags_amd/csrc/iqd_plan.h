@@ -23,8 +23,12 @@ namespace iqd {
 // (second probe, around the thresholds: FM 640 x 2^16 0.085 / 0.088, 768 x 2^16 0.087 / 0.095; WBFM 384 x 2^16 0.120 / 0.099; AM / USB
 // 768 x 2^16 0.075 / 0.074 and 0.087 / 0.082, 896 x 2^16 0.075 / 0.083 and 0.086 / 0.093, 1024 x 2^14 0.074 / 0.079 and 0.084 / 0.082;
 // several families: 128 x 2^14 0.099 / 0.125, 16 x 2^16 0.100 / 0.120, 1024 x 2^12 0.098 / 0.101, 512 x 2^12 0.096 / 0.076)
-constexpr uint64_t STREAM_MIN_SEG_WBFM = 600, STREAM_MIN_SEG_FM = 900, STREAM_MIN_SEG_AM = 1000, STREAM_MIN_SEG_SSB = 1100,
-                   STREAM_MIN_SEG_AM_SHORT = 320, STREAM_MIN_SEG_SSB_SHORT = 450,   // rows of up to 2^14 samples
+// Round 5 (workgroups of fewer rings for small launches, rings_of(); tools/r5_fourth.sh, profiles/r5_threshold_probe.txt, default /
+// tiles / stream): USB 1024 x 2^14 0.0828 / 0.0808 / 0.0693 and 768 x 2^16 0.0814 / 0.0823 / 0.0776 - the SSB thresholds came down
+// (1100 -> 1000, short rows 450 -> 330); every other crossover stayed where it was (FM 512 x 2^16 0.0697 tiles / 0.0848 stream,
+// 768 x 2^16 0.0945 / 0.0859; AM 512 x 2^16 0.0545 / 0.0662, 1024 x 2^14 0.0784 / 0.0626; WBFM 256 x 2^16 0.0844 / 0.1015, 512 x 2^16 0.1469 / 0.1164).
+constexpr uint64_t STREAM_MIN_SEG_WBFM = 600, STREAM_MIN_SEG_FM = 900, STREAM_MIN_SEG_AM = 1000, STREAM_MIN_SEG_SSB = 1000,
+                   STREAM_MIN_SEG_AM_SHORT = 320, STREAM_MIN_SEG_SSB_SHORT = 330,   // rows of up to 2^14 samples
                    STREAM_MIN_SEG_MIXED = 16, STREAM_MIN_SEG_MIXED_SHORT = 96,      // one launch for all families; rows below 2^13 samples
                    STREAM_MIN_SEG_FORKED = 1024;                                    // several families as kernels on streams
 // AM / SSB rows at least this long (PCM samples) may take their streaming pipeline; the DC pass behind it is then the
@@ -45,6 +49,7 @@ struct PlanKnobs {
     bool env_mixed_forked = false;       // IQD_MIXED=forked: several families as kernels of their own side by side (A/B runs)
     bool env_shares_by_cost = false;     // IQD_SHARES=cost: round 3's proportional shares
     uint32_t env_stream_wgs = 0, env_plan_chunks = 0, env_stream_gran = 0;   // IQD_STREAM_WGS, IQD_PLAN_CHUNKS, IQD_STREAM_GRAN
+    uint32_t env_rings = 0;              // IQD_RINGS=1|2|3: rings per workgroup of every streaming launch (0: choose; measurement runs)
     // ns per sample of a segment (lead-in included) of one workgroup's 192 segments in lock step, inside the one launch that
     // holds all four pipelines: WBFM 224 us for 3072 + 768, FM 225 for 5120 + 768, AM 214 for 9472 + 384, SSB 226 for 9472 + 1280
     // (tools/mixed_probe.py, 4096 channels x 2^16).  IQD_FAMILY_NS=am,fm,wbfm,ssb
@@ -82,6 +87,7 @@ struct FamilyPlan {
     bool grouped = false;                // segment ids grouped by rotation selector, each group padded to 16 (WBFM: only if mixed)
     uint32_t group_start[4] = {0, 0, 0, 0}, group_li0[3] = {0, 0, 0}, group_nseg[3] = {0, 0, 0};
     uint32_t grid = 0, rounds = 0;       // workgroups launched, rounds each runs
+    uint32_t rings = 3;                  // rings of 64 segments per workgroup (StreamArgs::rings)
     uint32_t wg_first = 0;               // one launch for all families: the family's first workgroup
     bool epochs = false;                 // WBFM: the instantiation with the piecewise-gain lookup
 };

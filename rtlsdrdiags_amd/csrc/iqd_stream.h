@@ -25,7 +25,7 @@ constexpr int ST_WAVES = 15;
 constexpr int ST_THREADS = 64 * ST_WAVES;
 constexpr int ST_RINGS = 3;                 // = IIR waves
 constexpr int ST_P_PER_RING = 4;            // P waves feeding one ring (16 segments each)
-constexpr int ST_SEGS = 64 * ST_RINGS;      // segments per workgroup and round
+constexpr int ST_SEGS = 64 * ST_RINGS;      // segments per workgroup and round when all its rings run (StreamArgs::rings)
 constexpr int ST_HALO = FORCED_BACK;         // lead-in of every segment, 768 samples.  A warm segment (a call's first) runs
                                             // them from the carried exact state, which also rebuilds its decimator
                                             // histories.  A cold one uses them for the de-emphasis state to become exact
@@ -78,6 +78,9 @@ struct StreamArgs {
     const float *half_lut;    // [129][ST_ROW_FLOATS]: |atan2(-r, x - 128)|
     uint32_t n_segments;      // n_list * tiles_per_ch
     uint32_t rounds;          // rounds per workgroup
+    uint32_t rings;           // rings of 64 segments a workgroup runs, 1 .. ST_RINGS (round 5: a small launch spreads its segments over
+                              // all CUs as workgroups of one or two rings - a ring's pieces go by faster with fewer rings beside it -
+                              // instead of filling a third of the CUs with three; the waves of the other rings leave at once)
     // Channels of several rotation selectors in one launch (round 4; the kernel instantiation with ROT = 2): the channel
     // list is sorted by selector (+Fs/4, none, -Fs/4) and each group's segment ids are padded to a multiple of 16, so that
     // a P wave's 16 segments share their tap matrices - as the FM / AM / SSB pipelines do (D4Args).  grouped = 0: ids are
@@ -105,6 +108,7 @@ struct D4Args {
     uint32_t group_li0[3];       // first channel-list index of each group (the list is sorted by group)
     uint32_t group_nseg[3];      // real segments in each group
     uint32_t rounds;
+    uint32_t rings;              // rings a workgroup runs (StreamArgs::rings)
     int32_t halo;
     uint32_t s2p[6], s3p[8];     // AM/SSB stage 2 (12 taps, DOUBLED: the result is the accumulator's high half) and stage 3 (16 taps) as v_dot2 pairs, newest pair first
     uint32_t hilb[16];           // SSB: the nonzero Hilbert taps h[0], h[2], ..., h[30] (int16 in the low half)

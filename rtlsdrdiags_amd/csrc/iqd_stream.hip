@@ -41,6 +41,14 @@ __device__ __forceinline__ uint32_t st_table_read(uint32_t byte_offset) { return
 #ifndef IQD_ST_LEVEL_PROBE
 #define IQD_ST_LEVEL_PROBE 0
 #endif
+// Lead-in of a ring whose 64 segments are all cold and of full length (the IIR wave's fast path): a cold segment's lead-in only
+// has to make its de-emphasis state exact (its decimators' histories are replaced by the boundary fix-up), which takes 319 steps
+// on average, p99.9 446, maximum 554 over 10^6 starts (tools/deemph_convergence.py); a state that has not converged is caught by
+// the hand-off verification and repaired by the tile kernel.  768 = every segment runs the full ST_HALO (rounds 2-4).
+#ifndef IQD_ST_COLD_HALO
+#define IQD_ST_COLD_HALO 768
+#endif
+static_assert(IQD_ST_COLD_HALO % 128 == 0 && IQD_ST_COLD_HALO <= 768 && IQD_ST_COLD_HALO >= 256, "cold lead-in: whole quads of pieces within ST_HALO");
 #ifndef IQD_ST_TRACE      // diagnostic build: workgroup 5 writes clock64() of (hardware wave, piece, event k) to stamps[64 + ((wave * 256 + piece) * 4 + k)]
 #define IQD_ST_TRACE 0
 #endif
@@ -84,6 +92,8 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
     // writer has signalled, i.e. exactly when that writer begins its next piece)
     const int cg = pw / ST_RINGS, ring = (pw + (cg == ST_P_PER_RING - 1 ? IQD_ST_YOUNG_SHIFT : 0)) % ST_RINGS;
 #endif
+    if (ring >= (int)sa.rings) return;                           // (a workgroup of fewer rings: this wave's is not there)
+    const uint32_t wg_segs = 64u * sa.rings;                     // segments per workgroup and round
     const int g = lane >> 4, c = lane & 15;
     const uint32_t row = (uint32_t)(16 * cg + c);                // ring row of this lane's segment
     uint8_t *ring_base = lds + ST_TABLE_BYTES + ring * (ST_RING_SLOTS * ST_SLOT_BYTES);
@@ -106,11 +116,19 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
     uint64_t inv_2pi = 0x3e22f9843e22f984ull;                    // (float)(1 / (2 pi)) twice: the scalar operand of v_pk_mul_f32
     asm volatile("" : "+s"(inv_2pi));
     for (uint32_t round = 0; round < sa.rounds; round++) {
-        if ((round * chain_wgs(a) + chain_wg(a)) * ST_SEGS >= st_id_count(sa)) break;   // nothing left for this workgroup
-        const uint32_t sid = (round * chain_wgs(a) + chain_wg(a)) * ST_SEGS + ring * 64 + row;
+        if ((round * chain_wgs(a) + chain_wg(a)) * wg_segs >= st_id_count(sa)) break;   // nothing left for this workgroup
+        const uint32_t sid = (round * chain_wgs(a) + chain_wg(a)) * wg_segs + ring * 64 + row;
         int rot_of_id = ROT;
         const StSeg sg = BYGROUP ? st_segment_of(a, sa, sid, rot_of_id) : st_segment(a, sid, sa.n_segments);
         if (BYGROUP && __builtin_amdgcn_readfirstlane(rot_of_id) != ROT) continue;   // (uniform: groups are padded to 16 ids)
+        // pieces of the lead-in this ring skips (IQD_ST_COLD_HALO): the IIR wave's `fast` predicate, evaluated here over the ring's
+        // 64 ids, one per lane - the ring's five waves must agree on it
+        int q_first = 0;
+        if (IQD_ST_COLD_HALO < ST_HALO && !BYGROUP && !GATED && !EPOCHS) {
+            const StSeg ps = st_segment(a, sid - row + (uint32_t)lane, sa.n_segments);
+            q_first = __all(st_cold_and_full(ps, a.tile_len)) ? (ST_HALO - IQD_ST_COLD_HALO) / 32 : 0;
+        }
+        const int lead = ST_HALO - 32 * q_first;                 // this ring's lead-in, samples
         const ChanParams &p = a.params[sg.ech];
         const uint8_t *iq_ch = a.iq + (size_t)sg.ch * a.ch_stride_bytes;
         const uint8_t *tail = a.tails + ((size_t)sg.ech * FAM_COUNT + FAM_WBFM) * TAIL_BYTES + TAIL_BYTES;
@@ -164,11 +182,11 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
         // first segment's lead-in ends (below, once per segment) - instead of piece_address()'s six operations per piece.
         const int32_t pos_last = pos_max & ~31;
         const bool from_tail = sg.v0 == 0;                       // (tile_len >= ST_MIN_TILE = ST_HALO: only a first segment's lead-in reads the tail inside the loop)
-        const uint8_t *nxt = piece_address(-ST_HALO + 32 * ST_AHEAD);
-        uint4 prev = st_front<ROT>(*(const uint4 *)piece_address(-ST_HALO - 32), zero);
+        const uint8_t *nxt = piece_address(-lead + 32 * ST_AHEAD);
+        uint4 prev = st_front<ROT>(*(const uint4 *)piece_address(-lead - 32), zero);
         v4u raw[ST_AHEAD];
 #pragma unroll
-        for (int j = 0; j < ST_AHEAD; j++) raw[j] = gload16_untracked(piece_address(-ST_HALO + 32 * j));
+        for (int j = 0; j < ST_AHEAD; j++) raw[j] = gload16_untracked(piece_address(-lead + 32 * j));
         // theta' of the sample before the lead-in (a warm segment's carried state applies from the lead-in's very first
         // sample, whose delta theta needs it): the last output of the piece before, from that piece's "N" window
         float last_prev;                                         // theta'[3] of this lane's previous window
@@ -281,8 +299,12 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
                     m.y = __builtin_rintf(m.y);
                     d = __builtin_elementwise_fma(-m, v2f{6.28318548202514648f, 6.28318548202514648f}, d);
                     d = __builtin_elementwise_fma(-m, v2f{-1.74845553146951715e-7f, -1.74845553146951715e-7f}, d);
+#if IQD_RELAXED_TOL   // (timing A/B only: one rounding instead of two)
+                    const v2f w = d * v2f{kk * sa.b0, kk * sa.b0};
+#else
                     const v2f v = d * v2f{kk, kk};
                     const v2f w = v2f{sa.b0, sa.b0} * v;
+#endif
                     u[half][r] = w.x;
                     u[half][r + 1] = w.y;
                 }
@@ -311,7 +333,7 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
 #endif
         };
         uint4 other;
-        for (int q = 0; q < n_pieces; q += ST_AHEAD) {   // (n_pieces is a multiple of 4)
+        for (int q = q_first; q < n_pieces; q += ST_AHEAD) {   // (n_pieces and q_first are multiples of 4)
 #pragma unroll
             for (int j = 0; j < ST_AHEAD; j += 2) {
                 do_piece(q + j, j, prev, other);
@@ -543,11 +565,11 @@ __device__ __forceinline__ int st_iir_piece(const ChainLaunch &a, const StreamAr
 // The lead-in of a wave whose segments are all cold: only the de-emphasis recurrence (its state is what the lead-in is
 // for; a cold segment's decimators start with histories that the boundary fix-up replaces anyway).
 __device__ __forceinline__ void st_iir_lead_in(const StreamArgs &sa, uint8_t *ring_base, const uint32_t *full, uint32_t *consumed,
-                                               uint32_t &wg, StIir &s, uint32_t rd_off0, uint32_t rd_swz)
+                                               uint32_t &wg, StIir &s, uint32_t rd_off0, uint32_t rd_swz, int lead)
 {
     float y = s.y, up = s.up;
     const float a1 = sa.a1;
-    for (int piece = 0; piece < ST_HALO / 32; piece++) {
+    for (int piece = 0; piece < lead / 32; piece++) {   // (the ring's P waves skip the same pieces: st_p_wave, q_first)
         const uint32_t target = 4u * (wg / (uint32_t)ST_DEPTH + 1u);
         while ((int32_t)(lds_load_relaxed(ST_DEPTH > 1 ? full + (wg & (uint32_t)(ST_DEPTH - 1)) : full) - target) < 0) __builtin_amdgcn_s_sleep(IQD_ST_SLEEP_I);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -570,18 +592,22 @@ __device__ __forceinline__ void st_iir_lead_in(const StreamArgs &sa, uint8_t *ri
     s.up = up;
 }
 
+// lead_cold: the lead-in of a ring whose segments are all cold and of full length (IQD_ST_COLD_HALO where the launch's P waves
+// take it, ST_HALO otherwise)
 __device__ __forceinline__ void st_iir_wave(const ChainLaunch &a, const StreamArgs &sa, uint8_t *lds, uint32_t *sync,
-                                            int ring, int lane)
+                                            int ring, int lane, int lead_cold)
 {
     uint8_t *ring_base = lds + ST_TABLE_BYTES + ring * (ST_RING_SLOTS * ST_SLOT_BYTES);
     const uint32_t *full = sync + ring * 8;
     uint32_t *consumed = sync + ring * 8 + 4;
     const uint32_t rd_off0 = (uint32_t)lane * 64u, rd_swz = ((uint32_t)lane >> 2) & 3u;
     const int n_pieces = (ST_HALO + (int)a.tile_len) >> 5;       // a multiple of 4
+    if (ring >= (int)sa.rings) return;
+    const uint32_t wg_segs = 64u * sa.rings;
     uint32_t wg = 0;                                             // pieces read so far (all rounds)
     for (uint32_t round = 0; round < sa.rounds; round++) {
-        if ((round * chain_wgs(a) + chain_wg(a)) * ST_SEGS >= st_id_count(sa)) break;
-        const uint32_t sid = (round * chain_wgs(a) + chain_wg(a)) * ST_SEGS + ring * 64 + lane;
+        if ((round * chain_wgs(a) + chain_wg(a)) * wg_segs >= st_id_count(sa)) break;
+        const uint32_t sid = (round * chain_wgs(a) + chain_wg(a)) * wg_segs + ring * 64 + lane;
         StIirSeg q;
         int rot_unused;
         q.sg = st_segment_of(a, sa, sid, rot_unused);
@@ -640,11 +666,12 @@ __device__ __forceinline__ void st_iir_wave(const ChainLaunch &a, const StreamAr
         // wide stores need whole 512-sample groups per lane (tile_len a multiple of 512) and 32-byte aligned rows
         const bool wide = (a.tile_len & 511u) == 0 && (((uintptr_t)a.pcm | (a.pcm_stride * 2)) & 31u) == 0;
         // (a segment that is not there has tlen 0 and stores nothing: it may run along with any kind of wave)
+        // (the P waves evaluate the same predicate, st_cold_and_full(): a ring's waves must agree on its lead-in)
         const bool fast = __all(!q.sg.valid || (q.back < 0 && q.sg.tlen == (int32_t)a.tile_len && !keeps_restart)) != 0;
         const int rec_pos_uniform = (int)a.tile_len - FORCED_BACK;
         int pq0 = 0;
         if (fast) {
-            st_iir_lead_in(sa, ring_base, full, consumed, wg, s, rd_off0, rd_swz);
+            st_iir_lead_in(sa, ring_base, full, consumed, wg, s, rd_off0, rd_swz, lead_cold);
             q.rec.y_in = s.y;                                    // the warmed-up state, checked against the predecessor's end
             pq0 = ST_HALO / 32;
         }
@@ -728,7 +755,7 @@ __device__ __forceinline__ void wbfm_stream_body(const ChainLaunch &a, const Str
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     uint32_t pc = 0;                                             // pieces this wave's ring has seen (all rounds)
-    if (wave < ST_RINGS) st_iir_wave(a, sa, st_lds, sync, wave, lane);
+    if (wave < ST_RINGS) st_iir_wave(a, sa, st_lds, sync, wave, lane, ROT != 2 && !GATED && !EPOCHS ? IQD_ST_COLD_HALO : ST_HALO);
     else if (ROT != 2) st_p_wave<ROT, MAG, EPOCHS, GATED>(a, sa, st_lds, sync, wave - ST_RINGS, lane, pc);
     else {   // channels of several rotation selectors: the groups in their order
         st_p_wave<1, MAG, EPOCHS, GATED, true>(a, sa, st_lds, sync, wave - ST_RINGS, lane, pc);

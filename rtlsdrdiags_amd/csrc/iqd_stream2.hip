@@ -366,6 +366,8 @@ __device__ __forceinline__ void d4_p_wave(const ChainLaunch &a, const D4Args &da
 #else
     const int ring = pw % ST_RINGS, cg = pw / ST_RINGS;
 #endif
+    if (ring >= (int)da.rings) return;                         // (a workgroup of fewer rings, D4Args::rings: this wave's is not there)
+    const uint32_t wg_segs = 64u * da.rings;
     const int g = lane >> 4, c = lane & 15;
     const uint32_t row = (uint32_t)(16 * cg + c);
     uint8_t *ring_base = lds + ring * (D4_SLOTS * D4_SLOT_BYTES);
@@ -374,8 +376,8 @@ __device__ __forceinline__ void d4_p_wave(const ChainLaunch &a, const D4Args &da
     const uint32_t wr_off = MODE == D4_FM ? row * 16u + 4u * (uint32_t)g : d4_ring_off(row, (uint32_t)g);   // FM: one dword per lane
     uint32_t pg = 0;                                           // quads this ring has seen (all rounds)
     for (uint32_t round = 0; round < da.rounds; round++) {
-        if ((round * chain_wgs(a) + chain_wg(a)) * ST_SEGS >= da.group_start[3]) break;   // nothing left for this workgroup
-        const uint32_t sid0 = (round * chain_wgs(a) + chain_wg(a)) * ST_SEGS + ring * 64 + 16 * cg;
+        if ((round * chain_wgs(a) + chain_wg(a)) * wg_segs >= da.group_start[3]) break;   // nothing left for this workgroup
+        const uint32_t sid0 = (round * chain_wgs(a) + chain_wg(a)) * wg_segs + ring * 64 + 16 * cg;
         const D4Seg sg = d4_segment(a, da, sid0 + (uint32_t)c);
 #if IQD_D4_TRANSPOSE
         const D4Seg sgl = d4_segment(a, da, sid0 + (uint32_t)(lane >> 2));
@@ -546,10 +548,12 @@ __device__ __forceinline__ void d4_am_wave(const ChainLaunch &a, const D4Args &d
     const uint32_t *full = sync + ring * D4_QUADS;
     uint32_t *consumed = sync + ST_RINGS * D4_QUADS + ring;
     const int n_pieces = (da.halo + (int)a.tile_len) >> 5;
+    if (ring >= (int)da.rings) return;
+    const uint32_t wg_segs = 64u * da.rings;
     uint32_t pg = 0;
     for (uint32_t round = 0; round < da.rounds; round++) {
-        if ((round * chain_wgs(a) + chain_wg(a)) * ST_SEGS >= da.group_start[3]) break;
-        const uint32_t sid = (round * chain_wgs(a) + chain_wg(a)) * ST_SEGS + ring * 64 + lane;
+        if ((round * chain_wgs(a) + chain_wg(a)) * wg_segs >= da.group_start[3]) break;
+        const uint32_t sid = (round * chain_wgs(a) + chain_wg(a)) * wg_segs + ring * 64 + lane;
         const D4Seg sg = d4_segment(a, da, sid);
         const int lsb = a.params[sg.ech].ssb_lsb;
         int32_t *base_row = a.base8k + (size_t)sg.ch * a.base_stride_ch;
@@ -664,10 +668,12 @@ __device__ __forceinline__ void d4_fm_wave(const ChainLaunch &a, const D4Args &d
     const uint32_t *full = sync + ring * D4_QUADS;
     uint32_t *consumed = sync + ST_RINGS * D4_QUADS + ring;
     const int n_pieces = (da.halo + (int)a.tile_len) >> 5;
+    if (ring >= (int)da.rings) return;
+    const uint32_t wg_segs = 64u * da.rings;
     uint32_t pg = 0;
     for (uint32_t round = 0; round < da.rounds; round++) {
-        if ((round * chain_wgs(a) + chain_wg(a)) * ST_SEGS >= da.group_start[3]) break;
-        const uint32_t sid = (round * chain_wgs(a) + chain_wg(a)) * ST_SEGS + ring * 64 + lane;
+        if ((round * chain_wgs(a) + chain_wg(a)) * wg_segs >= da.group_start[3]) break;
+        const uint32_t sid = (round * chain_wgs(a) + chain_wg(a)) * wg_segs + ring * 64 + lane;
         const D4Seg sg = d4_segment(a, da, sid);
         int16_t *pcm_row = a.pcm + (size_t)sg.ch * a.pcm_stride;
         D4Fm s;

@@ -56,6 +56,15 @@ __device__ __forceinline__ StSeg st_segment_of(const ChainLaunch &a, const Strea
     // (an id that is padding maps to no segment: st_segment() then hands back the launch's first channel with length 0)
     return st_segment(a, there ? sa.group_li0[r] * a.tiles_per_ch + local : sa.n_segments, sa.n_segments);
 }
+// A segment that lets its ring take the IIR wave's fast path: not there at all, or cold (not its channel's first), of full length
+// and not the keeper of its channel's restart state (the one before a last segment shorter than FORCED_BACK).  (st_iir_wave)
+__device__ __forceinline__ bool st_cold_and_full(const StSeg &s, uint32_t tile_len)
+{
+    if (!s.valid) return true;
+    const bool not_last = s.vlen - s.v0 > s.tlen;
+    const bool keeps_restart = not_last && s.vlen - FORCED_BACK >= s.v0 && s.vlen - FORCED_BACK < s.v0 + s.tlen;
+    return s.tile != 0 && s.tlen == (int32_t)tile_len && !keeps_restart;
+}
 __device__ __forceinline__ uint32_t st_id_count(const StreamArgs &sa) { return !IQD_ST_NO_GROUPS && sa.grouped ? sa.group_start[3] : sa.n_segments; }
 
 // The first ST_FIX_PCM PCM samples of every cold segment, recomputed with the exact histories its predecessor left

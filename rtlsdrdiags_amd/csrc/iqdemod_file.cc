@@ -14,7 +14,11 @@
 //     demod                            the reference's offline harness instead (demodulatorResearch/demodulators/
 //                                      demod.cc:210-290): stdin holds SIGNED bytes, which go straight into a bare
 //                                      demodulator object - {Am,Fm,WbFm,Ssb}Demodulator::acceptIqData, no processor,
-//                                      no squelch; mode 4 / 5 select the SSB sideband first
+//                                      no squelch, 16384 bytes per read like the reference.  Types 4 AND 5 demodulate the
+//                                      UPPER sideband, as the reference program does: its switch has no break (demod.cc:232-242),
+//                                      so setLsbDemodulationMode() is followed by setUsbDemodulationMode().  Pinned by
+//                                      tests/golden/demod_tool.npz, the reference program's own output.
+//     sideband=lsb                     with `demod`: really the lower sideband (what -d 4 was meant to select)
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -41,7 +45,7 @@ int main(int argc, char **argv)
     return 2;
   }
   const char *scanSpec = 0, *dumpPath = 0, *blockSpec = 0, *timingPath = 0;
-  bool demodOnly = false;
+  bool demodOnly = false, forceLsb = false;
   int npos = 0;
   char *pos[8];
   for (int i = 1; i < argc && npos < 8; i++) {
@@ -50,6 +54,7 @@ int main(int argc, char **argv)
     else if (strncmp(argv[i], "blocks=", 7) == 0) blockSpec = argv[i] + 7;
     else if (strncmp(argv[i], "timing=", 7) == 0) timingPath = argv[i] + 7;
     else if (strcmp(argv[i], "demod") == 0) demodOnly = true;
+    else if (strcmp(argv[i], "sideband=lsb") == 0) forceLsb = true;
     else pos[npos++] = argv[i];
   }
   argc = npos + 1;
@@ -68,12 +73,15 @@ int main(int argc, char **argv)
     SsbDemodulator ssbAlone(processPcmData);
     const int type = atoi(argv[1]);
     if (type < 1 || type > 5) { fprintf(stderr, "iqdemod_file: demodulator type 1-5\n"); return 2; }
-    if (type == 4) ssbAlone.setLsbDemodulationMode();
-    if (type == 5) ssbAlone.setUsbDemodulationMode();
+    switch (type) {   // (the reference's switch, fall-through included: demod.cc:232-242)
+    case 4: ssbAlone.setLsbDemodulationMode();   // fall through
+    case 5: ssbAlone.setUsbDemodulationMode();
+    }
+    if (forceLsb) ssbAlone.setLsbDemodulationMode();
     DemodulatorHandle *d = type == 1 ? (DemodulatorHandle *)&amAlone : type == 2 ? (DemodulatorHandle *)&fmAlone
                          : type == 3 ? (DemodulatorHandle *)&wbfmAlone : (DemodulatorHandle *)&ssbAlone;
     for (;;) {
-      size_t want = nsizes ? sizes[next++ % nsizes] : sizeof(block);
+      size_t want = nsizes ? sizes[next++ % nsizes] : 16384;   // (demod.cc:249: fread(inputBuffer, sizeof(int8_t), 16384, stdin))
       if (want == 0 || want > sizeof(block)) want = sizeof(block);
       const size_t got = fread(block, 1, want, stdin);
       if (got == 0) break;

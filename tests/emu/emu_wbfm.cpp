@@ -266,9 +266,9 @@ void emu_plan_stream(uint32_t vlen, uint32_t n_channels, uint32_t streams, uint3
 }
 
 // plan_call (iqd_plan.cpp) on plain arrays.  knobs: {flags, n_cus, stream_ok, env_path (+1 / 0 / -1 as 1 / 0 / 2), env_stream_min_seg,
-// env_am_stream_min (0 = default), env_mixed_forked, env_shares_by_cost, env_stream_wgs, env_full_grid}; fam: per family
+// env_am_stream_min (0 = default), env_mixed_forked, env_shares_by_cost, env_stream_wgs, env_full_grid, env_rings}; fam: per family
 // {n_list, rot_count[3], cast_bounded, epochs_in_reach}; out: {n_fams, forked, shares_on, fused, mix_wgs, order[4]} then per family
-// {present, path, lane, wgs, tile_len, tiles_per_ch, grouped, group_start[4], group_nseg[3], grid, rounds, wg_first, epochs} (18 words).
+// {present, path, lane, wgs, tile_len, tiles_per_ch, grouped, group_start[4], group_nseg[3], grid, rounds, wg_first, epochs, rings} (19 words).
 void emu_plan_call(const uint32_t *knobs, uint32_t vlen, uint32_t pcm_per_ch, uint32_t gated, const uint32_t *fam, uint32_t *out)
 {
     iqd::PlanKnobs k;
@@ -277,6 +277,7 @@ void emu_plan_call(const uint32_t *knobs, uint32_t vlen, uint32_t pcm_per_ch, ui
     k.env_stream_min_seg = knobs[4];
     if (knobs[5]) k.env_am_stream_min = knobs[5];
     k.env_mixed_forked = knobs[6] != 0; k.env_shares_by_cost = knobs[7] != 0; k.env_stream_wgs = knobs[8]; k.env_full_grid = knobs[9] != 0;
+    k.env_rings = knobs[10];
     k.wbfm_chunk = iqd::WBFM_CHUNK; k.wbfm_cold_halo = iqd::COLD_HALO; k.ch_chunk = iqd::CH_CHUNK; k.fir_halo = iqd::FIR_HALO; k.dc_tile = iqd::DC_TILE;
     iqd::CallShape c;
     c.vlen = vlen; c.pcm_per_ch = pcm_per_ch; c.gated = gated != 0;
@@ -296,7 +297,7 @@ void emu_plan_call(const uint32_t *knobs, uint32_t vlen, uint32_t pcm_per_ch, ui
         *o++ = q.present; *o++ = (uint32_t)q.path; *o++ = (uint32_t)q.lane; *o++ = q.wgs; *o++ = q.tile_len; *o++ = q.tiles_per_ch; *o++ = q.grouped;
         for (int r = 0; r < 4; r++) *o++ = q.group_start[r];
         for (int r = 0; r < 3; r++) *o++ = q.group_nseg[r];
-        *o++ = q.grid; *o++ = q.rounds; *o++ = q.wg_first; *o++ = q.epochs;
+        *o++ = q.grid; *o++ = q.rounds; *o++ = q.wg_first; *o++ = q.epochs; *o++ = q.rings;
     }
 }
 

@@ -99,14 +99,33 @@ def capture(R):
                         threshold=-33, rx_gain_db=24, **g)
 
 
+def demod_tool(R):
+    """The reference's own offline harness as a PROGRAM (oracle/_ref/ref_demod = demodulatorResearch/demodulators/demod.cc,
+    unmodified, built by oracle/Makefile): signed bytes on stdin, `-d <1..5>`, PCM on stdout.  Pins the harness level of
+    rtlsdrdiags_amd/bin/iqdemod_file `demod` - including what the program really does for -d 4: its switch has no break
+    (demod.cc:232-242), so LSB falls through to USB and types 4 and 5 give the same PCM."""
+    import subprocess
+    tool = os.path.join(ROOT, "oracle", "_ref", "ref_demod")
+    x = (synth.fm_tone(5 * 8192 + 1024, seed=41).astype(np.int16) - 128).astype(np.int8)     # 5 reads of 16384 bytes and one of 2048
+    x[3 * 16384:3 * 16384 + 96] = -128
+    out = {"iq_s8": x}
+    for t in range(1, 6):
+        r = subprocess.run([tool, "-d", str(t)], input=x.tobytes(), stdout=subprocess.PIPE, check=True)
+        out["pcm_%d" % t] = np.frombuffer(r.stdout, dtype=np.int16)
+        assert len(out["pcm_%d" % t]) == len(x) // 64
+    assert np.array_equal(out["pcm_4"], out["pcm_5"]) and not np.array_equal(out["pcm_1"], out["pcm_5"])
+    np.savez_compressed(os.path.join(OUT, "demod_tool.npz"), **out)
+
+
 def main():
     R = B.Reference()
     if len(sys.argv) > 1:                    # only the named fixtures (python make_golden.py demod_entry capture)
         for name in sys.argv[1:]:
-            {"demod_entry": demod_entry, "capture": capture}[name](R)
+            {"demod_entry": demod_entry, "capture": capture, "demod_tool": demod_tool}[name](R)
         return
     demod_entry(R)
     capture(R)
+    demod_tool(R)
     blk = 16384
 
     # (i) modulated tone at -Fs/4 + noise, moderate amplitude

@@ -207,9 +207,22 @@ def test_offline_harness_through_the_cpp_demodulator_classes(oracle, mode):
     s8 = rng.integers(-128, 128, 3 * 32768 + 4096).astype(np.int8)
     c = oracle.chain()
     ref = np.concatenate([c.demod_accept(MODES[mode], s8[o:o + 32768]) for o in range(0, len(s8), 32768)])
-    r = subprocess.run([TOOL, str(mode), "demod"], input=s8.tobytes(), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    # (blocks=32768: the harness reads 16384 bytes at a time like the reference program; "sideband=lsb": its -d 4 is USB, see below)
+    r = subprocess.run([TOOL, str(mode), "demod", "blocks=32768"] + (["sideband=lsb"] if mode == 4 else []), input=s8.tobytes(),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode == 0, r.stderr.decode()
     assert np.array_equal(np.frombuffer(r.stdout, dtype=np.int16), ref)
+
+
+@pytest.mark.parametrize("dtype", [1, 2, 3, 4, 5])
+def test_file_tool_demod_harness_is_the_reference_program(golden, dtype):
+    """`iqdemod_file <type> demod` against the stdout of the reference's own demod program (tests/golden/demod_tool.npz, made by
+    oracle/_ref/ref_demod = demodulatorResearch/demodulators/demod.cc compiled unmodified): same reads of 16384 signed bytes,
+    same PCM - including -d 4, which in the reference falls through to USB (demod.cc:232-242: no break)."""
+    g = golden["demod_tool"]
+    r = subprocess.run([TOOL, str(dtype), "demod"], input=g["iq_s8"].tobytes(), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode == 0, r.stderr.decode()
+    assert np.array_equal(np.frombuffer(r.stdout, dtype=np.int16), g["pcm_%d" % dtype])
 
 
 @pytest.mark.parametrize("sizes", [[64, 64, 64, 64, 192, 320, 8256, 128, 16448, 64, 32768, 1984, 64],

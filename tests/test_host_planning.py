@@ -193,31 +193,31 @@ def _plan_lib():
 
 
 def plan_call(vlen, fams, flags=0, n_cus=256, stream_ok=True, env_path=0, min_seg=0, am_min=0, mixed_forked=False, by_cost=False,
-              stream_wgs=0, full_grid=False, gated=False):
+              stream_wgs=0, full_grid=False, gated=False, rings=0):
     """fams: {family: (rot_count tuple | channels, cast_bounded, epochs_in_reach)} -> the plan as a dict."""
     lib = _plan_lib()
     knobs = np.array([flags, n_cus, int(stream_ok), {0: 0, 1: 1, -1: 2}[env_path], min_seg, am_min, int(mixed_forked), int(by_cost),
-                      stream_wgs, int(full_grid)], np.uint32)
+                      stream_wgs, int(full_grid), rings], np.uint32)
     fam = np.zeros((4, 6), np.uint32)
     for f, name in enumerate(FAMS):
         if name in fams:
             rc, bounded, epochs = fams[name]
             rc = (rc, 0, 0) if isinstance(rc, int) else rc
             fam[f] = [sum(rc), rc[0], rc[1], rc[2], int(bounded), int(epochs)]
-    out = np.zeros(9 + 4 * 18, np.uint32)
+    out = np.zeros(9 + 4 * 19, np.uint32)
     lib.emu_plan_call(knobs.ctypes.data, vlen, vlen // 32, int(gated), fam.ctypes.data, out.ctypes.data)
     keys = ("present", "path", "lane", "wgs", "tile_len", "tiles_per_ch", "grouped", "gs0", "gs1", "gs2", "gs3", "gn0", "gn1", "gn2",
-            "grid", "rounds", "wg_first", "epochs")
+            "grid", "rounds", "wg_first", "epochs", "rings")
     plan = {"n_fams": int(out[0]), "forked": bool(out[1]), "shares_on": bool(out[2]), "fused": bool(out[3]), "mix_wgs": int(out[4]),
             "order": out[5:9].tolist(), "fam": {}}
     for f, name in enumerate(FAMS):
-        plan["fam"][name] = dict(zip(keys, (int(v) for v in out[9 + 18 * f: 9 + 18 * f + 18])))
+        plan["fam"][name] = dict(zip(keys, (int(v) for v in out[9 + 19 * f: 9 + 19 * f + 19])))
         plan["fam"][name]["n"] = int(fam[f][0])
         plan["fam"][name]["rot_count"] = fam[f][1:4].tolist()
     return plan
 
 
-def check_plan(p, vlen, flags, env_path, stream_ok, n_cus, fams):
+def check_plan(p, vlen, flags, env_path, stream_ok, n_cus, fams, rings_knob=0):
     lib = _plan_lib()
     st_segs, min_tile, dc_tile = lib.emu_plan_const(0), lib.emu_plan_const(1), lib.emu_plan_const(3)
     present = [n for n in FAMS if p["fam"][n]["n"]]
@@ -256,8 +256,11 @@ def check_plan(p, vlen, flags, env_path, stream_ok, n_cus, fams):
             else:
                 assert name == "wbfm" and sum(1 for c in q["rot_count"] if c) == 1
                 ids = q["n"] * q["tiles_per_ch"]
-            assert q["grid"] * q["rounds"] * st_segs >= ids                                  # every segment id has a workgroup and a round
-            assert (q["grid"] - 1) * q["rounds"] * st_segs < ids or q["rounds"] > 1 or q["grid"] == 1   # and no workgroup is launched for nothing
+            assert 1 <= q["rings"] <= 3 and (q["rings"] == 3 or ((q["rounds"] == 1 or rings_knob) and not p["fused"]))   # fewer rings: launches of one round
+            wg_segs = 64 * q["rings"]
+            assert wg_segs == st_segs or q["rings"] < 3
+            assert q["grid"] * q["rounds"] * wg_segs >= ids                                  # every segment id has a workgroup and a round
+            assert (q["grid"] - 1) * q["rounds"] * wg_segs < ids or q["rounds"] > 1 or q["grid"] == 1   # and no workgroup is launched for nothing
         else:
             if name == "wbfm":
                 assert not q["epochs"]
@@ -323,7 +326,13 @@ def test_plan_call_known_configurations():
     assert (q["path"], q["tile_len"], q["grid"], q["rounds"], q["grouped"]) == (PLAN_STREAM, 5632, 249, 1, 0) and not p["forked"]
     # configs[2]: 4096 FM channels x 2^16
     q = plan_call(1 << 16, {"fm": (4096, True, False)})["fam"]["fm"]
-    assert q["path"] == PLAN_STREAM and q["rounds"] == 1 and q["grid"] <= 256
+    assert q["path"] == PLAN_STREAM and q["rounds"] == 1 and q["grid"] <= 256 and q["rings"] == 3
+    # the reference's operating point with a thousand channels (one 64 ms block per channel and call): workgroups of ONE ring on
+    # every CU instead of 118 full ones - longer segments, faster pieces (tools/rings_probe.sh: AM 0.076 -> 0.064 ms)
+    q = plan_call(1 << 14, {"am": (1024, True, False)})["fam"]["am"]
+    assert (q["path"], q["rings"], q["tile_len"], q["grid"], q["rounds"]) == (PLAN_STREAM, 1, 1024, 256, 1), q
+    q = plan_call(1 << 14, {"am": (1024, True, False)}, rings=3)["fam"]["am"]          # (IQD_RINGS pins it)
+    assert (q["rings"], q["tile_len"]) == (3, 768) and q["grid"] < 128
     # configs[3]: the four families as ranges of one launch
     p = plan_call(1 << 16, {"am": (819, True, False), "fm": (819, True, False), "wbfm": (820, True, False), "ssb": (1638, True, False)})
     assert p["fused"] and p["mix_wgs"] <= 256 and all(q["path"] == PLAN_STREAM and q["rounds"] == 1 for q in p["fam"].values())

@@ -213,3 +213,20 @@ def test_demodulator_level_entry(oracle, golden, mode):
         else:
             pcm = c.demod_accept(mode, g["in%d" % k])
         assert np.array_equal(pcm, g["pcm_%s_%d" % (mode, k)]), (mode, k)
+
+
+@pytest.mark.parametrize("dtype", [1, 2, 3, 4, 5])
+def test_the_reference_demod_program(oracle, golden, dtype):
+    """tests/golden/demod_tool.npz = stdout of the reference's own offline harness as a program (demodulatorResearch/
+    demodulators/demod.cc, built unmodified by oracle/Makefile, `-d <type>`): signed bytes, 16384 per read, into a bare
+    demodulator.  The program's switch has no break, so -d 4 (LSB) falls through to USB: types 4 and 5 are both USB."""
+    g = golden["demod_tool"]
+    mode = {1: "am", 2: "fm", 3: "wbfm", 4: "usb", 5: "usb"}[dtype]
+    c = oracle.chain()
+    x = g["iq_s8"]
+    pcm = np.concatenate([c.demod_accept(mode, x[o:o + 16384]) for o in range(0, len(x), 16384)])
+    assert np.array_equal(pcm, g["pcm_%d" % dtype])
+    if dtype == 4:
+        c = oracle.chain()
+        lsb = np.concatenate([c.demod_accept("lsb", x[o:o + 16384]) for o in range(0, len(x), 16384)])
+        assert not np.array_equal(lsb, g["pcm_4"])          # (what -d 4 was meant to be is something else)

@@ -133,3 +133,15 @@ def test_survey_md5_anchors_on_the_reference_capture(oracle, reference, mode):
         pcm, _, _ = c.accept_stream(u8)
         assert pcm.nbytes == 65536
         assert hashlib.md5(pcm.tobytes()).hexdigest().startswith(YOYO_MD5[mode]), (mode, which)
+
+
+REF_DEMOD = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "ref_demod")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_DEMOD), reason="build container only: oracle/_ref/ref_demod is the reference's demod.cc compiled in place")
+@pytest.mark.parametrize("dtype", [1, 2, 3, 4, 5])
+def test_demod_tool_fixture_is_the_reference_programs_output(dtype):
+    import subprocess
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "demod_tool.npz"))
+    r = subprocess.run([REF_DEMOD, "-d", str(dtype)], input=g["iq_s8"].tobytes(), stdout=subprocess.PIPE, check=True)
+    assert np.array_equal(np.frombuffer(r.stdout, dtype=np.int16), g["pcm_%d" % dtype])

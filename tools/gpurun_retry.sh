@@ -1,0 +1,10 @@
+#!/bin/bash
+# gpurun with retries while no box or slot is free (exit code 3: nothing was charged):  tools/gpurun_retry.sh <timeout> '<command>'
+T=$1; shift
+for i in $(seq 1 20); do
+  /usr/local/graft/bin/gpurun --timeout $T -- "$@"
+  rc=$?
+  [ $rc -ne 3 ] && exit $rc
+  sleep 90
+done
+exit 3

@@ -10,3 +10,6 @@ for args in "" "--config 2" "--config 3" "--config 4" "--mode am --channels 4096
   out=$($B $args 2>/dev/null | grep '"metric"')
   echo "[$args] $(echo "$out" | grep -o '"ms_per_step": [0-9.]*') $(echo "$out" | grep -o '"from_idle_ms_per_step": [0-9.]*') $(echo "$out" | grep -o '"kernel_ms": [0-9.]*')"
 done 2>&1 | tee gpurun_out/r5_lines2.log
+# what the north-star's stated +-1 LSB tolerance would buy (a timing A/B only)
+cp rtlsdrdiags_amd/libiqdemod.so tmp_variants/lib_base.so
+tools/abn.sh 3 "" tmp_variants/lib_base.so tmp_variants/lib_relaxed.so 2>&1 | tee gpurun_out/r5_ab_relaxed.log
