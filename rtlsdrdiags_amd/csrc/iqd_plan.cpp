@@ -51,6 +51,21 @@ uint32_t group_ids(const FamilyShape &s, FamilyPlan &p)
 // 2^14 .. 2^16; profiles/r5_rings_probe.txt: the rule picks the fastest arrangement in 14 of the 15 cases measured, second by
 // 2 % in the other).  The estimate is pieces per segment x that factor.  Streaming launches of 1024 channels x 2^14: AM 0.076 ->
 // 0.064 ms per step, FM 0.087 -> 0.076, WBFM 0.124 -> 0.104; 4096 x 2^14: AM 0.085 -> 0.081, WBFM 0.164 -> 0.158; larger: three rings.
+// The segment length a streaming launch of `slots` segment slots would get (the plan's own search: first an exact fit, then
+// with 48 slots spare for the rotation groups' padding), and whether it fits one round.
+struct SegFit { uint32_t tile_len; bool one_round; };
+SegFit fit_segments(const FamilyShape &s, uint32_t vlen, uint32_t slots, uint32_t granule, bool grouped)
+{
+    FamilyPlan tmp;
+    for (uint32_t spare = 0;; spare += 48) {
+        const TilePlan sp = plan_stream(vlen, s.n_list, slots > spare ? slots - spare : slots, granule);
+        tmp.tile_len = sp.tile_len;
+        tmp.tiles_per_ch = sp.tiles_per_ch;
+        const uint32_t ids = grouped ? group_ids(s, tmp) : s.n_list * sp.tiles_per_ch;
+        if (ids <= slots || spare >= 48 || !grouped) return SegFit{sp.tile_len, ids <= slots};
+    }
+}
+
 uint32_t rings_of(const PlanKnobs &k, const CallShape &c, int f, uint32_t wgs, bool fused, bool grouped)
 {
     if (fused) return (uint32_t)ST_RINGS;   // (the shares of the one launch are planned in workgroups of three rings: plan_fused_by_time)
@@ -62,10 +77,9 @@ uint32_t rings_of(const PlanKnobs &k, const CallShape &c, int f, uint32_t wgs, b
     uint32_t best = (uint32_t)ST_RINGS;
     float best_t = 0.f;
     for (uint32_t r = (uint32_t)ST_RINGS; r >= 1; r--) {
-        const uint32_t slots = wgs * 64u * r;
-        const TilePlan sp = plan_stream(c.vlen, s.n_list, slots > 48 ? slots - (grouped ? 48u : 0u) : slots, granule);
-        if ((uint64_t)sp.tiles_per_ch * s.n_list > slots) continue;        // (a second round: never better)
-        const float t = per_piece[r] * (float)(sp.tile_len + halo_of(f));
+        const SegFit fit = fit_segments(s, c.vlen, wgs * 64u * r, granule, grouped);
+        if (!fit.one_round) continue;                                      // (a second round: never better)
+        const float t = per_piece[r] * (float)(fit.tile_len + halo_of(f));
         if (r == (uint32_t)ST_RINGS || t < 0.99f * best_t) { best = r; best_t = t; }
     }
     return best;
