@@ -3,7 +3,7 @@
 # trace + the PMC passes of tools/profile.sh, condensed by tools/pmc_summary.py; the summary and the kernel stats are
 # copied to profiles/<tag>_pmc.json and profiles/<tag>_kernel_stats.csv (copy them back from gpurun_out/profiles_out/).
 set -u
-R=${ROUND:-r4}
+R=${ROUND:-r5}
 OUT=gpurun_out/profiles_out
 mkdir -p $OUT
 run() { # tag needle samples args...
