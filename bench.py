@@ -40,6 +40,7 @@ import numpy as np  # noqa: E402
 
 ALGO_BYTES_PER_SAMPLE = 2.0 + 2.0 / 32.0     # int8 I + int8 Q in, int16 PCM out at 1/32 rate
 HBM_PEAK_GBS = 8000.0                        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+MAX_CLOCK_GHZ = 2.4                          # (same guide: max clock)
 METRIC = "IQ MSamples/s through WBFM chain at 1/2/4/8 GPUs; % HBM roofline"
 
 CONFIGS = {
@@ -523,14 +524,17 @@ def rank_body(args, rank, world, dev, make_engine, dist, torch, order_streams=No
                 # the time this instruction stream would take on perfectly levelled, never-idle vector ALUs: the ceiling of
                 # the formulation.  The HBM ceiling is `peak`.  The lower one binds; `achieved_over_ceiling` is how close the
                 # kernel runs to it.
-                busy_ms = c["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (ghz * 1e9) * 1e3
+                # (at the part's 2.4 GHz maximum clock: the counters are per launch of the dominant kernel, the live time covers the
+                #  whole step of a short child run, so a clock derived from the two is not to be trusted here - the maximum clock makes
+                #  this the most the formulation could reach, i.e. a ceiling)
+                busy_ms = c["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (MAX_CLOCK_GHZ * 1e9) * 1e3
                 algo = ALGO_BYTES_PER_SAMPLE * (timed_samples or n * n_ch)
                 ceil_gbs = algo / (busy_ms * 1e-3) / 1e9
                 roof["ceilings"] = {"hbm": {"GB/s": HBM_PEAK_GBS, "frac_of_hbm_peak": 1.0},
                                     "valu_issue": {"GB/s": round(ceil_gbs, 1), "frac_of_hbm_peak": round(ceil_gbs / HBM_PEAK_GBS, 4),
-                                                   "valu_busy_ms_levelled": round(busy_ms, 4), "clock_ghz": round(ghz, 3),
-                                                   "how": "SQ_ACTIVE_INST_VALU x 4 cycles / 1024 SIMDs / clock: the instruction stream's time on "
-                                                          "perfectly levelled, never-idle vector ALUs"}}
+                                                   "valu_busy_ms_levelled": round(busy_ms, 4), "clock_ghz": MAX_CLOCK_GHZ,
+                                                   "how": "SQ_ACTIVE_INST_VALU x 4 cycles / 1024 SIMDs / 2.4 GHz (the maximum clock): the instruction "
+                                                          "stream's time on perfectly levelled, never-idle vector ALUs"}}
                 roof["binds"] = "valu_issue" if ceil_gbs < HBM_PEAK_GBS else "hbm"
                 roof["achieved_over_binding_ceiling"] = round(roof["achieved"] / min(ceil_gbs, HBM_PEAK_GBS), 3)
             roof["traffic_over_algorithmic"] = round(roof["traffic"] / (ALGO_BYTES_PER_SAMPLE * (timed_samples or n * n_ch)), 3) if roof["traffic"] else None
