@@ -441,18 +441,11 @@ __device__ __forceinline__ void tail_update_body(const ChainLaunch &a, int famil
     if (vlen == 0) return;
     if (family == FAM_WBFM && threadIdx.x == 0) {
         const uint32_t ntiles = (vlen + a.tile_len - 1) / a.tile_len;
+        // (a streamed last segment shorter than FORCED_BACK took its own record inside its lead-in, before its state had become
+        //  exact: the segment before it kept the state at the restart point - wbfm_pick_carry, iqd_wbfm.h)
         const WbfmRecord r = a.records[(size_t)li * a.tiles_per_ch + ntiles - 1];
-        WbfmCarry cy;
-        cy.y = r.y_out; cy.u = r.u_out; cy.back = r.back_out;
-        if (a.verify_at_end && ntiles >= 2 && r.pad[0] == WBFM_REC_STREAMED && vlen - (ntiles - 1) * a.tile_len < (uint32_t)FORCED_BACK) {
-            // a streamed last segment shorter than FORCED_BACK: its own record was taken inside its lead-in, before its state had
-            // become exact - the segment before it kept the state at the restart point (WbfmRecord::pad)
-            const WbfmRecord p = a.records[(size_t)li * a.tiles_per_ch + ntiles - 2];
-            cy.y = u2f(p.pad[0]); cy.u = u2f(p.pad[1]); cy.back = FORCED_BACK;
-        }
-        cy.y_end = r.y_end; cy.u_end = r.u_end;
-        cy.pad[0] = cy.pad[1] = cy.pad[2] = 0;
-        a.wbfm_carry[ech] = cy;
+        const WbfmRecord p = a.records[(size_t)li * a.tiles_per_ch + (ntiles >= 2 ? ntiles - 2 : 0)];
+        a.wbfm_carry[ech] = wbfm_pick_carry(r, p, ntiles, vlen, a.tile_len, a.verify_at_end);
     }
     if (threadIdx.x < EPOCHS && (family == FAM_WBFM || family == FAM_FM)) {   // this call's samples now lie behind the gain changes
         uint32_t *since = (family == FAM_WBFM ? a.epochs[ech].wbfm.since : a.epochs[ech].fm.since) + threadIdx.x;

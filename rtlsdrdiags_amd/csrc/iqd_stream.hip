@@ -618,31 +618,27 @@ __device__ __forceinline__ void st_iir_wave(const ChainLaunch &a, const StreamAr
         q.c14 = 1 << 14;
         q.c15 = 1 << 15;
         asm volatile("" : "+v"(q.c14), "+v"(q.c15));
-        int32_t halo = ST_HALO;
+        int32_t carried_back = ST_HALO;
         if (q.sg.tile == 0) {
             const WbfmCarry cy = a.wbfm_carry[q.sg.ech];
             q.back = cy.back;
             q.cy_y = cy.y;
             q.cy_u = cy.u;
-            halo = cy.back;
+            carried_back = cy.back;
         }
-        q.rec_pos = q.sg.tlen - FORCED_BACK;
-        if (q.rec_pos < -halo) q.rec_pos = -halo;
+        // where the segment's record is taken, and whether it keeps the channel's restart state for a short last segment behind it
+        // (outside the fast path): iqd_wbfm.h, st_rec_plan - shared with the CPU tier's model of the hand-over
+        const StRecPlan rp = st_rec_plan(q.sg.valid, q.sg.tile, q.sg.v0, q.sg.tlen, q.sg.vlen, carried_back);
+        q.rec_pos = rp.park_pos;   // (= rec_pos unless the segment keeps: then its own record sits where every full segment's does, rec_pos_uniform)
         q.rec.y_in = q.cy_y;
         q.rec.y_out = q.cy_y;
         q.rec.u_out = q.cy_u;
-        q.rec.back_out = q.sg.tlen - q.rec_pos;
+        q.rec.back_out = rp.back_out;
         q.rec.y_end = 0.f;
         q.rec.u_end = 0.f;
         q.rec.pad[0] = q.rec.pad[1] = 0;
-        // The channel's restart point vlen - FORCED_BACK in a segment that is not the channel's last - because the last one is
-        // shorter than FORCED_BACK (WbfmRecord::pad): that segment leaves the state there, outside the fast path.
-        const bool not_last = q.sg.vlen - q.sg.v0 > q.sg.tlen;
-        const bool keeps_restart = q.sg.valid && not_last && q.sg.vlen - FORCED_BACK >= q.sg.v0 && q.sg.vlen - FORCED_BACK < q.sg.v0 + q.sg.tlen;
-        if (keeps_restart) {   // (a full segment, not the channel's last: its own record sits where every such segment's does, back_out = FORCED_BACK above)
-            q.rec_pos = q.sg.vlen - FORCED_BACK - q.sg.v0;
-            q.sg.valid |= 2u;
-        }
+        const bool keeps_restart = rp.keeps_restart != 0;
+        if (keeps_restart) q.sg.valid |= 2u;
         StIir s;
         s.y = 0.f; s.up = 0.f;
         s.wlast[0] = s.wlast[1] = 0;

@@ -746,6 +746,45 @@ struct WbfmRecord {  // what the tile reports for hand-off verification and the 
 };
 constexpr uint32_t WBFM_REC_STREAMED = 0x53545245u;
 
+// Where a STREAMED segment (iqd_stream.hip: st_iir_wave) takes its restart record, as plain arithmetic - shared by the kernel and by
+// the CPU tier's model of the restart state's journey from call to call (tests/test_emu_restart_model.py; round 4's three
+// restart-state bugs all lived in these few lines).  A segment's positions count from its own first sample; its lead-in is
+// FORCED_BACK samples (a channel's first segment: from the carried exact state, `carried_back` before the call).
+//   rec_pos       where the segment's own record (y_out, u_out) is taken: FORCED_BACK before its end, or at the carried state
+//                 itself when the segment is shorter than that (then back_out says how far before the new end that lies)
+//   keeps_restart the channel's restart point vlen - FORCED_BACK lies in THIS segment although it is not the last - because the
+//                 last one is shorter than FORCED_BACK and would take it inside its lead-in, where a cold segment's state is still
+//                 converging: this segment parks the state there (WbfmRecord::pad; `park_pos`), its own record stays where
+//                 every full segment's is
+struct StRecPlan { int32_t rec_pos, back_out, park_pos; uint32_t keeps_restart; };
+IQD_DEV StRecPlan st_rec_plan(uint32_t valid, uint32_t tile, int32_t v0, int32_t tlen, int32_t vlen, int32_t carried_back)
+{
+    StRecPlan r;
+    const int32_t halo = tile == 0 ? carried_back : FORCED_BACK;
+    r.rec_pos = tlen - FORCED_BACK;
+    if (r.rec_pos < -halo) r.rec_pos = -halo;
+    r.back_out = tlen - r.rec_pos;
+    const bool not_last = vlen - v0 > tlen;
+    r.keeps_restart = valid && not_last && vlen - FORCED_BACK >= v0 && vlen - FORCED_BACK < v0 + tlen ? 1u : 0u;
+    r.park_pos = r.keeps_restart ? vlen - FORCED_BACK - v0 : r.rec_pos;
+    return r;
+}
+
+// The restart state a channel carries out of a call: its last tile's / segment's record - or, when that last one was a streamed
+// segment shorter than FORCED_BACK, what the segment before it parked (tail_update_body; `before` = that segment's record).
+IQD_DEV WbfmCarry wbfm_pick_carry(const WbfmRecord &last, const WbfmRecord &before, uint32_t ntiles, uint32_t vlen, uint32_t tile_len,
+                                  uint32_t verify_at_end)
+{
+    WbfmCarry cy;
+    cy.y = last.y_out; cy.u = last.u_out; cy.back = last.back_out;
+    if (verify_at_end && ntiles >= 2 && last.pad[0] == WBFM_REC_STREAMED && vlen - (ntiles - 1) * tile_len < (uint32_t)FORCED_BACK) {
+        cy.y = u2f(before.pad[0]); cy.u = u2f(before.pad[1]); cy.back = FORCED_BACK;
+    }
+    cy.y_end = last.y_end; cy.u_end = last.u_end;
+    cy.pad[0] = cy.pad[1] = cy.pad[2] = 0;
+    return cy;
+}
+
 // Chunk boundaries of a tile: the lead-in [-halo, 0) is one chunk - or two, split where the demodulator gain last
 // changed (the channel's GainEpochList), so that every chunk has one gain.
 // The gain in force at call-relative position v < 0: the list is ordered, most recent change first.

@@ -301,6 +301,40 @@ void emu_plan_call(const uint32_t *knobs, uint32_t vlen, uint32_t pcm_per_ch, ui
     }
 }
 
+// ---- the WBFM restart state's journey from call to call (tests/test_emu_restart_model.py) ----------------------------------
+// st_rec_plan / wbfm_pick_carry are the kernel's own (iqd_wbfm.h): where a streamed segment takes its record, what the commit picks.
+void emu_st_rec_plan(uint32_t valid, uint32_t tile, int32_t v0, int32_t tlen, int32_t vlen, int32_t carried_back, int32_t *out4)
+{
+    const iqd::StRecPlan r = iqd::st_rec_plan(valid, tile, v0, tlen, vlen, carried_back);
+    out4[0] = r.rec_pos; out4[1] = r.back_out; out4[2] = r.park_pos; out4[3] = (int32_t)r.keeps_restart;
+}
+
+// records: 8 words each {y_in, y_out, u_out, back_out, y_end, u_end, pad[0], pad[1]} (iqd::WbfmRecord)
+void emu_wbfm_pick_carry(const uint32_t *last8, const uint32_t *before8, uint32_t ntiles, uint32_t vlen, uint32_t tile_len,
+                         uint32_t verify_at_end, iqd::WbfmCarry *out)
+{
+    static_assert(sizeof(iqd::WbfmRecord) == 32, "record layout");
+    iqd::WbfmRecord a, b;
+    memcpy(&a, last8, sizeof(a));
+    memcpy(&b, before8, sizeof(b));
+    *out = iqd::wbfm_pick_carry(a, b, ntiles, vlen, tile_len, verify_at_end);
+}
+
+// {FORCED_BACK, ST_HALO, ST_MIN_TILE, WBFM_REC_STREAMED, TAIL, WBFM_CHUNK}; a1, b0 of the de-emphasis filter; K for a demodulator gain
+void emu_restart_consts(uint32_t *out6, float *a1_b0, float gain, float *k_out)
+{
+    out6[0] = iqd::FORCED_BACK; out6[1] = iqd::ST_HALO; out6[2] = iqd::ST_MIN_TILE; out6[3] = iqd::WBFM_REC_STREAMED;
+    out6[4] = iqd::TAIL; out6[5] = iqd::WBFM_CHUNK;
+    iqd::Consts c;
+    iqd::build_consts(c);
+    a1_b0[0] = c.deemph_a1; a1_b0[1] = c.deemph_b0;
+    iqd::ChanParams p;
+    iqd::default_params(p);
+    p.gain[iqd::FAM_WBFM] = gain;
+    iqd::derive_params(p);
+    *k_out = p.wbfm_k;
+}
+
 uint32_t emu_plan_const(int which)   // geometry constants the plan tests need
 {
     switch (which) {
