@@ -23,7 +23,7 @@ namespace iqd {
 // (second probe, around the thresholds: FM 640 x 2^16 0.085 / 0.088, 768 x 2^16 0.087 / 0.095; WBFM 384 x 2^16 0.120 / 0.099; AM / USB
 // 768 x 2^16 0.075 / 0.074 and 0.087 / 0.082, 896 x 2^16 0.075 / 0.083 and 0.086 / 0.093, 1024 x 2^14 0.074 / 0.079 and 0.084 / 0.082;
 // several families: 128 x 2^14 0.099 / 0.125, 16 x 2^16 0.100 / 0.120, 1024 x 2^12 0.098 / 0.101, 512 x 2^12 0.096 / 0.076)
-// Round 5 (workgroups of fewer rings for small launches, rings_of(); tools/r5_fourth.sh, profiles/r5_threshold_probe.txt, default /
+// Round 5 (workgroups of fewer rings for small launches, rings_of(); tools/r5/r5_fourth.sh, profiles/r5_threshold_probe.txt, default /
 // tiles / stream): USB 1024 x 2^14 0.0828 / 0.0808 / 0.0693 and 768 x 2^16 0.0814 / 0.0823 / 0.0776 - the SSB thresholds came down
 // (1100 -> 1000, short rows 450 -> 330); every other crossover stayed where it was (FM 512 x 2^16 0.0697 tiles / 0.0848 stream,
 // 768 x 2^16 0.0945 / 0.0859; AM 512 x 2^16 0.0545 / 0.0662, 1024 x 2^14 0.0784 / 0.0626; WBFM 256 x 2^16 0.0844 / 0.1015, 512 x 2^16 0.1469 / 0.1164).

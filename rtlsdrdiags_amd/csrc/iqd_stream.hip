@@ -746,7 +746,21 @@ __device__ __forceinline__ void wbfm_stream_body(const ChainLaunch &a, const Str
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)st_lds != 0u) __builtin_trap();   // st_table_read()
     uint32_t *sync = (uint32_t *)(st_lds + ST_TABLE_BYTES + ST_RINGS * ST_RING_SLOTS * ST_SLOT_BYTES);
     const int tid = (int)threadIdx.x;
-    for (int i = tid; i < ST_TABLE_BYTES / 16; i += ST_THREADS) ((uint4 *)st_lds)[i] = ((const uint4 *)sa.half_lut)[i];
+    {   // the table: every thread's loads in flight together, then its stores (round 5: written as one loop, the compiler waited for
+        // each load before the next - nine trips to L2 one after the other at the start of every launch, 256 workgroups at once)
+        constexpr int N16 = ST_TABLE_BYTES / 16, TRIPS = (N16 + ST_THREADS - 1) / ST_THREADS;
+        uint4 t[TRIPS];
+#pragma unroll
+        for (int k = 0; k < TRIPS; k++) {
+            const int i = tid + k * ST_THREADS;
+            t[k] = ((const uint4 *)sa.half_lut)[i < N16 ? i : N16 - 1];
+        }
+#pragma unroll
+        for (int k = 0; k < TRIPS; k++) {
+            const int i = tid + k * ST_THREADS;
+            if (i < N16) ((uint4 *)st_lds)[i] = t[k];
+        }
+    }
     if (tid < ST_SYNC_WORDS) sync[tid] = 0;
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
