@@ -1,17 +1,18 @@
 #!/bin/bash
 # The fuzzer over the engine's path-pinning knobs on the final sources (run on the GPU box; about 25 minutes).
+OFF=${1:-0}   # added to every seed: a second campaign draws other cases
 run() { echo "## $*"; env "$@" 2>&1 | tail -1; }
-run timeout 260 python3 tools/gpu_fuzz.py 240 71
-run FUZZ_WIDE=1 timeout 200 python3 tools/gpu_fuzz.py 180 72
-run FUZZ_WIDE=1 FUZZ_WIDE_RANGE=24,600 timeout 170 python3 tools/gpu_fuzz.py 150 73
-run FUZZ_SHORT=1 timeout 140 python3 tools/gpu_fuzz.py 120 74
-run IQD_WBFM_PATH=stream timeout 200 python3 tools/gpu_fuzz.py 180 75
-run IQD_WBFM_PATH=stream FUZZ_SHORT=1 timeout 110 python3 tools/gpu_fuzz.py 90 76
-run IQD_WBFM_PATH=tiles timeout 140 python3 tools/gpu_fuzz.py 120 77
-run IQD_MIXED=forked FUZZ_WIDE=1 timeout 140 python3 tools/gpu_fuzz.py 120 78
-run IQD_MIXED=forked FUZZ_WIDE=1 FUZZ_WIDE_RANGE=24,600 timeout 110 python3 tools/gpu_fuzz.py 90 79
-run IQD_SHARES=cost FUZZ_WIDE=1 timeout 110 python3 tools/gpu_fuzz.py 90 80
-run IQD_STREAM_MIN_SEG=1 FUZZ_WIDE=1 FUZZ_WIDE_RANGE=24,600 timeout 110 python3 tools/gpu_fuzz.py 90 81
-run FUZZ_BIG=1 timeout 110 python3 tools/gpu_fuzz.py 90 82
-run IQD_STREAM_MIN_SEG=1 FUZZ_SHORT=1 timeout 110 python3 tools/gpu_fuzz.py 90 83
-run IQD_STREAM_MIN_SEG=1 timeout 110 python3 tools/gpu_fuzz.py 90 84
+run timeout 260 python3 tools/gpu_fuzz.py 240 $((71 + OFF))
+run FUZZ_WIDE=1 timeout 200 python3 tools/gpu_fuzz.py 180 $((72 + OFF))
+run FUZZ_WIDE=1 FUZZ_WIDE_RANGE=24,600 timeout 170 python3 tools/gpu_fuzz.py 150 $((73 + OFF))
+run FUZZ_SHORT=1 timeout 140 python3 tools/gpu_fuzz.py 120 $((74 + OFF))
+run IQD_WBFM_PATH=stream timeout 200 python3 tools/gpu_fuzz.py 180 $((75 + OFF))
+run IQD_WBFM_PATH=stream FUZZ_SHORT=1 timeout 110 python3 tools/gpu_fuzz.py 90 $((76 + OFF))
+run IQD_WBFM_PATH=tiles timeout 140 python3 tools/gpu_fuzz.py 120 $((77 + OFF))
+run IQD_MIXED=forked FUZZ_WIDE=1 timeout 140 python3 tools/gpu_fuzz.py 120 $((78 + OFF))
+run IQD_MIXED=forked FUZZ_WIDE=1 FUZZ_WIDE_RANGE=24,600 timeout 110 python3 tools/gpu_fuzz.py 90 $((79 + OFF))
+run IQD_SHARES=cost FUZZ_WIDE=1 timeout 110 python3 tools/gpu_fuzz.py 90 $((80 + OFF))
+run IQD_STREAM_MIN_SEG=1 FUZZ_WIDE=1 FUZZ_WIDE_RANGE=24,600 timeout 110 python3 tools/gpu_fuzz.py 90 $((81 + OFF))
+run FUZZ_BIG=1 timeout 110 python3 tools/gpu_fuzz.py 90 $((82 + OFF))
+run IQD_STREAM_MIN_SEG=1 FUZZ_SHORT=1 timeout 110 python3 tools/gpu_fuzz.py 90 $((83 + OFF))
+run IQD_STREAM_MIN_SEG=1 timeout 110 python3 tools/gpu_fuzz.py 90 $((84 + OFF))

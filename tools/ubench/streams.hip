@@ -137,6 +137,62 @@ static void run_n(const uint8_t *d, uint32_t *o, const char *what)
     printf("%-44s %.4f ms  %.2f TB/s\n", what, best, total / (best * 1e-3) / 1e12);
 }
 
+
+// The P waves' pattern with the loads of BURST consecutive pieces of a segment issued back to back (BURST x 64 bytes per
+// segment reach the memory system together), SETS such bursts in flight, and SLEEP x 64 cycles of "work" per piece
+// (round 5: does the DRAM see longer runs per stream if the pieces are asked for in bursts rather than one per piece time?)
+template <int BURST, int SETS, int SLEEP>
+__global__ __launch_bounds__(768) void streams_burst(const uint8_t *in, uint32_t *out, uint32_t seg_bytes, int n_pieces)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, c = lane & 15;
+    const uint32_t seg = (blockIdx.x * 12 + wave) * 16 + c;
+    const uint8_t *p = in + (size_t)seg * seg_bytes + g * 16;
+    uint4 acc = {0, 0, 0, 0};
+    uint4 buf[SETS][BURST];
+#pragma unroll
+    for (int s = 0; s < SETS; s++)
+#pragma unroll
+        for (int j = 0; j < BURST; j++) buf[s][j] = *(const uint4 *)(p + (s * BURST + j) * 64);
+    for (int q = 0; q < n_pieces; q += SETS * BURST) {
+#pragma unroll
+        for (int s = 0; s < SETS; s++) {
+            uint4 v[BURST];
+#pragma unroll
+            for (int j = 0; j < BURST; j++) {
+                v[j] = buf[s][j];
+                acc.x ^= v[j].x; acc.y += v[j].y; acc.z ^= v[j].z; acc.w += v[j].w;
+                if (SLEEP) __builtin_amdgcn_s_sleep(SLEEP);
+            }
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int j = 0; j < BURST; j++) {
+                int nq = q + (s + SETS) * BURST + j;
+                nq = nq < n_pieces ? nq : n_pieces - 1;
+                buf[s][j] = *(const uint4 *)(p + (size_t)nq * 64);
+            }
+        }
+    }
+    out[blockIdx.x * 768 + threadIdx.x] = acc.x + acc.y + acc.z + acc.w;
+}
+template <int BURST, int SETS, int SLEEP>
+static void run_burst(const uint8_t *d, uint32_t *o, const char *what, uint32_t seg_bytes = 19712)   // (9472 + 384) samples
+{
+    const uint32_t nseg = 256 * 12 * 16;
+    const size_t total = (size_t)seg_bytes * nseg;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    float best = 1e9f;
+    for (int it = 0; it < 6; it++) {
+        hipEventRecord(e0);
+        hipLaunchKernelGGL((streams_burst<BURST, SETS, SLEEP>), dim3(256), dim3(768), 0, 0, d, o, seg_bytes, (int)(seg_bytes / 64));
+        hipEventRecord(e1);
+        hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (it && ms < best) best = ms;
+    }
+    printf("%-44s %.4f ms  %.2f TB/s\n", what, best, total / (best * 1e-3) / 1e12);
+}
+
 // the same bytes, fully coalesced: a workgroup streams through its contiguous share, a wave takes 1 KiB at a time
 template <int AHEAD>
 __global__ __launch_bounds__(768) void coalesced(const uint8_t *in, uint32_t *out, uint32_t wg_bytes)
@@ -225,6 +281,29 @@ int main()
     run_n<2, 1>(d, o, "2 segments x 512 B per load, 1 ahead");
     run4<1>(d, o, total, "4 segments x 256 B per load, 1 step ahead");
     run4<2>(d, o, total, "4 segments x 256 B per load, 2 steps ahead");
+    run_burst<1, 4, 0>(d, o, "burst 1 x 4 sets, no work, 11264 B segments", 11264);
+    run_burst<1, 4, 0>(d, o, "burst 1 x 4 sets, no work, 15360 B segments", 15360);
+    run_burst<1, 4, 0>(d, o, "burst 1 x 4 sets, no work, 18944 B segments", 18944);
+    run<16, 4>(d, o, total, "64 B pieces, 4 ahead, segments 19712 bytes", 19712);
+    run<16, 4>(d, o, total, "64 B pieces, 4 ahead, segments 18944 bytes", 18944);
+    run<16, 8>(d, o, total, "64 B pieces, 8 ahead, segments 19712 bytes", 19712);
+    run_burst<1, 4, 0>(d, o, "burst 1 x 4 sets, no work");
+    run_burst<1, 8, 0>(d, o, "burst 1 x 8 sets, no work");
+    run_burst<2, 2, 0>(d, o, "burst 2 x 2 sets, no work");
+    run_burst<2, 4, 0>(d, o, "burst 2 x 4 sets, no work");
+    run_burst<4, 1, 0>(d, o, "burst 4 x 1 set, no work");
+    run_burst<4, 2, 0>(d, o, "burst 4 x 2 sets, no work");
+    run_burst<8, 1, 0>(d, o, "burst 8 x 1 set, no work");
+    run_burst<1, 4, 12>(d, o, "burst 1 x 4 sets, 768 cycles per piece");
+    run_burst<1, 8, 12>(d, o, "burst 1 x 8 sets, 768 cycles per piece");
+    run_burst<2, 2, 12>(d, o, "burst 2 x 2 sets, 768 cycles per piece");
+    run_burst<2, 4, 12>(d, o, "burst 2 x 4 sets, 768 cycles per piece");
+    run_burst<4, 1, 12>(d, o, "burst 4 x 1 set, 768 cycles per piece");
+    run_burst<4, 2, 12>(d, o, "burst 4 x 2 sets, 768 cycles per piece");
+    run_burst<8, 1, 12>(d, o, "burst 8 x 1 set, 768 cycles per piece");
+    run_burst<1, 4, 16>(d, o, "burst 1 x 4 sets, 1024 cycles per piece");
+    run_burst<4, 2, 16>(d, o, "burst 4 x 2 sets, 1024 cycles per piece");
+    run_burst<8, 1, 16>(d, o, "burst 8 x 1 set, 1024 cycles per piece");
     run_coalesced<4>(d, o, total, 256, "coalesced, 256 workgroups, 4 ahead");
     run_coalesced<8>(d, o, total, 256, "coalesced, 256 workgroups, 8 ahead");
     run_coalesced<4>(d, o, total, 1024, "coalesced, 1024 workgroups, 4 ahead");
