@@ -181,6 +181,21 @@ IQD_DEV int32_t cast_i16(float f)
 // The same cast when the caller has proved |f| < 2^31 (v_cvt_i32_f32 truncates toward zero).
 IQD_DEV uint32_t cast_i16_bounded(float f) { return (uint32_t)(int32_t)f; }
 
+// Two such casts and the packing of their low halves in two instructions instead of three: v_cvt_i32_f32 with an SDWA
+// destination puts the low 16 bits of its result into one half of the register and leaves (or clears) the other.
+// (round 5; IQD_NO_CVT_SDWA: the two plain conversions and a v_perm_b32, for the A/B)
+IQD_DEV uint32_t cast_pack_i16_bounded(float lo, float hi)
+{
+#if IQD_ON_DEVICE && !defined(IQD_NO_CVT_SDWA)
+    uint32_t r;
+    asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD" : "=v"(r) : "v"(lo));
+    asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(r) : "v"(hi));
+    return r;
+#else
+    return ((uint32_t)(int32_t)lo & 0xffffu) | ((uint32_t)(int32_t)hi << 16);
+#endif
+}
+
 // low halves of two dwords -> one dword (a.lo | b.lo << 16), v_perm_b32
 IQD_DEV uint32_t pack_lo16(uint32_t a, uint32_t b) { return perm(b, a, 0x05040100u); }
 // high halves of two dwords -> one dword (a.hi | b.hi << 16)

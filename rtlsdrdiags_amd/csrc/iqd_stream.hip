@@ -212,6 +212,13 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
             const int pos = -ST_HALO + 32 * q;
             ST_TRACE(a.stamps, pw + 3, q, 0);
             ST_T(t0);
+#ifdef IQD_ST_BURN_SIMD   // measurement build: the P waves of ONE SIMD (hardware wave % 4) issue IQD_ST_BURN_N idle vector instructions per piece
+            if (((pw + ST_RINGS) & 3) == IQD_ST_BURN_SIMD) {
+                float burn = 1.0f;
+#pragma unroll
+                for (int k = 0; k < IQD_ST_BURN_N; k++) asm volatile("v_add_f32 %0, %0, %0" : "+v"(burn));
+            }
+#endif
             gload_wait<ST_AHEAD - 1>(raw[j]);                    // younger than this buffer's load: the other buffers' loads
             ST_T(t1);
             const uint4 raw_cur = as_uint4(raw[j]);              // (offset binary, as loaded: the squelch magnitudes below)
@@ -393,21 +400,20 @@ struct StIir {
 // /4 output with 12 taps.  Returns that stage-2 output.
 __device__ __forceinline__ int st_iir_window(const StreamArgs &sa, StIir &s, const float (&u)[16], int c14, int c15)
 {
-    uint32_t wv[16];
+    uint32_t wq[10];                                   // 20 samples: the last quad, then this window's four
     float y = s.y, up = s.up;
     const float a1 = sa.a1;
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        IQD_IIR_STEP(u[k])
-        wv[k] = cast_i16_bounded(y);
+    for (int k = 0; k < 8; k++) {
+        IQD_IIR_STEP(u[2 * k])
+        const float y_even = y;
+        IQD_IIR_STEP(u[2 * k + 1])
+        wq[2 + k] = cast_pack_i16_bounded(y_even, y);
     }
     s.y = y;
     s.up = up;
-    uint32_t wq[10];                                   // 20 samples: the last quad, then this window's four
     wq[0] = s.wlast[0];
     wq[1] = s.wlast[1];
-#pragma unroll
-    for (int k = 0; k < 8; k++) wq[2 + k] = pack_lo16(wv[2 * k], wv[2 * k + 1]);
     s.wlast[0] = wq[8];
     s.wlast[1] = wq[9];
     s.wq0[0] = wq[2];

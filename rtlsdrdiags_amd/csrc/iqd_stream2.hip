@@ -233,9 +233,8 @@ __device__ __forceinline__ void d4_p_round(const ChainLaunch &a, const D4Args &d
             // with the gain of the time; changes fall on call boundaries = multiples of 128 samples.)
             float kk = k_now;
             if (ep_reach) kk = epoch_gain_search(ep, k_now, sg.v0 + pos + (g == 3 ? 32 : 0));
-            const uint32_t ea = cast_i16_bounded(kk * wrap_delta(ta - before_a));   // branch cut, K, cast; (int16) = the low half
-            const uint32_t eb = cast_i16_bounded(kk * wrap_delta(tb - before_b));
-            hand_over(u32x2{pack_lo16(ea, eb), 0u}, sq);
+            // branch cut, K, cast; (int16) = the low half
+            hand_over(u32x2{cast_pack_i16_bounded(kk * wrap_delta(ta - before_a), kk * wrap_delta(tb - before_b)), 0u}, sq);
         };
         // Four pieces of input in flight - a piece's arithmetic is much shorter than a trip to HBM - in four named
         // buffers of a loop unrolled by four: handing a buffer on with register moves would wait for the load it has

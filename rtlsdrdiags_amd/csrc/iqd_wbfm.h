@@ -483,17 +483,17 @@ IQD_DEV void iir_real(const Consts &c, WbfmLds &lds, int nseg, int lane, bool bo
         for (int gi = gi0; gi < gi1; gi += 2) {
             if (lane == mark.lane && gi == mark.gi) { lds.z[0] = y; lds.z[1] = up; }
             const u32x4 a4 = lds.t4[t_slot(lane, gi)], b4 = lds.t4[t_slot(lane, gi + 1)];
-            uint32_t w[8];
-            IQD_IIR_STEP(u2f(a4.x)) w[0] = cast_i16_bounded(y);
-            IQD_IIR_STEP(u2f(a4.y)) w[1] = cast_i16_bounded(y);
-            IQD_IIR_STEP(u2f(a4.z)) w[2] = cast_i16_bounded(y);
-            IQD_IIR_STEP(u2f(a4.w)) w[3] = cast_i16_bounded(y);
-            IQD_IIR_STEP(u2f(b4.x)) w[4] = cast_i16_bounded(y);
-            IQD_IIR_STEP(u2f(b4.y)) w[5] = cast_i16_bounded(y);
-            IQD_IIR_STEP(u2f(b4.z)) w[6] = cast_i16_bounded(y);
-            IQD_IIR_STEP(u2f(b4.w)) w[7] = cast_i16_bounded(y);
-            dst[gi >> 1] = u32x4{pack_lo16(w[0], w[1]), pack_lo16(w[2], w[3]),
-                                 pack_lo16(w[4], w[5]), pack_lo16(w[6], w[7])};
+            uint32_t w[4];
+            float ye;
+            IQD_IIR_STEP(u2f(a4.x)) ye = y;
+            IQD_IIR_STEP(u2f(a4.y)) w[0] = cast_pack_i16_bounded(ye, y);
+            IQD_IIR_STEP(u2f(a4.z)) ye = y;
+            IQD_IIR_STEP(u2f(a4.w)) w[1] = cast_pack_i16_bounded(ye, y);
+            IQD_IIR_STEP(u2f(b4.x)) ye = y;
+            IQD_IIR_STEP(u2f(b4.y)) w[2] = cast_pack_i16_bounded(ye, y);
+            IQD_IIR_STEP(u2f(b4.z)) ye = y;
+            IQD_IIR_STEP(u2f(b4.w)) w[3] = cast_pack_i16_bounded(ye, y);
+            dst[gi >> 1] = u32x4{w[0], w[1], w[2], w[3]};
         }
         lds.e[lane] = y;
         return;
