@@ -7,6 +7,7 @@
 #include "iqd_wbfm.h"
 #include "iqd_mfma.h"
 #include "iqd_stream_fix.h"
+#include "iqd_taps.h"
 
 namespace iqd {
 
@@ -34,6 +35,14 @@ __device__ __forceinline__ uint32_t st_table_read(uint32_t byte_offset) { return
 #endif
 #ifndef IQD_ST_RUNPTR     // 1: the P waves' input addresses as a running pointer (0: piece_address() per piece, A/B builds)
 #define IQD_ST_RUNPTR 1
+#endif
+// The IIR lanes' decimator taps: literals of the v_dot2c instructions (the designs are fixed, iqd_taps.h: STREAM_TAPS) instead of
+// 30 scalar registers that the wave could not keep (85 of its scalar registers spilled to vector lanes, 14 v_readlane per piece).
+// IQD_ST_TAPS_IN_SGPRS: from the kernel arguments as before (the A/B).
+#ifdef IQD_ST_TAPS_IN_SGPRS
+#define ST_TAP(WHICH, Q) sa.WHICH[Q]
+#else
+#define ST_TAP(WHICH, Q) (uint32_t)taps::STREAM_TAPS.WHICH[Q]
 #endif
 #ifndef IQD_ST_YOUNG_SHIFT
 #define IQD_ST_YOUNG_SHIFT 0
@@ -426,17 +435,17 @@ __device__ __forceinline__ int st_iir_window(const StreamArgs &sa, StIir &s, con
 #pragma unroll
     for (int o = 0; o < 4; o++) {                      // window x[4m-4 .. 4m+3] <-> taps h[7 .. 0]
         int acc = c15;
-        acc = dot2(wq[2 * o], sa.d1p2[0], acc);
-        acc = dot2(wq[2 * o + 1], sa.d1p2[1], acc);
-        acc = dot2(wq[2 * o + 2], sa.d1p2[2], acc);
-        acc = dot2(wq[2 * o + 3], sa.d1p2[3], acc);
+        acc = dot2(wq[2 * o], ST_TAP(d1p2, 0), acc);
+        acc = dot2(wq[2 * o + 1], ST_TAP(d1p2, 1), acc);
+        acc = dot2(wq[2 * o + 2], ST_TAP(d1p2, 2), acc);
+        acc = dot2(wq[2 * o + 3], ST_TAP(d1p2, 3), acc);
         y1[o] = (uint32_t)acc;
     }
     // stage 2: output k from y1[4k-8 .. 4k+3], 12 taps, newest pair first
     const uint32_t d[6] = {s.y1h[0], s.y1h[1], s.y1h[2], s.y1h[3], pack_hi16(y1[0], y1[1]), pack_hi16(y1[2], y1[3])};
     int acc = c14;
 #pragma unroll
-    for (int q = 0; q < 6; q++) acc = dot2(d[5 - q], sa.p12p[q], acc);
+    for (int q = 0; q < 6; q++) acc = dot2(d[5 - q], ST_TAP(p12p, q), acc);
     s.y1h[0] = d[2];
     s.y1h[1] = d[3];
     s.y1h[2] = d[4];
@@ -452,12 +461,12 @@ __device__ __forceinline__ int st_audio(const StreamArgs &sa, const StIir &s, bo
     int acc = c14;
     if (quiet) {
 #pragma unroll
-        for (int q = 0; q < 20; q++) acc = dot2(s.y2p[V + 20 - q], sa.a40p[q], acc);
+        for (int q = 0; q < 20; q++) acc = dot2(s.y2p[V + 20 - q], ST_TAP(a40p, q), acc);
     } else {
 #pragma unroll
         for (int q = 0; q < 20; q++) {
-            acc = clamp_q30(dot2(s.y2p[V + 20 - q], sa.a40p[q] & 0xffff0000u, acc));   // newer sample of the pair: h[2q]
-            acc = clamp_q30(dot2(s.y2p[V + 20 - q], sa.a40p[q] & 0x0000ffffu, acc));   // older: h[2q+1]
+            acc = clamp_q30(dot2(s.y2p[V + 20 - q], ST_TAP(a40p, q) & 0xffff0000u, acc));   // newer sample of the pair: h[2q]
+            acc = clamp_q30(dot2(s.y2p[V + 20 - q], ST_TAP(a40p, q) & 0x0000ffffu, acc));   // older: h[2q+1]
         }
     }
     return acc >> 15;

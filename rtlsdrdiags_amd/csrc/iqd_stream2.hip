@@ -31,6 +31,7 @@
 #include "iqd_stream.h"
 #include "iqd_wbfm.h"
 #include "iqd_mfma.h"
+#include "iqd_taps.h"
 
 // build-time experiments (tools/variant.sh): all off in the shipped library
 #ifndef IQD_D4_SPLIT
@@ -50,6 +51,14 @@
 #endif
 #ifndef IQD_D4_WAITSTAT
 #define IQD_D4_WAITSTAT 0
+#endif
+// The FM consumer lanes' decimator taps as literals of the v_dot2c instructions (iqd_taps.h: STREAM_TAPS, the designs are fixed)
+// instead of 26 scalar registers (the FM kernels had 33-35 of their scalar registers spilled to vector lanes).
+// IQD_D4_TAPS_IN_SGPRS: from the kernel arguments as before (the A/B).
+#ifdef IQD_D4_TAPS_IN_SGPRS
+#define D4_TAP(WHICH, Q) da.WHICH[Q]
+#else
+#define D4_TAP(WHICH, Q) (uint32_t)taps::STREAM_TAPS.WHICH[Q]
 #endif
 #ifndef IQD_D4_SLEEP_P      // s_sleep argument (x 64 cycles) between two looks at a ring counter: P waves / consumer waves
 #define IQD_D4_SLEEP_P 1
@@ -615,16 +624,16 @@ __device__ __forceinline__ int d4_fm_piece(const D4Args &da, const uint8_t *ring
     if (!__any(s.loud_e > 0)) {
 #pragma unroll
         for (int q = 0; q < 6; q++) {
-            a0 = dot2(w[5 - q], da.p12p[q], a0);
-            a1 = dot2(w[7 - q], da.p12p[q], a1);
+            a0 = dot2(w[5 - q], D4_TAP(p12p, q), a0);
+            a1 = dot2(w[7 - q], D4_TAP(p12p, q), a1);
         }
     } else {
 #pragma unroll
         for (int q = 0; q < 6; q++) {
-            a0 = clamp_q30(dot2(w[5 - q], da.p12p[q] & 0xffff0000u, a0));
-            a0 = clamp_q30(dot2(w[5 - q], da.p12p[q] & 0x0000ffffu, a0));
-            a1 = clamp_q30(dot2(w[7 - q], da.p12p[q] & 0xffff0000u, a1));
-            a1 = clamp_q30(dot2(w[7 - q], da.p12p[q] & 0x0000ffffu, a1));
+            a0 = clamp_q30(dot2(w[5 - q], D4_TAP(p12p, q) & 0xffff0000u, a0));
+            a0 = clamp_q30(dot2(w[5 - q], D4_TAP(p12p, q) & 0x0000ffffu, a0));
+            a1 = clamp_q30(dot2(w[7 - q], D4_TAP(p12p, q) & 0xffff0000u, a1));
+            a1 = clamp_q30(dot2(w[7 - q], D4_TAP(p12p, q) & 0x0000ffffu, a1));
         }
     }
     if (s.loud_e > 0) s.loud_e--;
@@ -640,21 +649,21 @@ __device__ __forceinline__ int d4_fm_piece(const D4Args &da, const uint8_t *ring
         int accb = 0, accc = 0, accd = 0;              // (four chains of 5: without the clamps int32 sums wrap, any order is exact)
 #pragma unroll
         for (int q = 0; q < 5; q++) {
-            acc = dot2(s.y2p[V + 20 - q], da.a40p[q], acc);
-            accb = dot2(s.y2p[V + 15 - q], da.a40p[q + 5], accb);
-            accc = dot2(s.y2p[V + 10 - q], da.a40p[q + 10], accc);
-            accd = dot2(s.y2p[V + 5 - q], da.a40p[q + 15], accd);
+            acc = dot2(s.y2p[V + 20 - q], D4_TAP(a40p, q), acc);
+            accb = dot2(s.y2p[V + 15 - q], D4_TAP(a40p, q + 5), accb);
+            accc = dot2(s.y2p[V + 10 - q], D4_TAP(a40p, q + 10), accc);
+            accd = dot2(s.y2p[V + 5 - q], D4_TAP(a40p, q + 15), accd);
         }
         acc = (acc + accb) + (accc + accd);
 #else
 #pragma unroll
-        for (int q = 0; q < 20; q++) acc = dot2(s.y2p[V + 20 - q], da.a40p[q], acc);
+        for (int q = 0; q < 20; q++) acc = dot2(s.y2p[V + 20 - q], D4_TAP(a40p, q), acc);
 #endif
     } else {
 #pragma unroll
         for (int q = 0; q < 20; q++) {
-            acc = clamp_q30(dot2(s.y2p[V + 20 - q], da.a40p[q] & 0xffff0000u, acc));
-            acc = clamp_q30(dot2(s.y2p[V + 20 - q], da.a40p[q] & 0x0000ffffu, acc));
+            acc = clamp_q30(dot2(s.y2p[V + 20 - q], D4_TAP(a40p, q) & 0xffff0000u, acc));
+            acc = clamp_q30(dot2(s.y2p[V + 20 - q], D4_TAP(a40p, q) & 0x0000ffffu, acc));
         }
     }
     if (s.loud_y2 > 0) s.loud_y2--;

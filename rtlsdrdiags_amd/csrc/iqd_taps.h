@@ -54,5 +54,26 @@ constexpr float DEEMPH_B0 = 0.0253863f;   // both numerator taps
 constexpr float DEEMPH_A1 = -0.9492274f;
 constexpr float DCBLOCK_A1 = -0.95f;      // numerator {1, -1}
 
+// quantize_q15() (iqd_host.cpp: h * 32768, roundf, int16) at compile time: the designs are fixed, so a kernel can carry its taps
+// as literals of the instructions instead of in scalar registers (|h * 32768| < 2^15: the sum with 0.5 is exact).
+// tests/test_host_logic.py compares with what the host builds.
+constexpr int q15(float h)
+{
+    const float s = h * 32768.0f;
+    return (int)(s + (s >= 0.f ? 0.5f : -0.5f));
+}
+constexpr unsigned pair16(int lo, int hi) { return ((unsigned)lo & 0xffffu) | ((unsigned)hi << 16); }
+// The WBFM streaming kernel's IIR lanes (build_stream_taps(): StreamArgs::d1p2, p12p, a40p) and the FM pipeline's consumer lanes.
+struct StreamTaps {
+    unsigned d1p2[4], p12p[6], a40p[20];
+    constexpr StreamTaps() : d1p2{}, p12p{}, a40p{}
+    {
+        for (int q = 0; q < 4; q++) d1p2[q] = pair16(2 * q15(WBFM_D1[7 - 2 * q]), 2 * q15(WBFM_D1[6 - 2 * q]));
+        for (int q = 0; q < 6; q++) p12p[q] = pair16(q15(POST12[2 * q + 1]), q15(POST12[2 * q]));
+        for (int q = 0; q < 20; q++) a40p[q] = pair16(q15(AUDIO40[2 * q + 1]), q15(AUDIO40[2 * q]));
+    }
+};
+constexpr StreamTaps STREAM_TAPS{};
+
 }  // namespace taps
 }  // namespace iqd

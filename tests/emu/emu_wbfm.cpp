@@ -15,6 +15,7 @@
 #include "iqd_host.h"
 #include "iqd_plan.h"
 #include "iqd_stream.h"
+#include "iqd_taps.h"
 #include "iqd_chains.h"
 #include "iqd_wbfm.h"
 
@@ -333,6 +334,22 @@ void emu_restart_consts(uint32_t *out6, float *a1_b0, float gain, float *k_out)
     p.gain[iqd::FAM_WBFM] = gain;
     iqd::derive_params(p);
     *k_out = p.wbfm_k;
+}
+
+// The decimator taps the streaming kernels carry as instruction literals (iqd_taps.h: STREAM_TAPS, compile time) beside the ones
+// the host builds for the kernel arguments (build_consts + build_stream_taps): 30 words each, d1p2 | p12p | a40p.
+void emu_stream_taps(uint32_t *literal30, uint32_t *host30)
+{
+    for (int q = 0; q < 4; q++) literal30[q] = iqd::taps::STREAM_TAPS.d1p2[q];
+    for (int q = 0; q < 6; q++) literal30[4 + q] = iqd::taps::STREAM_TAPS.p12p[q];
+    for (int q = 0; q < 20; q++) literal30[10 + q] = iqd::taps::STREAM_TAPS.a40p[q];
+    iqd::Consts c;
+    iqd::build_consts(c);
+    iqd::StreamArgs sa{};
+    iqd::build_stream_taps(c.wbfm_d1, c.post12, c.audio40, sa);
+    for (int q = 0; q < 4; q++) host30[q] = sa.d1p2[q];
+    for (int q = 0; q < 6; q++) host30[4 + q] = sa.p12p[q];
+    for (int q = 0; q < 20; q++) host30[10 + q] = sa.a40p[q];
 }
 
 uint32_t emu_plan_const(int which)   // geometry constants the plan tests need

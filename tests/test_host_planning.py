@@ -359,3 +359,15 @@ def test_planning_a_long_row_is_cheap_now():
         p = plan_call(1 << 28, fams)
     per_call = (time.perf_counter() - t0) / 20
     assert p["fused"] and per_call < 1.5e-3, per_call       # (ctypes and numpy around it included; it was 2 ms in C alone)
+
+
+def test_the_taps_the_kernels_carry_as_literals_are_the_ones_the_host_quantises():
+    """Round 5: the IIR lanes of the WBFM streaming kernel take their decimator taps as instruction literals (iqd_taps.h:
+    STREAM_TAPS, quantised at compile time) - the same 30 words build_consts() + build_stream_taps() put into the kernel
+    arguments (which the fix-up kernel and the tile kernels keep using)."""
+    lib = _plan_lib()
+    lit, host = np.zeros(30, np.uint32), np.zeros(30, np.uint32)
+    lib.emu_stream_taps.restype = None
+    lib.emu_stream_taps.argtypes = [C.c_void_p, C.c_void_p]
+    lib.emu_stream_taps(lit.ctypes.data, host.ctypes.data)
+    assert host.any() and np.array_equal(lit, host), (lit, host)
