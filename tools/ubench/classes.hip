@@ -58,6 +58,10 @@ __device__ __forceinline__ unsigned long long memtime()
     X(ashrrev_i32, "v_ashrrev_i32 %0, 3, %0", "")                                                   \
     X(mov_b32, "v_mov_b32 %0, %1", "")                                                              \
     X(cndmask_vcc, "v_cndmask_b32 %0, %0, %1, vcc", "")                                             \
+    X(cndmask_e64_vcc, "v_cndmask_b32_e64 %0, %0, %1, vcc", "")                                     \
+    X(cndmask_sgpr_pair, "v_cndmask_b32_e64 %0, %0, %1, s[20:21]", "")                              \
+    X(cndmask_alternating, "v_cndmask_b32_e64 %0, %0, %1, s[20:21]", "v_cndmask_b32_e64 %0, %1, %0, s[22:23]") \
+    X(mix_cndmask_add_f32, "v_cndmask_b32_e64 %0, %0, %1, s[20:21]", "v_add_f32 %0, %0, %1")          \
     X(max_u32, "v_max_u32 %0, %0, %1", "")                                                          \
     X(min_i32, "v_min_i32 %0, %0, %1", "")                                                          \
     X(mul_u32_u24, "v_mul_u32_u24 %0, %0, %1", "")                                                  \
@@ -103,10 +107,47 @@ __device__ __forceinline__ unsigned long long memtime()
 OPS(X)
 #undef X
 
+// the same with T2 in ONE of 16 places (k == 0), T1 in the other 15: the marginal cost of an instruction among plain ones
+#define KERNEL1(NAME, T1, T2)                                                                                        \
+    __global__ void NAME(uint32_t *out, unsigned long long *cyc, int iters, uint32_t b, uint32_t c)                  \
+    {                                                                                                                \
+        uint32_t a[16];                                                                                              \
+        for (int k = 0; k < 16; k++) a[k] = threadIdx.x * 977u + k * 131u + b;                                       \
+        __syncthreads();                                                                                             \
+        const unsigned long long t0 = memtime();                                                                     \
+        for (int i = 0; i < iters; i++) {                                                                            \
+            _Pragma("unroll") for (int r = 0; r < 4; r++) {                                                          \
+                _Pragma("unroll") for (int k = 0; k < 16; k++) {                                                     \
+                    if (k != 0) asm volatile(T1 : "+v"(a[k]) : "v"(b), "v"(c));                                      \
+                    else asm volatile(T2 : "+v"(a[k]) : "v"(b), "v"(c) : "vcc");                                     \
+                }                                                                                                    \
+            }                                                                                                        \
+        }                                                                                                            \
+        const unsigned long long t1 = memtime();                                                                     \
+        uint32_t s = 0;                                                                                              \
+        for (int k = 0; k < 16; k++) s += a[k];                                                                      \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = s;                                                              \
+        if ((threadIdx.x & 63) == 0) cyc[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;                    \
+    }
+#define OPS1(X)                                                                                     \
+    X(one_add_f32_in_16_add_f32, "v_add_f32 %0, %0, %1", "v_add_f32 %0, %0, %1")                    \
+    X(one_cndmask_vcc_in_16_add_f32, "v_add_f32 %0, %0, %1", "v_cndmask_b32 %0, %0, %1, vcc")       \
+    X(one_cndmask_e64_vcc_in_16_add_f32, "v_add_f32 %0, %0, %1", "v_cndmask_b32_e64 %0, %0, %1, vcc") \
+    X(one_cndmask_pair_in_16_add_f32, "v_add_f32 %0, %0, %1", "v_cndmask_b32_e64 %0, %0, %1, s[20:21]") \
+    X(one_cmp_cndmask_vcc_in_16, "v_add_f32 %0, %0, %1", "v_cmp_lt_u32 vcc, %1, %0\n\tv_cndmask_b32 %0, %0, %1, vcc") \
+    X(one_cmp_cndmask_pair_in_16, "v_add_f32 %0, %0, %1", "v_cmp_lt_u32_e64 s[20:21], %1, %0\n\tv_cndmask_b32_e64 %0, %0, %1, s[20:21]") \
+    X(one_addc_vcc_in_16_add_f32, "v_add_f32 %0, %0, %1", "v_addc_co_u32 %0, vcc, %0, %1, vcc")     \
+    X(one_cndmask_vcc_in_16_dot2, "v_dot2_i32_i16 %0, %1, %2, %0", "v_cndmask_b32 %0, %0, %1, vcc")
+#define X(N, A, B) KERNEL1(k1_##N, A, B)
+OPS1(X)
+#undef X
+
 typedef void (*Kern)(uint32_t *, unsigned long long *, int, uint32_t, uint32_t);
 struct Entry { const char *name; Kern k; };
 #define X(N, A, B) {#N, k_##N},
-static const Entry entries[] = {OPS(X)};
+#define X1(N, A, B) {#N, k1_##N},
+static const Entry entries[] = {OPS(X) OPS1(X1)};
+#undef X1
 #undef X
 
 int main()
