@@ -206,6 +206,12 @@ __device__ __forceinline__ void st_p_wave(const ChainLaunch &a, const StreamArgs
             const v4i qlo = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[2], bn, cbias, 0, 0, 0);
             const v4i qhi = __builtin_amdgcn_mfma_i32_16x16x64_i8(A[3], bn, czero, 0, 0, 0);
             const uint32_t ti = (uint32_t)ilo[3] + ((uint32_t)ihi[3] << 8), tq = (uint32_t)qlo[3] + ((uint32_t)qhi[3] << 8);
+            // Only row 3 of the four results is used.  Left to itself the allocator hands the twelve dead registers out again
+            // at once - in the squelch-gated instantiations to an UNTRACKED load issued right behind the matrix instruction,
+            // which the compiler does not guard against the matrix unit's pending write (tools/isa_lint.py: lint_mfma_readers;
+            // benign in practice, the load's bytes arrive long after, but not by construction).  Kept alive until the
+            // compiler's own first use above has waited for the results.
+            asm volatile("" :: "v"(ilo), "v"(ihi), "v"(qlo), "v"(qhi), "v"(ti), "v"(tq));
             uint32_t rr;
             asm("v_msad_u8 %0, %1, %2, 0" : "=v"(rr) : "v"(tq), "s"(0x00800000u));
             const uint32_t t = st_table_read(rr * (uint32_t)(ST_ROW_FLOATS * 4) + (bfe(ti, 16, 8) << 2));

@@ -42,3 +42,30 @@ def test_untracked_loads_of_the_mixed_launch():
     last = r.stdout.strip().splitlines()[-1]
     assert "0 finding(s)" in last and " 3 kernels" in last and "0 kernel(s) with scratch" in last, last
     assert int(last.split(" global loads")[0].split()[-1]) > 100
+
+
+def test_lint_flags_inline_assembly_as_first_reader_of_a_matrix_result():
+    """Round 5: the compiler counts the wait states between a matrix instruction and a VALU read of its result only for
+    instructions it knows; an inline-assembly first reader gets none (seen on the device: wrong table rows).  The lint's
+    second check on two synthetic listings."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_lint
+    bad = """
+	v_mfma_i32_16x16x64_i8 v[54:57], v[30:33], v[46:49], v[74:77]
+	;;#ASMSTART
+	v_msad_u8 v60, v54, s77, 0
+	;;#ASMEND
+	s_nop 2
+""".splitlines()
+    good = """
+	v_mfma_i32_16x16x64_i8 v[54:57], v[30:33], v[46:49], v[74:77]
+	s_nop 6
+	v_lshl_add_u32 v50, v57, 8, v54
+	v_lshl_add_u32 v51, v56, 8, v55
+	;;#ASMSTART
+	v_msad_u8 v60, v50, s77, 0
+	;;#ASMEND
+	v_mfma_i32_16x16x64_i8 v[54:57], v[30:33], v[46:49], v[54:57]
+""".splitlines()
+    assert len(isa_lint.lint_mfma_readers("k", list(enumerate(bad, 1)))) == 1
+    assert isa_lint.lint_mfma_readers("k", list(enumerate(good, 1))) == []

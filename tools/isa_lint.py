@@ -8,7 +8,9 @@ assembly and runs a forward data flow over every kernel's control-flow graph (wh
 
     python3 tools/isa_lint.py rtlsdrdiags_amd/csrc/iqd_stream2.hip
 
-Exit status 1 and a listing if a destination register of a pending untracked load is touched before its arrival."""
+Exit status 1 and a listing if a destination register of a pending untracked load is touched before its arrival.
+
+Second check (round 5): the first reader of a matrix instruction's result must not be inline assembly (lint_mfma_readers)."""
 import re
 import subprocess
 import sys
@@ -134,6 +136,48 @@ def lint_kernel(name, lines):
     return findings
 
 
+def lint_mfma_readers(name, lines):
+    """The first reader of a matrix instruction's destination must be an instruction the compiler knows: it counts the wait
+    states a VALU read of an MFMA result needs and fills them with s_nop - but not for inline assembly, whose operands it
+    does not look into.  (Round 5: a build whose first reader was an inline `v_msad_u8` read the accumulator too early -
+    wrong table rows, every hand-off failed.)  Linear scan in program order; a finding = an ASM-block instruction naming a
+    register that an MFMA wrote and nothing else has touched since (the scan forgets at an unconditional branch)."""
+    fresh, findings, in_asm = {}, [], False
+    for no, raw in lines:
+        line = raw.strip()
+        if line.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if line.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if not line or line.startswith(";") or line.startswith(".") or re.match(r"^\.?\w+:", line):
+            continue
+        code = line.partition(";")[0].strip()
+        if not code:
+            continue
+        op = code.split()[0]
+        if op in ("s_branch", "s_endpgm", "s_setpc_b64"):   # what follows is not reached from here
+            fresh = {}
+            continue
+        if op.startswith("v_mfma") or op.startswith("v_smfmac"):
+            ops = code[len(op):].split(",")
+            for part in ops[1:]:
+                for r in regs_of(part):
+                    fresh.pop(r, None)          # MFMA -> MFMA dependencies are the compiler's (and the hardware's) business
+            for r in regs_of(ops[0]):
+                fresh[r] = no
+            continue
+        touched = regs_of(code) & set(fresh)
+        if not touched:
+            continue
+        if in_asm:
+            findings.append((name, no, line, sorted(touched), sorted({fresh[r] for r in touched})))
+        owners = {fresh[r] for r in touched}      # the wait the compiler placed covers the whole result of those matrix instructions
+        fresh = {r: o for r, o in fresh.items() if o not in owners}
+    return findings
+
+
 def main():
     src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "rtlsdrdiags_amd", "csrc", "iqd_stream2.hip")
     text = compile_to_asm(src)
@@ -154,6 +198,12 @@ def main():
     for name, lines in kernels.items():
         n_loads += sum(1 for _, l in lines if "global_load_dword" in l)
         findings += lint_kernel(name, lines)
+    mfma_findings = []
+    for name, lines in kernels.items():
+        mfma_findings += lint_mfma_readers(name, lines)
+    for name, no, raw, regs, owners in mfma_findings:
+        print("%s: line %d (inline assembly) is the first reader of v%s, written by the matrix instruction(s) at line(s) %s:\n    %s"
+              % (name, no, regs, owners, raw))
     seen = set()
     for name, no, raw, regs, owners in findings:
         key = (name, no)
@@ -172,8 +222,8 @@ def main():
         if name in kernels and any("global_load_dword" in l for _, l in kernels[name]) and (priv or spills):
             scratch.append(name)
             print("scratch: %s: private segment of %d bytes, %d vector registers spilled" % (name, priv, spills))
-    print("%s: %d kernels, %d global loads, %d finding(s), %d kernel(s) with scratch" % (os.path.basename(src), len(kernels), n_loads, len(seen), len(scratch)))
-    return 1 if seen else 0
+    print("%s: %d kernels, %d global loads, %d finding(s), %d kernel(s) with scratch" % (os.path.basename(src), len(kernels), n_loads, len(seen) + len(mfma_findings), len(scratch)))
+    return 1 if seen or mfma_findings else 0
 
 
 if __name__ == "__main__":
