@@ -181,6 +181,20 @@ IQD_DEV int32_t cast_i16(float f)
 // The same cast when the caller has proved |f| < 2^31 (v_cvt_i32_f32 truncates toward zero).
 IQD_DEV uint32_t cast_i16_bounded(float f) { return (uint32_t)(int32_t)f; }
 
+// The first product of a chain whose accumulator starts from a rounding term held in a register: the three-address form
+// (v_dot2_i32_i16 d, a, b, c) leaves the term where it is; the compiler's choice, the two-address v_dot2c, needs a move of the
+// term into the accumulator first.  b: a scalar register (the three-address encoding takes no literal).
+IQD_DEV int dot2_from(uint32_t a, uint32_t b_scalar, int start)
+{
+#if IQD_ON_DEVICE
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_scalar), "v"(start));
+    return r;
+#else
+    return dot2(a, b_scalar, start);
+#endif
+}
+
 // Two such casts and the packing of their low halves in two instructions instead of three: v_cvt_i32_f32 with an SDWA
 // destination puts the low 16 bits of its result into one half of the register and leaves (or clears) the other.
 // (round 5; IQD_NO_CVT_SDWA: the two plain conversions and a v_perm_b32, for the A/B)

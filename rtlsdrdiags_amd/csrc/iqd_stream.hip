@@ -44,6 +44,9 @@ __device__ __forceinline__ uint32_t st_table_read(uint32_t byte_offset) { return
 #else
 #define ST_TAP(WHICH, Q) (uint32_t)taps::STREAM_TAPS.WHICH[Q]
 #endif
+#ifndef IQD_ST_DOT2_FROM   // a chain's first product in the three-address form (iqd_prims.h: dot2_from); 0: the A/B
+#define IQD_ST_DOT2_FROM 1
+#endif
 #ifndef IQD_ST_YOUNG_SHIFT
 #define IQD_ST_YOUNG_SHIFT 0
 #endif
@@ -440,8 +443,12 @@ __device__ __forceinline__ int st_iir_window(const StreamArgs &sa, StIir &s, con
     uint32_t y1[4];
 #pragma unroll
     for (int o = 0; o < 4; o++) {                      // window x[4m-4 .. 4m+3] <-> taps h[7 .. 0]
+#if IQD_ST_DOT2_FROM
+        int acc = dot2_from(wq[2 * o], sa.d1p2[0], c15);
+#else
         int acc = c15;
         acc = dot2(wq[2 * o], ST_TAP(d1p2, 0), acc);
+#endif
         acc = dot2(wq[2 * o + 1], ST_TAP(d1p2, 1), acc);
         acc = dot2(wq[2 * o + 2], ST_TAP(d1p2, 2), acc);
         acc = dot2(wq[2 * o + 3], ST_TAP(d1p2, 3), acc);
@@ -449,9 +456,15 @@ __device__ __forceinline__ int st_iir_window(const StreamArgs &sa, StIir &s, con
     }
     // stage 2: output k from y1[4k-8 .. 4k+3], 12 taps, newest pair first
     const uint32_t d[6] = {s.y1h[0], s.y1h[1], s.y1h[2], s.y1h[3], pack_hi16(y1[0], y1[1]), pack_hi16(y1[2], y1[3])};
+#if IQD_ST_DOT2_FROM
+    int acc = dot2_from(d[5], sa.p12p[0], c14);
+#pragma unroll
+    for (int q = 1; q < 6; q++) acc = dot2(d[5 - q], ST_TAP(p12p, q), acc);
+#else
     int acc = c14;
 #pragma unroll
     for (int q = 0; q < 6; q++) acc = dot2(d[5 - q], ST_TAP(p12p, q), acc);
+#endif
     s.y1h[0] = d[2];
     s.y1h[1] = d[3];
     s.y1h[2] = d[4];
@@ -466,8 +479,14 @@ __device__ __forceinline__ int st_audio(const StreamArgs &sa, const StIir &s, bo
 {
     int acc = c14;
     if (quiet) {
+#if IQD_ST_DOT2_FROM
+        acc = dot2_from(s.y2p[V + 20], sa.a40p[0], c14);
+#pragma unroll
+        for (int q = 1; q < 20; q++) acc = dot2(s.y2p[V + 20 - q], ST_TAP(a40p, q), acc);
+#else
 #pragma unroll
         for (int q = 0; q < 20; q++) acc = dot2(s.y2p[V + 20 - q], ST_TAP(a40p, q), acc);
+#endif
     } else {
 #pragma unroll
         for (int q = 0; q < 20; q++) {

@@ -46,8 +46,13 @@
 #ifndef IQD_D4_TRANSPOSE
 #define IQD_D4_TRANSPOSE 0
 #endif
+// Squelch magnitudes of the P waves: 3 = one quad-SAD per dword on the raw bytes (iqd_mfma.h: st_mag_raw_chunk), no table; 1 = the
+// 68 KB table in LDS of rounds 3-4.  Round 5 (profiles/r5_d4_ring_depth.txt, one box, interleaved): these kernels do not wait for
+// issue slots - 32 idle vector instructions per piece in the P waves or in the consumer waves cost +0.5 % - so the SADs' extra
+// instructions are free, and the LDS the table leaves behind holds rings of 16 pieces instead of 8: AM 0.1913 -> 0.1826 (no
+// table) -> 0.1821 (16 slots), USB 0.2057 -> 0.1982 -> 0.1915, FM 0.2495 -> 0.2443 -> 0.2435 ms.
 #ifndef IQD_D4_MAGLUT
-#define IQD_D4_MAGLUT 1
+#define IQD_D4_MAGLUT 3
 #endif
 #ifndef IQD_D4_WAITSTAT
 #define IQD_D4_WAITSTAT 0
@@ -70,7 +75,7 @@
 namespace iqd {
 
 #ifndef IQD_D4_SLOTS
-#define IQD_D4_SLOTS 8
+#define IQD_D4_SLOTS 16
 #endif
 constexpr int D4_SLOTS = IQD_D4_SLOTS;            // ring depth in pieces: whole quads, a power of two of them
 constexpr int D4_QUADS = D4_SLOTS / 4;            // the waves shake hands once per quad (4 pieces = 128 samples), not per piece
@@ -78,10 +83,16 @@ constexpr int D4_QUADS = D4_SLOTS / 4;            // the waves shake hands once 
 // a "consumed" counter per ring (quads the consumer wave has read)
 constexpr int D4_SYNC_WORDS = ST_RINGS * D4_QUADS + 8;
 static_assert(D4_SLOTS % 4 == 0 && (D4_QUADS & (D4_QUADS - 1)) == 0 && D4_QUADS >= 2, "ring depth");
-constexpr int D4_AHEAD = 4;                       // pieces of input a P wave keeps in flight
+// Pieces of input a P wave keeps in flight: 4.  (FM's two angle loads per piece are counted with them.  IQD_D4_AHEAD_AM=8: AM / SSB
+// with eight - built and bit-exact in round 5 on the thought that kernels which do not wait for issue slots wait for memory; they
+// do not: AM 0.1735 -> 0.1811 ms, USB 0.1931 -> 0.1936, profiles/r5_d4_ring_depth.txt.)
+#ifndef IQD_D4_AHEAD_AM
+#define IQD_D4_AHEAD_AM 4
+#endif
+template <int MODE> constexpr int d4_ahead() { return MODE == D4_FM ? 4 : IQD_D4_AHEAD_AM; }
 constexpr int D4_SLOT_BYTES = 64 * 32;            // 64 segments x (4 lanes x 8 bytes) per piece
 constexpr int D4_MAGLUT_OFF = (ST_RINGS * D4_SLOTS * D4_SLOT_BYTES + D4_SYNC_WORDS * 4 + 15) & ~15;   // squelch magnitude table (iqd_mfma.h)
-constexpr int D4_LDS_BYTES = D4_MAGLUT_OFF + ST_MAGLUT_BYTES;
+constexpr int D4_LDS_BYTES = D4_MAGLUT_OFF + (IQD_D4_MAGLUT == 1 ? ST_MAGLUT_BYTES : 0);   // (no table in LDS with the SAD magnitudes)
 
 struct D4Seg {
     uint32_t valid, li, tile, ch, ech;
@@ -249,6 +260,8 @@ __device__ __forceinline__ void d4_p_round(const ChainLaunch &a, const D4Args &d
         // buffers of a loop unrolled by four: handing a buffer on with register moves would wait for the load it has
         // just issued.  Waits count the loads issued since (iqd_mfma.h): per piece one of these, for FM two angles more.
         constexpr int PER_PIECE = MODE == D4_FM ? 3 : 1;
+        constexpr int D4_AHEAD = d4_ahead<MODE>();             // (4 or 8: whole quads; the ring slot of buffer j is j & 3)
+        static_assert(D4_AHEAD % 4 == 0 && (PER_PIECE == 1 || D4_AHEAD == 4), "prefetch depth");
         v4u raw_before = load_piece(-da.halo - 32);
         v4u raw[D4_AHEAD];
 #pragma unroll
@@ -260,6 +273,13 @@ __device__ __forceinline__ void d4_p_round(const ChainLaunch &a, const D4Args &d
         // time made the compiler copy the buffer, still in flight, in front of one of the two waits.
         auto piece = [&](auto first, int q0, int j) {
             const int pos = -da.halo + 32 * (q0 + j);
+#ifdef IQD_D4_BURN_SIMD   // measurement build: the P waves of ONE SIMD (hardware wave % 4) issue IQD_D4_BURN_N idle vector instructions per piece
+            if (((int)(threadIdx.x >> 6) & 3) == IQD_D4_BURN_SIMD) {
+                float burn = 1.0f;
+#pragma unroll
+                for (int k = 0; k < IQD_D4_BURN_N; k++) asm volatile("v_add_f32 %0, %0, %0" : "+v"(burn));
+            }
+#endif
 #if IQD_D4_TIMING
             const long long tA = clock64();
 #endif
@@ -295,7 +315,7 @@ __device__ __forceinline__ void d4_p_round(const ChainLaunch &a, const D4Args &d
                 const uint32_t m = st_mag_chunk(cur);
 #endif
                 macc += mcount && pos < mlimit ? m : 0u;
-                if (j == 3) {   // blocks, segments and lead-ins are whole quads: the boundary test once per quad
+                if ((j & 3) == 3) {   // blocks, segments and lead-ins are whole quads: the boundary test once per quad
                     minblk += 128;
                     if (minblk >= a.block_samples) {
                         if (macc) atomicAdd(&mag_row[mblk], macc);
@@ -326,7 +346,7 @@ __device__ __forceinline__ void d4_p_round(const ChainLaunch &a, const D4Args &d
                 }
             } else {
                 // I' outputs 2g, 2g+1 | Q'
-                hand_over(u32x2{pack_lo16((uint32_t)y[0], (uint32_t)y[2]), pack_lo16((uint32_t)y[1], (uint32_t)y[3])}, j);
+                hand_over(u32x2{pack_lo16((uint32_t)y[0], (uint32_t)y[2]), pack_lo16((uint32_t)y[1], (uint32_t)y[3])}, j & 3);
             }
             prev = cur;
 #if IQD_D4_TIMING
@@ -343,9 +363,16 @@ __device__ __forceinline__ void d4_p_round(const ChainLaunch &a, const D4Args &d
             for (int j = 0; j < D4_AHEAD; j++) piece(std::true_type{}, 0, j);
             q_start = D4_AHEAD;
         }
-        for (int q0 = q_start; q0 < n_pieces; q0 += D4_AHEAD) {
+        int q0 = q_start;
+        for (; q0 + D4_AHEAD <= n_pieces; q0 += D4_AHEAD) {
 #pragma unroll
             for (int j = 0; j < D4_AHEAD; j++) piece(std::false_type{}, q0, j);
+        }
+        // eight in flight and an odd number of quads: the last quad is the start of another trip (buffers 0 .. 3; the loads
+        // younger than each of them are the same seven as in every trip)
+        if (D4_AHEAD > 4 && q0 < n_pieces) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) piece(std::false_type{}, q0, j);
         }
         // the loads asked for beyond the last piece (clamped re-reads) must have landed before their registers move on
 #pragma unroll
@@ -523,6 +550,13 @@ __device__ __forceinline__ int d4_am_piece(const D4Args &da, const uint8_t *ring
     d4_read_row(d4_take_piece<V>(ring_base, full, pg), row, p);
     d4_piece_taken<V>(consumed, pg);
     const uint32_t ni[4] = {p[0].x, p[1].x, p[2].x, p[3].x}, nq[4] = {p[0].y, p[1].y, p[2].y, p[3].y};
+#ifdef IQD_D4_BURN_CONSUMER   // measurement build: the consumer waves issue this many idle vector instructions per piece
+    {
+        float burn = 1.0f;
+#pragma unroll
+        for (int k = 0; k < IQD_D4_BURN_CONSUMER; k++) asm volatile("v_add_f32 %0, %0, %0" : "+v"(burn));
+    }
+#endif
     const int iv = d4_am_rail<V>(da, ri, ni, c14, c15), qv = d4_am_rail<V>(da, rq, nq, c14, c15);
     if (MODE == D4_AM) {   // AmDemodulator.cc:446-459: max(|i|,|q|) + min(|i|,|q|)/2 in int16 arithmetic
         const int im = (int)(int16_t)(iv < 0 ? -iv : iv), qm = (int)(int16_t)(qv < 0 ? -qv : qv);
@@ -719,7 +753,7 @@ __device__ __forceinline__ void d4_stream_body(const ChainLaunch &a, const D4Arg
     uint32_t *sync = (uint32_t *)(d4_lds + ST_RINGS * D4_SLOTS * D4_SLOT_BYTES);
     const int tid = (int)threadIdx.x;
     if (tid < D4_SYNC_WORDS) sync[tid] = 0;
-    if (MAG) st_maglut_build(d4_lds + D4_MAGLUT_OFF, tid, ST_THREADS);
+    if (MAG && IQD_D4_MAGLUT == 1) st_maglut_build(d4_lds + D4_MAGLUT_OFF, tid, ST_THREADS);
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
 #if IQD_D4_TIMING == 2
