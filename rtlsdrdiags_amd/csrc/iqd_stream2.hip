@@ -3,7 +3,8 @@
 // at a time.
 //
 //   12 P waves, 16 segments each: raw bytes (four pieces of input in flight per wave, iqd_mfma.h: gload16_untracked)
-//       -> squelch magnitude of the raw samples through a 68 KiB table in LDS -> signed, rotation signs (SDWA) -> the
+//       -> squelch magnitude of the raw samples, one quad-SAD per dword (rounds 3-4: through a 68 KiB table in LDS; since round 5
+//       that LDS holds rings of 16 pieces instead of 8, IQD_D4_MAGLUT / IQD_D4_SLOTS) -> signed, rotation signs (SDWA) -> the
 //       chain's first /4 decimator on both rails as v_mfma_i32_16x16x64_i8 (FM: 32-tap tuner filter, AM/SSB: 8 taps;
 //       the part of the window that lies in the previous piece through a second, chained MFMA) ->
 //       AM/SSB: 8 + 8 int16 outputs per piece into the ring
