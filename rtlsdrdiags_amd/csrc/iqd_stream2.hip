@@ -44,8 +44,12 @@
 #ifndef IQD_D4_TIMING
 #define IQD_D4_TIMING 0
 #endif
+// 1: a segment's four lanes LOAD as neighbours (lane 4 c + k: 64 contiguous bytes per segment and load instruction) and four
+// ds_bpermute put the bytes where the matrix instruction wants them (lane 16 k + c).  Built in round 3 and then ±2 %: the LDS
+// pipe was busy with the magnitude table's gathers.  With those gone (IQD_D4_MAGLUT=3) the permutes are cheap and the better
+// read pattern shows: FM 0.2439 -> 0.2207 ms, USB 0.1961 -> 0.1849, AM 0.1731 -> 0.1707 (profiles/r5_d4_ring_depth.txt).  0: the A/B.
 #ifndef IQD_D4_TRANSPOSE
-#define IQD_D4_TRANSPOSE 0
+#define IQD_D4_TRANSPOSE 1
 #endif
 // Squelch magnitudes of the P waves: 3 = one quad-SAD per dword on the raw bytes (iqd_mfma.h: st_mag_raw_chunk), no table; 1 = the
 // 68 KB table in LDS of rounds 3-4.  Round 5 (profiles/r5_d4_ring_depth.txt, one box, interleaved): these kernels do not wait for
