@@ -1,7 +1,9 @@
 #!/bin/bash
 # The fuzzer over the engine's path-pinning knobs on the final sources (run on the GPU box; about 25 minutes).
 OFF=${1:-0}   # added to every seed: a second campaign draws other cases
-run() { echo "## $*"; env "$@" 2>&1 | tail -1; }
+MAX=${2:-99}  # only the first MAX runs (a shorter campaign)
+N=0
+run() { N=$((N + 1)); [ $N -gt $MAX ] && return; echo "## $*"; env "$@" 2>&1 | tail -1; }
 run timeout 260 python3 tools/gpu_fuzz.py 240 $((71 + OFF))
 run FUZZ_WIDE=1 timeout 200 python3 tools/gpu_fuzz.py 180 $((72 + OFF))
 run FUZZ_WIDE=1 FUZZ_WIDE_RANGE=24,600 timeout 170 python3 tools/gpu_fuzz.py 150 $((73 + OFF))
