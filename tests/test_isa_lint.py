@@ -1,6 +1,8 @@
 """CPU tier: the generated gfx950 code of the streaming kernels never touches a register that an untracked prefetch
 load (iqd_mfma.h: gload16_untracked) still owns - tools/isa_lint.py compiles the file and follows the control flow.
-(The hazard is silent on a quiet machine: the bytes usually have arrived long before.  It was found by this lint.)"""
+(The hazard is silent on a quiet machine: the bytes usually have arrived long before.  It was found by this lint.)
+Round 5: and no inline assembly is the first to touch a matrix instruction's result (the compiler counts those wait
+states only for instructions it knows) - the same runs check it, the last test shows the check on two listings."""
 import os
 import subprocess
 import sys
