@@ -25,7 +25,7 @@ def oracle_run(oracle, mode, u8, rotation=1, gain=None):
 
 @pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("call_samples,tile_len", [(4 * 16384, 65536), (4 * 16384, 16384), (16384, 8192),
-                                                   (4096, 8192), (128, 8192), (1152, 384)])
+                                                   (4096, 8192), (128, 8192), (1152, 384), (16384, 2048), (16384, 4096)])
 def test_calls_and_tiles(emu, oracle, mode, call_samples, tile_len):
     u8 = synth.fm_tone(4 * 16384, seed=41) if mode == "fm" else synth.am_tone(4 * 16384, seed=42)
     ref, ref_mag, _ = oracle_run(oracle, mode, u8)
