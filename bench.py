@@ -89,6 +89,94 @@ def _cpu_worker(mode, period_u8, seconds, q, start_at=None):
     q.put((done, dt))
 
 
+def host_cores():
+    """What this process may really use of the host: hardware threads it is allowed on (affinity), the cgroup's CPU quota
+    (cpu.max of cgroup v2, cfs_quota_us / cfs_period_us of v1), physical cores and threads per core as /proc/cpuinfo lists them.
+    `cores_effective` = the smaller of affinity and quota: the most cores' worth of time the baseline can get."""
+    logical = os.cpu_count() or 1
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else logical
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+            quota = None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, per = float(f.read()), float(g.read())
+                quota = None if q <= 0 else q / per
+        except (OSError, ValueError):
+            pass
+    physical, tpc = None, None
+    try:
+        cores, sib = set(), None
+        phys = core = None
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                k, _, v = ln.partition(":")
+                k = k.strip()
+                if k == "physical id":
+                    phys = v.strip()
+                elif k == "core id":
+                    core = v.strip()
+                    cores.add((phys, core))
+                elif k == "siblings" and sib is None:
+                    sib = int(v)
+                elif k == "cpu cores" and tpc is None and sib:
+                    tpc = max(1, sib // max(1, int(v)))
+        physical = len(cores) or None
+    except (OSError, ValueError):
+        pass
+    eff = min(affinity, quota) if quota else affinity
+    return {"logical": logical, "affinity": affinity, "cgroup_quota_cores": None if quota is None else round(quota, 2),
+            "physical_cores": physical, "threads_per_core": tpc, "cores_effective": round(eff, 2)}
+
+
+def _cpu_level(ctx, cpu_mode, period_u8, n_procs, seconds):
+    """n_procs independent channels, one process each, from a common start; (aggregate MS/s, slowest process's seconds)."""
+    q = ctx.Queue()
+    start_at = time.time() + 0.4 + 0.006 * n_procs        # (forking 256 workers takes about a second)
+    procs = [ctx.Process(target=_cpu_worker, args=(cpu_mode, period_u8, seconds, q, start_at)) for _ in range(n_procs)]
+    for p in procs:
+        p.start()
+    got = [q.get() for _ in procs]
+    for p in procs:
+        p.join()
+    return sum(d for d, _ in got) / max(t for _, t in got) / 1e6, max(t for _, t in got)
+
+
+def cpu_all_cores(cpu_mode, period_u8, kind, one_core_value, seconds_target):
+    """The reference on every host core this process may use - as a SERIES over 1, 2, 4, ... processes (one independent channel
+    each: the reference is single-threaded per channel, src_diags/DataConsumer.cc:52), so that the knee shows: where the
+    aggregate stops following the process count is where the box stops giving cores (a cgroup quota, SMT siblings, memory).
+    VERDICT r5 item 7: 256 processes had given ten cores' worth, and the line said "256 cores"."""
+    import multiprocessing as mp
+    host = host_cores()
+    ctx = mp.get_context("fork")
+    n_max = host["affinity"]
+    levels = sorted({min(n_max, 1 << k) for k in range(0, 12)} | {n_max})
+    per_level = max(1.0, min(2.0, 0.8 * seconds_target / len(levels)))
+    t0 = time.perf_counter()
+    series = []
+    for n_procs in levels:
+        agg, _ = _cpu_level(ctx, cpu_mode, period_u8, n_procs, per_level)
+        if series and agg < series[-1]["value"]:        # more processes, less done: a neighbour's load or a late start - once more
+            agg = max(agg, _cpu_level(ctx, cpu_mode, period_u8, n_procs, per_level)[0])
+        series.append({"processes": n_procs, "value": round(agg, 3), "per_process": round(agg / n_procs, 3)})
+    wall = time.perf_counter() - t0
+    best = max(series, key=lambda e: e["value"])
+    knee = next(e["processes"] for e in series if e["value"] >= 0.9 * best["value"])
+    full = series[-1]
+    return {"value": full["value"], "unit": "MSamples/s", "cores": n_max, "kind": kind, "wall_s": round(wall, 2),
+            "host": host, "cores_effective": host["cores_effective"],
+            "cores_worth": round(full["value"] / one_core_value, 1) if one_core_value else None,
+            "series": series, "knee_processes": knee, "best": best,
+            "sample": "%d processes (one per hardware thread this process may run on), one independent %s channel each, 2^20-sample calls "
+                      "of the bench signal for %.1f s from a common start; `series` = the same with 1, 2, 4, ... processes; `cores_worth` = "
+                      "value / the one-core figure; `host` = affinity, cgroup quota, physical cores as the box reports them"
+                      % (n_max, cpu_mode.upper(), per_level)}
+
+
 def cpu_baseline(period_u8, mode="wbfm", seconds_target=10.0, all_cores=True):
     """The reference CPU chain itself (oracle/_ref: the unmodified reference sources; `kind` says "port" when that
     library is absent and the oracle restatement is timed instead) on a bounded sample of the bench signal: one host
@@ -109,23 +197,7 @@ def cpu_baseline(period_u8, mode="wbfm", seconds_target=10.0, all_cores=True):
            "sample": "%s, 1 channel, %d x 2^%d samples of the bench signal through IqDataProcessor::acceptIqData in "
                      "32768-byte blocks, 1 thread" % (cpu_mode.upper(), reps, int(np.log2(n_period)))}
     if all_cores:
-        import multiprocessing as mp
-        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        ctx = mp.get_context("fork")
-        q = ctx.Queue()
-        start_at = time.time() + 1.5 + 0.006 * cores      # (forking 256 workers takes about a second)
-        procs = [ctx.Process(target=_cpu_worker, args=(cpu_mode, period_u8, 0.8 * seconds_target, q, start_at)) for _ in range(cores)]
-        t0 = time.perf_counter()
-        for p in procs:
-            p.start()
-        got = [q.get() for _ in procs]
-        for p in procs:
-            p.join()
-        wall = time.perf_counter() - t0
-        out["all_cores"] = {"value": round(sum(d for d, _ in got) / max(t for _, t in got) / 1e6, 3), "unit": "MSamples/s",
-                            "cores": cores, "kind": kind, "wall_s": round(wall, 2),
-                            "sample": "%d processes (one per usable host core), one independent %s channel each, 2^20-sample "
-                                      "calls of the bench signal for %.0f s from a common start" % (cores, cpu_mode.upper(), 0.8 * seconds_target)}
+        out["all_cores"] = cpu_all_cores(cpu_mode, period_u8, kind, out["value"], seconds_target)
     return out
 
 
@@ -166,7 +238,10 @@ def profile_summary(tag):
     return None, None
 
 
-def live_pmc(argv, needle, samples_per_launch):
+PMC_PASSES = (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("sq1", ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE"]))
+
+
+def live_pmc(argv, needle, samples_per_launch, passes=("fetch", "write", "sq1")):
     """HBM traffic and vector-ALU counters of the SAME command, collected now: three short rocprofv3 passes of this
     script as child processes (--pmc on its own, no trace domain beside it, the program itself after `--`, from /tmp:
     MI355X_MICROARCH.md), condensed by tools/pmc_summary.py.  None if rocprofv3 is not there or a pass fails."""
@@ -185,12 +260,13 @@ def live_pmc(argv, needle, samples_per_launch):
     import pmc_summary
     tmp = tempfile.mkdtemp(prefix="iqd_pmc_", dir="/tmp")
     child = [sys.executable, os.path.abspath(__file__)] + [a for a in argv if a not in ("--gather",)] + \
-            ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-host-path", "--no-live-pmc", "--prewarm-ms", "0"]
+            ["--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-host-path", "--no-live-pmc", "--prewarm-ms", "0", "--no-other-configs"]
     env = dict(os.environ, TMPDIR="/tmp")
     child_ms = None
     try:
-        for sub, counters in (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]),
-                              ("sq1", ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "GRBM_GUI_ACTIVE"])):
+        for sub, counters in PMC_PASSES:
+            if sub not in passes:
+                continue
             r = subprocess.run([rocprof, "--pmc"] + counters + ["--output-format", "csv", "-d", os.path.join(tmp, sub), "--"] + child,
                                cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=240)
             if r.returncode != 0:
@@ -198,7 +274,7 @@ def live_pmc(argv, needle, samples_per_launch):
             if sub == "sq1":   # the kernel time of the very pass the VALU counters come from (its own HIP events)
                 m = re.search(r'"kernel_ms": ([0-9.]+)', r.stdout.decode(errors="replace"))
                 child_ms = float(m.group(1)) if m else None
-        res = pmc_summary.summarize(tmp, needle, float(samples_per_launch), passes=("fetch", "write", "sq1"), notes=False)
+        res = pmc_summary.summarize(tmp, needle, float(samples_per_launch), passes=tuple(passes), notes=False)
         if not res.get("counters_per_launch", {}).get("FETCH_SIZE"):
             return {"skipped": "the counter passes ran but held no FETCH_SIZE rows for %s" % needle}
         res["child_kernel_ms"] = child_ms
@@ -494,7 +570,8 @@ def rank_body(args, rank, world, dev, make_engine, dist, torch, order_streams=No
                   "mixed": "mixed_stream_kernel"}.get("am" if args.mode in ("am", "lsb", "usb", "ssb_stress") else args.mode)
         live = None
         if world == 1 and dev.type == "cuda" and not args.no_live_pmc and (timed_samples is not None or mixed_one or args.mode != "mixed"):
-            live = live_pmc(args.argv, needle, timed_samples or n * n_ch)   # (counters per launch of the dominant kernel)
+            live = live_pmc(args.argv, needle, timed_samples or n * n_ch,   # (counters per launch of the dominant kernel)
+                            passes=getattr(args, "pmc_passes", None) or ("fetch", "write", "sq1"))
         roof = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "kernel": timed, "kernel_ms": round(kern_ms, 4)}
         if timed_samples is not None and kern_ms > 0:
             achieved = ALGO_BYTES_PER_SAMPLE * timed_samples / (kern_ms * 1e-3) / 1e9
@@ -614,6 +691,12 @@ def parse_args(argv=None):
                     help="squelch-gated runs: the magnitude pre-pass inside each step's own stream order (default: one step ahead, IQD_F_PREPASS_OVERLAP)")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="diagnostic: time the steps without the engine's per-kernel HIP events (no roofline.kernel_ms then)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="the default run (configs[1]) also times configs[0], [2], [3], [4] and AM / USB at 4096 x 2^16 for a few steps each "
+                         "and reports them as `other_configs`; this flag skips that")
+    ap.add_argument("--force-launch", action="store_true",
+                    help="start the ranks through bench.py's own launcher (torch.distributed.run as a child process) even for --gpus 1: "
+                         "the N > 1 code path - nccl process group, device_id, the engine's RCCL gatherer - on a one-GPU box")
     ap.add_argument("--standin", default=None, help=argparse.SUPPRESS)   # module:Class of a host-memory engine (CPU tests of the launcher)
     args = ap.parse_args(argv)
     args.argv = list(sys.argv[1:] if argv is None else argv)
@@ -627,6 +710,9 @@ def parse_args(argv=None):
     same = (args.mode, args.channels, args.log2_samples) == (preset["mode"], preset["channels"], preset["log2"])
     args.what = preset["what"] if (same or not custom) else None
     args.tag = preset["tag"] if (same or not custom) and args.signal == "fm_tone" and not args.no_magnitude else None
+    # the driver's own run (`python bench.py --gpus 1 --steps K --warmup W`): configs[1] as the contract names it, nothing pinned
+    args.is_default_workload = (args.config in (None, 1) and not custom and args.signal == "fm_tone" and not args.no_magnitude
+                                and args.squelch is None and args.wbfm_path == "auto" and not args.gather and args.channel_chunks == 1)
     return args
 
 
@@ -654,6 +740,40 @@ def self_launch(argv, n_gpus):
         print(line)
     sys.stdout.flush()
     return p.returncode if (p.returncode != 0 or line is not None) else 1
+
+
+# What the default run times besides its headline: every other BASELINE configuration and the two single-family
+# AM / SSB workloads DESIGN.md quotes, a few steps each in the same process, so that their figures come off the driver's own run.
+OTHER_CONFIGS = (["--config", "0"], ["--config", "2"], ["--config", "3"], ["--config", "4"],
+                 ["--mode", "am", "--channels", "4096", "--log2-samples", "16"],
+                 ["--mode", "usb", "--channels", "4096", "--log2-samples", "16"])
+SUB_KEYS = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "config", "roofline", "state_repairs", "block_latency_us",
+            "device_ops_per_block", "real_time_factor", "parity")
+
+
+def other_configs(args, torch, dev, make_engine, order_streams):
+    """Sub-lines of the default run: each one is what `python bench.py <argv>` prints, cut down to SUB_KEYS - the same rank_body,
+    the same engine event timing, HBM traffic from two rocprofv3 --pmc child passes of that very command (FETCH_SIZE, WRITE_SIZE)."""
+    lines = []
+    for argv in OTHER_CONFIGS:
+        t0 = time.perf_counter()
+        try:
+            sub = parse_args(argv + ["--steps", "10", "--warmup", "3", "--prewarm-ms", "60", "--no-from-idle", "--no-cpu-baseline",
+                                     "--no-host-path", "--no-other-configs"] + (["--no-live-pmc"] if args.no_live_pmc else []))
+            sub.argv = list(argv)
+            sub.pmc_passes = ("fetch", "write")
+            if sub.config == 0:
+                sub.steps, sub.warmup, sub.no_cpu_baseline = 61, 3, False      # (its CPU leg is the parity check of that file: 64 blocks)
+                d = config0(sub)
+            else:
+                d = rank_body(sub, 0, 1, dev, make_engine, None, torch, order_streams)
+            line = {"argv": " ".join(argv)}
+            line.update({k: d[k] for k in SUB_KEYS if k in d})
+            line["seconds"] = round(time.perf_counter() - t0, 1)
+        except (Exception, SystemExit) as exc:          # a sub-line must never cost the run its headline
+            line = {"argv": " ".join(argv), "error": repr(exc)[:300]}
+        lines.append(line)
+    return lines
 
 
 def config0(args):
@@ -710,15 +830,16 @@ def config0(args):
         if not np.array_equal(pcm, ref):
             print(json.dumps(out))
             sys.exit("bench.py --config 0: PCM differs from the CPU chain")
-    print(json.dumps(out))
+    return out
 
 
 def main():
     args = parse_args()
     if args.config == 0:
-        return config0(args)
+        print(json.dumps(config0(args)))
+        return
     world_env = os.environ.get("WORLD_SIZE")
-    if world_env is None and args.gpus > 1:
+    if world_env is None and (args.gpus > 1 or args.force_launch):
         if not args.standin:   # before any rank starts (counting devices does not initialise the GPU on this image)
             import torch
             visible = torch.cuda.device_count()
@@ -770,6 +891,10 @@ def main():
             ext.wait_stream(torch.cuda.current_stream())
 
     out = rank_body(args, rank, world, torch.device("cuda", local_rank), make_engine, dist, torch, order_streams)
+    # (the full default form only: a run trimmed with --no-cpu-baseline / --no-host-path is a measurement tool's, tools/*.sh)
+    if (out is not None and world == 1 and dist is None and args.is_default_workload
+            and not (args.no_other_configs or args.no_cpu_baseline or args.no_host_path)):
+        out["other_configs"] = other_configs(args, torch, torch.device("cuda", local_rank), make_engine, order_streams)
     if out is not None:
         print(json.dumps(out))
     if dist is not None:

@@ -175,6 +175,9 @@ __device__ __forceinline__ void d4_p_round(const ChainLaunch &a, const D4Args &d
         auto load_piece = [&](int pos) -> v4u {
             const int32_t pc = pos < pos_max ? pos : pos_max;
             if (!GATED) {
+#ifdef IQD_D4_PROBE_CACHED   // TIMING PROBE ONLY (wrong results): every lane re-reads a 512-byte window of its segment - the loads hit L2
+                return gload16_untracked(base_iq + 2 * (int64_t)(pc & 0xff));
+#endif
                 const uint8_t *base = pc < -vlane ? base_tail : base_iq;
                 return gload16_untracked(base + 2 * (int64_t)pc);
             }
@@ -200,6 +203,9 @@ __device__ __forceinline__ void d4_p_round(const ChainLaunch &a, const D4Args &d
         uint32_t *mag_row = MAG ? a.mag_sums + (size_t)sgl.ch * a.n_blocks : nullptr;
         const bool mcount = MAG && sgl.valid;
         const int32_t mlimit = sgl.tlen - 8 * gl;
+#if IQD_D4_TIMING
+        long long t_ring_wait = 0;
+#endif
         uint32_t macc = 0;
         uint32_t mblk = (uint32_t)(sgl.v0 + 8 * gl) / a.block_samples;
         uint32_t minblk = (uint32_t)(sgl.v0 + 8 * gl) - mblk * a.block_samples;
@@ -210,6 +216,9 @@ __device__ __forceinline__ void d4_p_round(const ChainLaunch &a, const D4Args &d
         auto hand_over = [&](u32x2 payload, int sq) {
             if (sq == 0 && pg >= (uint32_t)D4_QUADS) {
                 uint32_t seen = lds_load_relaxed(consumed);
+#if IQD_D4_TIMING
+                const long long tw0 = clock64();
+#endif
                 while ((int32_t)(seen - (pg - (D4_QUADS - 1))) < 0) {
 #if IQD_D4_WAITSTAT
                     if (lane == 0) atomicAdd(&sync[D4_SYNC_WORDS - 2], 1u);
@@ -217,6 +226,9 @@ __device__ __forceinline__ void d4_p_round(const ChainLaunch &a, const D4Args &d
                     __builtin_amdgcn_s_sleep(IQD_D4_SLEEP_P);
                     seen = lds_load_relaxed(consumed);
                 }
+#if IQD_D4_TIMING
+                t_ring_wait += clock64() - tw0;
+#endif
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             }
             uint8_t *slot = ring_base + ((pg & (D4_QUADS - 1)) * 4 + (uint32_t)sq) * D4_SLOT_BYTES + wr_off;
@@ -390,8 +402,8 @@ __device__ __forceinline__ void d4_p_round(const ChainLaunch &a, const D4Args &d
         if (MAG && macc) atomicAdd(&mag_row[mblk], macc);
 #if IQD_D4_TIMING
         if ((blockIdx.x & 63) == 7 && lane == 0)
-            printf("wg %u P wave: round %lld cycles for %d pieces: wait_raw %lld front+mfma+mag %lld post+handover %lld\n", blockIdx.x,
-                   clock64() - t_round0, n_pieces, t_wait_raw, t_front_mag, t_post_hand);
+            printf("wg %u P wave %d: round %lld cycles for %d pieces: wait_raw %lld front+mfma+mag %lld post+handover %lld (of which ring-space wait %lld)\n", blockIdx.x,
+                   (int)(threadIdx.x >> 6), clock64() - t_round0, n_pieces, t_wait_raw, t_front_mag, t_post_hand, t_ring_wait);
 #endif
 }
 
@@ -407,6 +419,9 @@ __device__ __forceinline__ void d4_p_wave(const ChainLaunch &a, const D4Args &da
     const int ring = pw % ST_RINGS, cg = pw / ST_RINGS;
 #endif
     if (ring >= (int)da.rings) return;                         // (a workgroup of fewer rings, D4Args::rings: this wave's is not there)
+#ifdef IQD_D4_PRIO_YOUNG   // measurement build: the youngest P wave of every ring (hardware waves 12-14, the fourth wave of SIMDs 0-2) at a raised priority
+    if (pw >= 3 * (ST_P_PER_RING - 1)) __builtin_amdgcn_s_setprio(IQD_D4_PRIO_YOUNG);
+#endif
     const uint32_t wg_segs = 64u * da.rings;
     const int g = lane >> 4, c = lane & 15;
     const uint32_t row = (uint32_t)(16 * cg + c);
@@ -453,7 +468,7 @@ __device__ __forceinline__ void d4_read_row(const uint8_t *slot, uint32_t row, u
     for (int g = 0; g < 4; g++) p[g] = *(const u32x2 *)(slot + d4_ring_off(row, (uint32_t)g));
 }
 
-#if IQD_D4_WAITSTAT
+#if IQD_D4_WAITSTAT || IQD_D4_TIMING
 __device__ __forceinline__ uint32_t *d4_stat_word(int i)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t d4_lds[];
@@ -463,12 +478,18 @@ __device__ __forceinline__ uint32_t *d4_stat_word(int i)
 __device__ __forceinline__ void d4_wait_quad(const uint32_t *full, uint32_t pg)   // all four P waves have stored quad pg
 {
     const uint32_t target = 4u * ((pg / D4_QUADS) + 1u);
+#if IQD_D4_TIMING
+    const long long tw0 = clock64();
+#endif
     while ((int32_t)(lds_load_relaxed(&full[pg & (D4_QUADS - 1)]) - target) < 0) {
 #if IQD_D4_WAITSTAT
         if ((threadIdx.x & 63) == 0) atomicAdd(d4_stat_word(D4_SYNC_WORDS - 1), 1u);
 #endif
         __builtin_amdgcn_s_sleep(IQD_D4_SLEEP_C);
     }
+#if IQD_D4_TIMING   // cycles this consumer wave waited for its P waves, per hardware wave 0..2 (= ring)
+    if ((threadIdx.x & 63) == 0) atomicAdd(d4_stat_word(ST_RINGS * D4_QUADS + ST_RINGS + (int)(threadIdx.x >> 6)), (uint32_t)(clock64() - tw0));
+#endif
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 // piece V of quad pg: its slot; the consumer waits before a quad's first piece and hands the quad back after its last
@@ -765,12 +786,27 @@ __device__ __forceinline__ void d4_stream_body(const ChainLaunch &a, const D4Arg
     const long long t_wave0 = clock64();
     const long long t_real0 = wall_clock64();
 #endif
-    if (wave < ST_RINGS) {
+#ifdef IQD_D4_CONSUMERS_ON_SIMD3   // measurement build: the consumer waves are hardware waves 3, 7, 11 (all on the SIMD that holds three waves)
+    const bool is_consumer = (wave & 3) == 3;
+    const int c_ring = wave >> 2, p_index = wave - (wave > 3) - (wave > 7) - (wave > 11);
+#else
+    const bool is_consumer = wave < ST_RINGS;
+    const int c_ring = wave, p_index = wave - ST_RINGS;
+#endif
+    if (is_consumer) {
         if (IQD_D4_PRIO) __builtin_amdgcn_s_setprio(IQD_D4_PRIO);
-        if (MODE == D4_FM) d4_fm_wave(a, da, d4_lds, sync, wave, lane);
-        else d4_am_wave<MODE>(a, da, d4_lds, sync, wave, lane);
+#if IQD_D4_TIMING == 1
+        const long long t_c0 = clock64();
+#endif
+        if (MODE == D4_FM) d4_fm_wave(a, da, d4_lds, sync, c_ring, lane);
+        else d4_am_wave<MODE>(a, da, d4_lds, sync, c_ring, lane);
+#if IQD_D4_TIMING == 1
+        if ((blockIdx.x & 63) == 7 && lane == 0)
+            printf("wg %u consumer wave %d: %lld cycles for %d pieces, of which waiting for a full quad %u\n", blockIdx.x, wave, clock64() - t_c0,
+                   (da.halo + (int)a.tile_len) >> 5, sync[ST_RINGS * D4_QUADS + ST_RINGS + wave]);
+#endif
     } else {
-        d4_p_wave<MODE, MAG, GATED>(a, da, d4_lds, sync, wave - ST_RINGS, lane);
+        d4_p_wave<MODE, MAG, GATED>(a, da, d4_lds, sync, p_index, lane);
     }
 #if IQD_D4_TIMING == 2
     {
