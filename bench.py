@@ -550,10 +550,10 @@ def rank_body(args, rank, world, dev, make_engine, dist, torch, order_streams=No
         if mixed_one:
             kernels_ran = "every family's streaming pipeline as a range of one launch's workgroups (mixed_stream_kernel)"
         if args.mode == "mixed":
-            # (one launch + its followers: their HIP-event time against the step's algorithmic bytes; kernels on streams: only the
-            #  first family's is timed, so the step time is used instead)
+            # (every launch of the step either way: the one launch + its followers, or - several families as kernels of their own
+            #  on side streams - from in front of the fork to behind the join and the closing launch, iqd_engine.cpp)
             timed, timed_samples = ("mixed_stream_kernel (all families' streaming pipelines in one launch) + mixed_tail_kernel" if mixed_one else
-                                    "the first demodulator family launched (WBFM's stream / chain kernel)"), (n * n_ch if mixed_one else None)
+                                    "every family's kernels on their side streams, fork to join"), n * n_ch
         elif args.mode in ("am", "lsb", "usb", "ssb_stress"):
             timed, timed_samples = ("d4_stream_kernel" if streamed else "am_chain_kernel") + " + its DC-removal kernels", n * n_ch
             if gating or args.squelch is not None:   # a gated call: the timed kernels see the open blocks only and the magnitude
@@ -562,7 +562,7 @@ def rank_body(args, rank, world, dev, make_engine, dist, torch, order_streams=No
             timed, timed_samples = ("d4_stream_kernel" if streamed else "fm_chain_kernel"), n * n_ch
         else:
             timed, timed_samples = ("wbfm_stream_kernel + wbfm_stream_fixup_kernel" if streamed else "wbfm_chain_kernel"), n * n_ch
-        if args.mode != "mixed" or mixed_one:   # (the engine's event pair closes behind the step's LAST launch: iqd_engine.cpp, evp_open)
+        if True:   # (the engine's event pair closes behind the step's LAST launch in every arrangement: iqd_engine.cpp, evp_open)
             timed += " + the step's closing launch (repair check, state commit, tails, squelch pass): every launch of the step"
         prof, prof_path = profile_summary(args.tag) if args.tag else (None, None)
         needle = {"wbfm": "wbfm_stream_kernel" if streamed else "wbfm_chain_kernel", "fm": "d4_stream_kernel" if streamed else "fm_chain_kernel",

@@ -15,7 +15,8 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(HERE, "libiqd_oracle.so")
-REF_SO = os.path.join(HERE, "_ref", "libiqd_ref.so")
+REF_SO = os.path.join(HERE, "_ref", "libiqd_ref.so")            # the reference's hot path (no AGC, no scanner, no Radio test double)
+REF_AGC_SO = os.path.join(HERE, "_ref", "libiqd_ref_agc.so")    # ... plus AutomaticGainControl.cc, FrequencyScanner.cc and their owner's double
 
 MODES = {"none": 0, "am": 1, "fm": 2, "wbfm": 3, "lsb": 4, "usb": 5}
 TAP_SETS = ["wbfm_pre", "wbfm_d1", "wbfm_d2", "audio40", "fm_tuner", "fm_post",
@@ -301,6 +302,26 @@ class Reference:
         _sig(L.ref_squelch_destroy, None, [vp])
         _sig(L.ref_squelch_run, C.c_int, [vp, C.c_uint32, vp, C.c_uint32, vp])
         _sig(L.ref_dbfs, C.c_int32, [C.c_uint32])
+        self._agc_lib = None
+
+    def _with_owner(self):
+        """The second library (oracle/Makefile: -DIQD_REF_WITH_OWNER): the same chain with the reference's AGC and scanner and the
+        harness' test double of their owner.  Loaded only by the (f)-2 / (f)-3 pins; the hot-path pin never maps it."""
+        if self._agc_lib is not None:
+            return self._agc_lib
+        if not os.path.exists(REF_AGC_SO):
+            raise FileNotFoundError(REF_AGC_SO)
+        L = self._agc_lib = C.CDLL(REF_AGC_SO)
+        vp, sz = C.c_void_p, C.c_size_t
+        _sig(L.ref_create, vp, [])
+        _sig(L.ref_destroy, None, [vp])
+        _sig(L.ref_reset, None, [vp])
+        _sig(L.ref_set_mode, None, [vp, C.c_int])
+        _sig(L.ref_set_gain, None, [vp, C.c_int, C.c_float])
+        _sig(L.ref_set_squelch, None, [vp, C.c_int32])
+        _sig(L.ref_set_rx_gain_db, None, [C.c_uint32])
+        _sig(L.ref_accept_stream, C.c_long, [vp, vp, sz, sz, vp, sz, vp, vp])
+        _sig(L.ref_demod_accept, C.c_long, [vp, C.c_int, vp, C.c_uint32, vp, sz])
         _sig(L.ref_agc_attach, None, [vp, C.c_int32])
         _sig(L.ref_agc_set, C.c_int, [vp, C.c_int, C.c_float])
         _sig(L.ref_agc_run, None, [vp, C.c_uint32])
@@ -308,13 +329,14 @@ class Reference:
         _sig(L.ref_scanner_attach, None, [vp])
         _sig(L.ref_scanner_cmd, C.c_int, [vp, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64])
         _sig(L.ref_scanner_frequency, C.c_uint64, [vp, C.POINTER(C.c_uint32)])
+        return L
 
     def chain(self, agc=False, operating_point=-12, scanner=False):
         """agc=True attaches the reference's AutomaticGainControl the way Radio.cc:184 does; the chain then has
         its own IF gain (the harness' Radio double) instead of the process-global one, and per-block magnitudes
         read 0xffffffff (the AGC owns the single magnitude-callback slot).  scanner=True attaches the reference's
         FrequencyScanner (it owns the signal-state slot: `allowed` then reads 0xff)."""
-        L = self.lib
+        L = self._with_owner() if (agc or scanner) else self.lib
         c = _Chain(L, "ref_")
         c.set_rx_gain_db = lambda g: L.ref_set_rx_gain_db(int(g))  # a process global
         if agc:

@@ -26,6 +26,7 @@
 #include "iqd_taps.h"
 #include "iqd_wbfm.h"
 #include "iqd_chains.h"
+#include "iqd_d4_fix.h"
 
 using namespace iqd;
 
@@ -127,6 +128,7 @@ struct iqd_engine {
     D4Args d4_args{};
     std::vector<float> fm_kmax;          // [n_ch]: like wbfm_kmax, for the FM chain
     bool stream_ok = false;              // the half table's symmetry holds on this host's libm
+    std::vector<uint32_t> mode_gen, rot_gen;   // [n_ch]: bumped by iqd_set_mode / iqd_set_rotation (iqd_demod_accept restores only what nobody set meanwhile)
     std::vector<float> wbfm_kmax;        // [n_ch]: largest |K| a channel has run with since creation (casts stay bounded)
     StreamArgs stream_args{};
     uint64_t stream_handoffs = 0;        // cold segments launched so far (their verification counts only mismatches)
@@ -136,6 +138,7 @@ struct iqd_engine {
 
     // per-call scratch
     DevBuf stream_hist;   // boundary records of the streaming WBFM kernel, one StHist per segment
+    DevBuf d4_rec[FAM_COUNT];   // ... of the FM / AM / SSB pipelines (iqd_d4_fix.h), one buffer per family: they may run side by side
     DevBuf lists[FAM_COUNT + 1], mag_sums, blk_lists, vlen, records, base8k, base8k2, gain_trace, freq_trace, dc_records, dc_records2, repair_flags;
     size_t mag_sums_zero = 0;            // leading elements of mag_sums known to be zero (left so by the last squelch pass)
     // IQD_F_PREPASS_OVERLAP: a squelch-gated call's pre-pass (magnitudes of every block, decisions, open-block lists) runs on a
@@ -265,6 +268,7 @@ int iqd_create(const iqd_config *cfg, iqd_t **out)
             for (int f = 0; f < FAM_COUNT; f++) kn.fam_ns[f] = w[f];
     }
     if (const char *env = getenv("IQD_D4_GRAN")) kn.env_d4_gran = (uint32_t)atoi(env);
+    if (const char *env = getenv("IQD_D4_LEADFREE")) kn.d4_leadfree = atoi(env) != 0;
     if (const char *env = getenv("IQD_STREAM_MIN_SEG")) kn.env_stream_min_seg = atoi(env) > 0 ? (uint64_t)atoi(env) : 0;
     if (const char *env = getenv("IQD_AM_STREAM_MIN")) kn.env_am_stream_min = atoi(env) > 0 ? (uint32_t)atoi(env) : AM_STREAM_MIN_PCM;
     if (const char *env = getenv("IQD_MIXED")) kn.env_mixed_forked = env[0] == 'f' && env[1] == 'o';
@@ -409,7 +413,7 @@ void iqd_destroy(iqd_t *e)
         if (p) (void)hipFree(p);
     if (e->h_counters) (void)hipHostFree(e->h_counters);
     for (auto &b : e->lists) b.release();
-    DevBuf *bufs[] = {&e->stream_hist, &e->mag_sums, &e->blk_lists, &e->vlen, &e->records, &e->base8k, &e->base8k2, &e->gain_trace, &e->freq_trace, &e->dc_records, &e->dc_records2, &e->repair_flags,
+    DevBuf *bufs[] = {&e->d4_rec[0], &e->d4_rec[1], &e->d4_rec[2], &e->d4_rec[3], &e->stream_hist, &e->mag_sums, &e->blk_lists, &e->vlen, &e->records, &e->base8k, &e->base8k2, &e->gain_trace, &e->freq_trace, &e->dc_records, &e->dc_records2, &e->repair_flags,
                       &e->st_iq, &e->st_pcm, &e->st_count, &e->st_mag, &e->st_allowed};
     for (DevBuf *b : bufs) b->release();
     for (int b = 0; b < 2; b++) {
@@ -449,8 +453,10 @@ int iqd_set_mode(iqd_t *e, uint32_t first_ch, uint32_t n_ch, int mode)
 {
     if (!range_ok(e, first_ch, n_ch) || mode < IQD_MODE_NONE || mode > IQD_MODE_USB) return IQD_EINVAL;
     std::lock_guard<std::mutex> lk(e->mu);
+    if (e->mode_gen.size() < e->h_params.size()) e->mode_gen.resize(e->h_params.size(), 0u);
     for (uint32_t c = first_ch; c < first_ch + n_ch; c++) {
         e->h_params[c].mode = mode;
+        e->mode_gen[c]++;
         if (mode == IQD_MODE_LSB) e->h_params[c].ssb_lsb = 1;  // IqDataProcessor.cc:244-256
         if (mode == IQD_MODE_USB) e->h_params[c].ssb_lsb = 0;
     }
@@ -746,7 +752,11 @@ int iqd_set_rotation(iqd_t *e, uint32_t first_ch, uint32_t n_ch, int rotation)
 {
     if (!range_ok(e, first_ch, n_ch) || rotation < -1 || rotation > 1) return IQD_EINVAL;
     std::lock_guard<std::mutex> lk(e->mu);
-    for (uint32_t c = first_ch; c < first_ch + n_ch; c++) e->h_params[c].rotation = rotation;
+    if (e->rot_gen.size() < e->h_params.size()) e->rot_gen.resize(e->h_params.size(), 0u);
+    for (uint32_t c = first_ch; c < first_ch + n_ch; c++) {
+        e->h_params[c].rotation = rotation;
+        e->rot_gen[c]++;
+    }
     e->params_dirty = e->lists_dirty = true;   // (the families' channel lists are grouped by selector for the streaming kernels)
     return IQD_OK;
 }
@@ -1219,7 +1229,9 @@ static void describe_call(const iqd_t *e, const CallCtx &x, CallShape &c)
         s.n_list = (uint32_t)l.size();
         if (l.empty()) continue;
         for (int r = 0; r < 3; r++) s.rot_count[r] = e->rot_count[f][r];
-        s.rot_first = e->h_params[x.first_ch + l[0]].rotation;
+        // (from the snapshot prepare_call took under the lock, not from the live parameters a setter may be writing: ADVICE r5.
+        //  The list is sorted +Fs/4, none, -Fs/4, so its first channel's selector is the first non-empty group's)
+        s.rot_first = s.rot_count[0] ? 1 : (s.rot_count[1] ? 0 : -1);
         if (f == FAM_WBFM)
             for (uint32_t ch : l) {
                 s.cast_bounded = s.cast_bounded && e->wbfm_kmax[x.first_ch + ch] * 3.1730f < 2147483648.0f;
@@ -1433,7 +1445,7 @@ static int queue_family(iqd_t *e, CallCtx &x, int f)
         }
         a.repair_flags = e->repair_flags.as<uint32_t>();
         if (streams) {
-            const int stream_rot = e->h_params[x.first_ch + e->h_lists[FAM_WBFM][0]].rotation;
+            const int stream_rot = e->plan_shape.fam[FAM_WBFM].rot_first;   // (the plan's snapshot: queue_* decide nothing and read no live parameter)
             StreamArgs sa = e->stream_args;
             sa.amat = e->d_amat[stream_rot + 1];
             sa.half_lut = e->d_half_lut;
@@ -1475,9 +1487,17 @@ static int queue_family(iqd_t *e, CallCtx &x, int f)
             d4.group_start[3] = fp.group_start[3];
             d4.amat = e->d_amat4 + (size_t)(f == FAM_FM ? 0 : 3) * 4 * 64 * 4;
             d4.fm_lut = e->d_fmlut;
-            d4.halo = f == FAM_FM ? D4_HALO_FM : (f == FAM_AM ? D4_HALO_AM : D4_HALO_SSB);
+            d4.halo = (int32_t)fp.halo;
+            d4.lead_shift = fp.lead_shift;
             d4.rounds = fp.rounds;
             d4.rings = fp.rings;
+            if (fp.lead_shift) {   // short lead-ins: a boundary record per segment, read by the launch that closes the step (iqd_d4_fix.h)
+                DevBuf &rb = e->d4_rec[f];
+                HIP_TRY(e, rb.ensure((size_t)n_list * a.tiles_per_ch * d4_rec_bytes(f)));
+                d4.rec = rb.p;
+                a.d4_rec = rb.p;
+                a.d4_shift = fp.lead_shift;
+            }
         }
         if (f != FAM_FM) {
             int rc = attach_dc_buffers(e, x, f, a, s);
@@ -1507,15 +1527,9 @@ static int queue_family(iqd_t *e, CallCtx &x, int f)
         }
     }
     if (e->profiling && !x.timed && !fused) {
-        // a call of one family: the pair closes behind the step's last launch (queue_commit), so that the timed region holds
-        // EVERY launch of the step (the repair-check / commit / squelch launch was left out);
-        // several families on their own streams: only the first family's launches, as before
-        if (forked) {
-            HIP_TRY(e, hipEventRecord(x.evp.second, s));
-            e->ev_pending.push_back(x.evp);
-        } else {
-            x.evp_open = true;
-        }
+        // the pair closes behind the step's last launch (queue_commit), so that the timed region holds EVERY launch of the step
+        // (the repair-check / commit / squelch launch was left out)
+        x.evp_open = true;   // (forked plans opened theirs in front of the fork: iqd_accept_iq_device)
         x.timed = true;
     }
     e->stats.kernel_launches++;
@@ -1674,6 +1688,15 @@ int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch, const void 
         // the detector-stream buffers before the fork (an allocation that grows one must not free what a side stream still reads)
         if (!e->h_lists[FAM_AM].empty()) HIP_TRY(e, e->base8k.ensure((size_t)n_ch * x.base.pcm_stride * sizeof(int32_t)));
         if (!e->h_lists[FAM_SSB].empty()) HIP_TRY(e, e->base8k2.ensure((size_t)n_ch * x.base.pcm_stride * sizeof(int32_t)));
+        // several families as kernels of their own on side streams: the timed region opens in front of the fork and closes behind
+        // the join and the closing launch (queue_commit), like every other arrangement's - every launch of the step (ADVICE r5:
+        // it used to hold the first family's launches only, so kernel_ms was not comparable across arrangements)
+        if (!plan.fused && e->profiling) {
+            rc = take_event_pair(e, x, x.s_main);
+            if (rc != IQD_OK) return rc;
+            x.timed = true;
+            x.evp_open = true;
+        }
         if (!plan.fused) HIP_TRY(e, hipEventRecord(e->fam_fork, x.s_main));
     }
     for (int oi = 0; oi < FAM_COUNT; oi++) {
@@ -1898,10 +1921,15 @@ int iqd_demod_accept(iqd_t *e, uint32_t first_ch, uint32_t n_ch, int demod, cons
     // wanted mode with selector 0 is left alone: a bare demodulator object driven call after call (demod.cc, one block per
     // call) then costs no parameter upload, no list rebuild and no tail rewrite at all.
     std::vector<int32_t> mode0(n_ch), rot0(n_ch), mode1(n_ch);
+    std::vector<uint32_t> mgen(n_ch), rgen(n_ch);   // the setters' generation counters as this call found them
     bool touched = false;
     {
         std::lock_guard<std::mutex> lk(e->mu);
+        if (e->mode_gen.size() < e->h_params.size()) e->mode_gen.resize(e->h_params.size(), 0u);
+        if (e->rot_gen.size() < e->h_params.size()) e->rot_gen.resize(e->h_params.size(), 0u);
         for (uint32_t c = 0; c < n_ch; c++) {
+            mgen[c] = e->mode_gen[first_ch + c];
+            rgen[c] = e->rot_gen[first_ch + c];
             ChanParams &p = e->h_params[first_ch + c];
             mode0[c] = p.mode;
             rot0[c] = p.rotation;
@@ -1939,13 +1967,13 @@ int iqd_demod_accept(iqd_t *e, uint32_t first_ch, uint32_t n_ch, int demod, cons
     }
     e->demod_bypass = false;
     if (touched) {
-        // only what this call wrote and nobody has changed since: a setter that ran meanwhile (the mutex is there for setters
-        // against accepts) keeps its value
+        // only what this call wrote and no setter has written since - by the setters' generation counters, not by value: a
+        // set_mode to the demodulator's own mode or a set_rotation(0) issued during the call keeps its value too
         std::lock_guard<std::mutex> lk(e->mu);
         for (uint32_t c = 0; c < n_ch; c++) {
             ChanParams &p = e->h_params[first_ch + c];
-            if (p.mode == mode1[c]) p.mode = mode0[c];
-            if (p.rotation == 0) p.rotation = rot0[c];
+            if (e->mode_gen[first_ch + c] == mgen[c]) p.mode = mode0[c];
+            if (e->rot_gen[first_ch + c] == rgen[c]) p.rotation = rot0[c];
         }
         e->params_dirty = e->lists_dirty = true;
     }

@@ -396,18 +396,20 @@ bool plan_fused_by_time(uint32_t vlen, int n, const FusedFamily *fam, uint32_t n
         if (!n_ch) continue;
         const uint32_t g = fam[f].granule == 128 || fam[f].granule == 256 ? fam[f].granule : 512;
         uint32_t last_len = 0;
-        for (uint32_t k = 1; last_len != (uint32_t)ST_MIN_TILE && k <= vlen;) {   // (down to the shortest segment there is)
-            uint64_t len = ((uint64_t)vlen + k - 1) / k;
+        const uint64_t span = (uint64_t)vlen + fam[f].shift;     // (short lead-ins: the segments cover [-shift, vlen), plan_stream)
+        const uint32_t min_tile = fam[f].shift ? std::max<uint32_t>((uint32_t)ST_MIN_TILE, fam[f].shift + 128) : (uint32_t)ST_MIN_TILE;
+        for (uint32_t k = 1; last_len != min_tile && k <= vlen;) {   // (down to the shortest segment there is)
+            uint64_t len = (span + k - 1) / k;
             len = (len + g - 1) / g * g;
-            if (len < ST_MIN_TILE) len = ST_MIN_TILE;
+            if (len < min_tile) len = min_tile;
             // the next k worth a look is the first that gives a shorter segment: ceil(vlen / k) <= len - g (one k at a
             // time this walked vlen / 768 values of k - 2 ms of host time for a 2^28-sample row, more than its kernels run)
             const uint64_t shorter = len > g ? len - g : 1;
-            const uint32_t k_next = (uint32_t)std::max<uint64_t>(k + 1, ((uint64_t)vlen + shorter - 1) / shorter);
+            const uint32_t k_next = (uint32_t)std::max<uint64_t>(k + 1, (span + shorter - 1) / shorter);
             if ((uint32_t)len == last_len) { k = k_next; continue; }
             last_len = (uint32_t)len;
             k = k_next;
-            const uint32_t tiles = (uint32_t)(((uint64_t)vlen + len - 1) / len);
+            const uint32_t tiles = (uint32_t)((span + len - 1) / len);
             uint64_t ids = 0;
             for (int r = 0; r < 3; r++) ids += ((uint64_t)fam[f].rot_count[r] * tiles + 15) / 16 * 16;
             const uint64_t wgs = (ids + ST_SEGS - 1) / ST_SEGS;
@@ -451,22 +453,26 @@ bool plan_fused_by_time(uint32_t vlen, int n, const FusedFamily *fam, uint32_t n
     return false;
 }
 
-TilePlan plan_stream(uint32_t vlen, uint32_t n_channels, uint32_t streams, uint32_t granule)
+TilePlan plan_stream(uint32_t vlen, uint32_t n_channels, uint32_t streams, uint32_t granule, uint32_t shift)
 {
     TilePlan p;
     // As many segments as fit ONE round of the persistent workgroups (all segments of a round advance in lock step,
     // so a second round with a handful of stragglers would cost as much as the first).
+    // shift: the channel's segments cover [-shift, vlen) - its first one starts that far before the call's first sample (its
+    // full lead-in, from the kept tail) - and a segment is longer than the shift, so that the first one holds samples of the call.
     uint32_t per_ch = n_channels ? streams / n_channels : 1;
     if (per_ch == 0) per_ch = 1;
-    uint64_t len = ((uint64_t)vlen + per_ch - 1) / per_ch;
+    const uint64_t span = (uint64_t)vlen + shift;
+    const uint64_t min_tile = shift ? std::max<uint64_t>(ST_MIN_TILE, shift + 128) : (uint64_t)ST_MIN_TILE;
+    uint64_t len = (span + per_ch - 1) / per_ch;
     if (granule != 128 && granule != 256) granule = 512;
     len = (len + granule - 1) / granule * granule;   // 512: whole 32-byte PCM sectors per segment (16 PCM samples)
-    if (len < ST_MIN_TILE) len = ST_MIN_TILE;   // a segment's end histories must be its own
+    if (len < min_tile) len = min_tile;   // a segment's end histories must be its own
     // (the minimum itself is not a multiple of the 512 granule: take it where it fits the round - 4096-sample rows on 6 segments
     //  per channel are 6 x 768, not 4 x 1024)
-    if (len > ST_MIN_TILE && ((uint64_t)vlen + ST_MIN_TILE - 1) / ST_MIN_TILE <= per_ch) len = ST_MIN_TILE;
+    if (len > min_tile && (span + min_tile - 1) / min_tile <= per_ch) len = min_tile;
     p.tile_len = (uint32_t)len;
-    p.tiles_per_ch = (uint32_t)(((uint64_t)vlen + len - 1) / len);
+    p.tiles_per_ch = (uint32_t)((span + len - 1) / len);
     if (p.tiles_per_ch == 0) p.tiles_per_ch = 1;
     return p;
 }

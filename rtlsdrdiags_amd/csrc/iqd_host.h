@@ -31,13 +31,14 @@ struct TilePlan { uint32_t tile_len, tiles_per_ch; };
 TilePlan plan_tiles(uint32_t vlen, uint32_t n_channels, uint32_t chunk, uint32_t halo, uint32_t resident_wgs,
                     uint32_t force_chunks = 0 /* experiments: k chunks per tile */);
 
-TilePlan plan_stream(uint32_t vlen, uint32_t n_channels, uint32_t streams, uint32_t granule = 512 /* segment lengths are multiples of this: 128, 256 or 512 samples */);
+TilePlan plan_stream(uint32_t vlen, uint32_t n_channels, uint32_t streams, uint32_t granule = 512 /* segment lengths are multiples of this: 128, 256 or 512 samples */,
+                     uint32_t shift = 0 /* FM / AM / SSB with short lead-ins (iqd_d4_fix.h): segment t covers [t * tile_len - shift, ...) */);
 // Several demodulator families in one call, each with its streaming kernel: the CUs each family's persistent workgroups
 // get, in proportion to cost[f] (0 = family absent: its entry becomes n_cus).  Whole multiples of 8, at least 8, two CUs
 // per XCD left unplanned; false (and every entry n_cus) when that cannot be had.  See iqd_host.cpp.
 bool plan_family_shares(const float *cost, int n, uint32_t n_cus, uint32_t *share);
 void plan_fused_shares(const float *cost, int n, uint32_t n_wgs, uint32_t *share);   // several families as ranges of one launch
-struct FusedFamily { uint32_t rot_count[3]; uint32_t halo, granule; float ns_per_sample; };
+struct FusedFamily { uint32_t rot_count[3]; uint32_t halo, granule; float ns_per_sample; uint32_t shift = 0; /* see plan_stream */ };
 bool plan_fused_by_time(uint32_t vlen, int n, const FusedFamily *fam, uint32_t n_wgs, uint32_t *share);
 
 uint32_t block_magic(uint32_t block_samples);

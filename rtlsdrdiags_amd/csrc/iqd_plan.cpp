@@ -23,9 +23,11 @@ uint64_t stream_min_seg(const PlanKnobs &k, int f, uint64_t vlen, int several_fa
 
 namespace {
 
-uint32_t halo_of(int f)
+// lead-in samples every segment of family f's streaming launch runs, and the shift of a channel's segments (plan_stream)
+uint32_t shift_of(const PlanKnobs &k, int f) { return f != FAM_WBFM && k.d4_leadfree ? (uint32_t)d4_lead_shift(f) : 0u; }
+uint32_t halo_of(const PlanKnobs &k, int f)
 {
-    return f == FAM_WBFM ? (uint32_t)ST_HALO : f == FAM_FM ? (uint32_t)D4_HALO_FM : f == FAM_AM ? (uint32_t)D4_HALO_AM : (uint32_t)D4_HALO_SSB;
+    return f == FAM_WBFM ? (uint32_t)ST_HALO : (uint32_t)d4_full_halo(f) - shift_of(k, f);
 }
 
 // the segment ids of a streaming launch grouped by rotation selector, each group padded to a multiple of 16
@@ -43,6 +45,21 @@ uint32_t group_ids(const FamilyShape &s, FamilyPlan &p)
     return at;
 }
 
+// The segments a streaming launch of `slots` segment slots cuts family s's rows into - the ONE search both rings_of() and
+// plan_once() use (they each had a copy): the shortest segments that fit one round (plan_stream); when the rotation
+// groups' padding to 16 ids pushes an exact fit into a second round, once more with 48 slots spare.  Fills p.tile_len,
+// p.tiles_per_ch and (grouped) the group_* fields; returns the segment ids the launch needs.
+uint32_t fit_stream(const FamilyShape &s, uint32_t vlen, uint32_t slots, uint32_t granule, bool grouped, uint32_t shift, FamilyPlan &p)
+{
+    for (uint32_t spare = 0;; spare += 48) {
+        const TilePlan sp = plan_stream(vlen, s.n_list, grouped && slots > spare ? slots - spare : slots, granule, shift);
+        p.tile_len = sp.tile_len;
+        p.tiles_per_ch = sp.tiles_per_ch;
+        const uint32_t ids = grouped ? group_ids(s, p) : s.n_list * sp.tiles_per_ch;
+        if (!grouped || ids <= slots || spare >= 48 || s.n_list >= slots) return ids;
+    }
+}
+
 // Rings of 64 segments per workgroup of family f's streaming launch (StreamArgs::rings), round 5.  A launch too small to give
 // every CU a full workgroup of three rings used to fill a part of the chip with full workgroups of minimum-length segments;
 // spread over all CUs as workgroups of one or two rings its segments are longer (less lead-in per sample) and a ring's pieces go
@@ -51,21 +68,6 @@ uint32_t group_ids(const FamilyShape &s, FamilyPlan &p)
 // 2^14 .. 2^16; profiles/r5_rings_probe.txt: the rule picks the fastest arrangement in 14 of the 15 cases measured, second by
 // 2 % in the other).  The estimate is pieces per segment x that factor.  Streaming launches of 1024 channels x 2^14: AM 0.076 ->
 // 0.064 ms per step, FM 0.087 -> 0.076, WBFM 0.124 -> 0.104; 4096 x 2^14: AM 0.085 -> 0.081, WBFM 0.164 -> 0.158; larger: three rings.
-// The segment length a streaming launch of `slots` segment slots would get (the plan's own search: first an exact fit, then
-// with 48 slots spare for the rotation groups' padding), and whether it fits one round.
-struct SegFit { uint32_t tile_len; bool one_round; };
-SegFit fit_segments(const FamilyShape &s, uint32_t vlen, uint32_t slots, uint32_t granule, bool grouped)
-{
-    FamilyPlan tmp;
-    for (uint32_t spare = 0;; spare += 48) {
-        const TilePlan sp = plan_stream(vlen, s.n_list, slots > spare ? slots - spare : slots, granule);
-        tmp.tile_len = sp.tile_len;
-        tmp.tiles_per_ch = sp.tiles_per_ch;
-        const uint32_t ids = grouped ? group_ids(s, tmp) : s.n_list * sp.tiles_per_ch;
-        if (ids <= slots || spare >= 48 || !grouped) return SegFit{sp.tile_len, ids <= slots};
-    }
-}
-
 uint32_t rings_of(const PlanKnobs &k, const CallShape &c, int f, uint32_t wgs, bool fused, bool grouped)
 {
     if (fused) return (uint32_t)ST_RINGS;   // (the shares of the one launch are planned in workgroups of three rings: plan_fused_by_time)
@@ -77,9 +79,10 @@ uint32_t rings_of(const PlanKnobs &k, const CallShape &c, int f, uint32_t wgs, b
     uint32_t best = (uint32_t)ST_RINGS;
     float best_t = 0.f;
     for (uint32_t r = (uint32_t)ST_RINGS; r >= 1; r--) {
-        const SegFit fit = fit_segments(s, c.vlen, wgs * 64u * r, granule, grouped);
-        if (!fit.one_round) continue;                                      // (a second round: never better)
-        const float t = per_piece[r] * (float)(fit.tile_len + halo_of(f));
+        FamilyPlan tmp;
+        const uint32_t ids = fit_stream(s, c.vlen, wgs * 64u * r, granule, grouped, shift_of(k, f), tmp);
+        if (ids > wgs * 64u * r) continue;                                 // (a second round: never better)
+        const float t = per_piece[r] * (float)(tmp.tile_len + halo_of(k, f));
         if (r == (uint32_t)ST_RINGS || t < 0.99f * best_t) { best = r; best_t = t; }
     }
     return best;
@@ -146,7 +149,8 @@ bool plan_once(const PlanKnobs &k, const CallShape &c, bool allow_fused, CallPla
         FusedFamily ff[FAM_COUNT];
         for (int f = 0; f < FAM_COUNT; f++) {
             for (int r = 0; r < 3; r++) ff[f].rot_count[r] = c.fam[f].n_list ? c.fam[f].rot_count[r] : 0u;
-            ff[f].halo = halo_of(f);
+            ff[f].halo = halo_of(k, f);
+            ff[f].shift = shift_of(k, f);
             ff[f].granule = f == FAM_WBFM ? k.env_stream_gran : k.env_d4_gran;
             ff[f].ns_per_sample = k.fam_ns[f];
         }
@@ -198,15 +202,7 @@ bool plan_once(const PlanKnobs &k, const CallShape &c, bool allow_fused, CallPla
                 p.rings = rings_of(k, c, f, p.wgs, fused, p.grouped);
                 for (;;) {
                     const uint32_t wg_segs = 64u * p.rings;
-                    for (uint32_t spare = 0;; spare += 48) {   // (the groups' padding may push an exact fit into a second round)
-                        const TilePlan sp = plan_stream(vlen, s.n_list, p.wgs * wg_segs - (p.grouped ? spare : 0u), k.env_stream_gran);
-                        p.tile_len = sp.tile_len;
-                        p.tiles_per_ch = sp.tiles_per_ch;
-                        if (!p.grouped) break;
-                        const uint32_t at = group_ids(s, p);
-                        if (at <= p.wgs * wg_segs || spare >= 48 || s.n_list * 1u >= p.wgs * wg_segs) break;
-                    }
-                    const uint32_t ids = p.grouped ? p.group_start[3] : s.n_list * p.tiles_per_ch;
+                    const uint32_t ids = fit_stream(s, vlen, p.wgs * wg_segs, k.env_stream_gran, p.grouped, 0u, p);
                     const uint32_t wgs_needed = (ids + wg_segs - 1) / wg_segs;
                     p.grid = wgs_needed < p.wgs ? wgs_needed : p.wgs;
                     p.rounds = (wgs_needed + p.grid - 1) / p.grid;
@@ -222,17 +218,13 @@ bool plan_once(const PlanKnobs &k, const CallShape &c, bool allow_fused, CallPla
             if (ok && want >= 0 && enough) {
                 p.path = PLAN_STREAM;
                 p.grouped = true;
+                p.halo = halo_of(k, f);
+                p.lead_shift = shift_of(k, f);
                 p.rings = rings_of(k, c, f, p.wgs, fused, true);
                 for (;;) {
                     const uint32_t wg_segs = 64u * p.rings;
-                    for (uint32_t spare = 0;; spare += 48) {   // (the rotation groups' padding may push an exact fit into a second round)
-                        // (these pipelines store 8 or 16 bytes per 128 samples: no wide stores to keep whole)
-                        const TilePlan sp = plan_stream(vlen, s.n_list, p.wgs * wg_segs - spare, k.env_d4_gran);
-                        p.tile_len = sp.tile_len;
-                        p.tiles_per_ch = sp.tiles_per_ch;
-                        const uint32_t at = group_ids(s, p);
-                        if (at <= p.wgs * wg_segs || spare >= 48 || s.n_list * 1u >= p.wgs * wg_segs) break;
-                    }
+                    // (these pipelines store 8 or 16 bytes per 128 samples: no wide stores to keep whole)
+                    fit_stream(s, vlen, p.wgs * wg_segs, k.env_d4_gran, true, p.lead_shift, p);
                     const uint32_t wgs_needed = (p.group_start[3] + wg_segs - 1) / wg_segs;
                     p.grid = wgs_needed < p.wgs ? wgs_needed : p.wgs;
                     p.rounds = (wgs_needed + p.grid - 1) / p.grid;

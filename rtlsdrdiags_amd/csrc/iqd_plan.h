@@ -45,6 +45,8 @@ struct PlanKnobs {
     uint64_t env_stream_min_seg = 0;     // IQD_STREAM_MIN_SEG (0: the measured per-family thresholds)
     uint32_t env_am_stream_min = AM_STREAM_MIN_PCM;   // IQD_AM_STREAM_MIN (measurement runs: 513 = the rule of rounds 2-3)
     uint32_t env_d4_gran = 128;          // IQD_D4_GRAN: segment-length granule of the FM / AM / SSB pipelines (measurement runs)
+    bool d4_leadfree = true;             // FM / AM / SSB streaming segments with 128-sample lead-ins, boundary records and a fix-up (round 6,
+                                         // iqd_d4_fix.h); IQD_D4_LEADFREE=0: every segment with its family's full lead-in (rounds 2-5, the A/B)
     bool env_full_grid = false;          // IQD_FULL_GRID
     bool env_mixed_forked = false;       // IQD_MIXED=forked: several families as kernels of their own side by side (A/B runs)
     bool env_shares_by_cost = false;     // IQD_SHARES=cost: round 3's proportional shares
@@ -84,6 +86,7 @@ struct FamilyPlan {
     uint32_t wgs = 0;                    // the family's share of the CUs / of the one launch's workgroups
     uint32_t tile_len = 0, tiles_per_ch = 0;
     // streaming pipelines
+    uint32_t halo = 0, lead_shift = 0;   // FM / AM / SSB: lead-in samples every segment runs; how far a channel's segments are shifted (iqd_d4_fix.h)
     bool grouped = false;                // segment ids grouped by rotation selector, each group padded to 16 (WBFM: only if mixed)
     uint32_t group_start[4] = {0, 0, 0, 0}, group_li0[3] = {0, 0, 0}, group_nseg[3] = {0, 0, 0};
     uint32_t grid = 0, rounds = 0;       // workgroups launched, rounds each runs

@@ -100,7 +100,12 @@ struct StreamArgs {
 // FM / AM / SSB as streaming pipelines (iqd_stream2.hip): the chain's first /4 decimator on the matrix cores in
 // P waves, everything behind it in consumer lanes.
 enum { D4_AM = 0, D4_SSB = 1, D4_FM = 2 };
-constexpr int D4_HALO_AM = 384, D4_HALO_SSB = 1280, D4_HALO_FM = 768;   // lead-in samples (the chains need 260 / 1220 / 684)
+constexpr int D4_HALO_AM = 384, D4_HALO_SSB = 1280, D4_HALO_FM = 768;   // FULL lead-in samples (the chains need 260 / 1220 / 684): a channel's first segment, from the kept tail
+// Round 6 (iqd_d4_fix.h): every segment but a channel's first runs D4_HALO_SHORT samples of lead-in and takes what its first
+// outputs reach back for from its predecessor's boundary record; a channel's segments are shifted by full lead-in - 128.
+constexpr int D4_HALO_SHORT = 128;
+constexpr int d4_full_halo(int family) { return family == FAM_FM ? D4_HALO_FM : family == FAM_AM ? D4_HALO_AM : D4_HALO_SSB; }
+constexpr int d4_lead_shift(int family) { return d4_full_halo(family) - D4_HALO_SHORT; }
 struct D4Args {
     const uint32_t *amat;        // [3 rotation selectors -1, 0, +1][4][64][4]: build_decim4_amat()
     const float *fm_lut;         // 283 x 283 phase angles
@@ -109,7 +114,9 @@ struct D4Args {
     uint32_t group_nseg[3];      // real segments in each group
     uint32_t rounds;
     uint32_t rings;              // rings a workgroup runs (StreamArgs::rings)
-    int32_t halo;
+    int32_t halo;                // lead-in samples every segment of the launch runs (the family's full lead-in, or D4_HALO_SHORT)
+    uint32_t lead_shift;         // round 6 (iqd_d4_fix.h): segment t covers [t * tile_len - lead_shift, ...) - full lead-in minus halo; 0 = every segment with its full lead-in
+    void *rec;                   // ... and leaves a boundary record here, [n_list * tiles_per_ch] D4RecAm / D4RecSsb / D4RecFm (nullptr: none)
     uint32_t s2p[6], s3p[8];     // AM/SSB stage 2 (12 taps, DOUBLED: the result is the accumulator's high half) and stage 3 (16 taps) as v_dot2 pairs, newest pair first
     uint32_t hilb[16];           // SSB: the nonzero Hilbert taps h[0], h[2], ..., h[30] (int16 in the low half)
     uint32_t p12p[6], a40p[20];  // FM post-discriminator decimators

@@ -33,6 +33,7 @@
 #include "iqd_wbfm.h"
 #include "iqd_mfma.h"
 #include "iqd_taps.h"
+#include "iqd_d4_fix.h"
 
 // build-time experiments (tools/variant.sh): all off in the shipped library
 #ifndef IQD_D4_SPLIT
@@ -124,8 +125,10 @@ __device__ __forceinline__ D4Seg d4_segment(const ChainLaunch &a, const D4Args &
     // virtual stream of vlen_gated[ch] samples; the segments are cut on that axis, those beyond its end are not there
     const uint32_t vlen = a.vlen_gated ? a.vlen_gated[s.ch] : a.vlen;
     s.vlen = (int32_t)vlen;
-    const int64_t v0 = (int64_t)s.tile * a.tile_len;
-    if (v0 >= (int64_t)vlen) { s.valid = 0; s.v0 = 0; s.tlen = 0; return s; }
+    // (round 6, iqd_d4_fix.h: segment t covers [t * tile_len - lead_shift, ...): a channel's first segment starts BEFORE the call's
+    //  first sample - its full lead-in from the kept tail -, and what it computes for positions before 0 is not stored)
+    const int64_t v0 = (int64_t)s.tile * a.tile_len - (int64_t)da.lead_shift;
+    if (vlen == 0 || v0 >= (int64_t)vlen) { s.valid = 0; s.v0 = 0; s.tlen = 0; return s; }
     s.v0 = (int32_t)v0;
     const int64_t rest = (int64_t)vlen - v0;
     s.tlen = s.valid ? (int32_t)(rest < (int64_t)a.tile_len ? rest : (int64_t)a.tile_len) : 0;
@@ -203,12 +206,13 @@ __device__ __forceinline__ void d4_p_round(const ChainLaunch &a, const D4Args &d
         uint32_t *mag_row = MAG ? a.mag_sums + (size_t)sgl.ch * a.n_blocks : nullptr;
         const bool mcount = MAG && sgl.valid;
         const int32_t mlimit = sgl.tlen - 8 * gl;
+        const int32_t mfirst = sgl.v0 < 0 ? -sgl.v0 : 0;          // (a channel's first segment: its samples before the call's first)
 #if IQD_D4_TIMING
         long long t_ring_wait = 0;
 #endif
         uint32_t macc = 0;
-        uint32_t mblk = (uint32_t)(sgl.v0 + 8 * gl) / a.block_samples;
-        uint32_t minblk = (uint32_t)(sgl.v0 + 8 * gl) - mblk * a.block_samples;
+        uint32_t mblk = sgl.v0 < 0 ? 0u : (uint32_t)(sgl.v0 + 8 * gl) / a.block_samples;
+        int32_t minblk = sgl.v0 + 8 * gl - (int32_t)(mblk * a.block_samples);   // position in the block (negative: before the call)
 
         // A piece into its ring slot.  `sq` (known after unrolling) is the slot's place in its quad: room is checked
         // before a quad's first store - its four slots are free once the consumer has read the quad D4_QUADS back - and
@@ -331,14 +335,14 @@ __device__ __forceinline__ void d4_p_round(const ChainLaunch &a, const D4Args &d
 #else
                 const uint32_t m = st_mag_chunk(cur);
 #endif
-                macc += mcount && pos < mlimit ? m : 0u;
+                macc += mcount && pos < mlimit && pos >= mfirst ? m : 0u;
                 if ((j & 3) == 3) {   // blocks, segments and lead-ins are whole quads: the boundary test once per quad
                     minblk += 128;
-                    if (minblk >= a.block_samples) {
+                    if (minblk >= (int32_t)a.block_samples) {
                         if (macc) atomicAdd(&mag_row[mblk], macc);
                         macc = 0;
                         mblk++;
-                        minblk -= a.block_samples;
+                        minblk -= (int32_t)a.block_samples;
                     }
                 }
             }
@@ -570,7 +574,8 @@ __device__ __forceinline__ int d4_hilbert(const D4Args &da, const uint32_t (&p)[
 
 template <int MODE, int V>
 __device__ __forceinline__ int d4_am_piece(const D4Args &da, const uint8_t *ring_base, const uint32_t *full, uint32_t *consumed,
-                                           uint32_t &pg, uint32_t row, int lane, D4Rail &ri, D4Rail &rq, D4Ssb &sb, int lsb, int c14, int c15)
+                                           uint32_t &pg, uint32_t row, int lane, D4Rail &ri, D4Rail &rq, D4Ssb &sb, int lsb, int c14, int c15,
+                                           uint32_t &rails)   // (out: this piece's 8 kS/s rail values, i in the low half - SSB boundary records)
 {
     u32x2 p[4];
     d4_read_row(d4_take_piece<V>(ring_base, full, pg), row, p);
@@ -584,6 +589,7 @@ __device__ __forceinline__ int d4_am_piece(const D4Args &da, const uint8_t *ring
     }
 #endif
     const int iv = d4_am_rail<V>(da, ri, ni, c14, c15), qv = d4_am_rail<V>(da, rq, nq, c14, c15);
+    if (MODE == D4_SSB) rails = pack_lo16((uint32_t)iv, (uint32_t)qv);
     if (MODE == D4_AM) {   // AmDemodulator.cc:446-459: max(|i|,|q|) + min(|i|,|q|)/2 in int16 arithmetic
         const int im = (int)(int16_t)(iv < 0 ? -iv : iv), qm = (int)(int16_t)(qv < 0 ? -qv : qv);
         return (int)(int16_t)((im > qm) ? im + (qm >> 1) : qm + (im >> 1));
@@ -637,15 +643,38 @@ __device__ __forceinline__ void d4_am_wave(const ChainLaunch &a, const D4Args &d
         for (int k = 0; k < 9; k++) sb.qe[k] = sb.qo[k] = 0;
 #pragma unroll
         for (int k = 0; k < 5; k++) sb.ie[k] = sb.io[k] = 0;
+        // boundary records (iqd_d4_fix.h): the y2 pairs of pieces 4..7 and of the last 7 pieces; SSB: the 8 kS/s rails of pieces
+        // 8..39 and of the last 32.  What the successor's first outputs reach back for.
+        uint8_t *rec = da.rec && sg.valid ? (uint8_t *)da.rec + (size_t)(sg.li * a.tiles_per_ch + sg.tile) * (MODE == D4_SSB ? sizeof(D4RecSsb) : sizeof(D4RecAm)) : nullptr;
         for (int pq = 0; pq < n_pieces; pq += 4) {
             const int pos = -da.halo + 32 * pq;
-            const int x0 = d4_am_piece<MODE, 0>(da, ring_base, full, consumed, pg, (uint32_t)lane, lane, ri, rq, sb, lsb, c14, c15);
-            const int x1 = d4_am_piece<MODE, 1>(da, ring_base, full, consumed, pg, (uint32_t)lane, lane, ri, rq, sb, lsb, c14, c15);
-            const int x2 = d4_am_piece<MODE, 2>(da, ring_base, full, consumed, pg, (uint32_t)lane, lane, ri, rq, sb, lsb, c14, c15);
-            const int x3 = d4_am_piece<MODE, 3>(da, ring_base, full, consumed, pg, (uint32_t)lane, lane, ri, rq, sb, lsb, c14, c15);
+            uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+            const int x0 = d4_am_piece<MODE, 0>(da, ring_base, full, consumed, pg, (uint32_t)lane, lane, ri, rq, sb, lsb, c14, c15, r0);
+            const int x1 = d4_am_piece<MODE, 1>(da, ring_base, full, consumed, pg, (uint32_t)lane, lane, ri, rq, sb, lsb, c14, c15, r1);
+            const int x2 = d4_am_piece<MODE, 2>(da, ring_base, full, consumed, pg, (uint32_t)lane, lane, ri, rq, sb, lsb, c14, c15, r2);
+            const int x3 = d4_am_piece<MODE, 3>(da, ring_base, full, consumed, pg, (uint32_t)lane, lane, ri, rq, sb, lsb, c14, c15, r3);
             // 128 samples = 4 detector inputs = one 16-byte store (segments start and end on multiples of 128)
-            if (sg.valid && pos >= 0 && pos < sg.tlen)
+            if (sg.valid && pos >= 0 && pos < sg.tlen && sg.v0 + pos >= 0)
                 *(u32x4 *)(base_row + ((sg.v0 + pos) >> 5)) = u32x4{(uint32_t)x0, (uint32_t)x1, (uint32_t)x2, (uint32_t)x3};
+            if (rec) {
+                if (pos == 0) {
+                    D4RecAm *ra = (D4RecAm *)rec;
+                    *(u32x4 *)ra->y2_head[0] = u32x4{ri.y2[7], ri.y2[8], ri.y2[9], ri.y2[10]};
+                    *(u32x4 *)ra->y2_head[1] = u32x4{rq.y2[7], rq.y2[8], rq.y2[9], rq.y2[10]};
+                }
+                if (MODE == D4_SSB) {
+                    D4RecSsb *rs = (D4RecSsb *)rec;
+                    const u32x2 iw = u32x2{pack_lo16(r0, r1), pack_lo16(r2, r3)}, qw = u32x2{pack_hi16(r0, r1), pack_hi16(r2, r3)};
+                    if (pos >= 128 && pos < 128 + 8 * 128) {             // pieces 8..39
+                        *(u32x2 *)&rs->head_i[(pos - 128) >> 6] = iw;
+                        *(u32x2 *)&rs->head_q[(pos - 128) >> 6] = qw;
+                    }
+                    if (pq >= n_pieces - 32) {                           // the last 32 pieces
+                        *(u32x2 *)&rs->tail_i[(pq - (n_pieces - 32)) >> 1] = iw;
+                        *(u32x2 *)&rs->tail_q[(pq - (n_pieces - 32)) >> 1] = qw;
+                    }
+                }
+            }
 #pragma unroll
             for (int k = 0; k < 7; k++) { ri.y2[k] = ri.y2[k + 4]; rq.y2[k] = rq.y2[k + 4]; }
             if (MODE == D4_SSB) {   // each parity stream gained one pair
@@ -654,6 +683,13 @@ __device__ __forceinline__ void d4_am_wave(const ChainLaunch &a, const D4Args &d
 #pragma unroll
                 for (int k = 0; k < 4; k++) { sb.ie[k] = sb.ie[k + 1]; sb.io[k] = sb.io[k + 1]; }
             }
+        }
+        if (rec) {   // y2[0..6]: the pairs of the last 7 pieces
+            D4RecAm *ra = (D4RecAm *)rec;
+            *(u32x4 *)&ra->y2_tail[0][0] = u32x4{ri.y2[0], ri.y2[1], ri.y2[2], ri.y2[3]};
+            *(u32x4 *)&ra->y2_tail[0][4] = u32x4{ri.y2[4], ri.y2[5], ri.y2[6], 0u};
+            *(u32x4 *)&ra->y2_tail[1][0] = u32x4{rq.y2[0], rq.y2[1], rq.y2[2], rq.y2[3]};
+            *(u32x4 *)&ra->y2_tail[1][4] = u32x4{rq.y2[4], rq.y2[5], rq.y2[6], 0u};
         }
     }
 }
@@ -751,6 +787,8 @@ __device__ __forceinline__ void d4_fm_wave(const ChainLaunch &a, const D4Args &d
 #pragma unroll
         for (int j = 0; j < 24; j++) s.y2p[j] = 0;
         s.loud_e = s.loud_y2 = 0;
+        // boundary record (iqd_d4_fix.h): the y2 pairs of pieces 4..23 and of the last 20 pieces
+        D4RecFm *rec = da.rec && sg.valid ? (D4RecFm *)da.rec + (size_t)(sg.li * a.tiles_per_ch + sg.tile) : nullptr;
         for (int pq = 0; pq < n_pieces; pq += 4) {
             const int pos = -da.halo + 32 * pq;
             int pcm[4];
@@ -758,10 +796,15 @@ __device__ __forceinline__ void d4_fm_wave(const ChainLaunch &a, const D4Args &d
             pcm[1] = d4_fm_piece<1>(da, ring_base, full, consumed, pg, (uint32_t)lane, s);
             pcm[2] = d4_fm_piece<2>(da, ring_base, full, consumed, pg, (uint32_t)lane, s);
             pcm[3] = d4_fm_piece<3>(da, ring_base, full, consumed, pg, (uint32_t)lane, s);
-            if (sg.valid && pos >= 0 && pos < sg.tlen)
+            if (sg.valid && pos >= 0 && pos < sg.tlen && sg.v0 + pos >= 0)
                 *(u32x2 *)(pcm_row + ((sg.v0 + pos) >> 5)) = u32x2{pack_lo16((uint32_t)pcm[0], (uint32_t)pcm[1]), pack_lo16((uint32_t)pcm[2], (uint32_t)pcm[3])};
+            if (rec && pos >= 0 && pos < 5 * 128) *(u32x4 *)&rec->y2_head[pos >> 5] = u32x4{s.y2p[20], s.y2p[21], s.y2p[22], s.y2p[23]};
 #pragma unroll
             for (int j = 0; j < 20; j++) s.y2p[j] = s.y2p[j + 4];
+        }
+        if (rec) {
+#pragma unroll
+            for (int j = 0; j < 20; j += 4) *(u32x4 *)&rec->y2_tail[j] = u32x4{s.y2p[j], s.y2p[j + 1], s.y2p[j + 2], s.y2p[j + 3]};
         }
     }
 }

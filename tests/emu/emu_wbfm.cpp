@@ -18,6 +18,7 @@
 #include "iqd_taps.h"
 #include "iqd_chains.h"
 #include "iqd_wbfm.h"
+#include "iqd_d4_fix.h"
 
 namespace {
 
@@ -269,7 +270,8 @@ void emu_plan_stream(uint32_t vlen, uint32_t n_channels, uint32_t streams, uint3
 // plan_call (iqd_plan.cpp) on plain arrays.  knobs: {flags, n_cus, stream_ok, env_path (+1 / 0 / -1 as 1 / 0 / 2), env_stream_min_seg,
 // env_am_stream_min (0 = default), env_mixed_forked, env_shares_by_cost, env_stream_wgs, env_full_grid, env_rings}; fam: per family
 // {n_list, rot_count[3], cast_bounded, epochs_in_reach}; out: {n_fams, forked, shares_on, fused, mix_wgs, order[4]} then per family
-// {present, path, lane, wgs, tile_len, tiles_per_ch, grouped, group_start[4], group_nseg[3], grid, rounds, wg_first, epochs, rings} (19 words).
+// {present, path, lane, wgs, tile_len, tiles_per_ch, grouped, group_start[4], group_nseg[3], grid, rounds, wg_first, epochs, rings, halo, lead_shift}
+// (21 words).  knobs[11]: 1 = IQD_D4_LEADFREE=0 (every FM / AM / SSB segment with its full lead-in).
 void emu_plan_call(const uint32_t *knobs, uint32_t vlen, uint32_t pcm_per_ch, uint32_t gated, const uint32_t *fam, uint32_t *out)
 {
     iqd::PlanKnobs k;
@@ -279,6 +281,7 @@ void emu_plan_call(const uint32_t *knobs, uint32_t vlen, uint32_t pcm_per_ch, ui
     if (knobs[5]) k.env_am_stream_min = knobs[5];
     k.env_mixed_forked = knobs[6] != 0; k.env_shares_by_cost = knobs[7] != 0; k.env_stream_wgs = knobs[8]; k.env_full_grid = knobs[9] != 0;
     k.env_rings = knobs[10];
+    k.d4_leadfree = knobs[11] == 0;
     k.wbfm_chunk = iqd::WBFM_CHUNK; k.wbfm_cold_halo = iqd::COLD_HALO; k.ch_chunk = iqd::CH_CHUNK; k.fir_halo = iqd::FIR_HALO; k.dc_tile = iqd::DC_TILE;
     iqd::CallShape c;
     c.vlen = vlen; c.pcm_per_ch = pcm_per_ch; c.gated = gated != 0;
@@ -298,8 +301,53 @@ void emu_plan_call(const uint32_t *knobs, uint32_t vlen, uint32_t pcm_per_ch, ui
         *o++ = q.present; *o++ = (uint32_t)q.path; *o++ = (uint32_t)q.lane; *o++ = q.wgs; *o++ = q.tile_len; *o++ = q.tiles_per_ch; *o++ = q.grouped;
         for (int r = 0; r < 4; r++) *o++ = q.group_start[r];
         for (int r = 0; r < 3; r++) *o++ = q.group_nseg[r];
-        *o++ = q.grid; *o++ = q.rounds; *o++ = q.wg_first; *o++ = q.epochs; *o++ = q.rings;
+        *o++ = q.grid; *o++ = q.rounds; *o++ = q.wg_first; *o++ = q.epochs; *o++ = q.rings; *o++ = q.halo; *o++ = q.lead_shift;
     }
+}
+
+// ---- FM / AM / SSB boundary fix-up (iqd_d4_fix.h) on plain arrays: tests/test_emu_d4_fix.py -----------------------------------
+// family: FAM_AM 0, FAM_FM 1, FAM_SSB 3.  rec: the channel's records in segment order; out: int32 detector stream (AM / SSB) or
+// int16 PCM row (FM), patched in place.
+void emu_d4_fix(int family, const void *rec, uint32_t n_tiles, uint32_t tile_len, uint32_t shift, uint32_t vlen, int lsb, void *out)
+{
+    HostExec ex;
+    static iqd::Consts c;
+    static bool ready = false;
+    if (!ready) { iqd::build_consts(c); ready = true; }
+    if (family == iqd::FAM_FM) {
+        static iqd::D4FixFmLds lds;
+        iqd::d4_fix_fm(ex, c, lds, (const iqd::D4RecFm *)rec, n_tiles, tile_len, shift, vlen, (int16_t *)out, iqd::WB_THREADS);
+    } else if (family == iqd::FAM_SSB) {
+        static iqd::D4FixLds lds;
+        iqd::d4_fix_am_ssb<iqd::FAM_SSB>(ex, c, lds, rec, n_tiles, tile_len, shift, vlen, lsb, (int32_t *)out, 1, iqd::WB_THREADS);
+    } else {
+        static iqd::D4FixLds lds;
+        iqd::d4_fix_am_ssb<iqd::FAM_AM>(ex, c, lds, rec, n_tiles, tile_len, shift, vlen, 0, (int32_t *)out, 1, iqd::WB_THREADS);
+    }
+}
+// the Q15 taps the fix-up uses: which 0 am_s2[12], 1 am_s3[16], 2 ssb_delay[16], 3 ssb_hilbert[31], 4 post12[12], 5 audio40[40], 6 am_s1[8]
+int emu_taps(int which, int16_t *out)
+{
+    static iqd::Consts c;
+    static bool ready = false;
+    if (!ready) { iqd::build_consts(c); ready = true; }
+    const int16_t *src[] = {c.am_s2, c.am_s3, c.ssb_delay, c.ssb_hilbert, c.post12, c.audio40, c.am_s1};
+    const int n[] = {12, 16, 16, 31, 12, 40, 8};
+    memcpy(out, src[which], n[which] * sizeof(int16_t));
+    return n[which];
+}
+uint32_t emu_d4_const(int which)
+{
+    switch (which) {
+    case 0: return sizeof(iqd::D4RecAm);
+    case 1: return sizeof(iqd::D4RecFm);
+    case 2: return sizeof(iqd::D4RecSsb);
+    case 3: return iqd::D4_HALO_SHORT;
+    case 4: return (uint32_t)iqd::d4_lead_shift(iqd::FAM_AM);
+    case 5: return (uint32_t)iqd::d4_lead_shift(iqd::FAM_FM);
+    case 6: return (uint32_t)iqd::d4_lead_shift(iqd::FAM_SSB);
+    }
+    return 0;
 }
 
 // ---- the WBFM restart state's journey from call to call (tests/test_emu_restart_model.py) ----------------------------------

@@ -97,7 +97,7 @@ def test_default_run_carries_every_other_configuration():
     fields, and `other_configs` - configs[0], [2], [3], [4] and AM / USB at 4096 x 2^16, a few steps each in the same process
      - each sub-line consistent in itself.  (Full size: this IS the driver's run, about three minutes.)"""
     import bench
-    d = check_contract(run_bench("--gpus", "1", "--steps", "6", "--warmup", "2", "--cpu-one-core-only"), 6, 2)
+    d = check_contract(run_bench("--gpus", "1", "--steps", "6", "--warmup", "2", "--cpu-one-core-only", "--no-live-pmc"), 6, 2)
     assert "wbfm_stream_kernel" in d["roofline"]["kernel"] and d["config"]["log2_samples_per_channel"] == 28
     subs = d["other_configs"]
     assert [s["argv"] for s in subs] == [" ".join(a) for a in bench.OTHER_CONFIGS]

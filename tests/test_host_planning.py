@@ -193,25 +193,25 @@ def _plan_lib():
 
 
 def plan_call(vlen, fams, flags=0, n_cus=256, stream_ok=True, env_path=0, min_seg=0, am_min=0, mixed_forked=False, by_cost=False,
-              stream_wgs=0, full_grid=False, gated=False, rings=0):
+              stream_wgs=0, full_grid=False, gated=False, rings=0, full_lead_ins=False):
     """fams: {family: (rot_count tuple | channels, cast_bounded, epochs_in_reach)} -> the plan as a dict."""
     lib = _plan_lib()
     knobs = np.array([flags, n_cus, int(stream_ok), {0: 0, 1: 1, -1: 2}[env_path], min_seg, am_min, int(mixed_forked), int(by_cost),
-                      stream_wgs, int(full_grid), rings], np.uint32)
+                      stream_wgs, int(full_grid), rings, int(full_lead_ins)], np.uint32)
     fam = np.zeros((4, 6), np.uint32)
     for f, name in enumerate(FAMS):
         if name in fams:
             rc, bounded, epochs = fams[name]
             rc = (rc, 0, 0) if isinstance(rc, int) else rc
             fam[f] = [sum(rc), rc[0], rc[1], rc[2], int(bounded), int(epochs)]
-    out = np.zeros(9 + 4 * 19, np.uint32)
+    out = np.zeros(9 + 4 * 21, np.uint32)
     lib.emu_plan_call(knobs.ctypes.data, vlen, vlen // 32, int(gated), fam.ctypes.data, out.ctypes.data)
     keys = ("present", "path", "lane", "wgs", "tile_len", "tiles_per_ch", "grouped", "gs0", "gs1", "gs2", "gs3", "gn0", "gn1", "gn2",
-            "grid", "rounds", "wg_first", "epochs", "rings")
+            "grid", "rounds", "wg_first", "epochs", "rings", "halo", "lead_shift")
     plan = {"n_fams": int(out[0]), "forked": bool(out[1]), "shares_on": bool(out[2]), "fused": bool(out[3]), "mix_wgs": int(out[4]),
             "order": out[5:9].tolist(), "fam": {}}
     for f, name in enumerate(FAMS):
-        plan["fam"][name] = dict(zip(keys, (int(v) for v in out[9 + 19 * f: 9 + 19 * f + 19])))
+        plan["fam"][name] = dict(zip(keys, (int(v) for v in out[9 + 21 * f: 9 + 21 * f + 21])))
         plan["fam"][name]["n"] = int(fam[f][0])
         plan["fam"][name]["rot_count"] = fam[f][1:4].tolist()
     return plan
@@ -232,12 +232,20 @@ def check_plan(p, vlen, flags, env_path, stream_ok, n_cus, fams, rings_knob=0):
         assert bool(q["present"]) == (q["n"] > 0)
         if not q["n"]:
             continue
-        assert q["tile_len"] > 0 and q["tile_len"] * q["tiles_per_ch"] >= vlen, (name, q)     # the tiles / segments cover the row
+        # the tiles / segments cover the row - from `lead_shift` samples before its first one for FM / AM / SSB pipelines with short
+        # lead-ins (round 6: a channel's first segment starts that far back, its full lead-in from the kept tail)
+        assert q["tile_len"] > 0 and q["tile_len"] * q["tiles_per_ch"] >= vlen + q["lead_shift"], (name, q)
+        assert q["tile_len"] * (q["tiles_per_ch"] - 1) < vlen + q["lead_shift"] or q["path"] != PLAN_STREAM, (name, q)   # and no segment lies behind its end
         assert 0 <= q["lane"] <= 3 and (q["lane"] == 0 or (p["forked"] and not p["fused"]))
         rc, bounded, epochs = fams[name]
         if q["path"] == PLAN_STREAM:
             assert vlen % 128 == 0 and not (flags & F_TILES) and env_path >= 0, (name, q)
             assert q["tile_len"] >= min_tile and q["tile_len"] % 128 == 0
+            if name == "wbfm":
+                assert q["lead_shift"] == 0
+            else:   # 128 samples of lead-in, the rest of the family's full lead-in as the shift; a segment holds more than the shift
+                full = {"am": 384, "fm": 768, "ssb": 1280}[name]
+                assert (q["halo"], q["lead_shift"]) == (128, full - 128) and q["tile_len"] >= full, (name, q)
             assert q["grid"] >= 1 and q["rounds"] >= 1 and q["grid"] <= max(q["wgs"], 1)
             if name == "wbfm":
                 assert stream_ok and bounded
@@ -329,8 +337,19 @@ def test_plan_call_known_configurations():
     assert q["path"] == PLAN_STREAM and q["rounds"] == 1 and q["grid"] <= 256 and q["rings"] == 3
     # the reference's operating point with a thousand channels (one 64 ms block per channel and call): workgroups of ONE ring on
     # every CU instead of 118 full ones - longer segments, faster pieces (tools/rings_probe.sh: AM 0.076 -> 0.064 ms)
+    q = plan_call(1 << 14, {"am": (1024, True, False)}, full_lead_ins=True)["fam"]["am"]
+    assert (q["path"], q["rings"], q["tile_len"], q["grid"], q["rounds"], q["lead_shift"]) == (PLAN_STREAM, 1, 1024, 256, 1, 0), q
+    # ... and with round 6's short lead-ins (128 samples + boundary records): the channel's 16 384 + 256 samples as 22 segments of 768
     q = plan_call(1 << 14, {"am": (1024, True, False)})["fam"]["am"]
-    assert (q["path"], q["rings"], q["tile_len"], q["grid"], q["rounds"]) == (PLAN_STREAM, 1, 1024, 256, 1), q
+    assert (q["path"], q["rings"], q["tile_len"], q["tiles_per_ch"], q["rounds"], q["halo"], q["lead_shift"]) == (PLAN_STREAM, 2, 768, 22, 1, 128, 256), q
+    # configs[2] / USB at 4096 x 2^16: twelve segments per channel, 5504 + 128 instead of 5504 + 768 / 5504 + 1280 samples each
+    q = plan_call(1 << 16, {"fm": (4096, True, False)})["fam"]["fm"]
+    assert (q["tile_len"], q["tiles_per_ch"], q["halo"], q["lead_shift"]) == (5632, 12, 128, 640), q
+    q = plan_call(1 << 16, {"ssb": (4096, True, False)})["fam"]["ssb"]
+    assert (q["tile_len"], q["tiles_per_ch"], q["halo"], q["lead_shift"]) == (5632, 12, 128, 1152), q
+    # the reference's operating point, 4096 channels x one 64 ms block: FM 1536 + 128 samples per segment where it was 1408 + 768
+    q = plan_call(1 << 14, {"fm": (4096, True, False)})["fam"]["fm"]
+    assert (q["path"], q["tile_len"], q["tiles_per_ch"]) == (PLAN_STREAM, 1536, 12), q
     q = plan_call(1 << 14, {"am": (1024, True, False)}, rings=3)["fam"]["am"]          # (IQD_RINGS pins it)
     assert (q["rings"], q["tile_len"]) == (3, 768) and q["grid"] < 128
     # configs[3]: the four families as ranges of one launch

@@ -71,3 +71,46 @@ def test_lint_flags_inline_assembly_as_first_reader_of_a_matrix_result():
 """.splitlines()
     assert len(isa_lint.lint_mfma_readers("k", list(enumerate(bad, 1)))) == 1
     assert isa_lint.lint_mfma_readers("k", list(enumerate(good, 1))) == []
+
+
+def test_lint_flags_a_vector_read_directly_behind_an_inline_sdwa_partial_write():
+    """Round 6: gfx940 / gfx950 want one wait state between a VALU write with a destination select and a VALU read
+    of that register; the compiler inserts it behind its own SDWA instructions, not behind inline assembly
+    (iqd_prims.h: cast_pack_i16_bounded - two partial writes of one register back to back would be exactly that).  The
+    lint's third check on three synthetic listings; the three files' own runs above hold the shipped kernels to it."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_lint
+    back_to_back = """
+	;;#ASMSTART
+	v_cvt_i32_f32_sdwa v7, v3 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD
+	;;#ASMEND
+	;;#ASMSTART
+	v_cvt_i32_f32_sdwa v7, v4 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD
+	;;#ASMEND
+	s_nop 0
+	v_dot2c_i32_i16_e32 v9, v7, v8
+""".splitlines()
+    read_next = """
+	;;#ASMSTART
+	v_cvt_i32_f32_sdwa v7, v4 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD
+	;;#ASMEND
+	v_dot2c_i32_i16_e32 v9, v7, v8
+""".splitlines()
+    spaced = """
+	;;#ASMSTART
+	v_cvt_i32_f32_sdwa v7, v3 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD
+	;;#ASMEND
+	;;#ASMSTART
+	v_cvt_i32_f32_sdwa v6, v5 dst_sel:WORD_0 dst_unused:UNUSED_PAD src0_sel:DWORD
+	;;#ASMEND
+	;;#ASMSTART
+	v_cvt_i32_f32_sdwa v7, v4 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD
+	;;#ASMEND
+	v_mul_f32_e32 v10, v11, v12
+	v_dot2c_i32_i16_e32 v9, v7, v8
+	v_add_u32_sdwa v3, v3, v3 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1
+	v_add_u32_e32 v65, v3, v65
+""".splitlines()
+    assert len(isa_lint.lint_sdwa_forwarding("k", list(enumerate(back_to_back, 1)))) == 1
+    assert len(isa_lint.lint_sdwa_forwarding("k", list(enumerate(read_next, 1)))) == 1
+    assert isa_lint.lint_sdwa_forwarding("k", list(enumerate(spaced, 1))) == []

@@ -145,3 +145,19 @@ def test_demod_tool_fixture_is_the_reference_programs_output(dtype):
     g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "demod_tool.npz"))
     r = subprocess.run([REF_DEMOD, "-d", str(dtype)], input=g["iq_s8"].tobytes(), stdout=subprocess.PIPE, check=True)
     assert np.array_equal(np.frombuffer(r.stdout, dtype=np.int16), g["pcm_%d" % dtype])
+
+
+def test_the_hot_path_pin_shares_no_binary_with_the_agc_test_double():
+    """oracle/_ref/libiqd_ref.so holds the reference's hot path and the two externals only; the AGC, the
+    scanner and the harness' test double of their owner (class Radio's five accessors) live in libiqd_ref_agc.so, which only
+    the (f)-2 / (f)-3 pins load."""
+    import subprocess
+    from oracle import bindings as B
+    if not B.have_ref():
+        pytest.skip("oracle/_ref not built")
+    hot = subprocess.run(["nm", "-D", "--defined-only", B.REF_SO], capture_output=True, text=True, check=True).stdout
+    agc = subprocess.run(["nm", "-D", "--defined-only", B.REF_AGC_SO], capture_output=True, text=True, check=True).stdout
+    for needle in ("5Radio", "AutomaticGainControl", "FrequencyScanner", "ref_agc_", "ref_scanner_"):
+        assert needle not in hot, needle
+        assert needle in agc, needle
+    assert "radio_adjustableReceiveGainInDb" in hot and "nprintf" in hot and "ref_accept_stream" in hot

@@ -10,7 +10,9 @@ assembly and runs a forward data flow over every kernel's control-flow graph (wh
 
 Exit status 1 and a listing if a destination register of a pending untracked load is touched before its arrival.
 
-Second check (round 5): the first reader of a matrix instruction's result must not be inline assembly (lint_mfma_readers)."""
+Second check (round 5): the first reader of a matrix instruction's result must not be inline assembly (lint_mfma_readers).
+Third check (round 6): no vector instruction reads a register in the instruction right behind an inline-assembly
+SDWA write of a part of it (lint_sdwa_forwarding)."""
 import re
 import subprocess
 import sys
@@ -178,6 +180,40 @@ def lint_mfma_readers(name, lines):
     return findings
 
 
+def lint_sdwa_forwarding(name, lines):
+    """gfx940 / gfx950 need one wait state between a VALU write with a destination select (SDWA dst_sel BYTE_n / WORD_n, which
+    writes a part of the register) and a VALU read of that register.  The compiler's hazard recognizer inserts it for the SDWA
+    instructions IT emits - not behind inline assembly (iqd_prims.h: cast_pack_i16_bounded, iqd_mfma.h: the byte negations),
+    whose operands it does not look into.  Linear scan: a finding = a vector instruction that names the register directly
+    behind such a write (as a source, or as the destination of another partial write, which reads the rest of it).  Anything
+    in between - an s_nop, a scalar, LDS or memory instruction, another vector instruction - is the wait state."""
+    findings, in_asm, pending = [], False, None     # pending: (register, line) of an inline partial write by the previous instruction
+    for no, raw in lines:
+        line = raw.strip()
+        if line.startswith(";;#ASMSTART"):
+            in_asm = True
+            continue
+        if line.startswith(";;#ASMEND"):
+            in_asm = False
+            continue
+        if not line or line.startswith(";") or line.startswith(".") or re.match(r"^\.?\w+:", line):
+            continue
+        code = line.partition(";")[0].strip()
+        if not code:
+            continue
+        op = code.split()[0]
+        if pending is not None and op.startswith("v_") and pending[0] in regs_of(code):
+            findings.append((name, no, line, [pending[0]], [pending[1]]))
+        pending = None
+        if in_asm and "_sdwa" in op:
+            m = re.search(r"dst_sel:(\w+)", code)
+            if m and m.group(1) != "DWORD":
+                dst = sorted(regs_of(code[len(op):].split(",")[0]))
+                if dst:
+                    pending = (dst[0], no)
+    return findings
+
+
 def main():
     src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "rtlsdrdiags_amd", "csrc", "iqd_stream2.hip")
     text = compile_to_asm(src)
@@ -201,7 +237,14 @@ def main():
     mfma_findings = []
     for name, lines in kernels.items():
         mfma_findings += lint_mfma_readers(name, lines)
-    for name, no, raw, regs, owners in mfma_findings:
+    sdwa_findings = []
+    for name, lines in kernels.items():
+        sdwa_findings += lint_sdwa_forwarding(name, lines)
+    for name, no, raw, regs, owners in sdwa_findings:
+        print("%s: line %d reads v%s directly behind the inline SDWA partial write at line %s (one wait state needed):\n    %s"
+              % (name, no, regs, owners, raw))
+    mfma_findings = mfma_findings + sdwa_findings
+    for name, no, raw, regs, owners in mfma_findings[:len(mfma_findings) - len(sdwa_findings)]:
         print("%s: line %d (inline assembly) is the first reader of v%s, written by the matrix instruction(s) at line(s) %s:\n    %s"
               % (name, no, regs, owners, raw))
     seen = set()
