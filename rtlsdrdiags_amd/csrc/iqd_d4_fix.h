@@ -5,9 +5,12 @@
 // 40 taps at 16 kS/s, the Hilbert transformer's 31 at 8 kS/s) - 7 / 14 / 23 % of a 5.5 k-sample segment, a third to a half of the
 // pieces at the reference's own operating point (one 64 ms block per call, DataConsumer.cc:333-346).  Now every segment runs a
 // lead-in of D4_HALO_SHORT = 128 samples (which the first two stages need), leaves a *record* of the few intermediate values
-// its successor's first outputs reach back for, and those outputs - 4 (AM), 34 (SSB), 18 (FM) per boundary - are recomputed
-// from the two records, in the reference's arithmetic, by the launch that closes the step (before the DC-removal pass reads the
-// detector stream / beside the tail update).  The reference carries exactly this state from call to call in its filters' ring
+// its successor's first outputs reach back for, and those outputs - 4 (AM), 34 (SSB), 18 (FM) per boundary - are recomputed.
+// WHERE: a channel's segments have consecutive segment ids, i.e. they sit in neighbouring lanes of a consumer wave, so at the end
+// of its run every lane takes the lane below's end state (DPP) and replays its own first outputs from inputs it kept in LDS
+// (iqd_stream2.hip: d4_am_wave, d4_fm_wave) - no memory traffic.  Only where the predecessor sits in another wave (every 64th
+// segment id) the two lanes leave the records below in global memory and the launch that closes the step recomputes those
+// outputs (this file; before the DC-removal pass reads the detector stream / beside the tail update).  The reference carries exactly this state from call to call in its filters' ring
 // buffers (Decimator_int16.cc:310-351, FirFilter_int16.cc:151-213); here it travels from segment to segment of one call.
 //
 // A channel's FIRST segment has no predecessor in the call: its histories come from the kept raw tail, as before.  So that all
@@ -91,23 +94,27 @@ IQD_DEV int am_detector(int iv, int qv)    // AmDemodulator.cc:446-459
 // stream (8 kS/s, one int per PCM sample, stride out_stride).  Phases separated by the machine's barrier (ex.all).
 template <int FAMILY, class Exec>
 IQD_DEV void d4_fix_am_ssb(Exec &ex, const Consts &c, D4FixLds &lds, const void *rec_v, uint32_t n_tiles, uint32_t tile_len,
-                           uint32_t shift, uint32_t vlen, int lsb, int32_t *out, size_t out_stride, int nthr)
+                           uint32_t shift, uint32_t vlen, int lsb, int32_t *out, size_t out_stride, int nthr, uint32_t t_first = 1, uint32_t t_step = 1)
 {
     constexpr bool SSB = FAMILY == FAM_SSB;
     constexpr uint32_t STRIDE = SSB ? sizeof(D4RecSsb) : sizeof(D4RecAm);
     const uint8_t *rec = (const uint8_t *)rec_v;
-    for (uint32_t t0 = 1; t0 < n_tiles; t0 += D4_FIX_BATCH) {
-        const int nb = (int)(n_tiles - t0 < (uint32_t)D4_FIX_BATCH ? n_tiles - t0 : (uint32_t)D4_FIX_BATCH);
+    // the boundaries to do: in front of the segments t_first, t_first + t_step, ... (all of them: 1, 1; the pipelines fix what lies
+    // inside a consumer wave themselves and leave every 64th segment id's - d4_am_wave)
+    const uint32_t n_todo = t_first < n_tiles ? (n_tiles - t_first + t_step - 1) / t_step : 0u;
+    for (uint32_t k0 = 0; k0 < n_todo; k0 += D4_FIX_BATCH) {
+        const int nb = (int)(n_todo - k0 < (uint32_t)D4_FIX_BATCH ? n_todo - k0 : (uint32_t)D4_FIX_BATCH);
+        auto tile_of = [&](int b) { return t_first + (k0 + (uint32_t)b) * t_step; };
         ex.all([&](int tid) {   // windows from the records: the predecessor's tail, then this segment's head
             for (int it = tid; it < nb * 2 * 11; it += nthr) {
                 const int b = it / 22, r = (it % 22) / 11, k = it % 11;
-                const D4RecAm *own = (const D4RecAm *)(rec + (size_t)(t0 + b) * STRIDE), *pred = (const D4RecAm *)(rec + (size_t)(t0 + b - 1) * STRIDE);
+                const D4RecAm *own = (const D4RecAm *)(rec + (size_t)tile_of(b) * STRIDE), *pred = (const D4RecAm *)(rec + (size_t)(tile_of(b) - 1) * STRIDE);
                 lds.y2[b][r][k] = k < 7 ? pred->y2_tail[r][k] : own->y2_head[r][k - 7];
             }
             if (SSB)
                 for (int it = tid; it < nb * 2 * 30; it += nthr) {   // rails of pieces -26..3 (dwords 0..14) and 8..37 (dwords 17..31)
                     const int b = it / 60, r = (it % 60) / 30, k = it % 30;
-                    const D4RecSsb *own = (const D4RecSsb *)(rec + (size_t)(t0 + b) * STRIDE), *pred = (const D4RecSsb *)(rec + (size_t)(t0 + b - 1) * STRIDE);
+                    const D4RecSsb *own = (const D4RecSsb *)(rec + (size_t)tile_of(b) * STRIDE), *pred = (const D4RecSsb *)(rec + (size_t)(tile_of(b) - 1) * STRIDE);
                     uint32_t *dst = r ? lds.rq[b] : lds.ri[b];
                     if (k < 15) dst[k] = (r ? pred->tail_q : pred->tail_i)[k + 1];
                     else dst[k + 2] = (r ? own->head_q : own->head_i)[k - 15];
@@ -116,7 +123,7 @@ IQD_DEV void d4_fix_am_ssb(Exec &ex, const Consts &c, D4FixLds &lds, const void 
         ex.all([&](int tid) {   // the rails of pieces 4..7 (/2, 16 taps over y2: AmDemodulator.cc:388-398) - AM: the detector right away
             for (int it = tid; it < nb * 4; it += nthr) {
                 const int b = it >> 2, j = it & 3;
-                const D4Span sp = d4_span(t0 + b, tile_len, shift, vlen);
+                const D4Span sp = d4_span(tile_of(b), tile_len, shift, vlen);
                 const int iv = q15_free<16>(c.am_s3, lds.y2[b][0], 2 * (j + 7) + 1), qv = q15_free<16>(c.am_s3, lds.y2[b][1], 2 * (j + 7) + 1);
                 if (!SSB) {
                     if (32 * j < sp.tlen) out[(size_t)((sp.v0 >> 5) + j) * out_stride] = am_detector(iv, qv);
@@ -130,7 +137,7 @@ IQD_DEV void d4_fix_am_ssb(Exec &ex, const Consts &c, D4FixLds &lds, const void 
             ex.all([&](int tid) {   // SsbDemodulator.cc:574-588: -i[n-15] -+ Hilbert31(q)
                 for (int it = tid; it < nb * D4_FIX_SSB; it += nthr) {
                     const int b = it / D4_FIX_SSB, j = it % D4_FIX_SSB;
-                    const D4Span sp = d4_span(t0 + b, tile_len, shift, vlen);
+                    const D4Span sp = d4_span(tile_of(b), tile_len, shift, vlen);
                     if (32 * j >= sp.tlen) continue;
                     const int idl = q15_free<16>(c.ssb_delay, lds.ri[b], 30 + j);
                     const int qh = q15_free<31>(c.ssb_hilbert, lds.rq[b], 30 + j);
@@ -143,20 +150,22 @@ IQD_DEV void d4_fix_am_ssb(Exec &ex, const Consts &c, D4FixLds &lds, const void 
 // FM: the first 18 PCM samples of every segment but the channel's first (/2, 40 taps with the per-MAC clamp, FmDemodulator.cc:548-556).
 template <class Exec>
 IQD_DEV void d4_fix_fm(Exec &ex, const Consts &c, D4FixFmLds &lds, const D4RecFm *rec, uint32_t n_tiles, uint32_t tile_len, uint32_t shift,
-                       uint32_t vlen, int16_t *pcm_row, int nthr)
+                       uint32_t vlen, int16_t *pcm_row, int nthr, uint32_t t_first = 1, uint32_t t_step = 1)
 {
-    for (uint32_t t0 = 1; t0 < n_tiles; t0 += D4_FIX_BATCH) {
-        const int nb = (int)(n_tiles - t0 < (uint32_t)D4_FIX_BATCH ? n_tiles - t0 : (uint32_t)D4_FIX_BATCH);
+    const uint32_t n_todo = t_first < n_tiles ? (n_tiles - t_first + t_step - 1) / t_step : 0u;
+    for (uint32_t k0 = 0; k0 < n_todo; k0 += D4_FIX_BATCH) {
+        const int nb = (int)(n_todo - k0 < (uint32_t)D4_FIX_BATCH ? n_todo - k0 : (uint32_t)D4_FIX_BATCH);
+        auto tile_of = [&](int b) { return t_first + (k0 + (uint32_t)b) * t_step; };
         ex.all([&](int tid) {   // pairs of pieces -15..3 from the predecessor's tail ([1..19]), 4..21 from this segment's head
             for (int it = tid; it < nb * 37; it += nthr) {
                 const int b = it / 37, k = it % 37;
-                lds.y2[b][k] = k < 19 ? rec[t0 + b - 1].y2_tail[k + 1] : rec[t0 + b].y2_head[k - 19];
+                lds.y2[b][k] = k < 19 ? rec[tile_of(b) - 1].y2_tail[k + 1] : rec[tile_of(b)].y2_head[k - 19];
             }
         });
         ex.all([&](int tid) {
             for (int it = tid; it < nb * D4_FIX_FM; it += nthr) {
                 const int b = it / D4_FIX_FM, j = it % D4_FIX_FM;
-                const D4Span sp = d4_span(t0 + b, tile_len, shift, vlen);
+                const D4Span sp = d4_span(tile_of(b), tile_len, shift, vlen);
                 if (32 * j >= sp.tlen) continue;
                 pcm_row[(sp.v0 >> 5) + j] = (int16_t)q15_seq<40>(c.audio40, lds.y2[b], 2 * (j + 19) + 1);
             }

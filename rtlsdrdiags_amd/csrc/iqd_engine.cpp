@@ -1491,12 +1491,14 @@ static int queue_family(iqd_t *e, CallCtx &x, int f)
             d4.lead_shift = fp.lead_shift;
             d4.rounds = fp.rounds;
             d4.rings = fp.rings;
-            if (fp.lead_shift) {   // short lead-ins: a boundary record per segment, read by the launch that closes the step (iqd_d4_fix.h)
+            static const bool norec = getenv("IQD_D4_NOREC") != nullptr;   // TIMING PROBE ONLY (wrong results at segment starts): no records, no fix-up
+            if (fp.lead_shift && !norec) {   // short lead-ins: a boundary record per segment, read by the launch that closes the step (iqd_d4_fix.h)
                 DevBuf &rb = e->d4_rec[f];
                 HIP_TRY(e, rb.ensure((size_t)n_list * a.tiles_per_ch * d4_rec_bytes(f)));
                 d4.rec = rb.p;
                 a.d4_rec = rb.p;
                 a.d4_shift = fp.lead_shift;
+                for (int r = 0; r < 3; r++) { a.d4_gs[r] = fp.group_start[r]; a.d4_gl[r] = fp.group_li0[r]; }
             }
         }
         if (f != FAM_FM) {

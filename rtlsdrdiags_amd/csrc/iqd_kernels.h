@@ -58,6 +58,8 @@ struct ChainLaunch {
     // (AM / SSB: in front of the DC pass; FM: beside the tail update).  nullptr: nothing to fix.
     const void *d4_rec;
     uint32_t d4_shift;
+    uint32_t d4_gs[3], d4_gl[3];  // the launch's segment ids by rotation group (D4Args::group_start / group_li0): the pipelines fix the
+                                  // boundaries inside a consumer wave themselves, what is left is every id that is a multiple of 64
 };
 #if defined(__HIPCC__)
 __device__ __forceinline__ uint32_t chain_wg(const ChainLaunch &a) { return blockIdx.x - a.wg_first; }

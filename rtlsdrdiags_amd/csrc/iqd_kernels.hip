@@ -87,21 +87,32 @@ __device__ __forceinline__ void rotation_selectors(int rotation, WbfmTile &t)
 // One tile of one channel: set-up, the chain, the hand-off record.  `start` is the state the tile begins with.
 // ---- FM / AM / SSB streaming launches with short lead-ins (iqd_d4_fix.h): the fix-up of one channel, by ALL threads of the
 // workgroup (the phases end in barriers).  AM / SSB: into the detector stream, in front of the DC pass; FM: into the PCM row.
+// The boundaries left to this launch: the pipelines' consumer lanes fix every boundary whose two segments sit in one wave (the
+// lane below holds the predecessor's end state); a segment whose id is a multiple of 64 is a wave's lane 0.  First such segment
+// of channel li (tile > 0), then every 64th.
+__device__ __forceinline__ uint32_t d4_first_left(const ChainLaunch &a, uint32_t li)
+{
+    const uint32_t r = (li >= a.d4_gl[1] ? 1u : 0u) + (li >= a.d4_gl[2] ? 1u : 0u);
+    const uint32_t sid0 = a.d4_gs[r] + (li - a.d4_gl[r]) * a.tiles_per_ch;   // the channel's segment 0
+    const uint32_t t = (64u - (sid0 & 63u)) & 63u;
+    return t ? t : 64u;
+}
 __device__ __forceinline__ void d4_fix_dc_channel(const ChainLaunch &a, int family, uint32_t li, D4FixLds &lds)
 {
     if (!a.d4_rec) return;
     const uint32_t ch = a.ch_list[li], ech = a.first_ch + ch;
     const uint32_t vlen = a.vlen_gated ? a.vlen_gated[ch] : a.vlen;
     const uint32_t nt = d4_tiles(a.tile_len, a.d4_shift, vlen);
-    if (nt < 2) return;
+    const uint32_t t_first = d4_first_left(a, li);
+    if (t_first >= nt) return;
     DeviceExec ex{(int)threadIdx.x};
     int32_t *out = a.base8k + (size_t)ch * a.base_stride_ch;
     if (family == FAM_SSB)
         d4_fix_am_ssb<FAM_SSB>(ex, g_consts, lds, (const uint8_t *)a.d4_rec + (size_t)li * a.tiles_per_ch * sizeof(D4RecSsb), nt, a.tile_len, a.d4_shift, vlen,
-                               a.params[ech].ssb_lsb, out, a.base_stride_t, (int)blockDim.x);
+                               a.params[ech].ssb_lsb, out, a.base_stride_t, (int)blockDim.x, t_first, 64u);
     else
         d4_fix_am_ssb<FAM_AM>(ex, g_consts, lds, (const uint8_t *)a.d4_rec + (size_t)li * a.tiles_per_ch * sizeof(D4RecAm), nt, a.tile_len, a.d4_shift, vlen, 0,
-                              out, a.base_stride_t, (int)blockDim.x);
+                              out, a.base_stride_t, (int)blockDim.x, t_first, 64u);
 }
 __device__ __forceinline__ void d4_fix_fm_channel(const ChainLaunch &a, uint32_t li, D4FixFmLds &lds)
 {
@@ -109,10 +120,11 @@ __device__ __forceinline__ void d4_fix_fm_channel(const ChainLaunch &a, uint32_t
     const uint32_t ch = a.ch_list[li];
     const uint32_t vlen = a.vlen_gated ? a.vlen_gated[ch] : a.vlen;
     const uint32_t nt = d4_tiles(a.tile_len, a.d4_shift, vlen);
-    if (nt < 2) return;
+    const uint32_t t_first = d4_first_left(a, li);
+    if (t_first >= nt) return;
     DeviceExec ex{(int)threadIdx.x};
     d4_fix_fm(ex, g_consts, lds, (const D4RecFm *)a.d4_rec + (size_t)li * a.tiles_per_ch, nt, a.tile_len, a.d4_shift, vlen, a.pcm + (size_t)ch * a.pcm_stride,
-              (int)blockDim.x);
+              (int)blockDim.x, t_first, 64u);
 }
 
 template <bool GATED, bool MAG>

@@ -98,7 +98,13 @@ static_assert(D4_SLOTS % 4 == 0 && (D4_QUADS & (D4_QUADS - 1)) == 0 && D4_QUADS 
 template <int MODE> constexpr int d4_ahead() { return MODE == D4_FM ? 4 : IQD_D4_AHEAD_AM; }
 constexpr int D4_SLOT_BYTES = 64 * 32;            // 64 segments x (4 lanes x 8 bytes) per piece
 constexpr int D4_MAGLUT_OFF = (ST_RINGS * D4_SLOTS * D4_SLOT_BYTES + D4_SYNC_WORDS * 4 + 15) & ~15;   // squelch magnitude table (iqd_mfma.h)
-constexpr int D4_LDS_BYTES = D4_MAGLUT_OFF + (IQD_D4_MAGLUT == 1 ? ST_MAGLUT_BYTES : 0);   // (no table in LDS with the SAD magnitudes)
+// Round 6 (iqd_d4_fix.h): every consumer lane keeps the inputs of its segment's first outputs here - the y2 pairs of pieces 4..7
+// (AM / SSB, both rails: 8 words), SSB's 8 kS/s rails of pieces 8..39 (32 words), FM's y2 pairs of pieces 4..23 (20 words) - and
+// replays those outputs at the end of its run with its predecessor's end state, which sits in the lane below.  [word][segment].
+constexpr int D4_HEAD_WORDS = 40;
+constexpr int D4_HEAD_OFF = D4_MAGLUT_OFF + (IQD_D4_MAGLUT == 1 ? ST_MAGLUT_BYTES : 0);
+constexpr int D4_LDS_BYTES = D4_HEAD_OFF + D4_HEAD_WORDS * ST_SEGS * 4;
+static_assert(D4_LDS_BYTES <= 160 * 1024, "rings + head store must fit the CU's LDS");
 
 struct D4Seg {
     uint32_t valid, li, tile, ch, ech;
@@ -218,6 +224,16 @@ __device__ __forceinline__ void d4_p_round(const ChainLaunch &a, const D4Args &d
         // before a quad's first store - its four slots are free once the consumer has read the quad D4_QUADS back - and
         // the quad is published after its last.
         auto hand_over = [&](u32x2 payload, int sq) {
+#ifdef IQD_D4_DYNPRIO
+            // A P wave that runs ahead of its ring's consumer yields to the ones that lag (the SIMD serves oldest first: the in-kernel
+            // timing shows the youngest P wave of a ring getting what the three older ones leave - 2200 cycles per piece against their
+            // 900 - while those then wait for ring space): priority by lag, once per quad, from the counter the wave reads anyway.
+            if (sq == 0) {
+                const uint32_t seen0 = lds_load_relaxed(consumed);
+                if ((int32_t)(pg - seen0) >= IQD_D4_DYNPRIO) __builtin_amdgcn_s_setprio(0);
+                else __builtin_amdgcn_s_setprio(2);
+            }
+#endif
             if (sq == 0 && pg >= (uint32_t)D4_QUADS) {
                 uint32_t seen = lds_load_relaxed(consumed);
 #if IQD_D4_TIMING
@@ -513,11 +529,28 @@ __device__ __forceinline__ void d4_piece_taken(uint32_t *consumed, uint32_t &pg)
     }
 }
 
+// the value the lane below holds (lane 0: its own) - v_mov_b32_dpp wave_shr:1
+__device__ __forceinline__ uint32_t d4_from_lane_below(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xf, 0xf, false);
+}
+
 // AM / SSB -----------------------------------------------------------------------------------------------
 struct D4Rail {
     uint32_t y1h[4];      // the last 8 stage-1 outputs of the rail
     uint32_t y2[11];      // stage-2 outputs as pairs; variant V of a piece uses [V .. V+7], its new pair is [V+7]
 };
+
+// stage 3 alone (/2, 16 taps over the y2 pairs) with this piece's pair given: the boundary replay
+template <int V>
+__device__ __forceinline__ int d4_s3(const D4Args &da, D4Rail &r, uint32_t pair, int c14)
+{
+    r.y2[V + 7] = pair;
+    int s3 = c14;
+#pragma unroll
+    for (int q = 0; q < 8; q++) s3 = dot2(r.y2[V + 7 - q], da.s3p[q], s3);
+    return s3 >> 15;
+}
 
 // one piece of one rail: 8 stage-1 outputs in, 2 stage-2 outputs (a pair) kept, 1 stage-3 output returned
 // (c14, c15: the rounding terms 1 << 14 and 1 << 15 in registers - as constants the compiler moves them into the
@@ -572,24 +605,10 @@ __device__ __forceinline__ int d4_hilbert(const D4Args &da, const uint32_t (&p)[
     return acc >> 15;
 }
 
+// the detector stage of one piece from its 8 kS/s rail values (the pipeline's pieces and the boundary replay)
 template <int MODE, int V>
-__device__ __forceinline__ int d4_am_piece(const D4Args &da, const uint8_t *ring_base, const uint32_t *full, uint32_t *consumed,
-                                           uint32_t &pg, uint32_t row, int lane, D4Rail &ri, D4Rail &rq, D4Ssb &sb, int lsb, int c14, int c15,
-                                           uint32_t &rails)   // (out: this piece's 8 kS/s rail values, i in the low half - SSB boundary records)
+__device__ __forceinline__ int d4_detect(const D4Args &da, D4Ssb &sb, int iv, int qv, int lsb)
 {
-    u32x2 p[4];
-    d4_read_row(d4_take_piece<V>(ring_base, full, pg), row, p);
-    d4_piece_taken<V>(consumed, pg);
-    const uint32_t ni[4] = {p[0].x, p[1].x, p[2].x, p[3].x}, nq[4] = {p[0].y, p[1].y, p[2].y, p[3].y};
-#ifdef IQD_D4_BURN_CONSUMER   // measurement build: the consumer waves issue this many idle vector instructions per piece
-    {
-        float burn = 1.0f;
-#pragma unroll
-        for (int k = 0; k < IQD_D4_BURN_CONSUMER; k++) asm volatile("v_add_f32 %0, %0, %0" : "+v"(burn));
-    }
-#endif
-    const int iv = d4_am_rail<V>(da, ri, ni, c14, c15), qv = d4_am_rail<V>(da, rq, nq, c14, c15);
-    if (MODE == D4_SSB) rails = pack_lo16((uint32_t)iv, (uint32_t)qv);
     if (MODE == D4_AM) {   // AmDemodulator.cc:446-459: max(|i|,|q|) + min(|i|,|q|)/2 in int16 arithmetic
         const int im = (int)(int16_t)(iv < 0 ? -iv : iv), qm = (int)(int16_t)(qv < 0 ? -qv : qv);
         return (int)(int16_t)((im > qm) ? im + (qm >> 1) : qm + (im >> 1));
@@ -613,6 +632,43 @@ __device__ __forceinline__ int d4_am_piece(const D4Args &da, const uint8_t *ring
         idl = V < 2 ? -(int)(int16_t)(sb.ie[0] >> 16) : -(int)(int16_t)(sb.ie[1] & 0xffffu);
     }
     return lsb ? (int)(int16_t)idl - (int)(int16_t)qh : (int)(int16_t)idl + (int)(int16_t)qh;
+}
+
+template <int MODE, int V>
+__device__ __forceinline__ int d4_am_piece(const D4Args &da, const uint8_t *ring_base, const uint32_t *full, uint32_t *consumed,
+                                           uint32_t &pg, uint32_t row, int lane, D4Rail &ri, D4Rail &rq, D4Ssb &sb, int lsb, int c14, int c15,
+                                           uint32_t &rails)   // (out: this piece's 8 kS/s rail values, i in the low half - SSB's boundary replay)
+{
+    u32x2 p[4];
+    d4_read_row(d4_take_piece<V>(ring_base, full, pg), row, p);
+    d4_piece_taken<V>(consumed, pg);
+    const uint32_t ni[4] = {p[0].x, p[1].x, p[2].x, p[3].x}, nq[4] = {p[0].y, p[1].y, p[2].y, p[3].y};
+#ifdef IQD_D4_BURN_CONSUMER   // measurement build: the consumer waves issue this many idle vector instructions per piece
+    {
+        float burn = 1.0f;
+#pragma unroll
+        for (int k = 0; k < IQD_D4_BURN_CONSUMER; k++) asm volatile("v_add_f32 %0, %0, %0" : "+v"(burn));
+    }
+#endif
+    const int iv = d4_am_rail<V>(da, ri, ni, c14, c15), qv = d4_am_rail<V>(da, rq, nq, c14, c15);
+    if (MODE == D4_SSB) rails = pack_lo16((uint32_t)iv, (uint32_t)qv);
+    return d4_detect<MODE, V>(da, sb, iv, qv, lsb);
+}
+
+// A quad of the boundary replay: the pieces' y2 pairs (first quad of the body: h != nullptr at q4 == 0) or their rails (SSB, later
+// quads) come from the lane's head store; stage 3 / the detector run with the state handed in.
+template <int MODE, int V>
+__device__ __forceinline__ int d4_replay_piece(const D4Args &da, D4Rail &ri, D4Rail &rq, D4Ssb &sb, int lsb, int c14, bool from_y2, uint32_t wi, uint32_t wq)
+{
+    int iv, qv;
+    if (from_y2) {   // wi, wq: this piece's y2 pairs of the two rails
+        iv = d4_s3<V>(da, ri, wi, c14);
+        qv = d4_s3<V>(da, rq, wq, c14);
+    } else {         // wi: the rails, i in the low half
+        iv = (int)(int16_t)(wi & 0xffffu);
+        qv = (int)(int16_t)(wi >> 16);
+    }
+    return d4_detect<MODE, V>(da, sb, iv, qv, lsb);
 }
 
 template <int MODE>
@@ -643,9 +699,11 @@ __device__ __forceinline__ void d4_am_wave(const ChainLaunch &a, const D4Args &d
         for (int k = 0; k < 9; k++) sb.qe[k] = sb.qo[k] = 0;
 #pragma unroll
         for (int k = 0; k < 5; k++) sb.ie[k] = sb.io[k] = 0;
-        // boundary records (iqd_d4_fix.h): the y2 pairs of pieces 4..7 and of the last 7 pieces; SSB: the 8 kS/s rails of pieces
-        // 8..39 and of the last 32.  What the successor's first outputs reach back for.
-        uint8_t *rec = da.rec && sg.valid ? (uint8_t *)da.rec + (size_t)(sg.li * a.tiles_per_ch + sg.tile) * (MODE == D4_SSB ? sizeof(D4RecSsb) : sizeof(D4RecAm)) : nullptr;
+        // Short lead-ins (iqd_d4_fix.h): the inputs of this segment's first outputs go into the lane's head store as they pass -
+        // the y2 pairs of pieces 4..7, SSB's rails of pieces 8..39 - and those outputs are replayed behind the loop with the
+        // predecessor's end state, which is the lane below's.
+        const bool lf = da.lead_shift != 0;
+        uint32_t *head = (uint32_t *)(lds + D4_HEAD_OFF) + ring * 64 + lane;       // [word][ST_SEGS]
         for (int pq = 0; pq < n_pieces; pq += 4) {
             const int pos = -da.halo + 32 * pq;
             uint32_t r0 = 0, r1 = 0, r2 = 0, r3 = 0;
@@ -656,24 +714,13 @@ __device__ __forceinline__ void d4_am_wave(const ChainLaunch &a, const D4Args &d
             // 128 samples = 4 detector inputs = one 16-byte store (segments start and end on multiples of 128)
             if (sg.valid && pos >= 0 && pos < sg.tlen && sg.v0 + pos >= 0)
                 *(u32x4 *)(base_row + ((sg.v0 + pos) >> 5)) = u32x4{(uint32_t)x0, (uint32_t)x1, (uint32_t)x2, (uint32_t)x3};
-            if (rec) {
-                if (pos == 0) {
-                    D4RecAm *ra = (D4RecAm *)rec;
-                    *(u32x4 *)ra->y2_head[0] = u32x4{ri.y2[7], ri.y2[8], ri.y2[9], ri.y2[10]};
-                    *(u32x4 *)ra->y2_head[1] = u32x4{rq.y2[7], rq.y2[8], rq.y2[9], rq.y2[10]};
-                }
-                if (MODE == D4_SSB) {
-                    D4RecSsb *rs = (D4RecSsb *)rec;
-                    const u32x2 iw = u32x2{pack_lo16(r0, r1), pack_lo16(r2, r3)}, qw = u32x2{pack_hi16(r0, r1), pack_hi16(r2, r3)};
-                    if (pos >= 128 && pos < 128 + 8 * 128) {             // pieces 8..39
-                        *(u32x2 *)&rs->head_i[(pos - 128) >> 6] = iw;
-                        *(u32x2 *)&rs->head_q[(pos - 128) >> 6] = qw;
-                    }
-                    if (pq >= n_pieces - 32) {                           // the last 32 pieces
-                        *(u32x2 *)&rs->tail_i[(pq - (n_pieces - 32)) >> 1] = iw;
-                        *(u32x2 *)&rs->tail_q[(pq - (n_pieces - 32)) >> 1] = qw;
-                    }
-                }
+            if (lf && pos == 0) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) { head[k * ST_SEGS] = ri.y2[7 + k]; head[(4 + k) * ST_SEGS] = rq.y2[7 + k]; }
+            }
+            if (lf && MODE == D4_SSB && pos >= 128 && pos < 128 + 8 * 128) {     // pieces 8..39
+                uint32_t *h = head + (8 + ((pos - 128) >> 5)) * ST_SEGS;
+                h[0] = r0; h[ST_SEGS] = r1; h[2 * ST_SEGS] = r2; h[3 * ST_SEGS] = r3;
             }
 #pragma unroll
             for (int k = 0; k < 7; k++) { ri.y2[k] = ri.y2[k + 4]; rq.y2[k] = rq.y2[k + 4]; }
@@ -684,12 +731,72 @@ __device__ __forceinline__ void d4_am_wave(const ChainLaunch &a, const D4Args &d
                 for (int k = 0; k < 4; k++) { sb.ie[k] = sb.ie[k + 1]; sb.io[k] = sb.io[k + 1]; }
             }
         }
-        if (rec) {   // y2[0..6]: the pairs of the last 7 pieces
+        if (!lf) continue;
+        // ---- the boundary: this lane's state now is its segment's END state = what its successor's first outputs reach back
+        // for.  The successor is the next segment id = the lane above (a channel's segments have consecutive ids), so every lane
+        // takes the state of the lane below and replays its own first outputs from its head store: 4 (AM), 36 (SSB: 34 needed).
+        // Lane 0's predecessor sits in another wave: that boundary (one in 64) goes through records in global memory and the
+        // launch that closes the step (iqd_kernels.hip: d4_fix_dc_channel) - lane 63 leaves its tail there, lane 0 its head.
+        uint8_t *rec = da.rec && sg.valid ? (uint8_t *)da.rec + (size_t)(sg.li * a.tiles_per_ch + sg.tile) * (MODE == D4_SSB ? sizeof(D4RecSsb) : sizeof(D4RecAm)) : nullptr;
+        if (rec && lane == 63) {
             D4RecAm *ra = (D4RecAm *)rec;
             *(u32x4 *)&ra->y2_tail[0][0] = u32x4{ri.y2[0], ri.y2[1], ri.y2[2], ri.y2[3]};
             *(u32x4 *)&ra->y2_tail[0][4] = u32x4{ri.y2[4], ri.y2[5], ri.y2[6], 0u};
             *(u32x4 *)&ra->y2_tail[1][0] = u32x4{rq.y2[0], rq.y2[1], rq.y2[2], rq.y2[3]};
             *(u32x4 *)&ra->y2_tail[1][4] = u32x4{rq.y2[4], rq.y2[5], rq.y2[6], 0u};
+            if (MODE == D4_SSB) {   // the rails of the last 32 (q) / 16 (i) pieces, by piece: the parity streams interleaved
+                D4RecSsb *rs = (D4RecSsb *)rec;
+#pragma unroll
+                for (int m = 0; m < 8; m++) { rs->tail_q[2 * m] = pack_lo16(sb.qe[m], sb.qo[m]); rs->tail_q[2 * m + 1] = pack_hi16(sb.qe[m], sb.qo[m]); }
+#pragma unroll
+                for (int m = 0; m < 4; m++) { rs->tail_i[8 + 2 * m] = pack_lo16(sb.ie[m], sb.io[m]); rs->tail_i[8 + 2 * m + 1] = pack_hi16(sb.ie[m], sb.io[m]); }
+            }
+        }
+        if (rec && lane == 0 && sg.tile > 0) {
+            D4RecAm *ra = (D4RecAm *)rec;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { ra->y2_head[0][k] = head[k * ST_SEGS]; ra->y2_head[1][k] = head[(4 + k) * ST_SEGS]; }
+            if (MODE == D4_SSB) {
+                D4RecSsb *rs = (D4RecSsb *)rec;
+                for (int m = 0; m < 16; m++) {
+                    const uint32_t ha = head[(8 + 2 * m) * ST_SEGS], hb = head[(8 + 2 * m + 1) * ST_SEGS];
+                    rs->head_i[m] = pack_lo16(ha, hb);
+                    rs->head_q[m] = pack_hi16(ha, hb);
+                }
+            }
+        }
+        // the lane below's end state
+#pragma unroll
+        for (int k = 0; k < 7; k++) { ri.y2[k] = d4_from_lane_below(ri.y2[k]); rq.y2[k] = d4_from_lane_below(rq.y2[k]); }
+        if (MODE == D4_SSB) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) { sb.qe[k] = d4_from_lane_below(sb.qe[k]); sb.qo[k] = d4_from_lane_below(sb.qo[k]); }
+#pragma unroll
+            for (int k = 0; k < 4; k++) { sb.ie[k] = d4_from_lane_below(sb.ie[k]); sb.io[k] = d4_from_lane_below(sb.io[k]); }
+        }
+        const bool mine = sg.valid && sg.tile > 0 && lane > 0;
+        constexpr int REPLAY_QUADS = MODE == D4_SSB ? 9 : 1;
+        for (int q4 = 0; q4 < REPLAY_QUADS; q4++) {
+            uint32_t wi[4], wq[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                wi[k] = q4 == 0 ? head[k * ST_SEGS] : head[(8 + 4 * (q4 - 1) + k) * ST_SEGS];
+                wq[k] = q4 == 0 ? head[(4 + k) * ST_SEGS] : 0u;
+            }
+            const int x0 = d4_replay_piece<MODE, 0>(da, ri, rq, sb, lsb, c14, q4 == 0, wi[0], wq[0]);
+            const int x1 = d4_replay_piece<MODE, 1>(da, ri, rq, sb, lsb, c14, q4 == 0, wi[1], wq[1]);
+            const int x2 = d4_replay_piece<MODE, 2>(da, ri, rq, sb, lsb, c14, q4 == 0, wi[2], wq[2]);
+            const int x3 = d4_replay_piece<MODE, 3>(da, ri, rq, sb, lsb, c14, q4 == 0, wi[3], wq[3]);
+            if (mine && 128 * q4 < sg.tlen)
+                *(u32x4 *)(base_row + ((sg.v0 + 128 * q4) >> 5)) = u32x4{(uint32_t)x0, (uint32_t)x1, (uint32_t)x2, (uint32_t)x3};
+#pragma unroll
+            for (int k = 0; k < 7; k++) { ri.y2[k] = ri.y2[k + 4]; rq.y2[k] = rq.y2[k + 4]; }
+            if (MODE == D4_SSB) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) { sb.qe[k] = sb.qe[k + 1]; sb.qo[k] = sb.qo[k + 1]; }
+#pragma unroll
+                for (int k = 0; k < 4; k++) { sb.ie[k] = sb.ie[k + 1]; sb.io[k] = sb.io[k + 1]; }
+            }
         }
     }
 }
@@ -701,6 +808,42 @@ struct D4Fm {
     uint32_t y2p[24];      // /4 outputs as pairs; variant V of a piece uses [V+1 .. V+20]
     int loud_e, loud_y2;   // pieces for which a value above the clamp-free bound stays in a window's reach
 };
+
+// the last stage of one piece (/2, 40 taps -> PCM, FmDemodulator.cc:548-556) from the piece's pair of /4 outputs: the pipeline's
+// pieces and the boundary replay
+template <int V>
+__device__ __forceinline__ int d4_fm_audio(D4Fm &s, uint32_t pair)
+{
+    const int y0 = (int)(int16_t)(pair & 0xffffu), y1 = (int)(int16_t)(pair >> 16);
+    const uint32_t m0 = (uint32_t)(y0 < 0 ? -y0 : y0), m1 = (uint32_t)(y1 < 0 ? -y1 : y1);
+    if ((m0 > m1 ? m0 : m1) > (uint32_t)AUDIO40_SAFE) s.loud_y2 = 21;
+    s.y2p[V + 20] = pair;
+    int acc = 1 << 14;                                 // /2, 40 taps -> PCM
+    if (!__any(s.loud_y2 > 0)) {
+#if IQD_D4_SPLIT
+        int accb = 0, accc = 0, accd = 0;              // (four chains of 5: without the clamps int32 sums wrap, any order is exact)
+#pragma unroll
+        for (int q = 0; q < 5; q++) {
+            acc = dot2(s.y2p[V + 20 - q], D4_TAP(a40p, q), acc);
+            accb = dot2(s.y2p[V + 15 - q], D4_TAP(a40p, q + 5), accb);
+            accc = dot2(s.y2p[V + 10 - q], D4_TAP(a40p, q + 10), accc);
+            accd = dot2(s.y2p[V + 5 - q], D4_TAP(a40p, q + 15), accd);
+        }
+        acc = (acc + accb) + (accc + accd);
+#else
+#pragma unroll
+        for (int q = 0; q < 20; q++) acc = dot2(s.y2p[V + 20 - q], D4_TAP(a40p, q), acc);
+#endif
+    } else {
+#pragma unroll
+        for (int q = 0; q < 20; q++) {
+            acc = clamp_q30(dot2(s.y2p[V + 20 - q], D4_TAP(a40p, q) & 0xffff0000u, acc));
+            acc = clamp_q30(dot2(s.y2p[V + 20 - q], D4_TAP(a40p, q) & 0x0000ffffu, acc));
+        }
+    }
+    if (s.loud_y2 > 0) s.loud_y2--;
+    return acc >> 15;
+}
 
 template <int V>
 __device__ __forceinline__ int d4_fm_piece(const D4Args &da, const uint8_t *ring_base, const uint32_t *full, uint32_t *consumed,
@@ -735,35 +878,7 @@ __device__ __forceinline__ int d4_fm_piece(const D4Args &da, const uint8_t *ring
     if (s.loud_e > 0) s.loud_e--;
 #pragma unroll
     for (int j = 0; j < 4; j++) s.eh[j] = w[4 + j];
-    const int y0 = a0 >> 15, y1 = a1 >> 15;
-    const uint32_t m0 = (uint32_t)(y0 < 0 ? -y0 : y0), m1 = (uint32_t)(y1 < 0 ? -y1 : y1);
-    if ((m0 > m1 ? m0 : m1) > (uint32_t)AUDIO40_SAFE) s.loud_y2 = 21;
-    s.y2p[V + 20] = pack_lo16((uint32_t)y0, (uint32_t)y1);
-    int acc = 1 << 14;                                 // /2, 40 taps -> PCM
-    if (!__any(s.loud_y2 > 0)) {
-#if IQD_D4_SPLIT
-        int accb = 0, accc = 0, accd = 0;              // (four chains of 5: without the clamps int32 sums wrap, any order is exact)
-#pragma unroll
-        for (int q = 0; q < 5; q++) {
-            acc = dot2(s.y2p[V + 20 - q], D4_TAP(a40p, q), acc);
-            accb = dot2(s.y2p[V + 15 - q], D4_TAP(a40p, q + 5), accb);
-            accc = dot2(s.y2p[V + 10 - q], D4_TAP(a40p, q + 10), accc);
-            accd = dot2(s.y2p[V + 5 - q], D4_TAP(a40p, q + 15), accd);
-        }
-        acc = (acc + accb) + (accc + accd);
-#else
-#pragma unroll
-        for (int q = 0; q < 20; q++) acc = dot2(s.y2p[V + 20 - q], D4_TAP(a40p, q), acc);
-#endif
-    } else {
-#pragma unroll
-        for (int q = 0; q < 20; q++) {
-            acc = clamp_q30(dot2(s.y2p[V + 20 - q], D4_TAP(a40p, q) & 0xffff0000u, acc));
-            acc = clamp_q30(dot2(s.y2p[V + 20 - q], D4_TAP(a40p, q) & 0x0000ffffu, acc));
-        }
-    }
-    if (s.loud_y2 > 0) s.loud_y2--;
-    return acc >> 15;
+    return d4_fm_audio<V>(s, pack_lo16((uint32_t)(a0 >> 15), (uint32_t)(a1 >> 15)));
 }
 
 __device__ __forceinline__ void d4_fm_wave(const ChainLaunch &a, const D4Args &da, uint8_t *lds, uint32_t *sync, int ring, int lane)
@@ -787,8 +902,10 @@ __device__ __forceinline__ void d4_fm_wave(const ChainLaunch &a, const D4Args &d
 #pragma unroll
         for (int j = 0; j < 24; j++) s.y2p[j] = 0;
         s.loud_e = s.loud_y2 = 0;
-        // boundary record (iqd_d4_fix.h): the y2 pairs of pieces 4..23 and of the last 20 pieces
-        D4RecFm *rec = da.rec && sg.valid ? (D4RecFm *)da.rec + (size_t)(sg.li * a.tiles_per_ch + sg.tile) : nullptr;
+        // Short lead-ins (iqd_d4_fix.h): the y2 pairs of pieces 4..23 go into the lane's head store as they pass; the first 20 PCM
+        // samples are replayed behind the loop with the predecessor's end state - the lane below's (see d4_am_wave).
+        const bool lf = da.lead_shift != 0;
+        uint32_t *head = (uint32_t *)(lds + D4_HEAD_OFF) + ring * 64 + lane;       // [word][ST_SEGS]
         for (int pq = 0; pq < n_pieces; pq += 4) {
             const int pos = -da.halo + 32 * pq;
             int pcm[4];
@@ -798,13 +915,38 @@ __device__ __forceinline__ void d4_fm_wave(const ChainLaunch &a, const D4Args &d
             pcm[3] = d4_fm_piece<3>(da, ring_base, full, consumed, pg, (uint32_t)lane, s);
             if (sg.valid && pos >= 0 && pos < sg.tlen && sg.v0 + pos >= 0)
                 *(u32x2 *)(pcm_row + ((sg.v0 + pos) >> 5)) = u32x2{pack_lo16((uint32_t)pcm[0], (uint32_t)pcm[1]), pack_lo16((uint32_t)pcm[2], (uint32_t)pcm[3])};
-            if (rec && pos >= 0 && pos < 5 * 128) *(u32x4 *)&rec->y2_head[pos >> 5] = u32x4{s.y2p[20], s.y2p[21], s.y2p[22], s.y2p[23]};
+            if (lf && pos >= 0 && pos < 5 * 128) {
+                uint32_t *h = head + (pos >> 5) * ST_SEGS;
+                h[0] = s.y2p[20]; h[ST_SEGS] = s.y2p[21]; h[2 * ST_SEGS] = s.y2p[22]; h[3 * ST_SEGS] = s.y2p[23];
+            }
 #pragma unroll
             for (int j = 0; j < 20; j++) s.y2p[j] = s.y2p[j + 4];
         }
-        if (rec) {
+        if (!lf) continue;
+        // lane 63's tail and lane 0's head also go to global memory: the one boundary in 64 that crosses waves (d4_fix_fm_channel)
+        D4RecFm *rec = da.rec && sg.valid ? (D4RecFm *)da.rec + (size_t)(sg.li * a.tiles_per_ch + sg.tile) : nullptr;
+        if (rec && lane == 63) {
 #pragma unroll
             for (int j = 0; j < 20; j += 4) *(u32x4 *)&rec->y2_tail[j] = u32x4{s.y2p[j], s.y2p[j + 1], s.y2p[j + 2], s.y2p[j + 3]};
+        }
+        if (rec && lane == 0 && sg.tile > 0)
+            for (int j = 0; j < 20; j++) rec->y2_head[j] = head[j * ST_SEGS];
+        // the lane below's end state: its last 20 pairs and how long a loud value stays in reach
+#pragma unroll
+        for (int j = 0; j < 20; j++) s.y2p[j] = d4_from_lane_below(s.y2p[j]);
+        s.loud_y2 = (int)d4_from_lane_below((uint32_t)s.loud_y2);
+        const bool mine = sg.valid && sg.tile > 0 && lane > 0;
+        for (int q4 = 0; q4 < 5; q4++) {
+            const uint32_t *h = head + 4 * q4 * ST_SEGS;
+            int pcm[4];
+            pcm[0] = d4_fm_audio<0>(s, h[0]);
+            pcm[1] = d4_fm_audio<1>(s, h[ST_SEGS]);
+            pcm[2] = d4_fm_audio<2>(s, h[2 * ST_SEGS]);
+            pcm[3] = d4_fm_audio<3>(s, h[3 * ST_SEGS]);
+            if (mine && 128 * q4 < sg.tlen)
+                *(u32x2 *)(pcm_row + ((sg.v0 + 128 * q4) >> 5)) = u32x2{pack_lo16((uint32_t)pcm[0], (uint32_t)pcm[1]), pack_lo16((uint32_t)pcm[2], (uint32_t)pcm[3])};
+#pragma unroll
+            for (int j = 0; j < 20; j++) s.y2p[j] = s.y2p[j + 4];
         }
     }
 }

@@ -308,7 +308,8 @@ void emu_plan_call(const uint32_t *knobs, uint32_t vlen, uint32_t pcm_per_ch, ui
 // ---- FM / AM / SSB boundary fix-up (iqd_d4_fix.h) on plain arrays: tests/test_emu_d4_fix.py -----------------------------------
 // family: FAM_AM 0, FAM_FM 1, FAM_SSB 3.  rec: the channel's records in segment order; out: int32 detector stream (AM / SSB) or
 // int16 PCM row (FM), patched in place.
-void emu_d4_fix(int family, const void *rec, uint32_t n_tiles, uint32_t tile_len, uint32_t shift, uint32_t vlen, int lsb, void *out)
+void emu_d4_fix(int family, const void *rec, uint32_t n_tiles, uint32_t tile_len, uint32_t shift, uint32_t vlen, int lsb, void *out,
+                uint32_t t_first, uint32_t t_step)   // the boundaries in front of segments t_first, t_first + t_step, ... (all: 1, 1)
 {
     HostExec ex;
     static iqd::Consts c;
@@ -316,13 +317,13 @@ void emu_d4_fix(int family, const void *rec, uint32_t n_tiles, uint32_t tile_len
     if (!ready) { iqd::build_consts(c); ready = true; }
     if (family == iqd::FAM_FM) {
         static iqd::D4FixFmLds lds;
-        iqd::d4_fix_fm(ex, c, lds, (const iqd::D4RecFm *)rec, n_tiles, tile_len, shift, vlen, (int16_t *)out, iqd::WB_THREADS);
+        iqd::d4_fix_fm(ex, c, lds, (const iqd::D4RecFm *)rec, n_tiles, tile_len, shift, vlen, (int16_t *)out, iqd::WB_THREADS, t_first, t_step);
     } else if (family == iqd::FAM_SSB) {
         static iqd::D4FixLds lds;
-        iqd::d4_fix_am_ssb<iqd::FAM_SSB>(ex, c, lds, rec, n_tiles, tile_len, shift, vlen, lsb, (int32_t *)out, 1, iqd::WB_THREADS);
+        iqd::d4_fix_am_ssb<iqd::FAM_SSB>(ex, c, lds, rec, n_tiles, tile_len, shift, vlen, lsb, (int32_t *)out, 1, iqd::WB_THREADS, t_first, t_step);
     } else {
         static iqd::D4FixLds lds;
-        iqd::d4_fix_am_ssb<iqd::FAM_AM>(ex, c, lds, rec, n_tiles, tile_len, shift, vlen, 0, (int32_t *)out, 1, iqd::WB_THREADS);
+        iqd::d4_fix_am_ssb<iqd::FAM_AM>(ex, c, lds, rec, n_tiles, tile_len, shift, vlen, 0, (int32_t *)out, 1, iqd::WB_THREADS, t_first, t_step);
     }
 }
 // the Q15 taps the fix-up uses: which 0 am_s2[12], 1 am_s3[16], 2 ssb_delay[16], 3 ssb_hilbert[31], 4 post12[12], 5 audio40[40], 6 am_s1[8]

@@ -7,6 +7,8 @@ Here a channel's intermediate streams (y2 at 16 kS/s, for SSB the 8 kS/s rails) 
 exactly where the consumer lanes take them (d4_am_wave / d4_fm_wave: pieces 4.. and the run's last pieces), every output the
 fix-up is responsible for is poisoned, and after the fix-up the whole row must be the direct computation's - for segment
 lengths, shifts and row lengths as the plan produces them, short last segments and more boundaries than one batch included.
+Since the pipelines fix the boundaries inside a consumer wave themselves (the lane below holds the predecessor's end state),
+the closing launch is left with every 64th segment id: the odd trials poison and fix only the boundaries t_first, t_first + 64, ...
 """
 import ctypes as C
 import os
@@ -23,7 +25,7 @@ FAM_AM, FAM_FM, FAM_SSB = 0, 1, 3
 def L():
     lib = emu_bind.lib()
     lib.emu_d4_fix.restype = None
-    lib.emu_d4_fix.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p]
+    lib.emu_d4_fix.argtypes = [C.c_int, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_void_p, C.c_uint32, C.c_uint32]
     lib.emu_d4_const.restype = C.c_uint32
     lib.emu_d4_const.argtypes = [C.c_int]
     lib.emu_taps.restype = C.c_int
@@ -79,6 +81,9 @@ def test_fixup_restores_every_output_the_short_lead_in_leaves_open(L, family):
         vlen = 128 * int(rng.integers(1, 400))
         if trial % 7 == 0:
             vlen = tile_len * int(rng.integers(13, 30)) - shift       # whole segments, more boundaries than one batch
+        if trial % 11 == 5:
+            tile_len = shift + 128
+            vlen = tile_len * int(rng.integers(80, 200)) - shift      # hundreds of segments: the every-64th stepping over several batches
         n_tiles, N = geometry(tile_len, shift, vlen)
         if n_tiles < 2:
             continue
@@ -123,13 +128,15 @@ def test_fixup_restores_every_output_the_short_lead_in_leaves_open(L, family):
                         rec[t, 24 + 16 * r: 24 + 16 * r + 16] = pairs(rails[r, p0 + 8: p0 + 40])
                         rec[t, 56 + 16 * r: 56 + 16 * r + 16] = pairs(rails[r, p0 + N - 32: p0 + N])
             out = truth.copy()
-        # poison what the fix-up must write: the first n_fix outputs of every segment but the first (as far as the segment goes)
-        for t in range(1, n_tiles):
+        # poison what the fix-up must write: the first n_fix outputs of every segment but the first (as far as the segment goes) -
+        # or, as the closing launch is asked, of the segments t_first, t_first + 64, ...
+        t_first, t_step = (1, 1) if trial % 2 == 0 or n_tiles < 4 else (int(rng.integers(1, min(n_tiles, 65))), 64 if n_tiles > 70 else 3)
+        for t in range(t_first, n_tiles, t_step):
             v0 = t * tile_len - shift
             tlen = min(tile_len, vlen - v0)
             out[v0 // 32: v0 // 32 + min(n_fix, tlen // 32)] = 0x5a5a if family != FAM_FM else 0x5a5a
         assert not np.array_equal(out, truth)
-        L.emu_d4_fix(family, rec.ctypes.data, n_tiles, tile_len, shift, vlen, lsb if family != FAM_FM else 0, out.ctypes.data)
+        L.emu_d4_fix(family, rec.ctypes.data, n_tiles, tile_len, shift, vlen, lsb if family != FAM_FM else 0, out.ctypes.data, t_first, t_step)
         bad = np.flatnonzero(out != truth)
         assert bad.size == 0, (family, trial, tile_len, vlen, n_tiles, bad[:8], out[bad[:8]], truth[bad[:8]])
     assert cases > 40
