@@ -26,7 +26,6 @@
 #include "iqd_taps.h"
 #include "iqd_wbfm.h"
 #include "iqd_chains.h"
-#include "iqd_d4_fix.h"
 
 using namespace iqd;
 
@@ -138,7 +137,6 @@ struct iqd_engine {
 
     // per-call scratch
     DevBuf stream_hist;   // boundary records of the streaming WBFM kernel, one StHist per segment
-    DevBuf d4_rec[FAM_COUNT];   // ... of the FM / AM / SSB pipelines (iqd_d4_fix.h), one buffer per family: they may run side by side
     DevBuf lists[FAM_COUNT + 1], mag_sums, blk_lists, vlen, records, base8k, base8k2, gain_trace, freq_trace, dc_records, dc_records2, repair_flags;
     size_t mag_sums_zero = 0;            // leading elements of mag_sums known to be zero (left so by the last squelch pass)
     // IQD_F_PREPASS_OVERLAP: a squelch-gated call's pre-pass (magnitudes of every block, decisions, open-block lists) runs on a
@@ -413,7 +411,7 @@ void iqd_destroy(iqd_t *e)
         if (p) (void)hipFree(p);
     if (e->h_counters) (void)hipHostFree(e->h_counters);
     for (auto &b : e->lists) b.release();
-    DevBuf *bufs[] = {&e->d4_rec[0], &e->d4_rec[1], &e->d4_rec[2], &e->d4_rec[3], &e->stream_hist, &e->mag_sums, &e->blk_lists, &e->vlen, &e->records, &e->base8k, &e->base8k2, &e->gain_trace, &e->freq_trace, &e->dc_records, &e->dc_records2, &e->repair_flags,
+    DevBuf *bufs[] = {&e->stream_hist, &e->mag_sums, &e->blk_lists, &e->vlen, &e->records, &e->base8k, &e->base8k2, &e->gain_trace, &e->freq_trace, &e->dc_records, &e->dc_records2, &e->repair_flags,
                       &e->st_iq, &e->st_pcm, &e->st_count, &e->st_mag, &e->st_allowed};
     for (DevBuf *b : bufs) b->release();
     for (int b = 0; b < 2; b++) {
@@ -1491,15 +1489,6 @@ static int queue_family(iqd_t *e, CallCtx &x, int f)
             d4.lead_shift = fp.lead_shift;
             d4.rounds = fp.rounds;
             d4.rings = fp.rings;
-            static const bool norec = getenv("IQD_D4_NOREC") != nullptr;   // TIMING PROBE ONLY (wrong results at segment starts): no records, no fix-up
-            if (fp.lead_shift && !norec) {   // short lead-ins: a boundary record per segment, read by the launch that closes the step (iqd_d4_fix.h)
-                DevBuf &rb = e->d4_rec[f];
-                HIP_TRY(e, rb.ensure((size_t)n_list * a.tiles_per_ch * d4_rec_bytes(f)));
-                d4.rec = rb.p;
-                a.d4_rec = rb.p;
-                a.d4_shift = fp.lead_shift;
-                for (int r = 0; r < 3; r++) { a.d4_gs[r] = fp.group_start[r]; a.d4_gl[r] = fp.group_li0[r]; }
-            }
         }
         if (f != FAM_FM) {
             int rc = attach_dc_buffers(e, x, f, a, s);

@@ -396,7 +396,9 @@ bool plan_fused_by_time(uint32_t vlen, int n, const FusedFamily *fam, uint32_t n
         if (!n_ch) continue;
         const uint32_t g = fam[f].granule == 128 || fam[f].granule == 256 ? fam[f].granule : 512;
         uint32_t last_len = 0;
-        const uint64_t span = (uint64_t)vlen + fam[f].shift;     // (short lead-ins: the segments cover [-shift, vlen), plan_stream)
+        // (short lead-ins: a channel's cold segments spend `shift` of their length on their lead-in, plan_stream; a channel of k
+        //  segments has at most d4_max_cold(k) of them - here the bound for up to 65 segments, two)
+        const uint64_t span = (uint64_t)vlen + (fam[f].shift ? 2ull * fam[f].shift : 0ull);
         const uint32_t min_tile = fam[f].shift ? std::max<uint32_t>((uint32_t)ST_MIN_TILE, fam[f].shift + 128) : (uint32_t)ST_MIN_TILE;
         for (uint32_t k = 1; last_len != min_tile && k <= vlen;) {   // (down to the shortest segment there is)
             uint64_t len = (span + k - 1) / k;
@@ -409,7 +411,9 @@ bool plan_fused_by_time(uint32_t vlen, int n, const FusedFamily *fam, uint32_t n
             if ((uint32_t)len == last_len) { k = k_next; continue; }
             last_len = (uint32_t)len;
             k = k_next;
-            const uint32_t tiles = (uint32_t)((span + len - 1) / len);
+            uint32_t tiles = (uint32_t)(((uint64_t)vlen + len - 1) / len);
+            if (!tiles) tiles = 1;
+            while ((uint64_t)tiles * len < (uint64_t)vlen + (fam[f].shift ? (uint64_t)fam[f].shift * d4_max_cold(tiles) : 0u)) tiles++;   // (as plan_stream)
             uint64_t ids = 0;
             for (int r = 0; r < 3; r++) ids += ((uint64_t)fam[f].rot_count[r] * tiles + 15) / 16 * 16;
             const uint64_t wgs = (ids + ST_SEGS - 1) / ST_SEGS;
@@ -458,22 +462,26 @@ TilePlan plan_stream(uint32_t vlen, uint32_t n_channels, uint32_t streams, uint3
     TilePlan p;
     // As many segments as fit ONE round of the persistent workgroups (all segments of a round advance in lock step,
     // so a second round with a handful of stragglers would cost as much as the first).
-    // shift: the channel's segments cover [-shift, vlen) - its first one starts that far before the call's first sample (its
-    // full lead-in, from the kept tail) - and a segment is longer than the shift, so that the first one holds samples of the call.
+    // shift (FM / AM / SSB with short lead-ins, iqd_stream.h: d4_geom): a channel's cold segments - its first one and those that
+    // are lane 0 of a consumer wave, at most d4_max_cold(n) of its n segments - spend `shift` samples of their length on their
+    // lead-in, so n segments of length L cover n * L - shift * cold samples; a segment is longer than the shift.
     uint32_t per_ch = n_channels ? streams / n_channels : 1;
     if (per_ch == 0) per_ch = 1;
-    const uint64_t span = (uint64_t)vlen + shift;
-    const uint64_t min_tile = shift ? std::max<uint64_t>(ST_MIN_TILE, shift + 128) : (uint64_t)ST_MIN_TILE;
-    uint64_t len = (span + per_ch - 1) / per_ch;
     if (granule != 128 && granule != 256) granule = 512;
+    const uint64_t min_tile = shift ? std::max<uint64_t>(ST_MIN_TILE, shift + 128) : (uint64_t)ST_MIN_TILE;
+    auto span_of = [&](uint64_t n_tiles) { return (uint64_t)vlen + (shift ? (uint64_t)shift * d4_max_cold((uint32_t)n_tiles) : 0u); };
+    uint64_t len = (span_of(per_ch) + per_ch - 1) / per_ch;
     len = (len + granule - 1) / granule * granule;   // 512: whole 32-byte PCM sectors per segment (16 PCM samples)
     if (len < min_tile) len = min_tile;   // a segment's end histories must be its own
     // (the minimum itself is not a multiple of the 512 granule: take it where it fits the round - 4096-sample rows on 6 segments
     //  per channel are 6 x 768, not 4 x 1024)
-    if (len > min_tile && (span + min_tile - 1) / min_tile <= per_ch) len = min_tile;
+    if (len > min_tile && (span_of(per_ch) + min_tile - 1) / min_tile <= per_ch) len = min_tile;
     p.tile_len = (uint32_t)len;
-    p.tiles_per_ch = (uint32_t)((span + len - 1) / len);
-    if (p.tiles_per_ch == 0) p.tiles_per_ch = 1;
+    // the fewest segments that cover the row whatever the channel's first segment id
+    uint64_t n = ((uint64_t)vlen + len - 1) / len;
+    if (n == 0) n = 1;
+    while (n * len < span_of(n)) n++;
+    p.tiles_per_ch = (uint32_t)n;
     return p;
 }
 

@@ -53,13 +53,6 @@ struct ChainLaunch {
     // A launch that runs several families' streaming pipelines side by side (iqd_stream_mixed.hip) gives each a range of
     // its workgroups; a kernel of its own leaves both zero (= the whole grid).
     uint32_t wg_first, wg_count;
-    // FM / AM / SSB streaming launches with short lead-ins (round 6, iqd_d4_fix.h): the segments' boundary records and how far a
-    // channel's segments are shifted; the launch that closes the step recomputes each later segment's first outputs from them
-    // (AM / SSB: in front of the DC pass; FM: beside the tail update).  nullptr: nothing to fix.
-    const void *d4_rec;
-    uint32_t d4_shift;
-    uint32_t d4_gs[3], d4_gl[3];  // the launch's segment ids by rotation group (D4Args::group_start / group_li0): the pipelines fix the
-                                  // boundaries inside a consumer wave themselves, what is left is every id that is a multiple of 64
 };
 #if defined(__HIPCC__)
 __device__ __forceinline__ uint32_t chain_wg(const ChainLaunch &a) { return blockIdx.x - a.wg_first; }

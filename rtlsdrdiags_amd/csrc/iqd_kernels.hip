@@ -5,7 +5,6 @@
 #include "iqd_chains.h"
 #include "iqd_wbfm.h"
 #include "iqd_stream_fix.h"
-#include "iqd_d4_fix.h"
 
 namespace iqd {
 
@@ -85,48 +84,6 @@ __device__ __forceinline__ void rotation_selectors(int rotation, WbfmTile &t)
 }
 
 // One tile of one channel: set-up, the chain, the hand-off record.  `start` is the state the tile begins with.
-// ---- FM / AM / SSB streaming launches with short lead-ins (iqd_d4_fix.h): the fix-up of one channel, by ALL threads of the
-// workgroup (the phases end in barriers).  AM / SSB: into the detector stream, in front of the DC pass; FM: into the PCM row.
-// The boundaries left to this launch: the pipelines' consumer lanes fix every boundary whose two segments sit in one wave (the
-// lane below holds the predecessor's end state); a segment whose id is a multiple of 64 is a wave's lane 0.  First such segment
-// of channel li (tile > 0), then every 64th.
-__device__ __forceinline__ uint32_t d4_first_left(const ChainLaunch &a, uint32_t li)
-{
-    const uint32_t r = (li >= a.d4_gl[1] ? 1u : 0u) + (li >= a.d4_gl[2] ? 1u : 0u);
-    const uint32_t sid0 = a.d4_gs[r] + (li - a.d4_gl[r]) * a.tiles_per_ch;   // the channel's segment 0
-    const uint32_t t = (64u - (sid0 & 63u)) & 63u;
-    return t ? t : 64u;
-}
-__device__ __forceinline__ void d4_fix_dc_channel(const ChainLaunch &a, int family, uint32_t li, D4FixLds &lds)
-{
-    if (!a.d4_rec) return;
-    const uint32_t ch = a.ch_list[li], ech = a.first_ch + ch;
-    const uint32_t vlen = a.vlen_gated ? a.vlen_gated[ch] : a.vlen;
-    const uint32_t nt = d4_tiles(a.tile_len, a.d4_shift, vlen);
-    const uint32_t t_first = d4_first_left(a, li);
-    if (t_first >= nt) return;
-    DeviceExec ex{(int)threadIdx.x};
-    int32_t *out = a.base8k + (size_t)ch * a.base_stride_ch;
-    if (family == FAM_SSB)
-        d4_fix_am_ssb<FAM_SSB>(ex, g_consts, lds, (const uint8_t *)a.d4_rec + (size_t)li * a.tiles_per_ch * sizeof(D4RecSsb), nt, a.tile_len, a.d4_shift, vlen,
-                               a.params[ech].ssb_lsb, out, a.base_stride_t, (int)blockDim.x, t_first, 64u);
-    else
-        d4_fix_am_ssb<FAM_AM>(ex, g_consts, lds, (const uint8_t *)a.d4_rec + (size_t)li * a.tiles_per_ch * sizeof(D4RecAm), nt, a.tile_len, a.d4_shift, vlen, 0,
-                              out, a.base_stride_t, (int)blockDim.x, t_first, 64u);
-}
-__device__ __forceinline__ void d4_fix_fm_channel(const ChainLaunch &a, uint32_t li, D4FixFmLds &lds)
-{
-    if (!a.d4_rec) return;
-    const uint32_t ch = a.ch_list[li];
-    const uint32_t vlen = a.vlen_gated ? a.vlen_gated[ch] : a.vlen;
-    const uint32_t nt = d4_tiles(a.tile_len, a.d4_shift, vlen);
-    const uint32_t t_first = d4_first_left(a, li);
-    if (t_first >= nt) return;
-    DeviceExec ex{(int)threadIdx.x};
-    d4_fix_fm(ex, g_consts, lds, (const D4RecFm *)a.d4_rec + (size_t)li * a.tiles_per_ch, nt, a.tile_len, a.d4_shift, vlen, a.pcm + (size_t)ch * a.pcm_stride,
-              (int)blockDim.x, t_first, 64u);
-}
-
 template <bool GATED, bool MAG>
 __device__ __forceinline__ void wbfm_run_tile(const ChainLaunch &a, WbfmLds &lds, uint32_t li, uint32_t tile,
                                               uint32_t ch, uint32_t vlen, const WbfmStart &start)
@@ -374,10 +331,8 @@ __global__ __launch_bounds__(64) void dc_kernel(const ChainLaunch a, int family)
 // The same for long streams: one wave per channel, segmented with exact verification.
 __global__ __launch_bounds__(64) void dc_wave_kernel(const ChainLaunch a, int family)
 {
-    __shared__ union Lds { DcLds dc; D4FixLds fix; __device__ Lds() {} } u;
-    DcLds &lds = u.dc;
+    __shared__ DcLds lds;
     const uint32_t li = blockIdx.x;
-    d4_fix_dc_channel(a, family, li, u.fix);   // (a streaming launch with short lead-ins: the segments' first outputs, before this pass reads them)
     const uint32_t ch = a.ch_list[li], ech = a.first_ch + ch;
     const uint32_t vlen = a.vlen_gated ? a.vlen_gated[ch] : a.vlen;
     const ChanParams &p = a.params[ech];
@@ -517,16 +472,7 @@ __device__ __forceinline__ void tail_update_body(const ChainLaunch &a, int famil
 
 __global__ __launch_bounds__(256) void tail_update_kernel(const ChainLaunch a, int family)
 {
-    __shared__ D4FixFmLds fix;
-    if (family == FAM_FM) d4_fix_fm_channel(a, blockIdx.x, fix);
     tail_update_body(a, family, blockIdx.x);
-}
-
-// The fix-up alone, one workgroup per channel: AM / SSB rows so long that their DC pass is the many-wave one (dc_tiled_kernel).
-__global__ __launch_bounds__(256) void d4_fix_kernel(const ChainLaunch a, int family)
-{
-    __shared__ D4FixLds fix;
-    d4_fix_dc_channel(a, family, blockIdx.x, fix);
 }
 
 // Per-block squelch magnitude sums for channels whose chain kernel does not produce them
@@ -583,13 +529,8 @@ __global__ void squelch_block_kernel(const SquelchLaunch q, int always_open)
 // part (the rest) share a launch - they are independent, tiny, and each launch of their own costs about as much as both.
 __global__ __launch_bounds__(256) void tail_squelch_kernel(const ChainLaunch a, int family, const SquelchLaunch q, int always_open)
 {
-    __shared__ D4FixFmLds fix;
-    if (blockIdx.x < a.n_list) {
-        if (family == FAM_FM) d4_fix_fm_channel(a, blockIdx.x, fix);   // (short lead-ins: the segments' first PCM samples, iqd_d4_fix.h)
-        tail_update_body(a, family, blockIdx.x);
-    } else {
-        squelch_block_body(q, always_open, (blockIdx.x - a.n_list) * 256u + threadIdx.x);
-    }
+    if (blockIdx.x < a.n_list) tail_update_body(a, family, blockIdx.x);
+    else squelch_block_body(q, always_open, (blockIdx.x - a.n_list) * 256u + threadIdx.x);
 }
 
 // ... and for a call whose one family is AM or SSB on its streaming pipeline (round 5): the DC-removal pass of the channels - the
@@ -597,14 +538,12 @@ __global__ __launch_bounds__(256) void tail_squelch_kernel(const ChainLaunch a, 
 // of the 0.2 ms step) - is a third role: workgroups n_list .. 2 n_list - 1, their first wave.  It depends on the pipeline only.
 __global__ __launch_bounds__(256) void tail_dc_squelch_kernel(const ChainLaunch a, int family, const SquelchLaunch q, int always_open)
 {
-    __shared__ union Lds { DcLds dc; D4FixLds fix; __device__ Lds() {} } u;
-    DcLds &lds = u.dc;
+    __shared__ DcLds lds;
     if (blockIdx.x < a.n_list) {
         tail_update_body(a, family, blockIdx.x);
     } else if (blockIdx.x < 2 * a.n_list) {
-        const uint32_t li = blockIdx.x - a.n_list;
-        d4_fix_dc_channel(a, family, li, u.fix);   // (all four waves; then the first runs the pass)
         if (threadIdx.x >= 64) return;
+        const uint32_t li = blockIdx.x - a.n_list;
         const uint32_t ch = a.ch_list[li], ech = a.first_ch + ch;
         const uint32_t vlen = a.vlen_gated ? a.vlen_gated[ch] : a.vlen;
         const ChanParams &p = a.params[ech];
@@ -636,17 +575,16 @@ struct MixedTailRoles { uint32_t end[6]; };
 __global__ __launch_bounds__(256) void mixed_tail_kernel(const ChainLaunch a_wbfm, const StreamArgs sa, const ChainLaunch a_am,
                                                          const ChainLaunch a_fm, const ChainLaunch a_ssb, const MixedTailRoles roles)
 {
-    __shared__ union Lds { DcLds dc; FixLds fix; D4FixLds d4fix; D4FixFmLds fmfix; __device__ Lds() {} } u;   // (a workgroup has one role: 14 KB, eleven of them per CU)
+    __shared__ union Lds { DcLds dc; FixLds fix; __device__ Lds() {} } u;   // (a workgroup has one role: 14 KB, eleven of them per CU)
     DcLds &lds = u.dc;
     const uint32_t b = blockIdx.x;
     if (b < roles.end[0]) {
         wbfm_stream_fixup_body(a_wbfm, sa, b, u.fix);
     } else if (b < roles.end[2]) {
+        if (threadIdx.x >= 64) return;
         const int family = b < roles.end[1] ? FAM_AM : FAM_SSB;
         const ChainLaunch &a = family == FAM_AM ? a_am : a_ssb;
         const uint32_t li = b - (family == FAM_AM ? roles.end[0] : roles.end[1]);
-        d4_fix_dc_channel(a, family, li, u.d4fix);
-        if (threadIdx.x >= 64) return;
         const uint32_t ch = a.ch_list[li], ech = a.first_ch + ch;
         DcCarry st = a.dc_carry[2 * (size_t)ech + (family == FAM_SSB ? 1 : 0)];
         DeviceExec ex{(int)threadIdx.x};
@@ -657,7 +595,6 @@ __global__ __launch_bounds__(256) void mixed_tail_kernel(const ChainLaunch a_wbf
     } else if (b < roles.end[3]) {
         tail_update_body(a_am, FAM_AM, b - roles.end[2]);
     } else if (b < roles.end[4]) {
-        d4_fix_fm_channel(a_fm, b - roles.end[3], u.fmfix);
         tail_update_body(a_fm, FAM_FM, b - roles.end[3]);
     } else if (b < roles.end[5]) {
         tail_update_body(a_ssb, FAM_SSB, b - roles.end[4]);
@@ -1140,7 +1077,6 @@ hipError_t launch_am_dc(const ChainLaunch &a_in, int family, hipStream_t s, bool
     if (batch) {
         hipLaunchKernelGGL(dc_kernel, dim3((a.n_list + 63) / 64), dim3(64), 0, s, a, family);
     } else if (a.dc_tiles >= 2 && a.dc_records) {   // rows longer than one tile: many waves per channel
-        if (a.d4_rec) hipLaunchKernelGGL(d4_fix_kernel, dim3(a.n_list), dim3(256), 0, s, a, family);
         hipLaunchKernelGGL(dc_tiled_kernel, dim3(a.dc_tiles, a.n_list), dim3(64), 0, s, a, family);
         hipLaunchKernelGGL(dc_chainup_kernel, dim3((a.n_list * a.dc_tiles + 255) / 256), dim3(256), 0, s, a, family);
         hipLaunchKernelGGL(dc_redo_kernel, dim3(a.n_list), dim3(64), 0, s, a, family);

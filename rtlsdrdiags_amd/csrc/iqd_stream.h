@@ -101,11 +101,44 @@ struct StreamArgs {
 // P waves, everything behind it in consumer lanes.
 enum { D4_AM = 0, D4_SSB = 1, D4_FM = 2 };
 constexpr int D4_HALO_AM = 384, D4_HALO_SSB = 1280, D4_HALO_FM = 768;   // FULL lead-in samples (the chains need 260 / 1220 / 684): a channel's first segment, from the kept tail
-// Round 6 (iqd_d4_fix.h): every segment but a channel's first runs D4_HALO_SHORT samples of lead-in and takes what its first
-// outputs reach back for from its predecessor's boundary record; a channel's segments are shifted by full lead-in - 128.
+// Round 6: FM / AM / SSB segments without their long lead-ins.  Every stage of these chains is a FIR, so a segment that starts
+// cold is exact once its filters' windows lie inside what it has run itself - rounds 2-5 gave EVERY segment the lead-in that
+// takes (AM 384, FM 768, SSB 1280 samples: 7 / 14 / 23 % of a 5.5 k-sample segment, a third to a half of the pieces at the
+// reference's own operating point, one 64 ms block per call: DataConsumer.cc:333-346).  The reference carries that state in its
+// filters' ring buffers from call to call (Decimator_int16.cc:310-351, FirFilter_int16.cc:151-213); here it travels from segment to
+// segment of one call: a channel's segments have consecutive segment ids, i.e. they sit in neighbouring lanes of a consumer
+// wave, so at the end of its run every lane takes the end state of the lane below (DPP) and replays its own first outputs -
+// 4 (AM), 36 (SSB), 20 (FM) - from inputs it kept in LDS (iqd_stream2.hip: d4_am_wave, d4_fm_wave).  Such a WARM segment runs
+// D4_HALO_SHORT = 128 samples of lead-in (what the first two stages need).  A COLD one - a channel's first segment, and every
+// segment that is lane 0 of a consumer wave (segment id a multiple of 64: its predecessor sits in another wave) - has nobody
+// to take a state from and runs the family's full lead-in.  So that all segments of a launch still run the same number of pieces
+// (they advance in lock step), a cold segment's lead-in comes out of its own length: it starts D = full lead-in - 128 samples
+// earlier than its outputs (D4Args::lead_shift), the segments behind it move up by D, and what it computes before its first
+// output is not stored.  Segment t of a channel whose segment 0 has id sid0:
+//     cold(t)  = t == 0 || (sid0 + t) % 64 == 0
+//     c(t)     = cold segments among 0 .. t = 1 + floor((sid0 + t) / 64) - floor(sid0 / 64)
+//     v0(t)    = t * tile_len - D * c(t)          nominal start: the run is [v0 - 128, v0 + tile_len)
+//     skip(t)  = cold(t) ? D : 0                  outputs from v0 + skip on
+// (tile 0 starts before the call's first sample: that part is the kept tail.)  Host + device.
 constexpr int D4_HALO_SHORT = 128;
 constexpr int d4_full_halo(int family) { return family == FAM_FM ? D4_HALO_FM : family == FAM_AM ? D4_HALO_AM : D4_HALO_SSB; }
 constexpr int d4_lead_shift(int family) { return d4_full_halo(family) - D4_HALO_SHORT; }
+struct D4Geom { int64_t v0; uint32_t skip, cold; };
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline D4Geom d4_geom(uint32_t sid, uint32_t tile, uint32_t tile_len, uint32_t shift)
+{
+    D4Geom g;
+    if (!shift) { g.v0 = (int64_t)tile * tile_len; g.skip = 0; g.cold = 1; return g; }   // (every segment with its full lead-in: rounds 2-5)
+    g.cold = tile == 0 || (sid & 63u) == 0 ? 1u : 0u;
+    const uint32_t c = 1u + (sid >> 6) - ((sid - tile) >> 6);
+    g.v0 = (int64_t)tile * tile_len - (int64_t)shift * c;
+    g.skip = g.cold ? shift : 0u;
+    return g;
+}
+// cold segments a channel of n_tiles segments can hold at most (whatever its first id): its first one + the lane-0 ones
+constexpr uint32_t d4_max_cold(uint32_t n_tiles) { return 1u + (n_tiles + 62u) / 64u; }
 struct D4Args {
     const uint32_t *amat;        // [3 rotation selectors -1, 0, +1][4][64][4]: build_decim4_amat()
     const float *fm_lut;         // 283 x 283 phase angles
@@ -115,8 +148,7 @@ struct D4Args {
     uint32_t rounds;
     uint32_t rings;              // rings a workgroup runs (StreamArgs::rings)
     int32_t halo;                // lead-in samples every segment of the launch runs (the family's full lead-in, or D4_HALO_SHORT)
-    uint32_t lead_shift;         // round 6 (iqd_d4_fix.h): segment t covers [t * tile_len - lead_shift, ...) - full lead-in minus halo; 0 = every segment with its full lead-in
-    void *rec;                   // ... and leaves a boundary record here, [n_list * tiles_per_ch] D4RecAm / D4RecSsb / D4RecFm (nullptr: none)
+    uint32_t lead_shift;         // round 6 (d4_geom above): full lead-in - halo; 0 = every segment with its full lead-in
     uint32_t s2p[6], s3p[8];     // AM/SSB stage 2 (12 taps, DOUBLED: the result is the accumulator's high half) and stage 3 (16 taps) as v_dot2 pairs, newest pair first
     uint32_t hilb[16];           // SSB: the nonzero Hilbert taps h[0], h[2], ..., h[30] (int16 in the low half)
     uint32_t p12p[6], a40p[20];  // FM post-discriminator decimators

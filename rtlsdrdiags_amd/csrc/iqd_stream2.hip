@@ -33,7 +33,6 @@
 #include "iqd_wbfm.h"
 #include "iqd_mfma.h"
 #include "iqd_taps.h"
-#include "iqd_d4_fix.h"
 
 // build-time experiments (tools/variant.sh): all off in the shipped library
 #ifndef IQD_D4_SPLIT
@@ -98,7 +97,7 @@ static_assert(D4_SLOTS % 4 == 0 && (D4_QUADS & (D4_QUADS - 1)) == 0 && D4_QUADS 
 template <int MODE> constexpr int d4_ahead() { return MODE == D4_FM ? 4 : IQD_D4_AHEAD_AM; }
 constexpr int D4_SLOT_BYTES = 64 * 32;            // 64 segments x (4 lanes x 8 bytes) per piece
 constexpr int D4_MAGLUT_OFF = (ST_RINGS * D4_SLOTS * D4_SLOT_BYTES + D4_SYNC_WORDS * 4 + 15) & ~15;   // squelch magnitude table (iqd_mfma.h)
-// Round 6 (iqd_d4_fix.h): every consumer lane keeps the inputs of its segment's first outputs here - the y2 pairs of pieces 4..7
+// Round 6 (iqd_stream.h, d4_geom): every consumer lane keeps the inputs of its segment's first outputs here - the y2 pairs of pieces 4..7
 // (AM / SSB, both rails: 8 words), SSB's 8 kS/s rails of pieces 8..39 (32 words), FM's y2 pairs of pieces 4..23 (20 words) - and
 // replays those outputs at the end of its run with its predecessor's end state, which sits in the lane below.  [word][segment].
 constexpr int D4_HEAD_WORDS = 40;
@@ -111,6 +110,8 @@ struct D4Seg {
     int32_t v0, tlen;
     int32_t vlen;          // samples this channel consumes in the call: all of them, or those of its open blocks (squelch)
     int rot;
+    int32_t skip;          // a cold segment (a channel's first, a consumer wave's lane 0: iqd_stream.h, d4_geom) stores nothing before v0 + skip
+    uint32_t cold;
 };
 
 // segment id -> (rotation group, channel, tile).  Groups in the order +Fs/4, none, -Fs/4, each padded to 16 ids.
@@ -131,9 +132,12 @@ __device__ __forceinline__ D4Seg d4_segment(const ChainLaunch &a, const D4Args &
     // virtual stream of vlen_gated[ch] samples; the segments are cut on that axis, those beyond its end are not there
     const uint32_t vlen = a.vlen_gated ? a.vlen_gated[s.ch] : a.vlen;
     s.vlen = (int32_t)vlen;
-    // (round 6, iqd_d4_fix.h: segment t covers [t * tile_len - lead_shift, ...): a channel's first segment starts BEFORE the call's
-    //  first sample - its full lead-in from the kept tail -, and what it computes for positions before 0 is not stored)
-    const int64_t v0 = (int64_t)s.tile * a.tile_len - (int64_t)da.lead_shift;
+    // (round 6, iqd_stream.h: d4_geom - warm segments run 128 samples of lead-in and take their predecessor's state from the lane
+    //  below; cold ones start lead_shift samples before their first output, the channel's first one in the kept tail)
+    const D4Geom g = d4_geom(sid, s.tile, a.tile_len, da.lead_shift);
+    s.skip = (int32_t)g.skip;
+    s.cold = g.cold;
+    const int64_t v0 = g.v0;
     if (vlen == 0 || v0 >= (int64_t)vlen) { s.valid = 0; s.v0 = 0; s.tlen = 0; return s; }
     s.v0 = (int32_t)v0;
     const int64_t rest = (int64_t)vlen - v0;
@@ -212,7 +216,7 @@ __device__ __forceinline__ void d4_p_round(const ChainLaunch &a, const D4Args &d
         uint32_t *mag_row = MAG ? a.mag_sums + (size_t)sgl.ch * a.n_blocks : nullptr;
         const bool mcount = MAG && sgl.valid;
         const int32_t mlimit = sgl.tlen - 8 * gl;
-        const int32_t mfirst = sgl.v0 < 0 ? -sgl.v0 : 0;          // (a channel's first segment: its samples before the call's first)
+        const int32_t mfirst = sgl.skip;                          // (a cold segment: what lies before its first output is lead-in)
 #if IQD_D4_TIMING
         long long t_ring_wait = 0;
 #endif
@@ -699,7 +703,7 @@ __device__ __forceinline__ void d4_am_wave(const ChainLaunch &a, const D4Args &d
         for (int k = 0; k < 9; k++) sb.qe[k] = sb.qo[k] = 0;
 #pragma unroll
         for (int k = 0; k < 5; k++) sb.ie[k] = sb.io[k] = 0;
-        // Short lead-ins (iqd_d4_fix.h): the inputs of this segment's first outputs go into the lane's head store as they pass -
+        // Short lead-ins (iqd_stream.h, d4_geom): the inputs of this segment's first outputs go into the lane's head store as they pass -
         // the y2 pairs of pieces 4..7, SSB's rails of pieces 8..39 - and those outputs are replayed behind the loop with the
         // predecessor's end state, which is the lane below's.
         const bool lf = da.lead_shift != 0;
@@ -712,7 +716,7 @@ __device__ __forceinline__ void d4_am_wave(const ChainLaunch &a, const D4Args &d
             const int x2 = d4_am_piece<MODE, 2>(da, ring_base, full, consumed, pg, (uint32_t)lane, lane, ri, rq, sb, lsb, c14, c15, r2);
             const int x3 = d4_am_piece<MODE, 3>(da, ring_base, full, consumed, pg, (uint32_t)lane, lane, ri, rq, sb, lsb, c14, c15, r3);
             // 128 samples = 4 detector inputs = one 16-byte store (segments start and end on multiples of 128)
-            if (sg.valid && pos >= 0 && pos < sg.tlen && sg.v0 + pos >= 0)
+            if (sg.valid && pos >= sg.skip && pos < sg.tlen)
                 *(u32x4 *)(base_row + ((sg.v0 + pos) >> 5)) = u32x4{(uint32_t)x0, (uint32_t)x1, (uint32_t)x2, (uint32_t)x3};
             if (lf && pos == 0) {
 #pragma unroll
@@ -735,36 +739,7 @@ __device__ __forceinline__ void d4_am_wave(const ChainLaunch &a, const D4Args &d
         // ---- the boundary: this lane's state now is its segment's END state = what its successor's first outputs reach back
         // for.  The successor is the next segment id = the lane above (a channel's segments have consecutive ids), so every lane
         // takes the state of the lane below and replays its own first outputs from its head store: 4 (AM), 36 (SSB: 34 needed).
-        // Lane 0's predecessor sits in another wave: that boundary (one in 64) goes through records in global memory and the
-        // launch that closes the step (iqd_kernels.hip: d4_fix_dc_channel) - lane 63 leaves its tail there, lane 0 its head.
-        uint8_t *rec = da.rec && sg.valid ? (uint8_t *)da.rec + (size_t)(sg.li * a.tiles_per_ch + sg.tile) * (MODE == D4_SSB ? sizeof(D4RecSsb) : sizeof(D4RecAm)) : nullptr;
-        if (rec && lane == 63) {
-            D4RecAm *ra = (D4RecAm *)rec;
-            *(u32x4 *)&ra->y2_tail[0][0] = u32x4{ri.y2[0], ri.y2[1], ri.y2[2], ri.y2[3]};
-            *(u32x4 *)&ra->y2_tail[0][4] = u32x4{ri.y2[4], ri.y2[5], ri.y2[6], 0u};
-            *(u32x4 *)&ra->y2_tail[1][0] = u32x4{rq.y2[0], rq.y2[1], rq.y2[2], rq.y2[3]};
-            *(u32x4 *)&ra->y2_tail[1][4] = u32x4{rq.y2[4], rq.y2[5], rq.y2[6], 0u};
-            if (MODE == D4_SSB) {   // the rails of the last 32 (q) / 16 (i) pieces, by piece: the parity streams interleaved
-                D4RecSsb *rs = (D4RecSsb *)rec;
-#pragma unroll
-                for (int m = 0; m < 8; m++) { rs->tail_q[2 * m] = pack_lo16(sb.qe[m], sb.qo[m]); rs->tail_q[2 * m + 1] = pack_hi16(sb.qe[m], sb.qo[m]); }
-#pragma unroll
-                for (int m = 0; m < 4; m++) { rs->tail_i[8 + 2 * m] = pack_lo16(sb.ie[m], sb.io[m]); rs->tail_i[8 + 2 * m + 1] = pack_hi16(sb.ie[m], sb.io[m]); }
-            }
-        }
-        if (rec && lane == 0 && sg.tile > 0) {
-            D4RecAm *ra = (D4RecAm *)rec;
-#pragma unroll
-            for (int k = 0; k < 4; k++) { ra->y2_head[0][k] = head[k * ST_SEGS]; ra->y2_head[1][k] = head[(4 + k) * ST_SEGS]; }
-            if (MODE == D4_SSB) {
-                D4RecSsb *rs = (D4RecSsb *)rec;
-                for (int m = 0; m < 16; m++) {
-                    const uint32_t ha = head[(8 + 2 * m) * ST_SEGS], hb = head[(8 + 2 * m + 1) * ST_SEGS];
-                    rs->head_i[m] = pack_lo16(ha, hb);
-                    rs->head_q[m] = pack_hi16(ha, hb);
-                }
-            }
-        }
+        // (Lane 0 and a channel's first segment have no such neighbour: they are the cold segments, which ran their full lead-in.)
         // the lane below's end state
 #pragma unroll
         for (int k = 0; k < 7; k++) { ri.y2[k] = d4_from_lane_below(ri.y2[k]); rq.y2[k] = d4_from_lane_below(rq.y2[k]); }
@@ -774,7 +749,7 @@ __device__ __forceinline__ void d4_am_wave(const ChainLaunch &a, const D4Args &d
 #pragma unroll
             for (int k = 0; k < 4; k++) { sb.ie[k] = d4_from_lane_below(sb.ie[k]); sb.io[k] = d4_from_lane_below(sb.io[k]); }
         }
-        const bool mine = sg.valid && sg.tile > 0 && lane > 0;
+        const bool mine = sg.valid && !sg.cold;
         constexpr int REPLAY_QUADS = MODE == D4_SSB ? 9 : 1;
         for (int q4 = 0; q4 < REPLAY_QUADS; q4++) {
             uint32_t wi[4], wq[4];
@@ -902,7 +877,7 @@ __device__ __forceinline__ void d4_fm_wave(const ChainLaunch &a, const D4Args &d
 #pragma unroll
         for (int j = 0; j < 24; j++) s.y2p[j] = 0;
         s.loud_e = s.loud_y2 = 0;
-        // Short lead-ins (iqd_d4_fix.h): the y2 pairs of pieces 4..23 go into the lane's head store as they pass; the first 20 PCM
+        // Short lead-ins (iqd_stream.h, d4_geom): the y2 pairs of pieces 4..23 go into the lane's head store as they pass; the first 20 PCM
         // samples are replayed behind the loop with the predecessor's end state - the lane below's (see d4_am_wave).
         const bool lf = da.lead_shift != 0;
         uint32_t *head = (uint32_t *)(lds + D4_HEAD_OFF) + ring * 64 + lane;       // [word][ST_SEGS]
@@ -913,7 +888,7 @@ __device__ __forceinline__ void d4_fm_wave(const ChainLaunch &a, const D4Args &d
             pcm[1] = d4_fm_piece<1>(da, ring_base, full, consumed, pg, (uint32_t)lane, s);
             pcm[2] = d4_fm_piece<2>(da, ring_base, full, consumed, pg, (uint32_t)lane, s);
             pcm[3] = d4_fm_piece<3>(da, ring_base, full, consumed, pg, (uint32_t)lane, s);
-            if (sg.valid && pos >= 0 && pos < sg.tlen && sg.v0 + pos >= 0)
+            if (sg.valid && pos >= sg.skip && pos < sg.tlen)
                 *(u32x2 *)(pcm_row + ((sg.v0 + pos) >> 5)) = u32x2{pack_lo16((uint32_t)pcm[0], (uint32_t)pcm[1]), pack_lo16((uint32_t)pcm[2], (uint32_t)pcm[3])};
             if (lf && pos >= 0 && pos < 5 * 128) {
                 uint32_t *h = head + (pos >> 5) * ST_SEGS;
@@ -923,19 +898,11 @@ __device__ __forceinline__ void d4_fm_wave(const ChainLaunch &a, const D4Args &d
             for (int j = 0; j < 20; j++) s.y2p[j] = s.y2p[j + 4];
         }
         if (!lf) continue;
-        // lane 63's tail and lane 0's head also go to global memory: the one boundary in 64 that crosses waves (d4_fix_fm_channel)
-        D4RecFm *rec = da.rec && sg.valid ? (D4RecFm *)da.rec + (size_t)(sg.li * a.tiles_per_ch + sg.tile) : nullptr;
-        if (rec && lane == 63) {
-#pragma unroll
-            for (int j = 0; j < 20; j += 4) *(u32x4 *)&rec->y2_tail[j] = u32x4{s.y2p[j], s.y2p[j + 1], s.y2p[j + 2], s.y2p[j + 3]};
-        }
-        if (rec && lane == 0 && sg.tile > 0)
-            for (int j = 0; j < 20; j++) rec->y2_head[j] = head[j * ST_SEGS];
         // the lane below's end state: its last 20 pairs and how long a loud value stays in reach
 #pragma unroll
         for (int j = 0; j < 20; j++) s.y2p[j] = d4_from_lane_below(s.y2p[j]);
         s.loud_y2 = (int)d4_from_lane_below((uint32_t)s.loud_y2);
-        const bool mine = sg.valid && sg.tile > 0 && lane > 0;
+        const bool mine = sg.valid && !sg.cold;
         for (int q4 = 0; q4 < 5; q4++) {
             const uint32_t *h = head + 4 * q4 * ST_SEGS;
             int pcm[4];

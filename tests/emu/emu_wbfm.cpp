@@ -18,7 +18,6 @@
 #include "iqd_taps.h"
 #include "iqd_chains.h"
 #include "iqd_wbfm.h"
-#include "iqd_d4_fix.h"
 
 namespace {
 
@@ -305,48 +304,26 @@ void emu_plan_call(const uint32_t *knobs, uint32_t vlen, uint32_t pcm_per_ch, ui
     }
 }
 
-// ---- FM / AM / SSB boundary fix-up (iqd_d4_fix.h) on plain arrays: tests/test_emu_d4_fix.py -----------------------------------
-// family: FAM_AM 0, FAM_FM 1, FAM_SSB 3.  rec: the channel's records in segment order; out: int32 detector stream (AM / SSB) or
-// int16 PCM row (FM), patched in place.
-void emu_d4_fix(int family, const void *rec, uint32_t n_tiles, uint32_t tile_len, uint32_t shift, uint32_t vlen, int lsb, void *out,
-                uint32_t t_first, uint32_t t_step)   // the boundaries in front of segments t_first, t_first + t_step, ... (all: 1, 1)
+// ---- FM / AM / SSB segments with short lead-ins: the geometry the kernels and the plan share (iqd_stream.h: d4_geom) ----------
+void emu_d4_geom(uint32_t sid, uint32_t tile, uint32_t tile_len, uint32_t shift, int64_t *v0, uint32_t *skip, uint32_t *cold)
 {
-    HostExec ex;
-    static iqd::Consts c;
-    static bool ready = false;
-    if (!ready) { iqd::build_consts(c); ready = true; }
-    if (family == iqd::FAM_FM) {
-        static iqd::D4FixFmLds lds;
-        iqd::d4_fix_fm(ex, c, lds, (const iqd::D4RecFm *)rec, n_tiles, tile_len, shift, vlen, (int16_t *)out, iqd::WB_THREADS, t_first, t_step);
-    } else if (family == iqd::FAM_SSB) {
-        static iqd::D4FixLds lds;
-        iqd::d4_fix_am_ssb<iqd::FAM_SSB>(ex, c, lds, rec, n_tiles, tile_len, shift, vlen, lsb, (int32_t *)out, 1, iqd::WB_THREADS, t_first, t_step);
-    } else {
-        static iqd::D4FixLds lds;
-        iqd::d4_fix_am_ssb<iqd::FAM_AM>(ex, c, lds, rec, n_tiles, tile_len, shift, vlen, 0, (int32_t *)out, 1, iqd::WB_THREADS, t_first, t_step);
-    }
+    const iqd::D4Geom g = iqd::d4_geom(sid, tile, tile_len, shift);
+    *v0 = g.v0; *skip = g.skip; *cold = g.cold;
 }
-// the Q15 taps the fix-up uses: which 0 am_s2[12], 1 am_s3[16], 2 ssb_delay[16], 3 ssb_hilbert[31], 4 post12[12], 5 audio40[40], 6 am_s1[8]
-int emu_taps(int which, int16_t *out)
+void emu_plan_stream2(uint32_t vlen, uint32_t n_channels, uint32_t streams, uint32_t granule, uint32_t shift, uint32_t *tile_len, uint32_t *tiles_per_ch)
 {
-    static iqd::Consts c;
-    static bool ready = false;
-    if (!ready) { iqd::build_consts(c); ready = true; }
-    const int16_t *src[] = {c.am_s2, c.am_s3, c.ssb_delay, c.ssb_hilbert, c.post12, c.audio40, c.am_s1};
-    const int n[] = {12, 16, 16, 31, 12, 40, 8};
-    memcpy(out, src[which], n[which] * sizeof(int16_t));
-    return n[which];
+    const iqd::TilePlan p = iqd::plan_stream(vlen, n_channels, streams, granule, shift);
+    *tile_len = p.tile_len;
+    *tiles_per_ch = p.tiles_per_ch;
 }
 uint32_t emu_d4_const(int which)
 {
     switch (which) {
-    case 0: return sizeof(iqd::D4RecAm);
-    case 1: return sizeof(iqd::D4RecFm);
-    case 2: return sizeof(iqd::D4RecSsb);
     case 3: return iqd::D4_HALO_SHORT;
     case 4: return (uint32_t)iqd::d4_lead_shift(iqd::FAM_AM);
     case 5: return (uint32_t)iqd::d4_lead_shift(iqd::FAM_FM);
     case 6: return (uint32_t)iqd::d4_lead_shift(iqd::FAM_SSB);
+    case 7: return iqd::TAIL;
     }
     return 0;
 }
