@@ -432,7 +432,8 @@ IQD_DEV void am_tile(Exec &ex, const Tile &t, const Consts &c, AmLds &lds, int s
 // DC-removal IIR + gain + (int16) cast for one channel (AmDemodulator.cc:462-465,
 // SsbDemodulator.cc:590-592; IirFilter.cc:161-176 with b = {1, -1}, a1 = -0.95):
 //   y[n] = ((0 + 1*x[n]) + (-1)*x[n-1]) - (0 + a1*y[n-1]);  pcm = (int16_t)(gain * y[n])
-IQD_DEV void dc_block_run(const int32_t *x, int n, float gain, float a1, DcCarry &st, int16_t *pcm)
+template <class SRC>
+IQD_DEV void dc_block_run(const SRC *x, int n, float gain, float a1, DcCarry &st, int16_t *pcm)   // (x may be pcm: x[i] is read before pcm[i] is written)
 {
     float xp = st.x_prev, yp = st.y_prev;
     for (int i = 0; i < n; i++) {
@@ -454,59 +455,87 @@ IQD_DEV void dc_block_run(const int32_t *x, int n, float gain, float a1, DcCarry
 // over the DC_WSEG segments in front of it from a close guess - two trajectories of this contraction (pole 0.95) that
 // start a fraction of a unit in the last place apart become bit-identical within those 128 steps - and is accepted
 // only if it reproduces its left neighbour's exact end state bit for bit; otherwise it restarts from that state.
-// The input differences x[n] - x[n-1] are formed once (they are exact), and the PCM leaves through LDS as whole
-// dwords: per pass of 2048 samples a lane runs 32 + 128 + 32 steps.
+// The input differences x[n] - x[n-1] are formed once (they are exact small integers: the detector's output is within
+// +-546, AM / SSB chains on int8 input), and the PCM leaves through LDS as whole dwords: per pass of 2048 samples a lane
+// runs 32 + 128 + 32 steps.
+// Round 6: a segment's row in LDS holds its 32 differences as int16 pairs until its lane has run them, then its 16 PCM
+// pairs IN THE SAME WORDS (5 KB per workgroup instead of 13: every channel's workgroup of a 4096- or 8192-row launch is
+// resident at once, where 11 per CU were - configs[4]'s pass, which runs beside the next call's magnitude pre-pass, took three
+// rounds of them); a pass whose hand-off check fails (a few per cent) fills its rows again before the lanes re-run.  The
+// source is the detector stream as int32 (the tile kernels' scratch) or as int16 in the PCM row itself (the streaming
+// pipelines, in place: x[n] is read before pcm[n] is written, pass by pass).
 constexpr int DC_S = 32;                    // samples per segment
 constexpr int DC_WSEG = 4;                  // segments of warm-up
 constexpr int DC_GUESS = 12;                // zero-state responses summed for the guess (0.95^(32*12) ~ 3e-9)
 constexpr int DC_SUPER = 64 * DC_S;         // PCM samples per pass of the wave
+constexpr int DC_ROW = DC_S / 2 + 1;        // words per segment row (padded: the lanes' rows start in different banks)
 struct DcLds {
-    float tn[64 * (DC_S + 1)];              // x[n] - x[n-1], one padded row per segment
-    uint32_t out[64 * (DC_S / 2 + 1)];      // PCM pairs of the pass, one padded row per segment
+    uint32_t row[64 * DC_ROW];              // per segment: int16 pairs - its input differences, then its PCM
     float z[DC_GUESS + 64], g[64], e[64];
     float x_carry, y_carry;                 // state entering the pass
+    float x_last;                           // the pass's last input sample (the next pass's x_carry; taken before the row is overwritten)
 };
 
-IQD_DEV void dc_fill(DcLds &lds, const int32_t *x, int at, int nseg, int lane)
+IQD_DEV float dc_lo(uint32_t pair) { return (float)(int)(int16_t)(pair & 0xffffu); }
+IQD_DEV float dc_hi(uint32_t pair) { return (float)((int)pair >> 16); }
+
+template <class SRC>
+IQD_DEV void dc_fill(DcLds &lds, const SRC *x, int at, int nseg, int lane, bool first_fill)
 {
-    // a lane takes 4 consecutive samples out of every 256; all of a pass's loads are issued before the first use
+    // a lane takes PER consecutive samples (16 bytes) out of every 64 * PER; all of a pass's loads are issued before the first use
     // (one after the other they cost a trip to memory each, which was most of this pass's time)
-    u32x4 v[DC_SUPER / 256];
-    int32_t before[DC_SUPER / 256];
+    constexpr int PER = 16 / (int)sizeof(SRC), LOADS = DC_SUPER / (64 * PER);
+    u32x4 v[LOADS];
+    int32_t before[LOADS];
 #pragma unroll
-    for (int k = 0; k < DC_SUPER / 256; k++) {        // (clamped, not predicated: nothing to wait for in between)
-        const int i = 4 * lane + 256 * k, ic = i < nseg * DC_S ? i : nseg * DC_S - 4;
+    for (int k = 0; k < LOADS; k++) {                 // (clamped, not predicated: nothing to wait for in between)
+        const int i = PER * lane + 64 * PER * k, ic = i < nseg * DC_S ? i : nseg * DC_S - PER;
 #if IQD_ON_DEVICE
-        v[k] = *(const u32x4 *)(x + at + ic);         // rows and passes start on multiples of 4 samples
+        v[k] = *(const u32x4 *)(x + at + ic);         // rows and passes start on multiples of 8 samples
 #else
         memcpy(&v[k], x + at + ic, 16);
 #endif
-        before[k] = x[at + ic > 0 ? at + ic - 1 : 0];
+        before[k] = (int32_t)x[at + ic > 0 ? at + ic - 1 : 0];
     }
 #if IQD_ON_DEVICE
     __builtin_amdgcn_sched_barrier(0);                // keep the loads together, ahead of the first use
 #endif
 #pragma unroll
-    for (int k = 0; k < DC_SUPER / 256; k++) {
-        const int i = 4 * lane + 256 * k;
+    for (int k = 0; k < LOADS; k++) {
+        const int i = PER * lane + 64 * PER * k;
         if (i >= nseg * DC_S) break;
-        float *dst = &lds.tn[(i / DC_S) * (DC_S + 1) + (i % DC_S)];
-        const float f0 = (float)(int32_t)v[k].x, f1 = (float)(int32_t)v[k].y, f2 = (float)(int32_t)v[k].z, f3 = (float)(int32_t)v[k].w;
-        dst[0] = f0 - (at + i == 0 ? lds.x_carry : (float)before[k]);
-        dst[1] = f1 - f0;
-        dst[2] = f2 - f1;
-        dst[3] = f3 - f2;
+        int32_t xs[PER];
+        if (sizeof(SRC) == 4) { xs[0] = (int32_t)v[k].x; xs[1] = (int32_t)v[k].y; xs[2] = (int32_t)v[k].z; xs[3] = (int32_t)v[k].w; }
+        else {
+            const uint32_t w[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+            for (int q = 0; q < 4; q++) { xs[(2 * q) % PER] = (int)(int16_t)(w[q] & 0xffffu); xs[(2 * q + 1) % PER] = (int)w[q] >> 16; }
+        }
+        // (the sample in front of a pass's first one is the carried x - an integer-valued float: it is always (float) of a detector
+        //  output - ; in place x[at - 1] already holds the previous pass's PCM)
+        int32_t prev = i == 0 ? (int32_t)lds.x_carry : before[k];
+        uint32_t *dst = &lds.row[(i / DC_S) * DC_ROW + (i % DC_S) / 2];
+#pragma unroll
+        for (int q = 0; q < PER; q += 2) {
+            const int32_t d0 = xs[q] - prev, d1 = xs[q + 1] - xs[q];
+            prev = xs[q + 1];
+            dst[q / 2] = ((uint32_t)d0 & 0xffffu) | ((uint32_t)d1 << 16);
+        }
+        if (i + PER == nseg * DC_S) lds.x_last = (float)xs[PER - 1];
     }
-    if (lane < DC_GUESS) lds.z[lane] = lane == DC_GUESS - 1 ? lds.y_carry : 0.f;
+    if (first_fill && lane < DC_GUESS) lds.z[lane] = lane == DC_GUESS - 1 ? lds.y_carry : 0.f;
 }
 
 IQD_DEV void dc_guess(const Consts &c, DcLds &lds, int nseg, int lane)
 {
     if (lane >= nseg) return;
     const float cc = -c.dc_a1;
-    const float *src = &lds.tn[lane * (DC_S + 1)];
+    const uint32_t *src = &lds.row[lane * DC_ROW];
     float z = 0.f;
-    for (int i = 0; i < DC_S; i++) z = __builtin_fmaf(cc, z, src[i]);
+    for (int i = 0; i < DC_S / 2; i++) {
+        z = __builtin_fmaf(cc, z, dc_lo(src[i]));
+        z = __builtin_fmaf(cc, z, dc_hi(src[i]));
+    }
     lds.z[DC_GUESS + lane] = z;
 }
 
@@ -524,29 +553,32 @@ IQD_DEV void dc_warm(const Consts &c, DcLds &lds, int nseg, int lane)
     }
     const float a1 = c.dc_a1;
     for (int sgm = m; sgm < lane; sgm++) {
-        const float *src = &lds.tn[sgm * (DC_S + 1)];
-        for (int i = 0; i < DC_S; i++) {
-            const float r = a1 * y;
-            y = src[i] - r;
+        const uint32_t *src = &lds.row[sgm * DC_ROW];
+        for (int i = 0; i < DC_S / 2; i++) {
+            float r = a1 * y;
+            y = dc_lo(src[i]) - r;
+            r = a1 * y;
+            y = dc_hi(src[i]) - r;
         }
     }
     lds.g[lane] = y;
 }
 
+// the lane's own segment for real: its differences out of its row, its PCM pairs into the same words
 IQD_DEV void dc_real(const Consts &c, DcLds &lds, int nseg, int lane, float gain)
 {
     if (lane >= nseg) return;
-    const float *src = &lds.tn[lane * (DC_S + 1)];
-    uint32_t *dst = &lds.out[lane * (DC_S / 2 + 1)];
+    uint32_t *row = &lds.row[lane * DC_ROW];
     float y = lds.g[lane];
     const float a1 = c.dc_a1;
-    for (int i = 0; i < DC_S; i += 2) {
+    for (int i = 0; i < DC_S / 2; i++) {
+        const uint32_t d = row[i];
         float r = a1 * y;
-        y = src[i] - r;
+        y = dc_lo(d) - r;
         const uint32_t lo = (uint32_t)cast_i16(gain * y);
         r = a1 * y;
-        y = src[i + 1] - r;
-        dst[i / 2] = pack_lo16(lo, (uint32_t)cast_i16(gain * y));
+        y = dc_hi(d) - r;
+        row[i] = pack_lo16(lo, (uint32_t)cast_i16(gain * y));
     }
     lds.e[lane] = y;
 }
@@ -566,12 +598,13 @@ IQD_DEV bool dc_check(DcLds &lds, int nseg, int lane, bool tiny_ok = false)
 IQD_DEV void dc_store(const DcLds &lds, int nseg, int lane, int16_t *pcm /* of the pass, 4-byte aligned */)
 {
     uint32_t *dst = (uint32_t *)pcm;
-    for (int d = lane; d < nseg * (DC_S / 2); d += 64) dst[d] = lds.out[(d / (DC_S / 2)) * (DC_S / 2 + 1) + (d % (DC_S / 2))];
+    for (int d = lane; d < nseg * (DC_S / 2); d += 64) dst[d] = lds.row[(d / (DC_S / 2)) * DC_ROW + (d % (DC_S / 2))];
 }
 
-// One channel, n PCM samples (multiple of 4; the last pass may be partial, its last segment too).
-template <class Exec>
-IQD_DEV void dc_block_wave(Exec &ex, const Consts &c, DcLds &lds, const int32_t *x, int n, float gain,
+// One channel, n PCM samples (multiple of 4; the last pass may be partial, its last segment too).  x may be the PCM row itself
+// (SRC = int16_t, in place).
+template <class Exec, class SRC>
+IQD_DEV void dc_block_wave(Exec &ex, const Consts &c, DcLds &lds, const SRC *x, int n, float gain,
                            DcCarry &st, int16_t *pcm)
 {
     ex.wave0([&](int lane) { if (lane == 0) { lds.x_carry = st.x_prev; lds.y_carry = st.y_prev; } });
@@ -579,17 +612,19 @@ IQD_DEV void dc_block_wave(Exec &ex, const Consts &c, DcLds &lds, const int32_t 
         const int len = n - base < DC_SUPER ? n - base : DC_SUPER;
         const int nfull = len / DC_S;             // whole segments: the segmented scheme
         if (nfull > 0) {
-            ex.wave0([&](int lane) { dc_fill(lds, x, base, nfull, lane); });
+            ex.wave0([&](int lane) { dc_fill(lds, x, base, nfull, lane, true); });
             ex.wave0([&](int lane) { dc_guess(c, lds, nfull, lane); });
             ex.wave0([&](int lane) { dc_warm(c, lds, nfull, lane); });
-            do {
+            for (bool again = false;; again = true) {
+                if (again) ex.wave0([&](int lane) { dc_fill(lds, x, base, nfull, lane, false); });   // (the rows hold PCM by now)
                 ex.wave0([&](int lane) { dc_real(c, lds, nfull, lane, gain); });
-            } while (!ex.wave0_all([&](int lane) { return dc_check(lds, nfull, lane, __builtin_fabsf(gain) <= 1e6f); }));
+                if (ex.wave0_all([&](int lane) { return dc_check(lds, nfull, lane, __builtin_fabsf(gain) <= 1e6f); })) break;
+            }
             ex.wave0([&](int lane) {
                 if (pcm) dc_store(lds, nfull, lane, pcm + base);
                 if (lane == 0) {
                     lds.y_carry = lds.e[nfull - 1];
-                    lds.x_carry = (float)x[base + nfull * DC_S - 1];
+                    lds.x_carry = lds.x_last;
                 }
             });
         }

@@ -266,7 +266,7 @@ int iqd_create(const iqd_config *cfg, iqd_t **out)
             for (int f = 0; f < FAM_COUNT; f++) kn.fam_ns[f] = w[f];
     }
     if (const char *env = getenv("IQD_D4_GRAN")) kn.env_d4_gran = (uint32_t)atoi(env);
-    if (const char *env = getenv("IQD_D4_LEADFREE")) kn.d4_leadfree = atoi(env) != 0;
+    if (const char *env = getenv("IQD_D4_LEADFREE")) kn.d4_leadfree = atoi(env);
     if (const char *env = getenv("IQD_STREAM_MIN_SEG")) kn.env_stream_min_seg = atoi(env) > 0 ? (uint64_t)atoi(env) : 0;
     if (const char *env = getenv("IQD_AM_STREAM_MIN")) kn.env_am_stream_min = atoi(env) > 0 ? (uint32_t)atoi(env) : AM_STREAM_MIN_PCM;
     if (const char *env = getenv("IQD_MIXED")) kn.env_mixed_forked = env[0] == 'f' && env[1] == 'o';
@@ -1487,6 +1487,8 @@ static int queue_family(iqd_t *e, CallCtx &x, int f)
             d4.fm_lut = e->d_fmlut;
             d4.halo = (int32_t)fp.halo;
             d4.lead_shift = fp.lead_shift;
+            static const uint32_t d4_probe = getenv("IQD_D4_PROBE") ? (uint32_t)atoi(getenv("IQD_D4_PROBE")) : 0u;   // timing probes only
+            d4.probe = d4_probe;
             d4.rounds = fp.rounds;
             d4.rings = fp.rings;
         }
@@ -1496,6 +1498,10 @@ static int queue_family(iqd_t *e, CallCtx &x, int f)
             if (streams) {   // (the pipeline writes the detector stream channel-major)
                 a.base_stride_ch = x.base.pcm_stride;
                 a.base_stride_t = 1;
+                // ... as int16 into the PCM rows themselves when the DC pass behind it is the one-wave pass (in place, round 6);
+                // rows so long that they take the many-wave pass keep the int32 stream: its tiles warm up over their neighbours' input
+                static const bool no_det16 = getenv("IQD_NO_DET16") != nullptr;   // (the A/B)
+                a.det16 = a.dc_tiles < 2 && !no_det16 ? 1u : 0u;
             }
         }
         if (streams) {

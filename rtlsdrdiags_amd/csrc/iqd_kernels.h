@@ -46,6 +46,8 @@ struct ChainLaunch {
     uint32_t *counters;           // [CNT_COUNT]
     int32_t *base8k;              // AM/SSB detector input at 8 kS/s, n_ch_call * pcm_stride ints
     size_t base_stride_ch, base_stride_t;   // its layout: channel-major or time-major
+    uint32_t det16;               // round 6: the streaming pipelines leave the detector input as int16 IN THE PCM ROWS (|x| <= 546) and the
+                                  // one-wave DC pass runs over them in place - half the bytes of the int32 stream, no second buffer
     uint32_t n_ch_call;           // channels in this accept call
     void *dc_records;             // long AM/SSB rows: [n_list][dc_tiles] DcRecord, then [n_list] redo flags
     uint32_t dc_tiles;            // tiles per channel of the many-wave DC pass (0: not used)

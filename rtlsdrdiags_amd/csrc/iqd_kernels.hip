@@ -328,19 +328,26 @@ __global__ __launch_bounds__(64) void dc_kernel(const ChainLaunch a, int family)
     a.dc_carry[2 * (size_t)ech + which] = st;
 }
 
-// The same for long streams: one wave per channel, segmented with exact verification.
-__global__ __launch_bounds__(64) void dc_wave_kernel(const ChainLaunch a, int family)
+// The one-wave DC pass of channel li (the workgroup's first wave): over the int32 detector stream, or - behind a streaming
+// pipeline (ChainLaunch::det16) - over the int16 detector values the pipeline left in the PCM row, in place.
+__device__ __forceinline__ void dc_channel_wave(const ChainLaunch &a, int family, uint32_t li, DcLds &lds)
 {
-    __shared__ DcLds lds;
-    const uint32_t li = blockIdx.x;
     const uint32_t ch = a.ch_list[li], ech = a.first_ch + ch;
     const uint32_t vlen = a.vlen_gated ? a.vlen_gated[ch] : a.vlen;
     const ChanParams &p = a.params[ech];
     DcCarry st = a.dc_carry[2 * (size_t)ech + (family == FAM_SSB ? 1 : 0)];
     DeviceExec ex{(int)threadIdx.x};
-    dc_block_wave(ex, g_consts, lds, a.base8k + (size_t)ch * a.base_stride_ch, (int)(vlen / 32), p.gain[family], st,
-                  a.pcm + (size_t)ch * a.pcm_stride);
+    int16_t *row = a.pcm + (size_t)ch * a.pcm_stride;
+    if (a.det16) dc_block_wave(ex, g_consts, lds, (const int16_t *)row, (int)(vlen / 32), p.gain[family], st, row);
+    else dc_block_wave(ex, g_consts, lds, a.base8k + (size_t)ch * a.base_stride_ch, (int)(vlen / 32), p.gain[family], st, row);
     if (threadIdx.x == 0) a.dc_carry[2 * (size_t)ech + (family == FAM_SSB ? 1 : 0)] = st;
+}
+
+// The same for long streams: one wave per channel, segmented with exact verification.
+__global__ __launch_bounds__(64) void dc_wave_kernel(const ChainLaunch a, int family)
+{
+    __shared__ DcLds lds;
+    dc_channel_wave(a, family, blockIdx.x, lds);
 }
 
 // Long rows: many waves per channel (dc_tile), the chain-up check, and the one-wave pass again for the
@@ -543,15 +550,7 @@ __global__ __launch_bounds__(256) void tail_dc_squelch_kernel(const ChainLaunch 
         tail_update_body(a, family, blockIdx.x);
     } else if (blockIdx.x < 2 * a.n_list) {
         if (threadIdx.x >= 64) return;
-        const uint32_t li = blockIdx.x - a.n_list;
-        const uint32_t ch = a.ch_list[li], ech = a.first_ch + ch;
-        const uint32_t vlen = a.vlen_gated ? a.vlen_gated[ch] : a.vlen;
-        const ChanParams &p = a.params[ech];
-        DcCarry st = a.dc_carry[2 * (size_t)ech + (family == FAM_SSB ? 1 : 0)];
-        DeviceExec ex{(int)threadIdx.x};
-        dc_block_wave(ex, g_consts, lds, a.base8k + (size_t)ch * a.base_stride_ch, (int)(vlen / 32), p.gain[family], st,
-                      a.pcm + (size_t)ch * a.pcm_stride);
-        if (threadIdx.x == 0) a.dc_carry[2 * (size_t)ech + (family == FAM_SSB ? 1 : 0)] = st;
+        dc_channel_wave(a, family, blockIdx.x - a.n_list, lds);
     } else {
         squelch_block_body(q, always_open, (blockIdx.x - 2 * a.n_list) * 256u + threadIdx.x);
     }
@@ -575,7 +574,7 @@ struct MixedTailRoles { uint32_t end[6]; };
 __global__ __launch_bounds__(256) void mixed_tail_kernel(const ChainLaunch a_wbfm, const StreamArgs sa, const ChainLaunch a_am,
                                                          const ChainLaunch a_fm, const ChainLaunch a_ssb, const MixedTailRoles roles)
 {
-    __shared__ union Lds { DcLds dc; FixLds fix; __device__ Lds() {} } u;   // (a workgroup has one role: 14 KB, eleven of them per CU)
+    __shared__ union Lds { DcLds dc; FixLds fix; __device__ Lds() {} } u;   // (a workgroup has one role)
     DcLds &lds = u.dc;
     const uint32_t b = blockIdx.x;
     if (b < roles.end[0]) {
@@ -585,13 +584,7 @@ __global__ __launch_bounds__(256) void mixed_tail_kernel(const ChainLaunch a_wbf
         const int family = b < roles.end[1] ? FAM_AM : FAM_SSB;
         const ChainLaunch &a = family == FAM_AM ? a_am : a_ssb;
         const uint32_t li = b - (family == FAM_AM ? roles.end[0] : roles.end[1]);
-        const uint32_t ch = a.ch_list[li], ech = a.first_ch + ch;
-        DcCarry st = a.dc_carry[2 * (size_t)ech + (family == FAM_SSB ? 1 : 0)];
-        DeviceExec ex{(int)threadIdx.x};
-        const uint32_t vlen = a.vlen_gated ? a.vlen_gated[ch] : a.vlen;
-        dc_block_wave(ex, g_consts, lds, a.base8k + (size_t)ch * a.base_stride_ch, (int)(vlen / 32), a.params[ech].gain[family], st,
-                      a.pcm + (size_t)ch * a.pcm_stride);
-        if (threadIdx.x == 0) a.dc_carry[2 * (size_t)ech + (family == FAM_SSB ? 1 : 0)] = st;
+        dc_channel_wave(a, family, li, lds);
     } else if (b < roles.end[3]) {
         tail_update_body(a_am, FAM_AM, b - roles.end[2]);
     } else if (b < roles.end[4]) {

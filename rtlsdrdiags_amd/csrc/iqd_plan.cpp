@@ -23,11 +23,10 @@ uint64_t stream_min_seg(const PlanKnobs &k, int f, uint64_t vlen, int several_fa
 
 namespace {
 
-// lead-in samples every segment of family f's streaming launch runs, and the shift of a channel's segments (plan_stream)
-uint32_t shift_of(const PlanKnobs &k, int f) { return f != FAM_WBFM && k.d4_leadfree ? (uint32_t)d4_lead_shift(f) : 0u; }
-uint32_t halo_of(const PlanKnobs &k, int f)
+// lead-in samples every segment of family f's streaming launch runs when its cold segments are shifted by `shift` (d4_geom)
+uint32_t halo_of(int f, uint32_t shift)
 {
-    return f == FAM_WBFM ? (uint32_t)ST_HALO : (uint32_t)d4_full_halo(f) - shift_of(k, f);
+    return f == FAM_WBFM ? (uint32_t)ST_HALO : (uint32_t)d4_full_halo(f) - shift;
 }
 
 // the segment ids of a streaming launch grouped by rotation selector, each group padded to a multiple of 16
@@ -68,7 +67,7 @@ uint32_t fit_stream(const FamilyShape &s, uint32_t vlen, uint32_t slots, uint32_
 // 2^14 .. 2^16; profiles/r5_rings_probe.txt: the rule picks the fastest arrangement in 14 of the 15 cases measured, second by
 // 2 % in the other).  The estimate is pieces per segment x that factor.  Streaming launches of 1024 channels x 2^14: AM 0.076 ->
 // 0.064 ms per step, FM 0.087 -> 0.076, WBFM 0.124 -> 0.104; 4096 x 2^14: AM 0.085 -> 0.081, WBFM 0.164 -> 0.158; larger: three rings.
-uint32_t rings_of(const PlanKnobs &k, const CallShape &c, int f, uint32_t wgs, bool fused, bool grouped)
+uint32_t rings_of(const PlanKnobs &k, const CallShape &c, int f, uint32_t wgs, bool fused, bool grouped, uint32_t shift)
 {
     if (fused) return (uint32_t)ST_RINGS;   // (the shares of the one launch are planned in workgroups of three rings: plan_fused_by_time)
     if (k.env_rings >= 1 && k.env_rings <= (uint32_t)ST_RINGS) return k.env_rings;
@@ -80,10 +79,10 @@ uint32_t rings_of(const PlanKnobs &k, const CallShape &c, int f, uint32_t wgs, b
     float best_t = 0.f;
     for (uint32_t r = (uint32_t)ST_RINGS; r >= 1; r--) {
         FamilyPlan tmp;
-        const uint32_t ids = fit_stream(s, c.vlen, wgs * 64u * r, granule, grouped, shift_of(k, f), tmp);
+        const uint32_t ids = fit_stream(s, c.vlen, wgs * 64u * r, granule, grouped, shift, tmp);
         if (ids > wgs * 64u * r) continue;                                 // (a second round: never better)
-        const float t = per_piece[r] * (float)(tmp.tile_len + halo_of(k, f));
-        if (r == (uint32_t)ST_RINGS || t < 0.99f * best_t) { best = r; best_t = t; }
+        const float t = per_piece[r] * (float)(tmp.tile_len + halo_of(f, shift));
+        if (r == (uint32_t)ST_RINGS || t < (shift ? 1.0f : 0.99f) * best_t) { best = r; best_t = t; }   // (short lead-ins: a tie goes to the fewer rings - AM 1024 x 2^14: 0.0584 ms on two, round 6)
     }
     return best;
 }
@@ -149,8 +148,8 @@ bool plan_once(const PlanKnobs &k, const CallShape &c, bool allow_fused, CallPla
         FusedFamily ff[FAM_COUNT];
         for (int f = 0; f < FAM_COUNT; f++) {
             for (int r = 0; r < 3; r++) ff[f].rot_count[r] = c.fam[f].n_list ? c.fam[f].rot_count[r] : 0u;
-            ff[f].halo = halo_of(k, f);
-            ff[f].shift = shift_of(k, f);
+            ff[f].shift = f != FAM_WBFM && k.d4_leadfree == 2 ? (uint32_t)d4_lead_shift(f) : 0u;   // (the one launch: full lead-ins unless asked)
+            ff[f].halo = halo_of(f, ff[f].shift);
             ff[f].granule = f == FAM_WBFM ? k.env_stream_gran : k.env_d4_gran;
             ff[f].ns_per_sample = k.fam_ns[f];
         }
@@ -199,7 +198,7 @@ bool plan_once(const PlanKnobs &k, const CallShape &c, bool allow_fused, CallPla
             if (ok && want >= 0 && enough) {
                 p.path = PLAN_STREAM;
                 p.grouped = mixed_selectors;
-                p.rings = rings_of(k, c, f, p.wgs, fused, p.grouped);
+                p.rings = rings_of(k, c, f, p.wgs, fused, p.grouped, 0u);
                 for (;;) {
                     const uint32_t wg_segs = 64u * p.rings;
                     const uint32_t ids = fit_stream(s, vlen, p.wgs * wg_segs, k.env_stream_gran, p.grouped, 0u, p);
@@ -218,18 +217,25 @@ bool plan_once(const PlanKnobs &k, const CallShape &c, bool allow_fused, CallPla
             if (ok && want >= 0 && enough) {
                 p.path = PLAN_STREAM;
                 p.grouped = true;
-                p.halo = halo_of(k, f);
-                p.lead_shift = shift_of(k, f);
-                p.rings = rings_of(k, c, f, p.wgs, fused, true);
+                // short lead-ins (d4_geom) where they pay: see PlanKnobs::d4_leadfree
+                uint32_t shift = (uint32_t)d4_lead_shift(f);
+                if (k.d4_leadfree == 0 || (fused && k.d4_leadfree != 2)) shift = 0;
                 for (;;) {
-                    const uint32_t wg_segs = 64u * p.rings;
-                    // (these pipelines store 8 or 16 bytes per 128 samples: no wide stores to keep whole)
-                    fit_stream(s, vlen, p.wgs * wg_segs, k.env_d4_gran, true, p.lead_shift, p);
-                    const uint32_t wgs_needed = (p.group_start[3] + wg_segs - 1) / wg_segs;
-                    p.grid = wgs_needed < p.wgs ? wgs_needed : p.wgs;
-                    p.rounds = (wgs_needed + p.grid - 1) / p.grid;
-                    if (p.rounds == 1 || p.rings == (uint32_t)ST_RINGS || k.env_rings) break;
-                    p.rings = (uint32_t)ST_RINGS;   // (workgroups of fewer rings are for launches of one round)
+                    p.lead_shift = shift;
+                    p.halo = halo_of(f, shift);
+                    p.rings = rings_of(k, c, f, p.wgs, fused, true, shift);
+                    for (;;) {
+                        const uint32_t wg_segs = 64u * p.rings;
+                        // (these pipelines store 8 or 16 bytes per 128 samples: no wide stores to keep whole)
+                        fit_stream(s, vlen, p.wgs * wg_segs, k.env_d4_gran, true, shift, p);
+                        const uint32_t wgs_needed = (p.group_start[3] + wg_segs - 1) / wg_segs;
+                        p.grid = wgs_needed < p.wgs ? wgs_needed : p.wgs;
+                        p.rounds = (wgs_needed + p.grid - 1) / p.grid;
+                        if (p.rounds == 1 || p.rings == (uint32_t)ST_RINGS || k.env_rings) break;
+                        p.rings = (uint32_t)ST_RINGS;   // (workgroups of fewer rings are for launches of one round)
+                    }
+                    if (!shift || k.d4_leadfree >= 0 || p.tiles_per_ch >= D4_LEADFREE_MIN_TILES) break;
+                    shift = 0;   // (the default rule: a channel of only a handful of segments keeps its full lead-ins)
                 }
             }
         }

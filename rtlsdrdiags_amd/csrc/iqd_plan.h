@@ -35,6 +35,7 @@ constexpr uint64_t STREAM_MIN_SEG_WBFM = 600, STREAM_MIN_SEG_FM = 900, STREAM_MI
 // one-wave pass whatever the row length (round 4: the rule used to be > 512, which kept the reference's own operating
 // point - one 64 ms block per channel per call, 512 PCM samples - on the tile kernels at 0.14 of the HBM peak).  IQD_AM_STREAM_MIN.
 constexpr uint32_t AM_STREAM_MIN_PCM = 128;
+constexpr uint32_t D4_LEADFREE_MIN_TILES = 8;
 
 // Engine-wide settings: iqd_config::flags and the IQD_* measurement knobs, read once by iqd_create.
 struct PlanKnobs {
@@ -45,8 +46,12 @@ struct PlanKnobs {
     uint64_t env_stream_min_seg = 0;     // IQD_STREAM_MIN_SEG (0: the measured per-family thresholds)
     uint32_t env_am_stream_min = AM_STREAM_MIN_PCM;   // IQD_AM_STREAM_MIN (measurement runs: 513 = the rule of rounds 2-3)
     uint32_t env_d4_gran = 128;          // IQD_D4_GRAN: segment-length granule of the FM / AM / SSB pipelines (measurement runs)
-    bool d4_leadfree = true;             // FM / AM / SSB streaming segments with 128-sample lead-ins, boundary records and a fix-up (round 6,
-                                         // iqd_d4_fix.h); IQD_D4_LEADFREE=0: every segment with its family's full lead-in (rounds 2-5, the A/B)
+    // FM / AM / SSB streaming segments with 128-sample lead-ins (round 6, iqd_stream.h: d4_geom).  IQD_D4_LEADFREE: 0 = every segment
+    // with its family's full lead-in (rounds 2-5), 1 = short lead-ins wherever the family streams as a kernel of its own, 2 = in
+    // the one launch for several families too; default (no variable): where a channel is cut into at least D4_LEADFREE_MIN_TILES
+    // segments - a channel's first segment and the lane-0 ones pay their full lead-in out of the segments' length, which costs
+    // more than it saves when a channel has only a handful of them (8192 channels x 2^16: six; profiles/r6_leadfree_ab.txt)
+    int d4_leadfree = -1;
     bool env_full_grid = false;          // IQD_FULL_GRID
     bool env_mixed_forked = false;       // IQD_MIXED=forked: several families as kernels of their own side by side (A/B runs)
     bool env_shares_by_cost = false;     // IQD_SHARES=cost: round 3's proportional shares

@@ -691,6 +691,7 @@ __device__ __forceinline__ void d4_am_wave(const ChainLaunch &a, const D4Args &d
         const D4Seg sg = d4_segment(a, da, sid);
         const int lsb = a.params[sg.ech].ssb_lsb;
         int32_t *base_row = a.base8k + (size_t)sg.ch * a.base_stride_ch;
+        int16_t *det_row = a.pcm + (size_t)sg.ch * a.pcm_stride;
         D4Rail ri, rq;
         D4Ssb sb;
         int c14 = 1 << 14, c15 = 1 << 15;
@@ -706,7 +707,7 @@ __device__ __forceinline__ void d4_am_wave(const ChainLaunch &a, const D4Args &d
         // Short lead-ins (iqd_stream.h, d4_geom): the inputs of this segment's first outputs go into the lane's head store as they pass -
         // the y2 pairs of pieces 4..7, SSB's rails of pieces 8..39 - and those outputs are replayed behind the loop with the
         // predecessor's end state, which is the lane below's.
-        const bool lf = da.lead_shift != 0;
+        const bool lf = da.lead_shift != 0 && !(da.probe & 2u);
         uint32_t *head = (uint32_t *)(lds + D4_HEAD_OFF) + ring * 64 + lane;       // [word][ST_SEGS]
         for (int pq = 0; pq < n_pieces; pq += 4) {
             const int pos = -da.halo + 32 * pq;
@@ -715,9 +716,12 @@ __device__ __forceinline__ void d4_am_wave(const ChainLaunch &a, const D4Args &d
             const int x1 = d4_am_piece<MODE, 1>(da, ring_base, full, consumed, pg, (uint32_t)lane, lane, ri, rq, sb, lsb, c14, c15, r1);
             const int x2 = d4_am_piece<MODE, 2>(da, ring_base, full, consumed, pg, (uint32_t)lane, lane, ri, rq, sb, lsb, c14, c15, r2);
             const int x3 = d4_am_piece<MODE, 3>(da, ring_base, full, consumed, pg, (uint32_t)lane, lane, ri, rq, sb, lsb, c14, c15, r3);
-            // 128 samples = 4 detector inputs = one 16-byte store (segments start and end on multiples of 128)
-            if (sg.valid && pos >= sg.skip && pos < sg.tlen)
-                *(u32x4 *)(base_row + ((sg.v0 + pos) >> 5)) = u32x4{(uint32_t)x0, (uint32_t)x1, (uint32_t)x2, (uint32_t)x3};
+            // 128 samples = 4 detector inputs = one store (segments start and end on multiples of 128): int16 into the PCM row, where
+            // the DC pass runs in place (ChainLaunch::det16; |x| <= 546), or int32 into the detector stream's own buffer
+            if (sg.valid && pos >= sg.skip && pos < sg.tlen) {
+                if (a.det16) *(u32x2 *)(det_row + ((sg.v0 + pos) >> 5)) = u32x2{pack_lo16((uint32_t)x0, (uint32_t)x1), pack_lo16((uint32_t)x2, (uint32_t)x3)};
+                else *(u32x4 *)(base_row + ((sg.v0 + pos) >> 5)) = u32x4{(uint32_t)x0, (uint32_t)x1, (uint32_t)x2, (uint32_t)x3};
+            }
             if (lf && pos == 0) {
 #pragma unroll
                 for (int k = 0; k < 4; k++) { head[k * ST_SEGS] = ri.y2[7 + k]; head[(4 + k) * ST_SEGS] = rq.y2[7 + k]; }
@@ -735,7 +739,7 @@ __device__ __forceinline__ void d4_am_wave(const ChainLaunch &a, const D4Args &d
                 for (int k = 0; k < 4; k++) { sb.ie[k] = sb.ie[k + 1]; sb.io[k] = sb.io[k + 1]; }
             }
         }
-        if (!lf) continue;
+        if (!lf || (da.probe & 1u)) continue;
         // ---- the boundary: this lane's state now is its segment's END state = what its successor's first outputs reach back
         // for.  The successor is the next segment id = the lane above (a channel's segments have consecutive ids), so every lane
         // takes the state of the lane below and replays its own first outputs from its head store: 4 (AM), 36 (SSB: 34 needed).
@@ -762,8 +766,10 @@ __device__ __forceinline__ void d4_am_wave(const ChainLaunch &a, const D4Args &d
             const int x1 = d4_replay_piece<MODE, 1>(da, ri, rq, sb, lsb, c14, q4 == 0, wi[1], wq[1]);
             const int x2 = d4_replay_piece<MODE, 2>(da, ri, rq, sb, lsb, c14, q4 == 0, wi[2], wq[2]);
             const int x3 = d4_replay_piece<MODE, 3>(da, ri, rq, sb, lsb, c14, q4 == 0, wi[3], wq[3]);
-            if (mine && 128 * q4 < sg.tlen)
-                *(u32x4 *)(base_row + ((sg.v0 + 128 * q4) >> 5)) = u32x4{(uint32_t)x0, (uint32_t)x1, (uint32_t)x2, (uint32_t)x3};
+            if (mine && 128 * q4 < sg.tlen) {
+                if (a.det16) *(u32x2 *)(det_row + ((sg.v0 + 128 * q4) >> 5)) = u32x2{pack_lo16((uint32_t)x0, (uint32_t)x1), pack_lo16((uint32_t)x2, (uint32_t)x3)};
+                else *(u32x4 *)(base_row + ((sg.v0 + 128 * q4) >> 5)) = u32x4{(uint32_t)x0, (uint32_t)x1, (uint32_t)x2, (uint32_t)x3};
+            }
 #pragma unroll
             for (int k = 0; k < 7; k++) { ri.y2[k] = ri.y2[k + 4]; rq.y2[k] = rq.y2[k + 4]; }
             if (MODE == D4_SSB) {
@@ -879,7 +885,7 @@ __device__ __forceinline__ void d4_fm_wave(const ChainLaunch &a, const D4Args &d
         s.loud_e = s.loud_y2 = 0;
         // Short lead-ins (iqd_stream.h, d4_geom): the y2 pairs of pieces 4..23 go into the lane's head store as they pass; the first 20 PCM
         // samples are replayed behind the loop with the predecessor's end state - the lane below's (see d4_am_wave).
-        const bool lf = da.lead_shift != 0;
+        const bool lf = da.lead_shift != 0 && !(da.probe & 2u);
         uint32_t *head = (uint32_t *)(lds + D4_HEAD_OFF) + ring * 64 + lane;       // [word][ST_SEGS]
         for (int pq = 0; pq < n_pieces; pq += 4) {
             const int pos = -da.halo + 32 * pq;
@@ -897,7 +903,7 @@ __device__ __forceinline__ void d4_fm_wave(const ChainLaunch &a, const D4Args &d
 #pragma unroll
             for (int j = 0; j < 20; j++) s.y2p[j] = s.y2p[j + 4];
         }
-        if (!lf) continue;
+        if (!lf || (da.probe & 1u)) continue;
         // the lane below's end state: its last 20 pairs and how long a loud value stays in reach
 #pragma unroll
         for (int j = 0; j < 20; j++) s.y2p[j] = d4_from_lane_below(s.y2p[j]);

@@ -270,7 +270,7 @@ void emu_plan_stream(uint32_t vlen, uint32_t n_channels, uint32_t streams, uint3
 // env_am_stream_min (0 = default), env_mixed_forked, env_shares_by_cost, env_stream_wgs, env_full_grid, env_rings}; fam: per family
 // {n_list, rot_count[3], cast_bounded, epochs_in_reach}; out: {n_fams, forked, shares_on, fused, mix_wgs, order[4]} then per family
 // {present, path, lane, wgs, tile_len, tiles_per_ch, grouped, group_start[4], group_nseg[3], grid, rounds, wg_first, epochs, rings, halo, lead_shift}
-// (21 words).  knobs[11]: 1 = IQD_D4_LEADFREE=0 (every FM / AM / SSB segment with its full lead-in).
+// (21 words).  knobs[11]: 0 = the default rule for short lead-ins, 1 + v = IQD_D4_LEADFREE=v.
 void emu_plan_call(const uint32_t *knobs, uint32_t vlen, uint32_t pcm_per_ch, uint32_t gated, const uint32_t *fam, uint32_t *out)
 {
     iqd::PlanKnobs k;
@@ -280,7 +280,7 @@ void emu_plan_call(const uint32_t *knobs, uint32_t vlen, uint32_t pcm_per_ch, ui
     if (knobs[5]) k.env_am_stream_min = knobs[5];
     k.env_mixed_forked = knobs[6] != 0; k.env_shares_by_cost = knobs[7] != 0; k.env_stream_wgs = knobs[8]; k.env_full_grid = knobs[9] != 0;
     k.env_rings = knobs[10];
-    k.d4_leadfree = knobs[11] == 0;
+    k.d4_leadfree = knobs[11] == 0 ? -1 : (int)knobs[11] - 1;   // 0: the default rule; 1 / 2 / 3: IQD_D4_LEADFREE = 0 / 1 / 2
     k.wbfm_chunk = iqd::WBFM_CHUNK; k.wbfm_cold_halo = iqd::COLD_HALO; k.ch_chunk = iqd::CH_CHUNK; k.fir_halo = iqd::FIR_HALO; k.dc_tile = iqd::DC_TILE;
     iqd::CallShape c;
     c.vlen = vlen; c.pcm_per_ch = pcm_per_ch; c.gated = gated != 0;

@@ -193,11 +193,11 @@ def _plan_lib():
 
 
 def plan_call(vlen, fams, flags=0, n_cus=256, stream_ok=True, env_path=0, min_seg=0, am_min=0, mixed_forked=False, by_cost=False,
-              stream_wgs=0, full_grid=False, gated=False, rings=0, full_lead_ins=False):
+              stream_wgs=0, full_grid=False, gated=False, rings=0, full_lead_ins=False, leadfree=None):
     """fams: {family: (rot_count tuple | channels, cast_bounded, epochs_in_reach)} -> the plan as a dict."""
     lib = _plan_lib()
     knobs = np.array([flags, n_cus, int(stream_ok), {0: 0, 1: 1, -1: 2}[env_path], min_seg, am_min, int(mixed_forked), int(by_cost),
-                      stream_wgs, int(full_grid), rings, int(full_lead_ins)], np.uint32)
+                      stream_wgs, int(full_grid), rings, 1 if full_lead_ins else (0 if leadfree is None else 1 + leadfree)], np.uint32)
     fam = np.zeros((4, 6), np.uint32)
     for f, name in enumerate(FAMS):
         if name in fams:
@@ -244,9 +244,11 @@ def check_plan(p, vlen, flags, env_path, stream_ok, n_cus, fams, rings_knob=0):
             assert q["tile_len"] >= min_tile and q["tile_len"] % 128 == 0
             if name == "wbfm":
                 assert q["lead_shift"] == 0
-            else:   # 128 samples of lead-in, the rest of the family's full lead-in as the shift; a segment holds more than the shift
-                full = {"am": 384, "fm": 768, "ssb": 1280}[name]
-                assert (q["halo"], q["lead_shift"]) == (128, full - 128) and q["tile_len"] >= full, (name, q)
+            else:   # short lead-ins: 128 samples, the rest of the family's full lead-in as the cold segments' shift, segments longer than
+                full = {"am": 384, "fm": 768, "ssb": 1280}[name]   # the shift; by default only where a channel has 8 segments or more and never in the one launch
+                assert (q["halo"], q["lead_shift"]) in ((128, full - 128), (full, 0)), (name, q)
+                if q["lead_shift"]:
+                    assert q["tile_len"] >= full and not p["fused"] and q["tiles_per_ch"] >= 8, (name, q)
             assert q["grid"] >= 1 and q["rounds"] >= 1 and q["grid"] <= max(q["wgs"], 1)
             if name == "wbfm":
                 assert stream_ok and bounded
