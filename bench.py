@@ -227,7 +227,7 @@ def profile_summary(tag):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import pmc_summary
     now = pmc_summary.source_hash()
-    for rnd in (5, 4, 3, 2, 1):
+    for rnd in (6, 5, 4, 3, 2, 1):
         path = os.path.join(ROOT, "profiles", "r%d_%s_pmc.json" % (rnd, tag))
         if os.path.exists(path):
             with open(path) as f:

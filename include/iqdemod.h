@@ -212,7 +212,8 @@ int iqd_accept_iq(iqd_t *e, uint32_t first_ch, uint32_t n_ch,
  * enqueued on the engine's stream and the call returns as soon as it is queued (the WBFM
  * hand-off verification and, if ever needed, its repair run on the device).  Keep the
  * buffers alive and use iqd_synchronize() - or synchronise iqd_stream() - before reading
- * results. */
+ * results.  Until then the PCM rows are the call's own: the AM / SSB pipelines keep intermediate
+ * (detector) values there before the DC-removal pass turns them into PCM in place. */
 int iqd_accept_iq_device(iqd_t *e, uint32_t first_ch, uint32_t n_ch,
                          const void *iq_dev, size_t bytes_per_ch,
                          void *pcm_dev, void *pcm_count_dev,

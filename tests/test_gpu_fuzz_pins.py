@@ -29,14 +29,20 @@ PINS = [
     ("shares_by_cost", {"IQD_SHARES": "cost", "FUZZ_WIDE": "1"}, 16, 509),
     ("min_seg_1_wide", {"IQD_STREAM_MIN_SEG": "1", "FUZZ_WIDE": "1", "FUZZ_WIDE_RANGE": "24,600"}, 16, 510),   # found: repaired keeper re-runs the short last segment
     ("min_seg_1_short", {"IQD_STREAM_MIN_SEG": "1", "FUZZ_SHORT": "1"}, 16, 511),
+    # round 6: FM / AM / SSB segments with short lead-ins (iqd_stream.h: d4_geom) - by default only where a channel is cut into 8
+    # segments or more; forced wherever a family streams (also for rows of a few segments and inside the one launch), and off
+    ("short_lead_ins_always", {"IQD_D4_LEADFREE": "1", "FUZZ_WIDE": "1", "FUZZ_WIDE_RANGE": "24,600"}, 16, 512),
+    ("short_lead_ins_min_seg_1", {"IQD_D4_LEADFREE": "1", "IQD_STREAM_MIN_SEG": "1", "FUZZ_WIDE": "1", "FUZZ_WIDE_RANGE": "24,600"}, 16, 513),
+    ("short_lead_ins_one_launch", {"IQD_D4_LEADFREE": "2", "FUZZ_WIDE": "1"}, 16, 514),
+    ("full_lead_ins", {"IQD_D4_LEADFREE": "0", "FUZZ_WIDE": "1"}, 16, 515),
 ]
 CLOCK_SECONDS = 8
 
 
 def _run(env_extra, seconds, seed):
     env = dict(os.environ)
-    for k in ("IQD_WBFM_PATH", "IQD_MIXED", "IQD_SHARES", "IQD_STREAM_MIN_SEG", "FUZZ_SHORT", "FUZZ_WIDE", "FUZZ_WIDE_RANGE", "FUZZ_BIG",
-              "FUZZ_REPLAY"):
+    for k in ("IQD_WBFM_PATH", "IQD_MIXED", "IQD_SHARES", "IQD_STREAM_MIN_SEG", "IQD_D4_LEADFREE", "FUZZ_SHORT", "FUZZ_WIDE", "FUZZ_WIDE_RANGE",
+              "FUZZ_BIG", "FUZZ_REPLAY"):
         env.pop(k, None)
     env.update(env_extra)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gpu_fuzz.py"), str(seconds), str(seed)], cwd=ROOT, env=env,

@@ -18,3 +18,9 @@ run IQD_STREAM_MIN_SEG=1 FUZZ_WIDE=1 FUZZ_WIDE_RANGE=24,600 timeout 110 python3 
 run FUZZ_BIG=1 timeout 110 python3 tools/gpu_fuzz.py 90 $((82 + OFF))
 run IQD_STREAM_MIN_SEG=1 FUZZ_SHORT=1 timeout 110 python3 tools/gpu_fuzz.py 90 $((83 + OFF))
 run IQD_STREAM_MIN_SEG=1 timeout 110 python3 tools/gpu_fuzz.py 90 $((84 + OFF))
+# round 6: short lead-ins forced wherever a family streams / inside the one launch too / off (by default: channels of >= 8 segments)
+run IQD_D4_LEADFREE=1 FUZZ_WIDE=1 FUZZ_WIDE_RANGE=24,600 timeout 140 python3 tools/gpu_fuzz.py 120 $((85 + OFF))
+run IQD_D4_LEADFREE=1 IQD_STREAM_MIN_SEG=1 FUZZ_WIDE=1 FUZZ_WIDE_RANGE=24,600 timeout 140 python3 tools/gpu_fuzz.py 120 $((86 + OFF))
+run IQD_D4_LEADFREE=2 FUZZ_WIDE=1 timeout 140 python3 tools/gpu_fuzz.py 120 $((87 + OFF))
+run IQD_D4_LEADFREE=1 IQD_WBFM_PATH=stream timeout 110 python3 tools/gpu_fuzz.py 90 $((88 + OFF))
+run IQD_D4_LEADFREE=0 FUZZ_WIDE=1 timeout 110 python3 tools/gpu_fuzz.py 90 $((89 + OFF))
