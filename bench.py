@@ -694,12 +694,17 @@ def parse_args(argv=None):
     ap.add_argument("--no-other-configs", action="store_true",
                     help="the default run (configs[1]) also times configs[0], [2], [3], [4] and AM / USB at 4096 x 2^16 for a few steps each "
                          "and reports them as `other_configs`; this flag skips that")
+    ap.add_argument("--pmc-passes", default=None, help=argparse.SUPPRESS)   # fetch,write[,sq1]: which counter passes live_pmc runs (the sub-lines: two)
     ap.add_argument("--force-launch", action="store_true",
                     help="start the ranks through bench.py's own launcher (torch.distributed.run as a child process) even for --gpus 1: "
                          "the N > 1 code path - nccl process group, device_id, the engine's RCCL gatherer - on a one-GPU box")
     ap.add_argument("--standin", default=None, help=argparse.SUPPRESS)   # module:Class of a host-memory engine (CPU tests of the launcher)
     args = ap.parse_args(argv)
     args.argv = list(sys.argv[1:] if argv is None else argv)
+    if args.pmc_passes:          # (not handed on to the counter passes' own child runs)
+        args.pmc_passes = tuple(x for x in args.pmc_passes.split(",") if x)
+        i = args.argv.index("--pmc-passes")
+        del args.argv[i:i + 2]
     preset = CONFIGS[1 if args.config is None else args.config]
     if args.config == 0 and args.steps == 20 and args.warmup == 3:
         args.steps, args.warmup = 61, 3          # 64 blocks = 2^20 samples, SURVEY 8(d) Config 1
@@ -751,27 +756,31 @@ SUB_KEYS = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "config
             "device_ops_per_block", "real_time_factor", "parity")
 
 
-def other_configs(args, torch, dev, make_engine, order_streams):
-    """Sub-lines of the default run: each one is what `python bench.py <argv>` prints, cut down to SUB_KEYS - the same rank_body,
-    the same engine event timing, HBM traffic from two rocprofv3 --pmc child passes of that very command (FETCH_SIZE, WRITE_SIZE)."""
+def other_configs(args):
+    """Sub-lines of the default run: each one is what `python bench.py <argv>` prints, cut down to SUB_KEYS - a CHILD process per
+    configuration (the same rank_body, the engine's event timing, HBM traffic from two rocprofv3 --pmc passes of that very command:
+    FETCH_SIZE, WRITE_SIZE), so that whatever happens in one of them costs a sub-line and never the headline."""
+    import subprocess
     lines = []
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
     for argv in OTHER_CONFIGS:
         t0 = time.perf_counter()
+        cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--no-other-configs", "--no-host-path", "--no-from-idle", "--pmc-passes", "fetch,write"]
+        if argv != ["--config", "0"]:   # (configs[0]: its 64 blocks, with the CPU chain beside them - the parity check of that file)
+            cmd += ["--steps", "10", "--warmup", "3", "--prewarm-ms", "60", "--no-cpu-baseline"]
+        if args.no_live_pmc:
+            cmd += ["--no-live-pmc"]
         try:
-            sub = parse_args(argv + ["--steps", "10", "--warmup", "3", "--prewarm-ms", "60", "--no-from-idle", "--no-cpu-baseline",
-                                     "--no-host-path", "--no-other-configs"] + (["--no-live-pmc"] if args.no_live_pmc else []))
-            sub.argv = list(argv)
-            sub.pmc_passes = ("fetch", "write")
-            if sub.config == 0:
-                sub.steps, sub.warmup, sub.no_cpu_baseline = 61, 3, False      # (its CPU leg is the parity check of that file: 64 blocks)
-                d = config0(sub)
-            else:
-                d = rank_body(sub, 0, 1, dev, make_engine, None, torch, order_streams)
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, cwd=ROOT, timeout=420)
+            out = [ln for ln in r.stdout.decode(errors="replace").splitlines() if ln.startswith('{"metric"')]
+            if r.returncode != 0 or not out:
+                raise RuntimeError("exit code %d: %s" % (r.returncode, r.stderr.decode(errors="replace")[-300:]))
+            d = json.loads(out[-1])
             line = {"argv": " ".join(argv)}
             line.update({k: d[k] for k in SUB_KEYS if k in d})
             line["seconds"] = round(time.perf_counter() - t0, 1)
-        except (Exception, SystemExit) as exc:          # a sub-line must never cost the run its headline
-            line = {"argv": " ".join(argv), "error": repr(exc)[:300]}
+        except Exception as exc:          # a sub-line must never cost the run its headline
+            line = {"argv": " ".join(argv), "error": repr(exc)[:400]}
         lines.append(line)
     return lines
 
@@ -894,7 +903,7 @@ def main():
     # (the full default form only: a run trimmed with --no-cpu-baseline / --no-host-path is a measurement tool's, tools/*.sh)
     if (out is not None and world == 1 and dist is None and args.is_default_workload
             and not (args.no_other_configs or args.no_cpu_baseline or args.no_host_path)):
-        out["other_configs"] = other_configs(args, torch, torch.device("cuda", local_rank), make_engine, order_streams)
+        out["other_configs"] = other_configs(args)
     if out is not None:
         print(json.dumps(out))
     if dist is not None:

@@ -94,7 +94,7 @@ def check_sub_line(s):
 
 def test_default_run_carries_every_other_configuration():
     """`python bench.py --gpus 1 --steps K --warmup W`, the driver's own command: the headline line of configs[1] with its usual
-    fields, and `other_configs` - configs[0], [2], [3], [4] and AM / USB at 4096 x 2^16, a few steps each in the same process
+    fields, and `other_configs` - configs[0], [2], [3], [4] and AM / USB at 4096 x 2^16, a few steps each, a child process each
      - each sub-line consistent in itself.  (Full size: this IS the driver's run, about three minutes.)"""
     import bench
     d = check_contract(run_bench("--gpus", "1", "--steps", "6", "--warmup", "2", "--cpu-one-core-only", "--no-live-pmc"), 6, 2)
