@@ -304,6 +304,27 @@ void emu_plan_call(const uint32_t *knobs, uint32_t vlen, uint32_t pcm_per_ch, ui
     }
 }
 
+// ---- the AM / SSB DC-removal pass of one channel row, one wave, IN PLACE over int16 detector values (round 6: what runs behind the
+// streaming pipelines, iqd_kernels.hip: dc_channel_wave) or from an int32 stream into a PCM row.  tests/test_emu_chains.py
+void emu_dc_row(int in_place, const int32_t *x32, int16_t *row, int n, float gain, iqd::DcCarry *st)
+{
+    using namespace iqd;
+    static Consts c;
+    static bool ready = false;
+    if (!ready) { build_consts(c); ready = true; }
+    static DcLds lds;
+    HostExec ex;
+    if (in_place) dc_block_wave(ex, c, lds, (const int16_t *)row, n, gain, *st, row);
+    else dc_block_wave(ex, c, lds, x32, n, gain, *st, row);
+}
+void emu_dc_serial(const int32_t *x32, int16_t *row, int n, float gain, iqd::DcCarry *st)
+{
+    static iqd::Consts c;
+    static bool ready = false;
+    if (!ready) { iqd::build_consts(c); ready = true; }
+    iqd::dc_block_run(x32, n, gain, c.dc_a1, *st, row);
+}
+
 // ---- FM / AM / SSB segments with short lead-ins: the geometry the kernels and the plan share (iqd_stream.h: d4_geom) ----------
 void emu_d4_geom(uint32_t sid, uint32_t tile, uint32_t tile_len, uint32_t shift, int64_t *v0, uint32_t *skip, uint32_t *cold)
 {

@@ -129,3 +129,37 @@ def test_device_agc_step_on_the_host():
         L.emu_agc_run(typ, op, dead, alpha, blank, C.byref(rx), C.byref(ifg), C.byref(filt), C.byref(bc), C.byref(adj),
                       mags.ctypes.data, len(mags), got.ctypes.data)
         assert got.tolist() == want, trial
+
+
+def test_dc_pass_in_place_over_int16_rows_is_the_serial_recurrence():
+    """Round 6: behind the streaming pipelines the AM / SSB DC-removal pass runs IN PLACE over int16 detector values in the PCM row,
+    with a segment's LDS row holding first its input differences, then its PCM (iqd_chains.h: dc_block_wave).  Stepped on the
+    host against the plain serial recurrence (dc_block_run = AmDemodulator.cc:462-465) for rows of one to five passes, ragged
+    ends, gains from 1e-3 to 1e5, constant rows (the state sticks at a denormal: the tiny-state rule) and a carried state."""
+    import ctypes as C
+    from tests import emu_bind
+    L = emu_bind.lib()
+
+    class Dc(C.Structure):
+        _fields_ = [("x_prev", C.c_float), ("y_prev", C.c_float)]
+    L.emu_dc_row.restype = None
+    L.emu_dc_row.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]
+    L.emu_dc_serial.restype = None
+    L.emu_dc_serial.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_void_p]
+    rng = np.random.default_rng(2026)
+    for trial in range(40):
+        n = 4 * int(rng.integers(1, 2700))                       # PCM samples: any multiple of 4, up to five passes of 2048
+        kind = trial % 4
+        x = (rng.integers(-546, 547, n) if kind < 2 else np.full(n, int(rng.integers(-546, 547))) if kind == 2
+             else np.round(300 * np.sin(np.arange(n) * 0.05) + rng.normal(0, 3, n))).astype(np.int32)
+        gain = float(10.0 ** rng.uniform(-3, 5)) * (1 if trial % 5 else -1)
+        st0 = (float(int(rng.integers(-546, 547))), float(rng.normal(0, 200))) if trial % 3 else (0.0, 0.0)
+        want, got16, got32 = np.zeros(n, np.int16), x.astype(np.int16).copy(), np.zeros(n, np.int16)
+        s_ref, s_a, s_b = Dc(*st0), Dc(*st0), Dc(*st0)
+        L.emu_dc_serial(x.ctypes.data, want.ctypes.data, n, gain, C.byref(s_ref))
+        L.emu_dc_row(1, None, got16.ctypes.data, n, gain, C.byref(s_a))              # in place over the int16 row
+        L.emu_dc_row(0, x.ctypes.data, got32.ctypes.data, n, gain, C.byref(s_b))     # from the int32 stream (the tile kernels' path)
+        assert np.array_equal(got16, want), (trial, n, gain, np.flatnonzero(got16 != want)[:5])
+        assert np.array_equal(got32, want), (trial, n, gain)
+        for s in (s_a, s_b):
+            assert s.x_prev == s_ref.x_prev and (s.y_prev == s_ref.y_prev or abs(s.y_prev) < 1e-30 and abs(s_ref.y_prev) < 1e-30), (trial, s.y_prev, s_ref.y_prev)
