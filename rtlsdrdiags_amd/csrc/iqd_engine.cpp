@@ -1487,8 +1487,6 @@ static int queue_family(iqd_t *e, CallCtx &x, int f)
             d4.fm_lut = e->d_fmlut;
             d4.halo = (int32_t)fp.halo;
             d4.lead_shift = fp.lead_shift;
-            static const uint32_t d4_probe = getenv("IQD_D4_PROBE") ? (uint32_t)atoi(getenv("IQD_D4_PROBE")) : 0u;   // timing probes only
-            d4.probe = d4_probe;
             d4.rounds = fp.rounds;
             d4.rings = fp.rings;
         }

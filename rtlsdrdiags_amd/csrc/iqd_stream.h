@@ -149,7 +149,6 @@ struct D4Args {
     uint32_t rings;              // rings a workgroup runs (StreamArgs::rings)
     int32_t halo;                // lead-in samples every segment of the launch runs (the family's full lead-in, or D4_HALO_SHORT)
     uint32_t lead_shift;         // round 6 (d4_geom above): full lead-in - halo; 0 = every segment with its full lead-in
-    uint32_t probe;              // TIMING PROBES ONLY (IQD_D4_PROBE, wrong results): 1 = no boundary replay behind the loop, 2 = no head stores either
     uint32_t s2p[6], s3p[8];     // AM/SSB stage 2 (12 taps, DOUBLED: the result is the accumulator's high half) and stage 3 (16 taps) as v_dot2 pairs, newest pair first
     uint32_t hilb[16];           // SSB: the nonzero Hilbert taps h[0], h[2], ..., h[30] (int16 in the low half)
     uint32_t p12p[6], a40p[20];  // FM post-discriminator decimators

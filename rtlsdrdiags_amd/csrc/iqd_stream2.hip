@@ -707,7 +707,7 @@ __device__ __forceinline__ void d4_am_wave(const ChainLaunch &a, const D4Args &d
         // Short lead-ins (iqd_stream.h, d4_geom): the inputs of this segment's first outputs go into the lane's head store as they pass -
         // the y2 pairs of pieces 4..7, SSB's rails of pieces 8..39 - and those outputs are replayed behind the loop with the
         // predecessor's end state, which is the lane below's.
-        const bool lf = da.lead_shift != 0 && !(da.probe & 2u);
+        const bool lf = da.lead_shift != 0;
         uint32_t *head = (uint32_t *)(lds + D4_HEAD_OFF) + ring * 64 + lane;       // [word][ST_SEGS]
         for (int pq = 0; pq < n_pieces; pq += 4) {
             const int pos = -da.halo + 32 * pq;
@@ -739,7 +739,7 @@ __device__ __forceinline__ void d4_am_wave(const ChainLaunch &a, const D4Args &d
                 for (int k = 0; k < 4; k++) { sb.ie[k] = sb.ie[k + 1]; sb.io[k] = sb.io[k + 1]; }
             }
         }
-        if (!lf || (da.probe & 1u)) continue;
+        if (!lf) continue;
         // ---- the boundary: this lane's state now is its segment's END state = what its successor's first outputs reach back
         // for.  The successor is the next segment id = the lane above (a channel's segments have consecutive ids), so every lane
         // takes the state of the lane below and replays its own first outputs from its head store: 4 (AM), 36 (SSB: 34 needed).
@@ -885,7 +885,7 @@ __device__ __forceinline__ void d4_fm_wave(const ChainLaunch &a, const D4Args &d
         s.loud_e = s.loud_y2 = 0;
         // Short lead-ins (iqd_stream.h, d4_geom): the y2 pairs of pieces 4..23 go into the lane's head store as they pass; the first 20 PCM
         // samples are replayed behind the loop with the predecessor's end state - the lane below's (see d4_am_wave).
-        const bool lf = da.lead_shift != 0 && !(da.probe & 2u);
+        const bool lf = da.lead_shift != 0;
         uint32_t *head = (uint32_t *)(lds + D4_HEAD_OFF) + ring * 64 + lane;       // [word][ST_SEGS]
         for (int pq = 0; pq < n_pieces; pq += 4) {
             const int pos = -da.halo + 32 * pq;
@@ -903,7 +903,7 @@ __device__ __forceinline__ void d4_fm_wave(const ChainLaunch &a, const D4Args &d
 #pragma unroll
             for (int j = 0; j < 20; j++) s.y2p[j] = s.y2p[j + 4];
         }
-        if (!lf || (da.probe & 1u)) continue;
+        if (!lf) continue;
         // the lane below's end state: its last 20 pairs and how long a loud value stays in reach
 #pragma unroll
         for (int j = 0; j < 20; j++) s.y2p[j] = d4_from_lane_below(s.y2p[j]);
