@@ -1093,6 +1093,16 @@ hipError_t launch_wbfm_repair(const ChainLaunch &a, bool gated, hipStream_t s)
     return hipGetLastError();
 }
 
+// Tail update and one-wave DC pass of an AM / SSB streaming launch as ONE launch where no squelch launch follows to ride in (gated
+// calls, several families as kernels of their own, the demodulator-level entry): the two depend on the pipeline only, not on each
+// other.  configs[4], where both run beside the next call's magnitude pre-pass: 100 + 34 us one behind the other (round 6).
+hipError_t launch_tail_dc(const ChainLaunch &a, int family, hipStream_t s)
+{
+    SquelchLaunch none{};
+    hipLaunchKernelGGL(tail_dc_squelch_kernel, dim3(2 * a.n_list), dim3(256), 0, s, a, family, none, 0);
+    return hipGetLastError();
+}
+
 hipError_t launch_tail_update(const ChainLaunch &a, int family, hipStream_t s)
 {
     hipLaunchKernelGGL(tail_update_kernel, dim3(a.n_list), dim3(256), 0, s, a, family);
