@@ -1261,12 +1261,7 @@ static int queue_prepass(iqd_t *e, CallCtx &x)
     const uint32_t n_ch = x.n_ch, n_blocks = x.n_blocks;
     // the pre-pass of a gated call one call ahead, on its own stream (include/iqdemod.h: IQD_F_PREPASS_OVERLAP)
     if (x.pre_overlap && !e->pre_stream) {
-        // (the pre-pass of the NEXT call runs beside this call's pipelines: at the lowest priority, IQD_PRE_PRIO=low (measurement runs) - the
-        //  pipelines, their DC pass and tail update are what the step waits for)
-        int lo = 0, hi = 0;   // numerically lower = higher priority
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        static const bool pre_low = getenv("IQD_PRE_PRIO") && !strcmp(getenv("IQD_PRE_PRIO"), "low");
-        HIP_TRY(e, hipStreamCreateWithPriority(&e->pre_stream, hipStreamNonBlocking, pre_low ? lo : 0));
+        HIP_TRY(e, hipStreamCreateWithFlags(&e->pre_stream, hipStreamNonBlocking));
         for (int k = 0; k < 2; k++) {
             HIP_TRY(e, hipEventCreateWithFlags(&e->ev_pre_done[k], hipEventDisableTiming));
             HIP_TRY(e, hipEventCreateWithFlags(&e->ev_chain_done[k], hipEventDisableTiming));
@@ -1414,7 +1409,6 @@ static int queue_family(iqd_t *e, CallCtx &x, int f)
     if (fp.lane != 0 && !x.lane_used[fp.lane]) HIP_TRY(e, hipStreamWaitEvent(s, e->fam_fork, 0));
     x.lane_used[fp.lane] = true;
 
-    bool dc_with_tail = false;
     ChainLaunch a = x.base;
     a.ch_list = e->lists[f].as<uint32_t>();
     a.n_list = n_list;
@@ -1518,11 +1512,7 @@ static int queue_family(iqd_t *e, CallCtx &x, int f)
                 // one-wave pass (round 5: 0.019 ms and a queue gap less per step); else its own launches
                 x.tail_dc = f != FAM_FM && a.dc_tiles < 2 && !forked && !x.gated && !e->demod_bypass &&
                             (x.want_mag || x.pcm_count_dev || x.signal_present_dev || e->trace_on);
-                // no closing launch to ride in (a gated call, several families as kernels of their own, the demodulator-level entry):
-                // the one-wave pass shares a launch with the family's tail update below; longer rows take their own launches
-                static const bool split_tail_dc = getenv("IQD_SPLIT_TAIL_DC") != nullptr;   // (the A/B: one behind the other, as until round 6)
-                dc_with_tail = f != FAM_FM && !x.tail_dc && a.dc_tiles < 2 && !split_tail_dc;
-                if (f != FAM_FM && !x.tail_dc && !dc_with_tail) HIP_LAUNCH(e, launch_am_dc(a, f, s, true));
+                if (f != FAM_FM && !x.tail_dc) HIP_LAUNCH(e, launch_am_dc(a, f, s, true));
             }
             e->stats.stream_launches++;
         } else if (f == FAM_FM) {
@@ -1564,8 +1554,6 @@ static int queue_family(iqd_t *e, CallCtx &x, int f)
         x.tail_a = a;        // the only family of the call: its tail update rides in the squelch launch
         x.tail_f = f;
         x.tail_pending = true;
-    } else if (dc_with_tail) {
-        HIP_LAUNCH(e, launch_tail_dc(a, f, s));
     } else {
         HIP_LAUNCH(e, launch_tail_update(a, f, s));
     }

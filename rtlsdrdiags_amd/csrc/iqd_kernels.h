@@ -109,7 +109,6 @@ hipError_t launch_rotate_signed(int8_t *buf_dev, size_t bytes, int rotation, hip
 hipError_t launch_agc_apply(const AgcConfig *cfg, AgcState *st, const ScanConfig *scfg, ScanState *sst,
                             ChanParams *params, GainEpoch *epochs, uint32_t n_ch, hipStream_t s);
 hipError_t launch_tail_update(const ChainLaunch &a, int family, hipStream_t s);
-hipError_t launch_tail_dc(const ChainLaunch &a, int family, hipStream_t s);   // tail update + one-wave DC pass of an AM / SSB streaming launch in one launch
 hipError_t launch_write_word(uint32_t *word, uint32_t value, hipStream_t s);   // one store, in stream order
 hipError_t launch_magnitude(const uint8_t *iq, size_t ch_stride_bytes, const uint32_t *ch_list, uint32_t n_list,
                             uint32_t block_samples, uint32_t n_blocks, uint32_t *mag_sums, hipStream_t s);

@@ -542,15 +542,17 @@ __global__ __launch_bounds__(256) void tail_squelch_kernel(const ChainLaunch a, 
 
 // ... and for a call whose one family is AM or SSB on its streaming pipeline (round 5): the DC-removal pass of the channels - the
 // one-wave pass of dc_wave_kernel, which used to be a launch of its own between the pipeline and this one (0.019 ms + a queue gap
-// of the 0.2 ms step) - is a third role: workgroups n_list .. 2 n_list - 1, their first wave.  It depends on the pipeline only.
+// of the 0.2 ms step) - is a third role: workgroups 0 .. n_list - 1, their first wave.  It depends on the pipeline only.
 __global__ __launch_bounds__(256) void tail_dc_squelch_kernel(const ChainLaunch a, int family, const SquelchLaunch q, int always_open)
 {
     __shared__ DcLds lds;
+    // (round 6: the DC passes - one serial recurrence per row, the launch's long pole - take the FIRST workgroups, so that they are
+    //  dispatched first and the tail updates fill in beside them: AM 4096 x 2^16 -2 %, 4096 x 2^14 -5 %, profiles/r6_dc_first_ab.txt)
     if (blockIdx.x < a.n_list) {
-        tail_update_body(a, family, blockIdx.x);
-    } else if (blockIdx.x < 2 * a.n_list) {
         if (threadIdx.x >= 64) return;
-        dc_channel_wave(a, family, blockIdx.x - a.n_list, lds);
+        dc_channel_wave(a, family, blockIdx.x, lds);
+    } else if (blockIdx.x < 2 * a.n_list) {
+        tail_update_body(a, family, blockIdx.x - a.n_list);
     } else {
         squelch_block_body(q, always_open, (blockIdx.x - 2 * a.n_list) * 256u + threadIdx.x);
     }
@@ -1090,16 +1092,6 @@ hipError_t launch_wbfm_repair(const ChainLaunch &a, bool gated, hipStream_t s)
 {
     if (gated) hipLaunchKernelGGL((wbfm_repair_kernel<true>), dim3(a.n_list), dim3(WB_THREADS), 0, s, a);
     else hipLaunchKernelGGL((wbfm_repair_kernel<false>), dim3(a.n_list), dim3(WB_THREADS), 0, s, a);
-    return hipGetLastError();
-}
-
-// Tail update and one-wave DC pass of an AM / SSB streaming launch as ONE launch where no squelch launch follows to ride in (gated
-// calls, several families as kernels of their own, the demodulator-level entry): the two depend on the pipeline only, not on each
-// other.  configs[4], where both run beside the next call's magnitude pre-pass: 100 + 34 us one behind the other (round 6).
-hipError_t launch_tail_dc(const ChainLaunch &a, int family, hipStream_t s)
-{
-    SquelchLaunch none{};
-    hipLaunchKernelGGL(tail_dc_squelch_kernel, dim3(2 * a.n_list), dim3(256), 0, s, a, family, none, 0);
     return hipGetLastError();
 }
 
