@@ -17,7 +17,8 @@ def capi():
     return c
 
 
-def _run_on_device(capi, rows, modes, rots=None, calls=2, threshold=None, agc=None, expect_streams=None, expect_mixed=None):
+def _run_on_device(capi, rows, modes, rots=None, calls=2, threshold=None, agc=None, expect_streams=None, expect_mixed=None,
+                   expect_launches=None):
     n_ch, nbytes = rows.shape
     nblk = nbytes // 32768
     eng = capi.Engine(n_ch)
@@ -45,6 +46,8 @@ def _run_on_device(capi, rows, modes, rots=None, calls=2, threshold=None, agc=No
             assert after["stream_launches"] - before["stream_launches"] == expect_streams, (call, after)
         if expect_mixed is not None:
             assert after["mixed_launches"] - before["mixed_launches"] == expect_mixed, (call, after)
+        if expect_launches is not None:
+            assert after["device_launches"] - before["device_launches"] == expect_launches, (call, before, after)
         got.append((eng.dev_download(pcm_d, n_ch * (nbytes // 64) * 2, np.int16).reshape(n_ch, -1),
                     eng.dev_download(cnt_d, n_ch * 4, np.uint32),
                     eng.dev_download(mag_d, n_ch * nblk * 4, np.uint32).reshape(n_ch, nblk),
@@ -74,6 +77,18 @@ def test_bench_single_family_paths_at_size_every_channel(capi, mode):
     rows = bench_rows(synth.fm_tone(n, seed=1234), n_ch, 0, 2 * n)
     modes = [mode] * n_ch
     got = _run_on_device(capi, rows, modes, expect_streams=1, expect_mixed=0)
+    _compare_all(got, rows, modes)
+
+
+@pytest.mark.parametrize("n_ch,blocks", [(1, 1), (3, 1), (700, 2), (64, 4), (257, 3)])
+def test_small_fm_calls_on_the_tile_kernels(capi, n_ch, blocks):
+    """configs[0] (one FM channel, one 32 768-byte block per call - the reference's own operating point) and its neighbours on the
+    tile kernels: three consecutive calls give the oracle's PCM, magnitudes, flags and counts for every channel (the second and
+    third calls read the tails and the zeroed sums the first one's closing launch left)."""
+    n = blocks * 16384
+    rows = bench_rows(synth.fm_tone(n, seed=77 + n_ch), n_ch, 0, 2 * n)
+    modes = ["fm"] * n_ch
+    got = _run_on_device(capi, rows, modes, calls=3, expect_streams=0, expect_launches=2)
     _compare_all(got, rows, modes)
 
 

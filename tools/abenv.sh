@@ -17,6 +17,6 @@ for E in "$@"; do
 import sys, statistics
 ks = [float(x.split(":")[0]) for x in sys.argv[2:] if x.split(":")[0]]
 ss = [float(x.split(":")[1]) for x in sys.argv[2:] if x.split(":")[1]]
-if ks: print("median [%-24s] kernel_ms %.4f  ms_per_step %.4f  (n=%d)" % (sys.argv[1], statistics.median(ks), statistics.median(ss), len(ks)))
+if ss: print("median [%-24s] kernel_ms %.4f  ms_per_step %.5f  (n=%d)" % (sys.argv[1], statistics.median(ks) if ks else float("nan"), statistics.median(ss), len(ss)))
 PY
 done
