@@ -123,6 +123,23 @@ constexpr int D4_HALO_AM = 384, D4_HALO_SSB = 1280, D4_HALO_FM = 768;   // FULL 
 constexpr int D4_HALO_SHORT = 128;
 constexpr int d4_full_halo(int family) { return family == FAM_FM ? D4_HALO_FM : family == FAM_AM ? D4_HALO_AM : D4_HALO_SSB; }
 constexpr int d4_lead_shift(int family) { return d4_full_halo(family) - D4_HALO_SHORT; }
+// The boundary replay of a warm segment (iqd_stream2.hip: d4_am_wave, d4_fm_wave; modelled stage by stage in
+// tests/test_emu_d4_handoff_model.py).  Pieces count from the start of the run: the 128-sample lead-in is pieces 0..3, the segment's
+// first output belongs to piece 4.  A consumer lane starts its run with empty histories; the P waves hand it exact values from
+// the run's first sample on (their first piece has the true piece before it for its window; FM: except the run's first two
+// discriminator outputs, which would need the phase angles in front of the run).  Stage 2 (/4, 12 taps: a piece's pair needs the
+// 8 values of the piece before) is therefore exact from piece 1 on for AM / SSB, from piece 2 on for FM.
+//   AM   stage 3 (/2, 16 taps = the pairs of 8 pieces) is exact in the loop from piece 8 on: the outputs of pieces 4..7 are
+//        replayed from their kept pairs behind the predecessor's last 7;
+//   SSB  the detector (i delayed by 15, Hilbert over 31 of q at 8 kS/s) reaches back 30 outputs: outputs 0..33 need the
+//        predecessor's rails - the first 4 come out of the replayed stage 3, the rails of pieces 8..39 are kept as well, and
+//        36 outputs (quads) are replayed;
+//   FM   the last stage (/2, 40 taps = the pairs of 20 pieces) is exact in the loop from piece 22 on: the 20 outputs of pieces
+//        4..23 are replayed from their kept pairs behind the predecessor's last 20.
+constexpr int D4_REPLAY_AM = 4, D4_REPLAY_SSB = 36, D4_REPLAY_FM = 20;   // outputs replayed (multiples of 4: a quad is one store)
+constexpr int D4_REPLAY_PAIRS_AMSSB = 4;                                  // AM / SSB: pieces 4..7 keep their stage-2 pairs of both rails
+constexpr int D4_RAILS_FROM_PIECE = 8;                                    // SSB: pieces 8..39 keep their rails
+constexpr int d4_replay_outputs(int family) { return family == FAM_FM ? D4_REPLAY_FM : family == FAM_AM ? D4_REPLAY_AM : D4_REPLAY_SSB; }
 struct D4Geom { int64_t v0; uint32_t skip, cold; };
 #if defined(__HIPCC__)
 __host__ __device__

@@ -100,7 +100,9 @@ constexpr int D4_MAGLUT_OFF = (ST_RINGS * D4_SLOTS * D4_SLOT_BYTES + D4_SYNC_WOR
 // Round 6 (iqd_stream.h, d4_geom): every consumer lane keeps the inputs of its segment's first outputs here - the y2 pairs of pieces 4..7
 // (AM / SSB, both rails: 8 words), SSB's 8 kS/s rails of pieces 8..39 (32 words), FM's y2 pairs of pieces 4..23 (20 words) - and
 // replays those outputs at the end of its run with its predecessor's end state, which sits in the lane below.  [word][segment].
-constexpr int D4_HEAD_WORDS = 40;
+constexpr int D4_HEAD_WORDS = 40;   // per segment: AM 2 x 4 pairs; SSB those + 32 rails; FM 20 pairs
+static_assert(D4_HEAD_WORDS >= 2 * D4_REPLAY_PAIRS_AMSSB + (D4_REPLAY_SSB - D4_REPLAY_PAIRS_AMSSB) && D4_HEAD_WORDS >= D4_REPLAY_FM, "head store");
+static_assert(D4_RAILS_FROM_PIECE == 4 + D4_REPLAY_PAIRS_AMSSB && D4_REPLAY_AM == D4_REPLAY_PAIRS_AMSSB, "replay layout");
 constexpr int D4_HEAD_OFF = D4_MAGLUT_OFF + (IQD_D4_MAGLUT == 1 ? ST_MAGLUT_BYTES : 0);
 constexpr int D4_LDS_BYTES = D4_HEAD_OFF + D4_HEAD_WORDS * ST_SEGS * 4;
 static_assert(D4_LDS_BYTES <= 160 * 1024, "rings + head store must fit the CU's LDS");
@@ -726,7 +728,7 @@ __device__ __forceinline__ void d4_am_wave(const ChainLaunch &a, const D4Args &d
 #pragma unroll
                 for (int k = 0; k < 4; k++) { head[k * ST_SEGS] = ri.y2[7 + k]; head[(4 + k) * ST_SEGS] = rq.y2[7 + k]; }
             }
-            if (lf && MODE == D4_SSB && pos >= 128 && pos < 128 + 8 * 128) {     // pieces 8..39
+            if (lf && MODE == D4_SSB && pos >= 128 && pos < 32 * D4_REPLAY_SSB) {     // pieces 8..39
                 uint32_t *h = head + (8 + ((pos - 128) >> 5)) * ST_SEGS;
                 h[0] = r0; h[ST_SEGS] = r1; h[2 * ST_SEGS] = r2; h[3 * ST_SEGS] = r3;
             }
@@ -754,7 +756,7 @@ __device__ __forceinline__ void d4_am_wave(const ChainLaunch &a, const D4Args &d
             for (int k = 0; k < 4; k++) { sb.ie[k] = d4_from_lane_below(sb.ie[k]); sb.io[k] = d4_from_lane_below(sb.io[k]); }
         }
         const bool mine = sg.valid && !sg.cold;
-        constexpr int REPLAY_QUADS = MODE == D4_SSB ? 9 : 1;
+        constexpr int REPLAY_QUADS = (MODE == D4_SSB ? D4_REPLAY_SSB : D4_REPLAY_AM) / 4;
         for (int q4 = 0; q4 < REPLAY_QUADS; q4++) {
             uint32_t wi[4], wq[4];
 #pragma unroll
@@ -896,7 +898,7 @@ __device__ __forceinline__ void d4_fm_wave(const ChainLaunch &a, const D4Args &d
             pcm[3] = d4_fm_piece<3>(da, ring_base, full, consumed, pg, (uint32_t)lane, s);
             if (sg.valid && pos >= sg.skip && pos < sg.tlen)
                 *(u32x2 *)(pcm_row + ((sg.v0 + pos) >> 5)) = u32x2{pack_lo16((uint32_t)pcm[0], (uint32_t)pcm[1]), pack_lo16((uint32_t)pcm[2], (uint32_t)pcm[3])};
-            if (lf && pos >= 0 && pos < 5 * 128) {
+            if (lf && pos >= 0 && pos < 32 * D4_REPLAY_FM) {
                 uint32_t *h = head + (pos >> 5) * ST_SEGS;
                 h[0] = s.y2p[20]; h[ST_SEGS] = s.y2p[21]; h[2 * ST_SEGS] = s.y2p[22]; h[3 * ST_SEGS] = s.y2p[23];
             }
@@ -909,7 +911,7 @@ __device__ __forceinline__ void d4_fm_wave(const ChainLaunch &a, const D4Args &d
         for (int j = 0; j < 20; j++) s.y2p[j] = d4_from_lane_below(s.y2p[j]);
         s.loud_y2 = (int)d4_from_lane_below((uint32_t)s.loud_y2);
         const bool mine = sg.valid && !sg.cold;
-        for (int q4 = 0; q4 < 5; q4++) {
+        for (int q4 = 0; q4 < D4_REPLAY_FM / 4; q4++) {
             const uint32_t *h = head + 4 * q4 * ST_SEGS;
             int pcm[4];
             pcm[0] = d4_fm_audio<0>(s, h[0]);

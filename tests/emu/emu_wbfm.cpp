@@ -345,6 +345,11 @@ uint32_t emu_d4_const(int which)
     case 5: return (uint32_t)iqd::d4_lead_shift(iqd::FAM_FM);
     case 6: return (uint32_t)iqd::d4_lead_shift(iqd::FAM_SSB);
     case 7: return iqd::TAIL;
+    case 8: return (uint32_t)iqd::d4_replay_outputs(iqd::FAM_AM);
+    case 9: return (uint32_t)iqd::d4_replay_outputs(iqd::FAM_FM);
+    case 10: return (uint32_t)iqd::d4_replay_outputs(iqd::FAM_SSB);
+    case 11: return (uint32_t)iqd::D4_REPLAY_PAIRS_AMSSB;
+    case 12: return (uint32_t)iqd::D4_RAILS_FROM_PIECE;
     }
     return 0;
 }
