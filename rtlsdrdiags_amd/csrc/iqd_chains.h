@@ -22,8 +22,7 @@ typedef WbfmTile Tile;
 #define IQD_CH_CHUNK 8192
 #endif
 constexpr int CH_CHUNK = IQD_CH_CHUNK;       // samples per chunk of the FM / AM / SSB tile kernels
-constexpr int FIR_HALO = 1280;       // raw history a tile rebuilds its FIR states from
-                                     // (FM needs 684, AM 260, SSB 1220 samples)
+// (raw history a tile rebuilds its FIR states from: fir_halo(family), iqd_device.h)
 
 // ---- shared front end: raw u8 -> signed -> rotated rail dwords in LDS, + squelch magnitude ----
 template <bool GATED, bool MAG, class Lds>
@@ -244,7 +243,7 @@ IQD_DEV void fm_tile(Exec &ex, const Tile &t, const Consts &c, FmLds &lds, const
         if (tid == 0) lds.e_peak = lds.e_peak_hist = lds.y2_peak = lds.y2_peak_hist = 0;
     });
     int prev_clen = 0;
-    for (int cstart = -FIR_HALO; cstart < t.tlen;) {
+    for (int cstart = -fir_halo(FAM_FM); cstart < t.tlen;) {
         const int clen = wbfm_chunk_len(t, cstart, CH_CHUNK);   // the lead-in splits where the gain last changed
         Tile tc = t;
         tc.k = wbfm_chunk_gain(t, cstart);
@@ -401,7 +400,7 @@ IQD_DEV void am_tile(Exec &ex, const Tile &t, const Consts &c, AmLds &lds, int s
         if (tid < CH_CHUNK / SEG + 2) lds.mag[tid] = 0;
     });
     int prev_clen = 0;
-    for (int cstart = -FIR_HALO; cstart < t.tlen;) {
+    for (int cstart = ssb ? -fir_halo(FAM_SSB) : -fir_halo(FAM_AM); cstart < t.tlen;) {
         const int clen = cstart < 0 ? -cstart : (t.tlen - cstart < CH_CHUNK ? t.tlen - cstart : CH_CHUNK);
         const ChunkBlocks cb = chunk_blocks(t, cstart);
         ex.all([&](int tid) {
@@ -607,19 +606,35 @@ template <class Exec, class SRC>
 IQD_DEV void dc_block_wave(Exec &ex, const Consts &c, DcLds &lds, const SRC *x, int n, float gain,
                            DcCarry &st, int16_t *pcm)
 {
+#if defined(IQD_DC_TIMING) && IQD_ON_DEVICE   // measurement build (tools/variant.sh dctiming iqd_kernels.hip -DIQD_DC_TIMING=1, tools/r6/r6_dctiming.sh):
+    long long tm[8];                           // where a row's pass goes, in shader clocks; profiles/r6_dc_timing.txt
+    const long long wall0 = wall_clock64();
+#define DC_T(K) tm[K] = clock64()
+    int redos = 0;
+#else
+#define DC_T(K)
+#endif
+    DC_T(0);
     ex.wave0([&](int lane) { if (lane == 0) { lds.x_carry = st.x_prev; lds.y_carry = st.y_prev; } });
     for (int base = 0; base < n; base += DC_SUPER) {
         const int len = n - base < DC_SUPER ? n - base : DC_SUPER;
         const int nfull = len / DC_S;             // whole segments: the segmented scheme
         if (nfull > 0) {
             ex.wave0([&](int lane) { dc_fill(lds, x, base, nfull, lane, true); });
+            DC_T(1);
             ex.wave0([&](int lane) { dc_guess(c, lds, nfull, lane); });
+            DC_T(2);
             ex.wave0([&](int lane) { dc_warm(c, lds, nfull, lane); });
+            DC_T(3);
             for (bool again = false;; again = true) {
+#if defined(IQD_DC_TIMING) && IQD_ON_DEVICE
+                redos += again;
+#endif
                 if (again) ex.wave0([&](int lane) { dc_fill(lds, x, base, nfull, lane, false); });   // (the rows hold PCM by now)
                 ex.wave0([&](int lane) { dc_real(c, lds, nfull, lane, gain); });
                 if (ex.wave0_all([&](int lane) { return dc_check(lds, nfull, lane, __builtin_fabsf(gain) <= 1e6f); })) break;
             }
+            DC_T(4);
             ex.wave0([&](int lane) {
                 if (pcm) dc_store(lds, nfull, lane, pcm + base);
                 if (lane == 0) {
@@ -641,6 +656,16 @@ IQD_DEV void dc_block_wave(Exec &ex, const Consts &c, DcLds &lds, const SRC *x, 
     }
     st.x_prev = lds.x_carry;
     st.y_prev = lds.y_carry;
+#if defined(IQD_DC_TIMING) && IQD_ON_DEVICE
+    DC_T(5);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DC_T(6);
+    if ((threadIdx.x & 63) == 0 && (blockIdx.x % 331) == 7 && n == DC_SUPER)
+        printf("dc row wg %u: wall start %lld (x10 ns) | fill %lld guess %lld warm %lld real+check %lld (redos %d) store-issue %lld store-done %lld | total %lld clocks, wall %lld\n",
+               blockIdx.x, wall0, tm[1] - tm[0], tm[2] - tm[1], tm[3] - tm[2], tm[4] - tm[3], redos, tm[5] - tm[4], tm[6] - tm[5], tm[6] - tm[0],
+               wall_clock64() - wall0);
+#endif
+#undef DC_T
 }
 
 // ---- long streams, many waves per channel -------------------------------------------------------------

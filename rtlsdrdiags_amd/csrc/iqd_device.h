@@ -28,6 +28,14 @@ constexpr int FM_LUT_R = 141;        // the FM tuner decimator fed with int8 can
 constexpr int FM_LUT_W = 2 * FM_LUT_R + 1;
 
 enum Family { FAM_AM = 0, FAM_FM = 1, FAM_WBFM = 2, FAM_SSB = 3, FAM_COUNT = 4 };
+// Raw history a tile / a cold streaming segment of the FIR chains rebuilds its filter states from (the chains need 260 / 684 / 1220
+// samples: AM 8 + 4 * 12 + 16 * 16 taps deep, FM 32 + 4 * 12 + 16 * 40, SSB the AM front + 32 * 31), and what the closing launch
+// keeps of a channel's stream for the next call: the lead-in, the piece in front of it the P waves' first window lies in, and
+// slack to 128 (round 6: it was the whole TAIL for every family - 4 KiB read and 4 KiB written per channel and call, a quarter
+// of the input at one 64 ms block per call; now 1 / 1.75 / 2.75 KiB).  WBFM keeps the whole TAIL (restart points, cold warm-ups).
+constexpr int fir_halo(int family) { return family == FAM_AM ? 384 : family == FAM_FM ? 768 : 1280; }
+constexpr int tail_keep(int family) { return family == FAM_WBFM ? TAIL : fir_halo(family) + 128; }
+static_assert(tail_keep(FAM_SSB) <= TAIL && tail_keep(FAM_AM) % 8 == 0 && tail_keep(FAM_FM) % 8 == 0 && tail_keep(FAM_SSB) % 8 == 0, "kept tails");
 
 // ---- per-channel parameters (host mirror uploaded when dirty) ---------------------------
 struct ChanParams {

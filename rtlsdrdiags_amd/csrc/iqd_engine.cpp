@@ -256,7 +256,7 @@ int iqd_create(const iqd_config *cfg, iqd_t **out)
     PlanKnobs &kn = e->knobs;
     kn.flags = cfg->flags;
     kn.n_cus = e->n_cus;
-    kn.wbfm_chunk = WBFM_CHUNK; kn.wbfm_cold_halo = COLD_HALO; kn.ch_chunk = CH_CHUNK; kn.fir_halo = FIR_HALO; kn.dc_tile = DC_TILE;
+    kn.wbfm_chunk = WBFM_CHUNK; kn.wbfm_cold_halo = COLD_HALO; kn.ch_chunk = CH_CHUNK; kn.dc_tile = DC_TILE;
     if (const char *env = getenv("IQD_WBFM_PATH")) kn.env_path = env[0] == 's' ? 1 : env[0] == 't' ? -1 : 0;
     kn.env_full_grid = getenv("IQD_FULL_GRID") != nullptr;
     if (const char *env = getenv("IQD_SHARES")) kn.env_shares_by_cost = env[0] == 'c';

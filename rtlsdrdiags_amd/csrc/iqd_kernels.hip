@@ -462,8 +462,11 @@ __device__ __forceinline__ void tail_update_body(const ChainLaunch &a, int famil
     uint8_t *tail = a.tails + ((size_t)ech * FAM_COUNT + family) * TAIL_BYTES;
     const uint8_t *iq_ch = a.iq + (size_t)ch * a.ch_stride_bytes;
     const uint32_t *blk_list = a.vlen_gated ? a.blk_lists + (size_t)ch * a.n_blocks : nullptr;
-    // thread i moves 8 samples (16 bytes): new tail samples [8i, 8i+8) = virtual vlen-TAIL+8i
-    const int64_t v = (int64_t)vlen - TAIL + 8 * (int64_t)threadIdx.x;
+    // thread i moves 8 samples (16 bytes) of the last `keep` the family can reach back for (tail_keep, iqd_device.h): kept sample
+    // 8i.. = virtual vlen-keep+8i, at the END of the channel's tail buffer (readers count back from there)
+    const int keep = family == FAM_WBFM ? tail_keep(FAM_WBFM) : family == FAM_FM ? tail_keep(FAM_FM) : family == FAM_AM ? tail_keep(FAM_AM) : tail_keep(FAM_SSB);
+    const bool mine = 8 * (int)threadIdx.x < keep;
+    const int64_t v = (int64_t)vlen - keep + 8 * (int64_t)(mine ? threadIdx.x : 0);
     const uint8_t *src;
     if (v < 0) src = tail + TAIL_BYTES + 2 * v;
     else if (!blk_list) src = iq_ch + 2 * v;
@@ -472,9 +475,10 @@ __device__ __forceinline__ void tail_update_body(const ChainLaunch &a, int famil
         const uint32_t off = (uint32_t)(v - (int64_t)blk * a.block_samples);
         src = iq_ch + ((int64_t)blk_list[blk] * a.block_samples + off) * 2;
     }
-    const uint4 val = *(const uint4 *)src;
+    uint4 val{};
+    if (mine) val = *(const uint4 *)src;
     __syncthreads();
-    ((uint4 *)tail)[threadIdx.x] = val;
+    if (mine) ((uint4 *)(tail + TAIL_BYTES - 2 * keep))[threadIdx.x] = val;
 }
 
 __global__ __launch_bounds__(256) void tail_update_kernel(const ChainLaunch a, int family)

@@ -178,7 +178,7 @@ bool plan_once(const PlanKnobs &k, const CallShape &c, bool allow_fused, CallPla
         p.wgs = k.env_stream_wgs ? k.env_stream_wgs : share[f];
         // workgroups a CU holds at once: WBFM 3 (LDS), the others 4 (registers)
         const TilePlan tp = f == FAM_WBFM ? plan_tiles(vlen, s.n_list, k.wbfm_chunk, k.wbfm_cold_halo, 3 * k.n_cus, k.env_plan_chunks)
-                                          : plan_tiles(vlen, s.n_list, k.ch_chunk, k.fir_halo, 4 * k.n_cus, k.env_plan_chunks);
+                                          : plan_tiles(vlen, s.n_list, k.ch_chunk, (uint32_t)fir_halo(f), 4 * k.n_cus, k.env_plan_chunks);
         p.tile_len = tp.tile_len;
         p.tiles_per_ch = tp.tiles_per_ch;
         int want = 0;   // 0 choose, 1 stream, -1 tiles

@@ -65,7 +65,7 @@ struct PlanKnobs {
     // 228 / 227 / 259 us on 32 / 56 / 96 / 56 CUs for 819 / 819 / 820 / 1638 channels x 2^16, profiles/r3_mixed_4096_kernel_stats.csv)
     float fam_weight[FAM_COUNT] = {3.4f, 6.3f, 10.8f, 3.6f};
     // geometry of the tile kernels and the DC pass (iqd_device.h, iqd_chains.h; handed in so that this file needs no kernel header)
-    uint32_t wbfm_chunk = 0, wbfm_cold_halo = 0, ch_chunk = 0, fir_halo = 0, dc_tile = 0;
+    uint32_t wbfm_chunk = 0, wbfm_cold_halo = 0, ch_chunk = 0, dc_tile = 0;
 };
 
 // One demodulator family's channels in the call.

@@ -100,7 +100,7 @@ struct StreamArgs {
 // FM / AM / SSB as streaming pipelines (iqd_stream2.hip): the chain's first /4 decimator on the matrix cores in
 // P waves, everything behind it in consumer lanes.
 enum { D4_AM = 0, D4_SSB = 1, D4_FM = 2 };
-constexpr int D4_HALO_AM = 384, D4_HALO_SSB = 1280, D4_HALO_FM = 768;   // FULL lead-in samples (the chains need 260 / 1220 / 684): a channel's first segment, from the kept tail
+constexpr int D4_HALO_AM = fir_halo(FAM_AM), D4_HALO_SSB = fir_halo(FAM_SSB), D4_HALO_FM = fir_halo(FAM_FM);   // FULL lead-in samples (the chains need 260 / 1220 / 684): a channel's first segment, from the kept tail
 // Round 6: FM / AM / SSB segments without their long lead-ins.  Every stage of these chains is a FIR, so a segment that starts
 // cold is exact once its filters' windows lie inside what it has run itself - rounds 2-5 gave EVERY segment the lead-in that
 // takes (AM 384, FM 768, SSB 1280 samples: 7 / 14 / 23 % of a 5.5 k-sample segment, a third to a half of the pieces at the

@@ -210,6 +210,9 @@ void emu_chain_accept(int family, int lsb, const uint8_t *iq, uint32_t n_samples
         nt[2 * i] = src[0];
         nt[2 * i + 1] = src[1];
     }
+    // (what the closing launch does not keep, tail_update_body: poisoned, so that a tile reaching back further than tail_keep shows)
+    const int keep = family == FAM_FM ? tail_keep(FAM_FM) : family == FAM_AM ? tail_keep(FAM_AM) : tail_keep(FAM_SSB);
+    for (int i = 0; i < 2 * (TAIL - keep); i++) nt[i] = (uint8_t)(0x5a + 37 * i);
     memcpy(tail, nt.data(), TAIL_BYTES);
 }
 
@@ -281,7 +284,7 @@ void emu_plan_call(const uint32_t *knobs, uint32_t vlen, uint32_t pcm_per_ch, ui
     k.env_mixed_forked = knobs[6] != 0; k.env_shares_by_cost = knobs[7] != 0; k.env_stream_wgs = knobs[8]; k.env_full_grid = knobs[9] != 0;
     k.env_rings = knobs[10];
     k.d4_leadfree = knobs[11] == 0 ? -1 : (int)knobs[11] - 1;   // 0: the default rule; 1 / 2 / 3: IQD_D4_LEADFREE = 0 / 1 / 2
-    k.wbfm_chunk = iqd::WBFM_CHUNK; k.wbfm_cold_halo = iqd::COLD_HALO; k.ch_chunk = iqd::CH_CHUNK; k.fir_halo = iqd::FIR_HALO; k.dc_tile = iqd::DC_TILE;
+    k.wbfm_chunk = iqd::WBFM_CHUNK; k.wbfm_cold_halo = iqd::COLD_HALO; k.ch_chunk = iqd::CH_CHUNK; k.dc_tile = iqd::DC_TILE;
     iqd::CallShape c;
     c.vlen = vlen; c.pcm_per_ch = pcm_per_ch; c.gated = gated != 0;
     for (int f = 0; f < iqd::FAM_COUNT; f++) {
