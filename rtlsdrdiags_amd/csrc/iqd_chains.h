@@ -597,7 +597,14 @@ IQD_DEV bool dc_check(DcLds &lds, int nseg, int lane, bool tiny_ok = false)
 IQD_DEV void dc_store(const DcLds &lds, int nseg, int lane, int16_t *pcm /* of the pass, 4-byte aligned */)
 {
     uint32_t *dst = (uint32_t *)pcm;
-    for (int d = lane; d < nseg * (DC_S / 2); d += 64) dst[d] = lds.row[(d / (DC_S / 2)) * DC_ROW + (d % (DC_S / 2))];
+    for (int d = lane; d < nseg * (DC_S / 2); d += 64) {
+        const uint32_t w = lds.row[(d / (DC_S / 2)) * DC_ROW + (d % (DC_S / 2))];
+#if defined(IQD_WT_STORES) && IQD_ON_DEVICE   // measurement build: write-through stores (nothing left dirty in the L2 for the kernel boundary to write back)
+        __hip_atomic_store(dst + d, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+        dst[d] = w;
+#endif
+    }
 }
 
 // One channel, n PCM samples (multiple of 4; the last pass may be partial, its last segment too).  x may be the PCM row itself

@@ -478,7 +478,16 @@ __device__ __forceinline__ void tail_update_body(const ChainLaunch &a, int famil
     uint4 val{};
     if (mine) val = *(const uint4 *)src;
     __syncthreads();
+#ifdef IQD_WT_STORES   // measurement build: write-through
+    if (mine) {
+        typedef uint32_t wt4 __attribute__((ext_vector_type(4)));
+        const wt4 vv = {val.x, val.y, val.z, val.w};
+        const void *dst = tail + TAIL_BYTES - 2 * keep + 16 * (int)threadIdx.x;
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(dst), "v"(vv) : "memory");
+    }
+#else
     if (mine) ((uint4 *)(tail + TAIL_BYTES - 2 * keep))[threadIdx.x] = val;
+#endif
 }
 
 __global__ __launch_bounds__(256) void tail_update_kernel(const ChainLaunch a, int family)

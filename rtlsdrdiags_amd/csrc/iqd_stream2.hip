@@ -541,6 +541,13 @@ __device__ __forceinline__ uint32_t d4_from_lane_below(uint32_t v)
     return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xf, 0xf, false);
 }
 
+// a consumer lane's 8-byte store of four outputs (IQD_D4_WT_STORES: measurement build, write-through)
+#ifdef IQD_D4_WT_STORES
+#define d4_store4(P, LO, HI) __hip_atomic_store((unsigned long long *)(P), (unsigned long long)(LO) | ((unsigned long long)(HI) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#else
+#define d4_store4(P, LO, HI) (*(u32x2 *)(P) = u32x2{LO, HI})
+#endif
+
 // AM / SSB -----------------------------------------------------------------------------------------------
 struct D4Rail {
     uint32_t y1h[4];      // the last 8 stage-1 outputs of the rail
@@ -721,7 +728,7 @@ __device__ __forceinline__ void d4_am_wave(const ChainLaunch &a, const D4Args &d
             // 128 samples = 4 detector inputs = one store (segments start and end on multiples of 128): int16 into the PCM row, where
             // the DC pass runs in place (ChainLaunch::det16; |x| <= 546), or int32 into the detector stream's own buffer
             if (sg.valid && pos >= sg.skip && pos < sg.tlen) {
-                if (a.det16) *(u32x2 *)(det_row + ((sg.v0 + pos) >> 5)) = u32x2{pack_lo16((uint32_t)x0, (uint32_t)x1), pack_lo16((uint32_t)x2, (uint32_t)x3)};
+                if (a.det16) d4_store4(det_row + ((sg.v0 + pos) >> 5), pack_lo16((uint32_t)x0, (uint32_t)x1), pack_lo16((uint32_t)x2, (uint32_t)x3));
                 else *(u32x4 *)(base_row + ((sg.v0 + pos) >> 5)) = u32x4{(uint32_t)x0, (uint32_t)x1, (uint32_t)x2, (uint32_t)x3};
             }
             if (lf && pos == 0) {
@@ -769,7 +776,7 @@ __device__ __forceinline__ void d4_am_wave(const ChainLaunch &a, const D4Args &d
             const int x2 = d4_replay_piece<MODE, 2>(da, ri, rq, sb, lsb, c14, q4 == 0, wi[2], wq[2]);
             const int x3 = d4_replay_piece<MODE, 3>(da, ri, rq, sb, lsb, c14, q4 == 0, wi[3], wq[3]);
             if (mine && 128 * q4 < sg.tlen) {
-                if (a.det16) *(u32x2 *)(det_row + ((sg.v0 + 128 * q4) >> 5)) = u32x2{pack_lo16((uint32_t)x0, (uint32_t)x1), pack_lo16((uint32_t)x2, (uint32_t)x3)};
+                if (a.det16) d4_store4(det_row + ((sg.v0 + 128 * q4) >> 5), pack_lo16((uint32_t)x0, (uint32_t)x1), pack_lo16((uint32_t)x2, (uint32_t)x3));
                 else *(u32x4 *)(base_row + ((sg.v0 + 128 * q4) >> 5)) = u32x4{(uint32_t)x0, (uint32_t)x1, (uint32_t)x2, (uint32_t)x3};
             }
 #pragma unroll
@@ -897,7 +904,7 @@ __device__ __forceinline__ void d4_fm_wave(const ChainLaunch &a, const D4Args &d
             pcm[2] = d4_fm_piece<2>(da, ring_base, full, consumed, pg, (uint32_t)lane, s);
             pcm[3] = d4_fm_piece<3>(da, ring_base, full, consumed, pg, (uint32_t)lane, s);
             if (sg.valid && pos >= sg.skip && pos < sg.tlen)
-                *(u32x2 *)(pcm_row + ((sg.v0 + pos) >> 5)) = u32x2{pack_lo16((uint32_t)pcm[0], (uint32_t)pcm[1]), pack_lo16((uint32_t)pcm[2], (uint32_t)pcm[3])};
+                d4_store4(pcm_row + ((sg.v0 + pos) >> 5), pack_lo16((uint32_t)pcm[0], (uint32_t)pcm[1]), pack_lo16((uint32_t)pcm[2], (uint32_t)pcm[3]));
             if (lf && pos >= 0 && pos < 32 * D4_REPLAY_FM) {
                 uint32_t *h = head + (pos >> 5) * ST_SEGS;
                 h[0] = s.y2p[20]; h[ST_SEGS] = s.y2p[21]; h[2 * ST_SEGS] = s.y2p[22]; h[3 * ST_SEGS] = s.y2p[23];
@@ -919,7 +926,7 @@ __device__ __forceinline__ void d4_fm_wave(const ChainLaunch &a, const D4Args &d
             pcm[2] = d4_fm_audio<2>(s, h[2 * ST_SEGS]);
             pcm[3] = d4_fm_audio<3>(s, h[3 * ST_SEGS]);
             if (mine && 128 * q4 < sg.tlen)
-                *(u32x2 *)(pcm_row + ((sg.v0 + 128 * q4) >> 5)) = u32x2{pack_lo16((uint32_t)pcm[0], (uint32_t)pcm[1]), pack_lo16((uint32_t)pcm[2], (uint32_t)pcm[3])};
+                d4_store4(pcm_row + ((sg.v0 + 128 * q4) >> 5), pack_lo16((uint32_t)pcm[0], (uint32_t)pcm[1]), pack_lo16((uint32_t)pcm[2], (uint32_t)pcm[3]));
 #pragma unroll
             for (int j = 0; j < 20; j++) s.y2p[j] = s.y2p[j + 4];
         }
