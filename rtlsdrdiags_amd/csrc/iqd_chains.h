@@ -599,7 +599,11 @@ IQD_DEV void dc_store(const DcLds &lds, int nseg, int lane, int16_t *pcm /* of t
     uint32_t *dst = (uint32_t *)pcm;
     for (int d = lane; d < nseg * (DC_S / 2); d += 64) {
         const uint32_t w = lds.row[(d / (DC_S / 2)) * DC_ROW + (d % (DC_S / 2))];
-#if defined(IQD_WT_STORES) && IQD_ON_DEVICE   // measurement build: write-through stores (nothing left dirty in the L2 for the kernel boundary to write back)
+#if !defined(IQD_NO_WT_STORES) && IQD_ON_DEVICE
+        // write-through (sc1): what a launch leaves dirty in the L2s is written back at its end, in front of whatever follows it on
+        // the stream (B / 6 TB/s: MI355X_MICROARCH.md, kernel boundaries) - the closing launch's PCM and tails go out while it still
+        // runs instead (round 6, profiles/r6_wt_ab.txt: AM 4096 x 2^16 -0.8 %, 4096 x 2^14 -1.7 %, configs[4] -0.9 %; the pipelines'
+        // own 8-byte stores the same way: +0.5 to +4 %, narrow write-throughs - not taken)
         __hip_atomic_store(dst + d, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
         dst[d] = w;

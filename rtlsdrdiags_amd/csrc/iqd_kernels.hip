@@ -478,7 +478,7 @@ __device__ __forceinline__ void tail_update_body(const ChainLaunch &a, int famil
     uint4 val{};
     if (mine) val = *(const uint4 *)src;
     __syncthreads();
-#ifdef IQD_WT_STORES   // measurement build: write-through
+#ifndef IQD_NO_WT_STORES   // write-through, like the DC pass's PCM (iqd_chains.h: dc_store)
     if (mine) {
         typedef uint32_t wt4 __attribute__((ext_vector_type(4)));
         const wt4 vv = {val.x, val.y, val.z, val.w};

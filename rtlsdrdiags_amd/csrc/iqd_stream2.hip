@@ -541,7 +541,8 @@ __device__ __forceinline__ uint32_t d4_from_lane_below(uint32_t v)
     return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xf, 0xf, false);
 }
 
-// a consumer lane's 8-byte store of four outputs (IQD_D4_WT_STORES: measurement build, write-through)
+// a consumer lane's 8-byte store of four outputs (IQD_D4_WT_STORES: measurement build, write-through - 64 narrow write-throughs per
+// instruction: USB 4096 x 2^16 +4 %, configs[4] +2.6 %, profiles/r6_wt_ab.txt; the closing launch's coalesced stores do go out that way)
 #ifdef IQD_D4_WT_STORES
 #define d4_store4(P, LO, HI) __hip_atomic_store((unsigned long long *)(P), (unsigned long long)(LO) | ((unsigned long long)(HI) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #else
