@@ -771,7 +771,7 @@ def other_configs(args):
         t0 = time.perf_counter()
         cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--no-other-configs", "--no-host-path", "--no-from-idle", "--pmc-passes", "fetch,write"]
         if argv != ["--config", "0"]:   # (configs[0]: its 64 blocks, with the CPU chain beside them - the parity check of that file)
-            cmd += ["--steps", "10", "--warmup", "3", "--prewarm-ms", "60", "--no-cpu-baseline"]
+            cmd += ["--steps", "20", "--warmup", "3", "--prewarm-ms", "100", "--no-cpu-baseline"]   # (the settings of a run of its own)
         if args.no_live_pmc:
             cmd += ["--no-live-pmc"]
         try:
