@@ -6,11 +6,11 @@ namespace iqd {
 
 // ---- geometry -------------------------------------------------------------------------
 // A channel's demodulator sees one continuous stream: the concatenation of its squelch-open
-// blocks.  Positions are counted in complex samples.  The engine keeps the last TAIL samples
-// each demodulator family consumed ("tail") instead of per-filter ring buffers: every FIR /
+// blocks.  Positions are counted in complex samples.  The engine keeps the last samples
+// each demodulator family consumed ("tail": as many as the family reaches back for, at most TAIL) instead of per-filter ring buffers: every FIR /
 // decimator history in the chains is then a pure function of raw bytes, and only the float
 // recurrences carry explicit state.
-constexpr int TAIL = 2048;          // raw samples of history kept per channel and demodulator
+constexpr int TAIL = 2048;          // raw samples a channel's slot per demodulator family holds (the family keeps tail_keep() of them, below)
 constexpr int TAIL_BYTES = 2 * TAIL;
 constexpr int SEG = 128;            // de-emphasis IIR segment (one lane's run)
 constexpr int FORCED_BACK = 768;    // an exact IIR restart point lies this far before a tile
