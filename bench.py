@@ -752,7 +752,7 @@ def self_launch(argv, n_gpus):
 
 
 # What the default run times besides its headline: every other BASELINE configuration and the two single-family
-# AM / SSB workloads DESIGN.md quotes, a few steps each in the same process, so that their figures come off the driver's own run.
+# AM / SSB workloads DESIGN.md quotes, each as a child process with a run's own settings, so that their figures come off the driver's own run.
 OTHER_CONFIGS = (["--config", "0"], ["--config", "2"], ["--config", "3"], ["--config", "4"],
                  ["--mode", "am", "--channels", "4096", "--log2-samples", "16"],
                  ["--mode", "usb", "--channels", "4096", "--log2-samples", "16"])
