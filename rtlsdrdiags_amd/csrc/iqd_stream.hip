@@ -11,6 +11,20 @@
 
 namespace iqd {
 
+// IQD_ST_WT_STORES (measurement build, tools/variant.sh): the IIR lanes' 16-byte stores - a lane's PCM leaves as whole 32-byte sectors,
+// its boundary record in 16-byte parts - as write-through stores, so that the launch leaves nothing dirty in the L2s for the
+// kernel boundary to write back (28.6 MB per 2^28-sample launch: PCM + records)
+#ifdef IQD_ST_WT_STORES
+__device__ __forceinline__ void st_store16(void *p, v4u v)
+{
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
+}
+#define ST_STORE16(P, A, B, C, D) st_store16((void *)(P), v4u{A, B, C, D})
+#else
+#define ST_STORE16(P, A, B, C, D) (*(u32x4 *)(P) = u32x4{A, B, C, D})
+#endif
+
+
 // The angle table starts at LDS address 0 (the kernel has no static LDS; checked when the kernel starts), so a table
 // cell's byte offset IS its LDS address: through the generic `lds + offset` form the compiler adds the base - a
 // relocated zero - to every one of the eight addresses of a piece.
@@ -532,10 +546,10 @@ __device__ __forceinline__ void st_iir_marks(const ChainLaunch &a, StIirSeg &q, 
         q.rec.y_end = s.y;
         q.rec.u_end = s.up;
         if (q.sg.valid) {
-            *(u32x4 *)q.hist->y1_last = u32x4{s.y1h[0], s.y1h[1], s.y1h[2], s.y1h[3]};
+            ST_STORE16(q.hist->y1_last, s.y1h[0], s.y1h[1], s.y1h[2], s.y1h[3]);
             *(u32x2 *)q.hist->w_last = u32x2{s.wlast[0], s.wlast[1]};
 #pragma unroll
-            for (int k = 0; k < 20; k += 4) *(u32x4 *)&q.hist->y2_last[k] = u32x4{s.y2p[k], s.y2p[k + 1], s.y2p[k + 2], s.y2p[k + 3]};
+            for (int k = 0; k < 20; k += 4) ST_STORE16(&q.hist->y2_last[k], s.y2p[k], s.y2p[k + 1], s.y2p[k + 2], s.y2p[k + 3]);
         }
     }
 }
@@ -585,7 +599,7 @@ __device__ __forceinline__ int st_iir_piece(const ChainLaunch &a, const StreamAr
         else if (wpos == rec_pos_uniform) { q.rec.y_out = s.y; q.rec.u_out = s.up; }
         const int y2 = st_iir_window(sa, s, u, q.c14, q.c15);
         if (wpos >= 0 && wpos < 48 && q.sg.valid) {    // (uniform) the segment's first values, for the boundary fix-up
-            if (wpos == 0) *(u32x4 *)q.hist->w_first = u32x4{s.wq0[0], s.wq0[1], s.y1h[2], s.y1h[3]};   // (w_first, y1_first[0..1])
+            if (wpos == 0) ST_STORE16(q.hist->w_first, s.wq0[0], s.wq0[1], s.y1h[2], s.y1h[3]);   // (w_first, y1_first[0..1])
             else *(u32x2 *)&q.hist->y1_first[wpos >> 3] = u32x2{s.y1h[2], s.y1h[3]};
         }
         const uint32_t mag = (uint32_t)(y2 < 0 ? -y2 : y2);
@@ -594,7 +608,7 @@ __device__ __forceinline__ int st_iir_piece(const ChainLaunch &a, const StreamAr
         else s.y2p[V + 20] = pack_lo16(s.y2lo, (uint32_t)y2);
     }
     if (V == 3 && pos >= 96 && pos < 768 && q.sg.valid)   // the four pairs of this run of 128 samples (pos = its last piece)
-        *(u32x4 *)&q.hist->y2_first[(pos - 96) >> 5] = u32x4{s.y2p[20], s.y2p[21], s.y2p[22], s.y2p[23]};
+        ST_STORE16(&q.hist->y2_first[(pos - 96) >> 5], s.y2p[20], s.y2p[21], s.y2p[22], s.y2p[23]);
     ST_TRACE(s.stamps, s.ring, wg - 1, 2);
     const bool quiet = !__any(s.loud > 0);
     const int pcm = quiet ? st_audio<V>(sa, s, true, q.c14) : st_audio<V>(sa, s, false, q.c14);
@@ -741,8 +755,8 @@ __device__ __forceinline__ void st_iir_wave(const ChainLaunch &a, const StreamAr
                     const int g0 = pos - 384;                    // the group [g0, g0 + 512)
                     int16_t *dst = q.pcm_row + ((q.sg.v0 + g0) >> 5);
                     if (g0 >= 0 && g0 + 512 <= q.sg.tlen) {
-                        ((u32x4 *)dst)[0] = u32x4{pbuf[0], pbuf[1], pbuf[2], pbuf[3]};
-                        ((u32x4 *)dst)[1] = u32x4{pbuf[4], pbuf[5], pbuf[6], pbuf[7]};
+                        ST_STORE16(dst, pbuf[0], pbuf[1], pbuf[2], pbuf[3]);
+                        ST_STORE16(dst + 8, pbuf[4], pbuf[5], pbuf[6], pbuf[7]);
                     } else {                                     // a segment's ragged end (or the lead-in): quarter by quarter
 #pragma unroll
                         for (int k = 0; k < 4; k++)
