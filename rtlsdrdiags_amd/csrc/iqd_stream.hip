@@ -20,6 +20,8 @@ __device__ __forceinline__ void st_store16(void *p, v4u v)
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" :: "v"(p), "v"(v) : "memory");
 }
 #define ST_STORE16(P, A, B, C, D) st_store16((void *)(P), v4u{A, B, C, D})
+#elif defined(IQD_ST_NT_STORES)   // the same as non-temporal stores (the compiler's own: no register tuple forced on the lanes)
+#define ST_STORE16(P, A, B, C, D) __builtin_nontemporal_store(v4u{A, B, C, D}, (v4u *)(P))
 #else
 #define ST_STORE16(P, A, B, C, D) (*(u32x4 *)(P) = u32x4{A, B, C, D})
 #endif

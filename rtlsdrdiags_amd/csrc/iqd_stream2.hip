@@ -545,6 +545,9 @@ __device__ __forceinline__ uint32_t d4_from_lane_below(uint32_t v)
 // instruction: USB 4096 x 2^16 +4 %, configs[4] +2.6 %, profiles/r6_wt_ab.txt; the closing launch's coalesced stores do go out that way)
 #ifdef IQD_D4_WT_STORES
 #define d4_store4(P, LO, HI) __hip_atomic_store((unsigned long long *)(P), (unsigned long long)(LO) | ((unsigned long long)(HI) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#elif defined(IQD_D4_NT_STORES)   // (non-temporal)
+typedef uint32_t d4_v2u __attribute__((ext_vector_type(2)));
+#define d4_store4(P, LO, HI) __builtin_nontemporal_store(d4_v2u{LO, HI}, (d4_v2u *)(P))
 #else
 #define d4_store4(P, LO, HI) (*(u32x2 *)(P) = u32x2{LO, HI})
 #endif
