@@ -840,7 +840,7 @@ __global__ __launch_bounds__(ST_THREADS, 4) void wbfm_stream_kernel(const ChainL
 #endif
 
 #ifndef IQD_STREAM_BODIES_ONLY
-__global__ __launch_bounds__(32 * FIX_SEGS) void wbfm_stream_fixup_kernel(const ChainLaunch a, const StreamArgs sa)
+__global__ __launch_bounds__(FIX_THREADS) void wbfm_stream_fixup_kernel(const ChainLaunch a, const StreamArgs sa)
 {
     __shared__ FixLds fl;
     wbfm_stream_fixup_body(a, sa, blockIdx.x, fl);
@@ -848,7 +848,7 @@ __global__ __launch_bounds__(32 * FIX_SEGS) void wbfm_stream_fixup_kernel(const 
 
 hipError_t launch_wbfm_stream_fixup(const ChainLaunch &a, const StreamArgs &sa, hipStream_t s)
 {
-    hipLaunchKernelGGL(wbfm_stream_fixup_kernel, dim3((sa.n_segments + FIX_SEGS - 1) / FIX_SEGS), dim3(32 * FIX_SEGS), 0, s, a, sa);
+    hipLaunchKernelGGL(wbfm_stream_fixup_kernel, dim3((sa.n_segments + FIX_SEGS - 1) / FIX_SEGS), dim3(FIX_THREADS), 0, s, a, sa);
     return hipGetLastError();
 }
 

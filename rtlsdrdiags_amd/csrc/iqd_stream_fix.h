@@ -70,9 +70,17 @@ __device__ __forceinline__ uint32_t st_id_count(const StreamArgs &sa) { return !
 // The first ST_FIX_PCM PCM samples of every cold segment, recomputed with the exact histories its predecessor left
 // (StHist): stage-1 output 0, stage-2 outputs 0..2, then the 40-tap audio decimator in the reference's MAC order with
 // the clamp after every MAC (Decimator_int16.cc:176-238) - which is also what the clamp-free fast path equals when
-// no clamp can fire.  A workgroup takes 8 consecutive segments: their 9 records (the predecessor of the first
-// included) are one contiguous 2304-byte read into LDS; then one thread per segment and PCM sample.
-constexpr int FIX_SEGS = 8;
+// no clamp can fire.  A workgroup takes FIX_SEGS consecutive segments: their FIX_SEGS + 1 records (the predecessor of the first
+// included) are one contiguous read into LDS (16 + 1 records: 4352 bytes); then FIX_LANES threads per segment, a PCM sample (or two) each.
+// (round 6: IQD_FIX_LANES threads per segment - 32 in rounds 2-5, one per PCM sample with 11 idle; 16 with two samples for the first
+// five halve the launch's waves, and its workgroups then nearly fit the chip at once: the kernel is its trips to memory)
+#ifndef IQD_FIX_LANES
+#define IQD_FIX_LANES 16
+#endif
+constexpr int FIX_LANES = IQD_FIX_LANES;
+constexpr int FIX_SEGS = 256 / FIX_LANES;
+constexpr int FIX_THREADS = FIX_LANES * FIX_SEGS;
+static_assert(FIX_LANES == 16 || FIX_LANES == 32, "threads per boundary");
 struct FixLds {
     uint32_t rec[(FIX_SEGS + 1) * 64];
     uint32_t y2x[FIX_SEGS][41];             // per segment: stage-2 pairs -40 .. 41 with the boundary ones exact
@@ -82,7 +90,7 @@ __device__ __forceinline__ void wbfm_stream_fixup_body(const ChainLaunch &a, con
     uint32_t (&rec)[(FIX_SEGS + 1) * 64] = fl.rec;
     uint32_t (&y2x)[FIX_SEGS][41] = fl.y2x;
     const uint32_t sid0 = block * FIX_SEGS;
-    const int tid = (int)threadIdx.x, sl = tid >> 5, i = tid & 31;
+    const int tid = (int)threadIdx.x, sl = tid / FIX_LANES, i = tid % FIX_LANES;
     // Everything this workgroup needs from memory is asked for at once - the segment's channel, the two states of the
     // hand-off, the nine records - instead of one dependent trip after the other (round 2: 17.6 us of latency for
     // 47 662 boundaries).
@@ -90,7 +98,7 @@ __device__ __forceinline__ void wbfm_stream_fixup_body(const ChainLaunch &a, con
     const StSeg sg = st_segment(a, sid < sa.n_segments ? sid : 0u, sa.n_segments);
     const bool live = sid < sa.n_segments && sg.valid && sg.tile != 0;
     float y_in = 0.f, y_end = 0.f;
-    if (live && i == 31) {
+    if (live && i == FIX_LANES - 1) {
         const WbfmRecord *r = a.records + (size_t)sg.li * a.tiles_per_ch;
         y_in = r[sg.tile].y_in;
         y_end = r[sg.tile - 1].y_end;
@@ -98,7 +106,7 @@ __device__ __forceinline__ void wbfm_stream_fixup_body(const ChainLaunch &a, con
     {
         const uint32_t *src = (const uint32_t *)sa.hist + ((size_t)sid0 - (sid0 ? 1 : 0)) * 64;
         const uint32_t n_avail = (sa.n_segments - sid0 < (uint32_t)FIX_SEGS ? sa.n_segments - sid0 : (uint32_t)FIX_SEGS) + (sid0 ? 1u : 0u);
-        for (uint32_t k = (uint32_t)tid; k < n_avail * 64; k += 32 * FIX_SEGS) rec[k + (sid0 ? 0 : 64)] = src[k];
+        for (uint32_t k = (uint32_t)tid; k < n_avail * 64; k += FIX_THREADS) rec[k + (sid0 ? 0 : 64)] = src[k];
     }
     __syncthreads();
     const StHist &prev = *(const StHist *)&rec[sl * 64], &own = *(const StHist *)&rec[(sl + 1) * 64];
@@ -122,7 +130,7 @@ __device__ __forceinline__ void wbfm_stream_fixup_body(const ChainLaunch &a, con
         }
         ((int16_t *)&y2x[sl][20])[i] = (int16_t)(s2 >> 15);   // outputs 0, 1 -> pair 20; output 2 -> low half of pair 21
     } else if (live) {                                 // the other pairs as they are (each thread a few)
-        for (int p = i - 3; p < 41; p += 29) {
+        for (int p = i - 3; p < 41; p += FIX_LANES - 3) {
             if (p == 20) continue;
             if (p == 21) ((int16_t *)&y2x[sl][21])[1] = (int16_t)(own.y2_first[1] >> 16);
             else y2x[sl][p] = p < 20 ? prev.y2_last[p] : own.y2_first[p - 20];
@@ -132,7 +140,7 @@ __device__ __forceinline__ void wbfm_stream_fixup_body(const ChainLaunch &a, con
     // warmed-up state at its start must be its predecessor's end state, bit for bit.  Only mismatches touch the
     // device counters (thousands of workgroups adding to one word would cost more than the whole kernel); the host
     // knows how many hand-offs a launch has.
-    if (live && i == 31 && f2u(y_in) != f2u(y_end)) {   // (bit-equal is the rule; the sub-2^-100 exception needs the channel's K: rare)
+    if (live && i == FIX_LANES - 1 && f2u(y_in) != f2u(y_end)) {   // (bit-equal is the rule; the sub-2^-100 exception needs the channel's K: rare)
         if (!iir_states_agree(y_in, y_end, a.params[sg.ech].wbfm_k >= 1.0f)) {
             atomicAdd(&a.counters[CNT_TILE_MISMATCH], 1u);
             atomicAdd(&a.counters[CNT_STREAM_MISMATCH], 1u);
@@ -140,16 +148,18 @@ __device__ __forceinline__ void wbfm_stream_fixup_body(const ChainLaunch &a, con
         }
     }
     __syncthreads();   // y2x[sl] was written by this segment's 32 threads, each reads the others' entries (uniform control flow up to here)
-    if (!live || i >= ST_FIX_PCM || i >= sg.tlen / 32) return;
-    // PCM i from stage-2 outputs 2i-38 .. 2i+1: pairs i+1 .. i+20, newest first
-    int s3 = 1 << 14;
+    if (!live) return;
+    for (int j = i; j < ST_FIX_PCM && j < sg.tlen / 32; j += FIX_LANES) {
+        // PCM j from stage-2 outputs 2j-38 .. 2j+1: pairs j+1 .. j+20, newest first
+        int s3 = 1 << 14;
 #pragma unroll
-    for (int q = 0; q < 20; q++) {
-        const uint32_t pair = y2x[sl][20 + i - q];
-        s3 = clamp_q30(dot2(pair, sa.a40p[q] & 0xffff0000u, s3));
-        s3 = clamp_q30(dot2(pair, sa.a40p[q] & 0x0000ffffu, s3));
+        for (int q = 0; q < 20; q++) {
+            const uint32_t pair = y2x[sl][20 + j - q];
+            s3 = clamp_q30(dot2(pair, sa.a40p[q] & 0xffff0000u, s3));
+            s3 = clamp_q30(dot2(pair, sa.a40p[q] & 0x0000ffffu, s3));
+        }
+        a.pcm[(size_t)sg.ch * a.pcm_stride + (sg.v0 >> 5) + j] = (int16_t)(s3 >> 15);
     }
-    a.pcm[(size_t)sg.ch * a.pcm_stride + (sg.v0 >> 5) + i] = (int16_t)(s3 >> 15);
 }
 
 }  // namespace iqd
