@@ -32,7 +32,7 @@ TilePlan plan_tiles(uint32_t vlen, uint32_t n_channels, uint32_t chunk, uint32_t
                     uint32_t force_chunks = 0 /* experiments: k chunks per tile */);
 
 TilePlan plan_stream(uint32_t vlen, uint32_t n_channels, uint32_t streams, uint32_t granule = 512 /* segment lengths are multiples of this: 128, 256 or 512 samples */,
-                     uint32_t shift = 0 /* FM / AM / SSB with short lead-ins (iqd_d4_fix.h): segment t covers [t * tile_len - shift, ...) */);
+                     uint32_t shift = 0 /* FM / AM / SSB with short lead-ins (iqd_stream.h: d4_geom): the full lead-in minus 128 that a cold segment takes out of its own length */);
 // Several demodulator families in one call, each with its streaming kernel: the CUs each family's persistent workgroups
 // get, in proportion to cost[f] (0 = family absent: its entry becomes n_cus).  Whole multiples of 8, at least 8, two CUs
 // per XCD left unplanned; false (and every entry n_cus) when that cannot be had.  See iqd_host.cpp.

@@ -91,7 +91,7 @@ struct FamilyPlan {
     uint32_t wgs = 0;                    // the family's share of the CUs / of the one launch's workgroups
     uint32_t tile_len = 0, tiles_per_ch = 0;
     // streaming pipelines
-    uint32_t halo = 0, lead_shift = 0;   // FM / AM / SSB: lead-in samples every segment runs; how far a channel's segments are shifted (iqd_d4_fix.h)
+    uint32_t halo = 0, lead_shift = 0;   // FM / AM / SSB: lead-in samples every segment runs; what a cold segment skips of its own length (iqd_stream.h: d4_geom)
     bool grouped = false;                // segment ids grouped by rotation selector, each group padded to 16 (WBFM: only if mixed)
     uint32_t group_start[4] = {0, 0, 0, 0}, group_li0[3] = {0, 0, 0}, group_nseg[3] = {0, 0, 0};
     uint32_t grid = 0, rounds = 0;       // workgroups launched, rounds each runs
