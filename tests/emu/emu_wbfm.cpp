@@ -353,6 +353,9 @@ uint32_t emu_d4_const(int which)
     case 10: return (uint32_t)iqd::d4_replay_outputs(iqd::FAM_SSB);
     case 11: return (uint32_t)iqd::D4_REPLAY_PAIRS_AMSSB;
     case 12: return (uint32_t)iqd::D4_RAILS_FROM_PIECE;
+    case 13: return (uint32_t)iqd::tail_keep(iqd::FAM_AM);
+    case 14: return (uint32_t)iqd::tail_keep(iqd::FAM_FM);
+    case 15: return (uint32_t)iqd::tail_keep(iqd::FAM_SSB);
     }
     return 0;
 }

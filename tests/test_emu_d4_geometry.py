@@ -37,7 +37,9 @@ def test_segments_tile_every_row_once_whatever_the_channels_first_id(L):
     rng = np.random.default_rng(77)
     tail = L.emu_d4_const(7)
     n_cases = 0
-    for shift in (L.emu_d4_const(4), L.emu_d4_const(5), L.emu_d4_const(6)):          # AM 256, FM 640, SSB 1152
+    for shift, keep in ((L.emu_d4_const(4), L.emu_d4_const(13)), (L.emu_d4_const(5), L.emu_d4_const(14)),
+                        (L.emu_d4_const(6), L.emu_d4_const(15))):                     # AM 256, FM 640, SSB 1152; what the family keeps of a channel's stream
+        assert shift + 128 + 32 <= keep <= tail
         for trial in range(120):
             vlen = 128 * int(rng.integers(1, 1 << int(rng.integers(1, 12))))
             n_ch = int(rng.integers(1, 5000))
@@ -57,7 +59,7 @@ def test_segments_tile_every_row_once_whatever_the_channels_first_id(L):
                         continue
                     first, end = v0 + skip, min(v0 + tile_len, vlen)
                     assert first == at, (vlen, tile_len, sid0, t, first, at)          # outputs start where the predecessor's ended
-                    assert v0 - 128 - 32 >= -tail                                     # the run (lead-in + the piece before it) stays in the tail's reach
+                    assert v0 - 128 - 32 >= -keep                                     # the run (lead-in + the piece before it) stays inside what the closing launch kept (tail_keep)
                     if not cold:                                                      # its predecessor: the lane below, ending at v0
                         pv0, _, _ = geom(L, sid0 + t - 1, t - 1, tile_len, shift)
                         assert pv0 + tile_len == v0 and (sid0 + t) % 64 != 0
